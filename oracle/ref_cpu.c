@@ -1,0 +1,797 @@
+/*
+ * oracle/ref_cpu.c -- plain-C fp64 restatement of TrackDLO's EM registration path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see ref_cpu.h).  PARITY PIN STATUS: PARTIAL (see ref_cpu.h).
+ *
+ * Follows, step for step and including the quirks:
+ *   trackdlo/src/trackdlo.cpp:92-159   get_nearest_indices / calc_LLE_weights
+ *   trackdlo/src/trackdlo.cpp:161-441  cpd_lle
+ *   trackdlo/src/trackdlo.cpp:584-898  traverse_euclidean
+ *   trackdlo/src/trackdlo.cpp:900-999  tracking_step
+ *   trackdlo/src/utils.cpp:13-19       pt2pt_dis_sq / pt2pt_dis
+ *   trackdlo/src/utils.cpp:172-241     isBetween / line_sphere_intersection
+ * and, behind the prototype-mode switches of ref_params, utils/tracking_test.py:233-423.
+ *
+ * Third-party arithmetic that is NOT under /root/reference: Eigen 3.3 (CMakeLists.txt:25)
+ * -- MatrixXd::inverse()/determinant() (PartialPivLU) and
+ * completeOrthogonalDecomposition().solve().  Restated here as partial-pivot LU and
+ * Householder QR with column pivoting; for the full-rank systems of this path all agree to
+ * cond(A)*eps.
+ *
+ * Deliberately NOT reproduced (they do not change results): per-call heap allocations of
+ * pt2pt_dis by-value MatrixXd arguments, the dead P_stored copy (:299) and diff_yy (:205-212).
+ * This makes the restatement FASTER than the real reference, so GPU/CPU ratios quoted against
+ * it are conservative.
+ */
+#include "ref_cpu.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <float.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---------------------------------------------------------------- small dense helpers */
+
+/* Householder QR with column pivoting; A n x n col-major (overwritten), B n x nrhs. */
+int ref_solve_qrcp(double *A, int n, double *B, int nrhs, double *X) {
+    int *perm = (int *)malloc(sizeof(int) * (size_t)n);
+    double *cn = (double *)malloc(sizeof(double) * (size_t)n);
+    double *v = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!perm || !cn || !v) { free(perm); free(cn); free(v); return -1; }
+    for (int j = 0; j < n; j++) {
+        perm[j] = j;
+        double s = 0;
+        for (int i = 0; i < n; i++) s += A[(size_t)j * n + i] * A[(size_t)j * n + i];
+        cn[j] = s;
+    }
+    int rank = n;
+    for (int k = 0; k < n; k++) {
+        /* pivot column: largest remaining norm (recomputed for robustness) */
+        int pj = k; double best = -1;
+        for (int j = k; j < n; j++) {
+            double s = 0;
+            for (int i = k; i < n; i++) s += A[(size_t)j * n + i] * A[(size_t)j * n + i];
+            cn[j] = s;
+            if (s > best) { best = s; pj = j; }
+        }
+        if (pj != k) {
+            for (int i = 0; i < n; i++) {
+                double t = A[(size_t)k * n + i]; A[(size_t)k * n + i] = A[(size_t)pj * n + i]; A[(size_t)pj * n + i] = t;
+            }
+            int t = perm[k]; perm[k] = perm[pj]; perm[pj] = t;
+        }
+        double normx = sqrt(cn[pj]);
+        if (normx == 0.0) { rank = k; break; }
+        double akk = A[(size_t)k * n + k];
+        double alpha = (akk > 0) ? -normx : normx;
+        /* v = x - alpha e1 */
+        for (int i = k; i < n; i++) v[i] = A[(size_t)k * n + i];
+        v[k] -= alpha;
+        double vnorm2 = 0;
+        for (int i = k; i < n; i++) vnorm2 += v[i] * v[i];
+        if (vnorm2 > 0) {
+            for (int j = k; j < n; j++) {
+                double dot = 0;
+                for (int i = k; i < n; i++) dot += v[i] * A[(size_t)j * n + i];
+                double f = 2.0 * dot / vnorm2;
+                for (int i = k; i < n; i++) A[(size_t)j * n + i] -= f * v[i];
+            }
+            for (int j = 0; j < nrhs; j++) {
+                double dot = 0;
+                for (int i = k; i < n; i++) dot += v[i] * B[(size_t)j * n + i];
+                double f = 2.0 * dot / vnorm2;
+                for (int i = k; i < n; i++) B[(size_t)j * n + i] -= f * v[i];
+            }
+        }
+        A[(size_t)k * n + k] = alpha;
+        for (int i = k + 1; i < n; i++) A[(size_t)k * n + i] = 0.0;
+    }
+    /* back substitution on the leading rank x rank block (minimum-norm completion = 0) */
+    for (int j = 0; j < nrhs; j++) {
+        for (int i = 0; i < n; i++) v[i] = 0.0;
+        for (int i = rank - 1; i >= 0; i--) {
+            double s = B[(size_t)j * n + i];
+            for (int c = i + 1; c < rank; c++) s -= A[(size_t)c * n + i] * v[c];
+            v[i] = s / A[(size_t)i * n + i];
+        }
+        for (int i = 0; i < n; i++) X[(size_t)j * n + perm[i]] = v[i];
+    }
+    free(perm); free(cn); free(v);
+    return rank == n ? 0 : 1;
+}
+
+/* partial-pivot LU inverse of a small n x n row-major matrix; returns determinant. */
+static double lu_inverse_small(const double *Ain, int n, double *inv) {
+    double a[12 * 12];
+    int piv[12];
+    memcpy(a, Ain, sizeof(double) * (size_t)(n * n));
+    double det = 1.0;
+    for (int i = 0; i < n; i++) piv[i] = i;
+    for (int k = 0; k < n; k++) {
+        int p = k; double best = fabs(a[k * n + k]);
+        for (int i = k + 1; i < n; i++) if (fabs(a[i * n + k]) > best) { best = fabs(a[i * n + k]); p = i; }
+        if (p != k) {
+            for (int j = 0; j < n; j++) { double t = a[k * n + j]; a[k * n + j] = a[p * n + j]; a[p * n + j] = t; }
+            int t = piv[k]; piv[k] = piv[p]; piv[p] = t;
+            det = -det;
+        }
+        det *= a[k * n + k];
+        if (a[k * n + k] == 0.0) continue;
+        for (int i = k + 1; i < n; i++) {
+            a[i * n + k] /= a[k * n + k];
+            for (int j = k + 1; j < n; j++) a[i * n + j] -= a[i * n + k] * a[k * n + j];
+        }
+    }
+    if (det == 0.0) return 0.0;
+    for (int c = 0; c < n; c++) {
+        double y[12];
+        for (int i = 0; i < n; i++) {
+            double s = (piv[i] == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; j++) s -= a[i * n + j] * y[j];
+            y[i] = s;
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = y[i];
+            for (int j = i + 1; j < n; j++) s -= a[i * n + j] * inv[j * n + c];
+            inv[i * n + c] = s / a[i * n + i];
+        }
+    }
+    return det;
+}
+
+/* ---------------------------------------------------------------- LLE (trackdlo.cpp:92-159) */
+
+static int nearest_indices(int k, int M, int idx, int extended, int *out) {
+    int n = 0;
+    if (!extended) {
+        /* trackdlo.cpp:92-117: truncated at the ends */
+        if (idx - k < 0) { for (int i = 0; i <= idx + k; i++) if (i != idx) out[n++] = i; }
+        else if (idx + k >= M) { for (int i = idx - k; i <= M - 1; i++) if (i != idx) out[n++] = i; }
+        else { for (int i = idx - k; i <= idx + k; i++) if (i != idx) out[n++] = i; }
+    } else {
+        /* tracking_test.py:233-247: extended on the other side */
+        if (idx - k < 0) {
+            for (int i = 0; i < idx; i++) out[n++] = i;
+            for (int i = idx + 1; i < idx + k + 1 + abs(idx - k); i++) out[n++] = i;
+        } else if (idx + k >= M) {
+            int last = M - 1;
+            for (int i = idx - k - (idx + k - last); i < idx; i++) out[n++] = i;
+            for (int i = idx + 1; i < last + 1; i++) out[n++] = i;
+        } else {
+            for (int i = idx - k; i < idx; i++) out[n++] = i;
+            for (int i = idx + 1; i < idx + k + 1; i++) out[n++] = i;
+        }
+    }
+    return n;
+}
+
+void ref_calc_lle_weights(int k, const double *Y, int M, int extended, double *L) {
+    memset(L, 0, sizeof(double) * (size_t)M * (size_t)M);
+    for (int i = 0; i < M; i++) {
+        int idx[16];
+        int nn = nearest_indices(k / 2, M, i, extended, idx);
+        double Gi[12 * 12] = {0}, Ginv[12 * 12] = {0};
+        for (int r = 0; r < nn; r++)
+            for (int s = 0; s < nn; s++) {
+                double acc = 0;
+                for (int d = 0; d < 3; d++)
+                    acc += (Y[d * M + i] - Y[d * M + idx[r]]) * (Y[d * M + i] - Y[d * M + idx[s]]);
+                Gi[r * nn + s] = acc;
+            }
+        double det = lu_inverse_small(Gi, nn, Ginv);
+        if (det == 0.0) {   /* trackdlo.cpp:139-144 */
+            for (int r = 0; r < nn; r++) Gi[r * nn + r] += 0.00001;
+            lu_inverse_small(Gi, nn, Ginv);
+        }
+        double w[12], tot = 0;
+        for (int r = 0; r < nn; r++) {
+            double s = 0;
+            for (int c = 0; c < nn; c++) s += Ginv[r * nn + c];
+            w[r] = s; tot += s;
+        }
+        for (int r = 0; r < nn; r++) L[(size_t)idx[r] * M + i] = w[r] / tot;   /* L(i, idx[r]) */
+    }
+}
+
+/* ---------------------------------------------------------------- kernel G (trackdlo.cpp:214-233) */
+
+void ref_kernel_G(const double *Y0, int M, double beta, int kernel, double *coord, double *G) {
+    coord[0] = 0.0;
+    double cur = 0;
+    for (int i = 0; i < M - 1; i++) {
+        double s = 0;
+        for (int d = 0; d < 3; d++) { double t = Y0[d * M + i + 1] - Y0[d * M + i]; s += t * t; }
+        cur += sqrt(s);
+        coord[i + 1] = cur;
+    }
+    for (int i = 0; i < M; i++)
+        for (int j = 0; j < M; j++) {
+            double g;
+            if (kernel == 0) {
+                double dd = fabs(coord[i] - coord[j]);
+                /* 1/(2*beta * 2*beta) * exp(-sqrt(2)*d/beta) * (2*d + sqrt(2)*beta), :233 */
+                g = 1.0 / (2 * beta * 2 * beta) * exp(-sqrt(2.0) * dd / beta) * (2 * dd + sqrt(2.0) * beta);
+            } else if (kernel == 1) {
+                double s = 0;
+                for (int d = 0; d < 3; d++) { double t = Y0[d * M + i] - Y0[d * M + j]; s += t * t; }
+                g = exp(-s / (2 * beta * beta));
+            } else {
+                double dd = fabs(coord[i] - coord[j]);
+                g = exp(-(dd * dd) / (2 * beta * beta));
+            }
+            G[(size_t)j * M + i] = g;
+        }
+}
+
+/* ---------------------------------------------------------------- cpd_lle (trackdlo.cpp:161-441) */
+
+static inline double sqdist3(const double *Y, int M, int m, double x, double y, double z) {
+    double a = Y[m] - x, b = Y[M + m] - y, c = Y[2 * M + m] - z;
+    return a * a + b * b + c * c;
+}
+
+int ref_cpd_lle(const double *X_orig, int N0, double *Y, int M, double *sigma2_io,
+                const ref_params *p, const double *priors, int K,
+                const int *visible_nodes, int n_vis, const double *H_override,
+                ref_stats *stats, ref_trace *trace) {
+    if (M < 4 || N0 <= 0) return -1;
+    const int D = 3;
+    double sigma2 = *sigma2_io;
+
+    /* ---- prune X (:177-195) */
+    double *X = (double *)malloc(sizeof(double) * 3 * (size_t)N0);
+    int *keep = (int *)malloc(sizeof(int) * (size_t)N0);
+    int N = 0;
+    for (int i = 0; i < N0; i++) {
+        int k = 1;
+        if (!p->no_prune) {
+            double shortest = 100000;
+            for (int j = 0; j < M; j++) {
+                double dist = sqrt(sqdist3(Y, M, j, X_orig[i], X_orig[N0 + i], X_orig[2 * (size_t)N0 + i]));
+                if (dist < shortest) shortest = dist;
+            }
+            k = shortest < 0.1;
+        }
+        keep[i] = k;
+        N += k;
+    }
+    if (N == 0) { free(X); free(keep); return -2; }
+    {
+        int c = 0;
+        for (int i = 0; i < N0; i++) if (keep[i]) {
+            X[c] = X_orig[i]; X[N + c] = X_orig[N0 + i]; X[2 * (size_t)N + c] = X_orig[2 * (size_t)N0 + i];
+            c++;
+        }
+    }
+    free(keep);
+    const double *Xx = X, *Xy = X + N, *Xz = X + 2 * (size_t)N;
+
+    int converged = 1;
+    size_t MM = (size_t)M * M;
+    double *Y0 = (double *)malloc(sizeof(double) * 3 * M);
+    memcpy(Y0, Y, sizeof(double) * 3 * M);
+    double *coord = (double *)malloc(sizeof(double) * M);
+    double *G = (double *)malloc(sizeof(double) * MM);
+    ref_kernel_G(Y0, M, p->beta, p->kernel, coord, G);
+
+    /* ---- LLE matrix (:236-237) */
+    double *H = (double *)calloc(MM, sizeof(double));
+    if (H_override) {
+        memcpy(H, H_override, sizeof(double) * MM);
+    } else if (p->include_lle) {   /* the reference always computes it; unused when include_lle is false */
+        double *L = (double *)malloc(sizeof(double) * MM);
+        ref_calc_lle_weights(6, Y0, M, p->lle_extended, L);
+        /* IL = I - L ; H = IL^T IL */
+        for (int i = 0; i < M; i++) for (int j = 0; j < M; j++) L[(size_t)j * M + i] = (i == j ? 1.0 : 0.0) - L[(size_t)j * M + i];
+        for (int i = 0; i < M; i++) for (int j = 0; j < M; j++) {
+            double s = 0;
+            for (int k = 0; k < M; k++) s += L[(size_t)i * M + k] * L[(size_t)j * M + k];
+            H[(size_t)j * M + i] = s;
+        }
+        free(L);
+    }
+    double *HG = NULL, *HY0 = NULL;
+    if (p->include_lle) {
+        HG = (double *)malloc(sizeof(double) * MM);
+        HY0 = (double *)malloc(sizeof(double) * 3 * M);
+        for (int i = 0; i < M; i++) for (int j = 0; j < M; j++) {
+            double s = 0;
+            for (int k = 0; k < M; k++) s += H[(size_t)k * M + i] * G[(size_t)j * M + k];
+            HG[(size_t)j * M + i] = s;
+        }
+        for (int i = 0; i < M; i++) for (int d = 0; d < 3; d++) {
+            double s = 0;
+            for (int k = 0; k < M; k++) s += H[(size_t)k * M + i] * Y0[d * M + k];
+            HY0[d * M + i] = s;
+        }
+    }
+
+    /* ---- J and Y_extended (:240-260) */
+    double *Jd = (double *)calloc(M, sizeof(double));       /* J is a 0/1 diagonal selector */
+    double *Yext = (double *)malloc(sizeof(double) * 3 * M);
+    memcpy(Yext, Y0, sizeof(double) * 3 * M);
+    for (int i = 0; i < K; i++) {
+        int index = (int)priors[4 * i + 0];
+        if (index < 0 || index >= M) { continue; }   /* reference: out-of-range row access is UB */
+        Jd[index] = 1.0;
+        for (int d = 0; d < 3; d++) Yext[d * M + index] = priors[4 * i + 1 + d];
+    }
+
+    /* ---- sigma2 init (:263-273) */
+    if (sigma2 == 0) {
+        double s = 0;
+        for (int i = 0; i < M; i++)
+            for (int j = 0; j < N; j++) s += sqdist3(Y0, M, i, Xx[j], Xy[j], Xz[j]);
+        sigma2 = s / (double)(D * M * N);
+    }
+
+    double *Pm = (double *)malloc(sizeof(double) * (size_t)M * N);    /* (m,n) at [n*M+m] */
+    double *P1 = (double *)malloc(sizeof(double) * M);
+    double *PX = (double *)malloc(sizeof(double) * 3 * M);
+    double *dmin = (double *)malloc(sizeof(double) * M);
+    double *A = (double *)malloc(sizeof(double) * MM);
+    double *B = (double *)malloc(sizeof(double) * 3 * M);
+    double *W = (double *)malloc(sizeof(double) * 3 * M);
+    double *T = (double *)malloc(sizeof(double) * 3 * M);
+    double *col = (double *)malloc(sizeof(double) * M);
+    double *geo = (double *)malloc(sizeof(double) * M);
+    double *pvis = (double *)malloc(sizeof(double) * M);
+    int gap_quirk = 0, it_done = 0;
+    int vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0);
+
+    double t0 = now_s();
+    for (int it = 0; it < p->max_iter; it++) {
+        /* ---- distances and per-node shortest distance (:278-296) */
+        for (int m = 0; m < M; m++) dmin[m] = 10000.0 * 10000.0;
+        for (int n = 0; n < N; n++) {
+            double *c_ = Pm + (size_t)n * M;
+            for (int m = 0; m < M; m++) {
+                double d2 = sqdist3(Y, M, m, Xx[n], Xy[n], Xz[n]);
+                c_[m] = d2;
+                if (d2 < dmin[m]) dmin[m] = d2;
+            }
+        }
+        for (int m = 0; m < M; m++) {
+            double sd = sqrt(dmin[m]);          /* min of sqrt == sqrt of min (monotone, correctly rounded) */
+            if (sd > 10000) sd = 10000;
+            if (sd <= p->visibility_threshold) sd = 0;
+            dmin[m] = sd;
+        }
+
+        /* ---- Euclidean membership, used for the per-point argmax (:298-301, :310) */
+        double c = pow(2 * M_PI * sigma2, (double)D / 2) * p->mu / (1 - p->mu) * (double)M / N;
+        double Np = 0;
+        memset(P1, 0, sizeof(double) * M);
+        memset(PX, 0, sizeof(double) * 3 * M);
+        double trXtdPt1X = 0;
+        if (vis_branch) {                        /* P_vis rows (:362-372) */
+            double total = 0;
+            for (int m = 0; m < M; m++) total += exp(-p->k_vis * dmin[m]);
+            for (int m = 0; m < M; m++) pvis[m] = exp(-p->k_vis * dmin[m]) * 1.0 / total;
+        }
+
+        for (int n = 0; n < N; n++) {
+            double *c_ = Pm + (size_t)n * M;     /* holds diff_xy column */
+            double colsum = 0;
+            for (int m = 0; m < M; m++) { col[m] = exp(-0.5 * c_[m] / sigma2); colsum += col[m]; }
+            if (p->den_guard && colsum == 0) colsum = DBL_EPSILON;
+            double den = colsum + c;
+            int a = 0; double best = col[0] / den;
+            for (int m = 0; m < M; m++) {
+                col[m] = col[m] / den;
+                if (col[m] > best) { best = col[m]; a = m; }     /* maxCoeff: first maximum */
+            }
+
+            double Pt1n;
+            if (p->e_mode == 1) {
+                /* prototype, use_geodesic=False: P is the Euclidean membership itself */
+                Pt1n = 0;
+                for (int m = 0; m < M; m++) { c_[m] = col[m]; Pt1n += col[m]; }
+            } else {
+                int b, lo, hi;
+                double da, db;
+                if (p->e_mode == 0) {
+                    /* ---- geodesic substitution (:313-351) */
+                    int c1 = a - 1; if (c1 == -1) c1 = 2;
+                    int c2 = a + 1; if (c2 == M) c2 = M - 3;
+                    double d1 = sqrt(sqdist3(Y, M, c1, Xx[n], Xy[n], Xz[n]));
+                    double d2_ = sqrt(sqdist3(Y, M, c2, Xx[n], Xy[n], Xz[n]));
+                    b = (d1 < d2_) ? c1 : c2;
+                } else {
+                    /* prototype (tracking_test.py:347-355): by membership value, clamps 1 / M-2 */
+                    int c1 = a - 1; if (c1 < 0) c1 = 1;
+                    int c2 = a + 1; if (c2 > M - 1) c2 = M - 2;
+                    b = (col[c1] > col[c2]) ? c1 : c2;
+                }
+                da = sqrt(sqdist3(Y, M, a, Xx[n], Xy[n], Xz[n]));
+                db = sqrt(sqdist3(Y, M, b, Xx[n], Xy[n], Xz[n]));
+                for (int m = 0; m < M; m++) geo[m] = 0.0;       /* fresh zero column (:305) */
+                if (p->e_mode == 0) {
+                    geo[a] = sqdist3(Y, M, a, Xx[n], Xy[n], Xz[n]);      /* :332 */
+                    geo[b] = sqdist3(Y, M, b, Xx[n], Xy[n], Xz[n]);      /* :333 */
+                    if (a < b) {
+                        for (int j = 0; j < a; j++) { double t = fabs(coord[j] - coord[a]) + da; geo[j] = t * t; }
+                        for (int j = b; j < M; j++) { double t = fabs(coord[j] - coord[b]) + db; geo[j] = t * t; }
+                    } else {
+                        for (int j = 0; j < b; j++) { double t = fabs(coord[j] - coord[b]) + db; geo[j] = t * t; }
+                        for (int j = a; j < M; j++) { double t = fabs(coord[j] - coord[a]) + da; geo[j] = t * t; }
+                    }
+                } else {
+                    /* tracking_test.py:362-372 (closed upper range on the low side) */
+                    if (a < b) {
+                        for (int j = 0; j <= a; j++) { double t = fabs(coord[a] - coord[j]) + da; geo[j] = t * t; }
+                        for (int j = b; j < M; j++) { double t = fabs(coord[b] - coord[j]) + db; geo[j] = t * t; }
+                    } else if (a > b) {
+                        for (int j = 0; j <= b; j++) { double t = fabs(coord[b] - coord[j]) + db; geo[j] = t * t; }
+                        for (int j = a; j < M; j++) { double t = fabs(coord[a] - coord[j]) + da; geo[j] = t * t; }
+                    }
+                }
+                lo = a < b ? a : b; hi = a < b ? b : a;
+                if (hi - lo == 2) gap_quirk++;
+
+                /* ---- final membership (:354-383) */
+                double cs = 0;
+                if (vis_branch && p->e_mode == 0) {
+                    for (int m = 0; m < M; m++) {
+                        col[m] = exp(-0.5 * geo[m] / sigma2) * pvis[m];      /* :375 */
+                        cs += col[m];
+                    }
+                    double c2v = pow(2 * M_PI * sigma2, (double)D / 2) * p->mu / (1 - p->mu) / N;   /* :378 */
+                    den = cs + c2v;
+                } else {
+                    for (int m = 0; m < M; m++) { col[m] = exp(-0.5 * geo[m] / sigma2); cs += col[m]; }
+                    if (p->den_guard && cs == 0) cs = DBL_EPSILON;
+                    den = cs + c;
+                }
+                Pt1n = 0;
+                for (int m = 0; m < M; m++) { c_[m] = col[m] / den; Pt1n += c_[m]; }
+            }
+            /* ---- reductions (:386-389) */
+            for (int m = 0; m < M; m++) {
+                double pv = c_[m];
+                P1[m] += pv;
+                PX[m] += pv * Xx[n]; PX[M + m] += pv * Xy[n]; PX[2 * M + m] += pv * Xz[n];
+            }
+            trXtdPt1X += Pt1n * (Xx[n] * Xx[n] + Xy[n] * Xy[n] + Xz[n] * Xz[n]);
+        }
+        for (int m = 0; m < M; m++) Np += P1[m];
+
+        /* ---- M step (:392-413) */
+        for (int i = 0; i < M; i++)
+            for (int j = 0; j < M; j++) {
+                double a_ = P1[i] * G[(size_t)j * M + i] + (i == j ? p->lambda * sigma2 : 0.0);
+                if (p->include_lle) a_ += sigma2 * p->lle_weight * HG[(size_t)j * M + i];
+                if (K != 0) a_ += p->alpha * Jd[i] * G[(size_t)j * M + i];
+                A[(size_t)j * M + i] = a_;
+            }
+        for (int i = 0; i < M; i++)
+            for (int d = 0; d < 3; d++) {
+                double b_ = PX[d * M + i] - P1[i] * Y0[d * M + i];
+                if (p->include_lle) b_ -= sigma2 * p->lle_weight * HY0[d * M + i];
+                if (K != 0) b_ += p->alpha * (Yext[d * M + i] - Y0[d * M + i]);
+                B[d * M + i] = b_;
+            }
+        ref_solve_qrcp(A, M, B, 3, W);          /* :415 */
+
+        /* ---- update (:417-422) */
+        for (int i = 0; i < M; i++)
+            for (int d = 0; d < 3; d++) {
+                double s = 0;
+                for (int k = 0; k < M; k++) s += G[(size_t)k * M + i] * W[d * M + k];
+                T[d * M + i] = Y0[d * M + i] + s;
+            }
+        double trPXtT = 0, trTtdP1T = 0;
+        for (int i = 0; i < M; i++)
+            for (int d = 0; d < 3; d++) {
+                trPXtT += PX[d * M + i] * T[d * M + i];
+                trTtdP1T += T[d * M + i] * P1[i] * T[d * M + i];
+            }
+        sigma2 = (trXtdPt1X - 2 * trPXtT + trTtdP1T) / (Np * D);
+
+        double crit = 0;
+        if (p->conv_rule == 0) {
+            for (int i = 0; i < M; i++) {
+                double s = 0;
+                for (int d = 0; d < 3; d++) { double t = Y[d * M + i] - T[d * M + i]; s += t * t; }
+                crit += sqrt(s);
+            }
+            crit /= M;                                   /* :424 */
+        } else {
+            for (int i = 0; i < 3 * M; i++) { double t = Y[i] - T[i]; crit += t * t; }
+        }
+        memcpy(Y, T, sizeof(double) * 3 * M);
+        it_done = it + 1;
+        if (trace) {
+            if (trace->P1) memcpy(trace->P1 + (size_t)it * M, P1, sizeof(double) * M);
+            if (trace->PX) memcpy(trace->PX + (size_t)it * 3 * M, PX, sizeof(double) * 3 * M);
+            if (trace->Np) trace->Np[it] = Np;
+            if (trace->sigma2) trace->sigma2[it] = sigma2;
+            if (trace->Y) memcpy(trace->Y + (size_t)it * 3 * M, Y, sizeof(double) * 3 * M);
+        }
+        if (crit < p->tol) break;
+        if (it == p->max_iter - 1) { converged = 0; break; }   /* :433-437 */
+    }
+    double t1 = now_s();
+
+    *sigma2_io = sigma2;
+    if (stats) {
+        stats->iters = it_done; stats->converged = converged; stats->n_kept = N;
+        stats->gap_quirk = gap_quirk; stats->loop_seconds = t1 - t0;
+    }
+    free(X); free(Y0); free(coord); free(G); free(H); free(HG); free(HY0); free(Jd); free(Yext);
+    free(Pm); free(P1); free(PX); free(dmin); free(A); free(B); free(W); free(T); free(col); free(geo); free(pvis);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- utils.cpp:172-241 */
+
+static double dist3(const double *a, const double *b) {
+    double s = 0;
+    for (int i = 0; i < 3; i++) s += (a[i] - b[i]) * (a[i] - b[i]);
+    return sqrt(s);
+}
+
+static int is_between(const double *x, const double *a, const double *b) {
+    int in_bound = 1;
+    for (int i = 0; i < 3; i++) {
+        if (!(a[i] - 0.0001 <= x[i] && x[i] <= b[i] + 0.0001) &&
+            !(b[i] - 0.0001 <= x[i] && x[i] <= a[i] + 0.0001)) in_bound = 0;
+    }
+    return in_bound;
+}
+
+int ref_line_sphere_intersection(const double A[3], const double B[3], const double C[3],
+                                 double radius, double out[6]) {
+    int n = 0;
+    double a = 0, b = 0, c = 0;
+    for (int i = 0; i < 3; i++) a += (A[i] - B[i]) * (A[i] - B[i]);
+    b = 2 * ((B[0] - A[0]) * (A[0] - C[0]) + (B[1] - A[1]) * (A[1] - C[1]) + (B[2] - A[2]) * (A[2] - C[2]));
+    for (int i = 0; i < 3; i++) c += (A[i] - C[i]) * (A[i] - C[i]);
+    c -= radius * radius;
+    double delta = b * b - 4 * a * c;
+    if (delta < 0) return 0;
+    if (delta > 0) {
+        double d1 = (-b + sqrt(delta)) / (2 * a);
+        double d2 = (-b - sqrt(delta)) / (2 * a);
+        double p1[3], p2[3];
+        for (int i = 0; i < 3; i++) { p1[i] = A[i] + d1 * (B[i] - A[i]); p2[i] = A[i] + d2 * (B[i] - A[i]); }
+        if (is_between(p1, A, B)) { memcpy(out + 3 * n, p1, sizeof p1); n++; }
+        if (is_between(p2, A, B)) { memcpy(out + 3 * n, p2, sizeof p2); n++; }
+    } else {
+        double d1 = -b / (2 * a);
+        double p1[3];
+        for (int i = 0; i < 3; i++) p1[i] = A[i] + d1 * (B[i] - A[i]);
+        if (is_between(p1, A, B)) { memcpy(out + 3 * n, p1, sizeof p1); n++; }
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------------- traverse_euclidean (:584-898) */
+
+static void grow(const double *g, int Mg, int i, double *o) { o[0] = g[i]; o[1] = g[Mg + i]; o[2] = g[2 * Mg + i]; }
+
+/* one pursuit step: scans segments, returns 1 and updates (last_found, center) when an intersection is accepted.
+ * dir = +1 scans i..i_end with neighbour i+1 ; dir = -1 scans downwards with neighbour i-1. */
+static int pursue(const double *guide, int Mg, int dir, int i_begin, long long i_limit,
+                  double look, double *center, int *last_found, double *hit) {
+    for (int i = i_begin; dir > 0 ? ((long long)i + 1 <= i_limit) : ((long long)i >= i_limit); i += dir) {
+        int nb = i + dir;
+        if (i < 0 || i >= Mg || nb < 0 || nb >= Mg) return -1;
+        double a[3], b[3], out[6];
+        grow(guide, Mg, i, a); grow(guide, Mg, nb, b);
+        int n = ref_line_sphere_intersection(a, b, center, look, out);
+        if (n == 0) continue;
+        if (n == 1 && dist3(out, b) > dist3(center, b)) continue;
+        *last_found = i;
+        if (n == 2) {
+            if (dist3(out, b) <= dist3(out + 3, b)) memcpy(hit, out, 3 * sizeof(double));
+            else memcpy(hit, out + 3, 3 * sizeof(double));
+        } else memcpy(hit, out, 3 * sizeof(double));
+        memcpy(center, hit, 3 * sizeof(double));
+        return 1;
+    }
+    return 0;
+}
+
+int ref_traverse_euclidean(const double *coord, int n_coord, const double *guide, int Mg,
+                           const int *vis, int n_vis, int alignment, int alignment_node_idx,
+                           double *out) {
+    int np = 0;
+    double center[3], hit[3];
+#define PUSH(idx, q) do { out[4 * np] = (double)(idx); out[4 * np + 1] = (q)[0]; out[4 * np + 2] = (q)[1]; out[4 * np + 3] = (q)[2]; np++; } while (0)
+    if (n_vis <= 0 || Mg <= 0) return -1;
+    if (Mg == 1) {                                   /* :590-595 */
+        grow(guide, Mg, 0, center); PUSH(vis[0], center); return np;
+    }
+    if (alignment == 0) {                            /* :597-671 */
+        grow(guide, Mg, 0, center); PUSH(vis[0], center);
+        int ncons = 0;
+        for (int i = 0; i < n_vis; i++) { if (i == vis[i]) ncons++; else break; }
+        if (ncons == 0) return -2;                   /* size()-1 wraps in the reference -> out-of-bounds */
+        int last_found = 0, seg = 0;
+        while (last_found + 1 <= ncons - 1 && seg + 1 <= n_coord - 1) {
+            double look = fabs(coord[seg + 1] - coord[seg]);
+            int r = pursue(guide, Mg, +1, last_found, (long long)ncons - 1, look, center, &last_found, hit);
+            if (r < 0) return -3;
+            if (r == 0) break;
+            PUSH(seg + 1, hit); seg++;
+        }
+    } else if (alignment == 1) {                     /* :672-748 */
+        grow(guide, Mg, Mg - 1, center); PUSH(vis[n_vis - 1], center);
+        int ncons = 0;
+        for (int i = 1; i <= n_vis; i++) { if (vis[n_vis - i] == n_coord - i) ncons++; else break; }
+        int last_found = Mg - 1, seg = n_coord - 1;
+        /* unsigned comparison in the reference: (size_t)(last_found-1) >= Mg - ncons */
+        while ((unsigned long long)(long long)(last_found - 1) >= (unsigned long long)((long long)Mg - ncons) && seg - 1 >= 0) {
+            double look = fabs(coord[seg] - coord[seg - 1]);
+            int r = pursue(guide, Mg, -1, last_found, (long long)Mg - ncons + 1, look, center, &last_found, hit);
+            if (r < 0) return -3;
+            if (r == 0) break;
+            PUSH(seg - 1, hit); seg--;
+        }
+    } else {                                         /* :749-895 */
+        int ai = alignment_node_idx;
+        if (ai < 0 || ai >= n_vis || ai >= Mg) return -2;
+        grow(guide, Mg, ai, center); PUSH(vis[ai], center);
+        int ncons2 = 1;
+        for (int i = ai + 1; i < n_vis; i++) { if (vis[i] - vis[i - 1] == 1) ncons2++; else break; }
+        int last_found = ai, seg = vis[ai];
+        while (last_found + 1 <= ai + ncons2 - 1 && seg + 1 <= n_coord - 1) {
+            double look = fabs(coord[seg + 1] - coord[seg]);
+            int r = pursue(guide, Mg, +1, last_found, (long long)ai + ncons2 - 1, look, center, &last_found, hit);
+            if (r < 0) return -3;
+            if (r == 0) break;
+            PUSH(seg + 1, hit); seg++;
+        }
+        /* head-ward: the reference's loop increments i (:828); reading past the end of
+         * visible_nodes is undefined there -- treated here as "not consecutive". */
+        int ncons1 = 1;
+        for (int i = ai - 1; i >= 0; i++) {
+            if (i + 1 >= n_vis) break;
+            if (vis[i + 1] - vis[i] == 1) ncons1++; else break;
+        }
+        last_found = ai; seg = vis[ai];
+        grow(guide, Mg, ai, center);
+        while ((unsigned long long)(long long)(last_found - 1) >= (unsigned long long)(long long)ai - (unsigned long long)ncons1 && seg - 1 >= 0) {
+            double look = fabs(coord[seg] - coord[seg - 1]);
+            int r = pursue(guide, Mg, -1, last_found, 1, look, center, &last_found, hit);
+            if (r < 0) return -3;
+            if (r == 0) break;
+            PUSH(seg - 1, hit); seg--;
+        }
+    }
+#undef PUSH
+    return np;
+}
+
+/* ---------------------------------------------------------------- class state + tracking_step */
+
+ref_tracker *ref_tracker_create(int M, double visibility_threshold, double beta, double lambda,
+                                double alpha, double k_vis, double mu, int max_iter, double tol,
+                                double beta_pre_proc, double lambda_pre_proc, double lle_weight) {
+    ref_tracker *t = (ref_tracker *)calloc(1, sizeof(ref_tracker));
+    t->M = M;
+    t->Y = (double *)calloc(3 * (size_t)M, sizeof(double));
+    t->guide_nodes = (double *)calloc(3 * (size_t)M, sizeof(double));
+    t->Mg = M;
+    t->sigma2 = 0.0;
+    t->visibility_threshold = visibility_threshold;
+    t->beta = beta; t->beta_pre_proc = beta_pre_proc; t->lambda = lambda; t->lambda_pre_proc = lambda_pre_proc;
+    t->alpha = alpha; t->lle_weight = lle_weight; t->k_vis = k_vis; t->mu = mu; t->max_iter = max_iter; t->tol = tol;
+    t->geodesic_coord = NULL; t->n_coord = 0;
+    t->priors = (double *)calloc(4 * (size_t)(2 * M + 2), sizeof(double)); t->K = 0;
+    return t;
+}
+
+void ref_tracker_destroy(ref_tracker *t) {
+    if (!t) return;
+    free(t->Y); free(t->guide_nodes); free(t->geodesic_coord); free(t->priors); free(t);
+}
+
+void ref_tracker_initialize_nodes(ref_tracker *t, const double *Y_init) {
+    memcpy(t->Y, Y_init, sizeof(double) * 3 * t->M);
+    memcpy(t->guide_nodes, Y_init, sizeof(double) * 3 * t->M);
+    t->Mg = t->M;
+}
+
+void ref_tracker_initialize_geodesic_coord(ref_tracker *t, const double *coord, int n) {
+    /* trackdlo.cpp:77-81 appends */
+    t->geodesic_coord = (double *)realloc(t->geodesic_coord, sizeof(double) * (size_t)(t->n_coord + n));
+    memcpy(t->geodesic_coord + t->n_coord, coord, sizeof(double) * (size_t)n);
+    t->n_coord += n;
+}
+
+int ref_tracking_step(ref_tracker *t, const double *X, int N, const int *vis, int n_vis,
+                      const int *vis_ext, int n_vis_ext, const double *H_pre,
+                      ref_stats *stats_pre, ref_stats *stats_main) {
+    int M = t->M;
+    if (n_vis_ext <= 0 || n_vis_ext > M) return -1;
+    t->K = 0;
+    /* guide nodes = visible sub-chain (:913-921) */
+    int Mg = n_vis_ext;
+    t->Mg = Mg;
+    if (Mg != M) {
+        for (int i = 0; i < Mg; i++) for (int d = 0; d < 3; d++) t->guide_nodes[d * Mg + i] = t->Y[d * M + vis_ext[i]];
+    } else {
+        memcpy(t->guide_nodes, t->Y, sizeof(double) * 3 * M);
+    }
+    /* pre-processing registration (:925-927) */
+    double sigma2_pre = t->sigma2;
+    ref_params pp; memset(&pp, 0, sizeof pp);
+    pp.beta = t->beta_pre_proc; pp.lambda = t->lambda_pre_proc; pp.lle_weight = t->lle_weight; pp.mu = t->mu;
+    pp.max_iter = t->max_iter; pp.tol = t->tol; pp.include_lle = 1;
+    pp.alpha = 0; pp.k_vis = 0; pp.visibility_threshold = 0.01;
+    int rc = ref_cpd_lle(X, N, t->guide_nodes, Mg, &sigma2_pre, &pp, NULL, 0, NULL, 0, H_pre, stats_pre, NULL);
+    if (rc) return rc;
+
+    double *pv1 = (double *)malloc(sizeof(double) * 4 * (size_t)(M + 2));
+    double *pv2 = (double *)malloc(sizeof(double) * 4 * (size_t)(M + 2));
+    int n1, n2, ret = 0;
+    if (Mg == M) {                                   /* :929-957 */
+        n1 = ref_traverse_euclidean(t->geodesic_coord, t->n_coord, t->guide_nodes, Mg, vis_ext, n_vis_ext, 0, -1, pv1);
+        n2 = ref_traverse_euclidean(t->geodesic_coord, t->n_coord, t->guide_nodes, Mg, vis_ext, n_vis_ext, 1, -1, pv2);
+        if (n1 <= 0 || n2 <= 0) { ret = -4; goto done; }
+        for (int i = 0; i < n2 / 2; i++)             /* std::reverse */
+            for (int c = 0; c < 4; c++) { double tmp = pv2[4 * i + c]; pv2[4 * i + c] = pv2[4 * (n2 - 1 - i) + c]; pv2[4 * (n2 - 1 - i) + c] = tmp; }
+        for (int i = 0; i < M; i++) {
+            unsigned long long j2 = (unsigned long long)i - ((unsigned long long)M - (unsigned long long)n2);
+            if ((double)i < pv2[0] && i < n1) {
+                memcpy(t->priors + 4 * t->K, pv1 + 4 * i, 4 * sizeof(double)); t->K++;
+            } else if ((double)i > pv1[4 * (n1 - 1)] && j2 < (unsigned long long)n2) {
+                memcpy(t->priors + 4 * t->K, pv2 + 4 * j2, 4 * sizeof(double)); t->K++;
+            } else {
+                if (i >= n1 || j2 >= (unsigned long long)n2) { ret = -5; goto done; }   /* reference: out-of-bounds */
+                for (int c = 0; c < 4; c++) t->priors[4 * t->K + c] = (pv1[4 * i + c] + pv2[4 * j2 + c]) / 2.0;
+                t->K++;
+            }
+        }
+    } else if (vis_ext[0] == 0 && vis_ext[n_vis_ext - 1] == M - 1) {       /* :958-967 */
+        n1 = ref_traverse_euclidean(t->geodesic_coord, t->n_coord, t->guide_nodes, Mg, vis_ext, n_vis_ext, 0, -1, pv1);
+        n2 = ref_traverse_euclidean(t->geodesic_coord, t->n_coord, t->guide_nodes, Mg, vis_ext, n_vis_ext, 1, -1, pv2);
+        if (n1 < 0 || n2 < 0) { ret = -4; goto done; }
+        memcpy(t->priors, pv1, sizeof(double) * 4 * (size_t)n1);
+        memcpy(t->priors + 4 * n1, pv2, sizeof(double) * 4 * (size_t)n2);
+        t->K = n1 + n2;
+    } else if (vis_ext[0] == 0) {                                          /* :968-973 */
+        n1 = ref_traverse_euclidean(t->geodesic_coord, t->n_coord, t->guide_nodes, Mg, vis_ext, n_vis_ext, 0, -1, pv1);
+        if (n1 < 0) { ret = -4; goto done; }
+        memcpy(t->priors, pv1, sizeof(double) * 4 * (size_t)n1); t->K = n1;
+    } else if (vis_ext[n_vis_ext - 1] == M - 1) {                          /* :974-979 */
+        n1 = ref_traverse_euclidean(t->geodesic_coord, t->n_coord, t->guide_nodes, Mg, vis_ext, n_vis_ext, 1, -1, pv1);
+        if (n1 < 0) { ret = -4; goto done; }
+        memcpy(t->priors, pv1, sizeof(double) * 4 * (size_t)n1); t->K = n1;
+    } else {                                                               /* :980-995 */
+        int ai = -1; double moved = 999999;
+        for (int i = 0; i < n_vis; i++) {
+            if (i >= Mg) break;      /* reference indexes guide_nodes_.row(i) with i over visible_nodes */
+            double a[3], b[3];
+            for (int d = 0; d < 3; d++) { a[d] = t->Y[d * M + vis[i]]; b[d] = t->guide_nodes[d * Mg + i]; }
+            double dd = dist3(a, b);
+            if (dd < moved) { moved = dd; ai = i; }
+        }
+        n1 = ref_traverse_euclidean(t->geodesic_coord, t->n_coord, t->guide_nodes, Mg, vis_ext, n_vis_ext, 2, ai, pv1);
+        if (n1 < 0) { ret = -4; goto done; }
+        memcpy(t->priors, pv1, sizeof(double) * 4 * (size_t)n1); t->K = n1;
+    }
+    {   /* main registration (:998) */
+        ref_params mp; memset(&mp, 0, sizeof mp);
+        mp.beta = t->beta; mp.lambda = t->lambda; mp.lle_weight = t->lle_weight; mp.mu = t->mu;
+        mp.max_iter = t->max_iter; mp.tol = t->tol; mp.include_lle = 0;
+        mp.alpha = t->alpha; mp.k_vis = t->k_vis; mp.visibility_threshold = t->visibility_threshold;
+        ret = ref_cpd_lle(X, N, t->Y, M, &t->sigma2, &mp, t->priors, t->K, vis_ext, n_vis_ext, NULL, stats_main, NULL);
+    }
+done:
+    free(pv1); free(pv2);
+    return ret;
+}

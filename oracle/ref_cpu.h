@@ -1,0 +1,135 @@
+/*
+ * oracle/ref_cpu.h -- CPU restatement of TrackDLO's EM registration path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under trackdlo_amd/ may include, link or
+ * call this.  Allowed users: tests/, __graft_entry__.smoke(), and the
+ * `cpu_baseline` leg of bench.py.
+ *
+ * PARITY PIN STATUS: PARTIAL.  The reference repository has no tests, golden
+ * vectors or fixtures for this path and its C++/Eigen build cannot be produced
+ * in this image (no Eigen/ROS/OpenCV/PCL).  The pieces of this restatement
+ * whose maths overlaps the reference's importable numpy prototype
+ * (utils/tracking_test.py: Euclidean E-step, reductions, M-step, sigma2 update,
+ * LLE weights) are pinned against outputs of that prototype
+ * (tests/golden/proto_*.npz, made by tests/golden/make_golden.py).  The
+ * C++-only pieces (Matern-type kernel, prune, geodesic substitution rule,
+ * visibility weighting, priors/J, traverse_euclidean) are "parity unpinned":
+ * they follow trackdlo/src/trackdlo.cpp line by line but could not be checked
+ * against an executable reference.
+ *
+ * All matrices are column-major (Eigen default): X is N x 3 with leading
+ * dimension N, Y is M x 3 with leading dimension M.
+ */
+#ifndef TDLO_ORACLE_REF_CPU_H
+#define TDLO_ORACLE_REF_CPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    /* arguments of trackdlo::cpd_lle (trackdlo/include/trackdlo.h:80-94) */
+    double beta;
+    double lambda;
+    double lle_weight;
+    double mu;
+    int max_iter;
+    double tol;
+    int include_lle;
+    double alpha;
+    double k_vis;
+    double visibility_threshold;
+    /* ---- prototype-mode switches; all zero = faithful C++ restatement ---- */
+    int kernel;      /* 0: C++ kernel on chain coordinate (trackdlo.cpp:233)
+                        1: Gaussian on Euclidean node distance (tracking_test.py:290)
+                        2: Gaussian on chain coordinate (tracking_test.py:305) */
+    int e_mode;      /* 0: C++ geodesic substitution (trackdlo.cpp:304-351)
+                        1: Euclidean membership only (tracking_test.py use_geodesic=False)
+                        2: prototype's geodesic variant (tracking_test.py:346-380) */
+    int no_prune;    /* 1: skip trackdlo.cpp:177-195 (prototype has no prune) */
+    int conv_rule;   /* 0: sum_m |dY_m| / M < tol (trackdlo.cpp:424)
+                        1: sum |dY|^2 < tol (tracking_test.py:411) */
+    int den_guard;   /* 1: colsum==0 -> eps (tracking_test.py:338) */
+    int lle_extended;/* 1: prototype's extended end neighbourhoods (tracking_test.py:233-247) */
+} ref_params;
+
+typedef struct {
+    int iters;        /* EM iterations executed */
+    int converged;    /* return value of cpd_lle */
+    int n_kept;       /* N after the prune */
+    int gap_quirk;    /* number of (point, iteration) pairs that hit the hi-lo==2 gap (trackdlo.cpp:313-350) */
+    double loop_seconds; /* wall time of the EM loop body only (trackdlo.cpp:275-438) */
+} ref_stats;
+
+/* Optional per-iteration dump; any pointer may be NULL. Sizes: max_iter * (..). */
+typedef struct {
+    double *P1;     /* [it][M]      */
+    double *PX;     /* [it][M*3] column-major M x 3 */
+    double *Np;     /* [it]         */
+    double *sigma2; /* [it] value AFTER the update of that iteration */
+    double *Y;      /* [it][M*3] column-major */
+} ref_trace;
+
+/* trackdlo::cpd_lle, trackdlo/src/trackdlo.cpp:161-441.
+ * priors: K rows of [idx, x, y, z] (row-major K x 4), may be NULL when K == 0.
+ * visible_nodes: n_vis ints, may be NULL.
+ * H_override: optional M x M column-major matrix used instead of the LLE-derived H.
+ * Returns 0 on success, <0 on invalid sizes (M < 4, N0 <= 0). */
+int ref_cpd_lle(const double *X_orig, int N0, double *Y, int M, double *sigma2,
+                const ref_params *p, const double *priors, int K,
+                const int *visible_nodes, int n_vis, const double *H_override,
+                ref_stats *stats, ref_trace *trace);
+
+/* trackdlo::calc_LLE_weights, trackdlo.cpp:119-159 (k = 6 in cpd_lle, :236).
+ * Y: M x 3 column-major; L: M x M column-major out. */
+void ref_calc_lle_weights(int k, const double *Y, int M, int extended, double *L);
+
+/* kernel of trackdlo.cpp:214-233: coord[M] and G (M x M column-major). */
+void ref_kernel_G(const double *Y0, int M, double beta, int kernel, double *coord, double *G);
+
+/* line_sphere_intersection, trackdlo/src/utils.cpp:185-241. out: up to 2 points (6 doubles). Returns count. */
+int ref_line_sphere_intersection(const double A[3], const double B[3], const double C[3],
+                                 double radius, double out[6]);
+
+/* trackdlo::traverse_euclidean, trackdlo.cpp:584-898.
+ * guide: Mg x 3 column-major.  out: up to (n_coord + 1) rows of [idx,x,y,z] row-major.
+ * Returns number of pairs, or <0 when the reference would read out of bounds. */
+int ref_traverse_euclidean(const double *coord, int n_coord, const double *guide, int Mg,
+                           const int *vis, int n_vis, int alignment, int alignment_node_idx,
+                           double *out);
+
+/* Tracker state of class trackdlo (trackdlo/include/trackdlo.h:104-121). */
+typedef struct {
+    int M;
+    double *Y;              /* M x 3 column-major */
+    double *guide_nodes;    /* Mg x 3 column-major (Mg = n of visible_nodes_extended of last step) */
+    int Mg;
+    double sigma2;
+    double beta, beta_pre_proc, lambda, lambda_pre_proc, alpha, k_vis, mu, tol, lle_weight;
+    double visibility_threshold;
+    int max_iter;
+    double *geodesic_coord; int n_coord;
+    double *priors; int K;  /* K x 4 row-major */
+} ref_tracker;
+
+ref_tracker *ref_tracker_create(int M, double visibility_threshold, double beta, double lambda,
+                                double alpha, double k_vis, double mu, int max_iter, double tol,
+                                double beta_pre_proc, double lambda_pre_proc, double lle_weight);
+void ref_tracker_destroy(ref_tracker *t);
+void ref_tracker_initialize_nodes(ref_tracker *t, const double *Y_init /* M x 3 col-major */);
+void ref_tracker_initialize_geodesic_coord(ref_tracker *t, const double *coord, int n);
+/* trackdlo::tracking_step, trackdlo.cpp:900-999. H_pre: optional Mg x Mg override for the
+ * pre-processing registration's LLE matrix (LLE weights are ill-conditioned). */
+int ref_tracking_step(ref_tracker *t, const double *X, int N, const int *vis, int n_vis,
+                      const int *vis_ext, int n_vis_ext, const double *H_pre,
+                      ref_stats *stats_pre, ref_stats *stats_main);
+
+/* dense helper exposed for tests: solve A x = B (A n x n col-major, B n x nrhs col-major)
+ * by Householder QR with column pivoting (what completeOrthogonalDecomposition reduces to for
+ * full-rank A, trackdlo.cpp:415). A and B are overwritten; solution returned in X (n x nrhs). */
+int ref_solve_qrcp(double *A, int n, double *B, int nrhs, double *X);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
