@@ -1,0 +1,203 @@
+/*
+ * trackdlo_hip.h -- C ABI of the MI355X (gfx950) implementation of TrackDLO's per-frame EM
+ * registration path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/Eigen/torch types.  Every entry
+ * point names the reference interface it replaces (paths relative to the RMDLO/trackdlo tree).
+ * All matrices are COLUMN-MAJOR doubles, the in-memory layout of Eigen::MatrixXd, so
+ * `X.data()` / `Y.data()` of the reference's arguments can be passed straight through:
+ *   X : N x 3, leading dimension N   (x[0..N) y[0..N) z[0..N))
+ *   Y : M x 3, leading dimension M
+ *
+ * Error convention: functions return 0 on success or a negative TDLO_E_* code and never throw;
+ * tdlo_last_error() returns a human-readable message for the last failure on that context.
+ * (The reference path has no error channel at all: cpd_lle only returns `converged`,
+ * trackdlo/src/trackdlo.cpp:433-440, which tracking_step discards, :927/:998.)
+ *
+ * Threading: a context is bound to one GPU and one HIP stream and is NOT thread-safe, matching the
+ * reference's single-threaded use (ros::spin(), trackdlo/src/trackdlo_node.cpp:643).
+ *
+ * There is no CPU fallback: every entry point fails with TDLO_E_NO_DEVICE when no gfx950 device
+ * is usable.
+ */
+#ifndef TRACKDLO_HIP_H
+#define TRACKDLO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDLO_ABI_VERSION 1
+
+enum {
+    TDLO_OK = 0,
+    TDLO_E_NO_DEVICE = -1,   /* no usable HIP device / kernel image */
+    TDLO_E_INVALID = -2,     /* bad argument (M < 4, N <= 0, bad slot, unsupported M, ...) */
+    TDLO_E_HIP = -3,         /* HIP runtime error, see tdlo_last_error */
+    TDLO_E_EMPTY = -4,       /* the prune (trackdlo.cpp:177-195) removed every point */
+    TDLO_E_NUMERIC = -5,     /* non-finite sigma2 / Y or singular system encountered */
+    TDLO_E_TRAVERSE = -6     /* traverse_euclidean would read out of bounds in the reference */
+};
+
+/* tdlo_params.precision */
+enum {
+    TDLO_PREC_F32 = 0,       /* fp32 E-step (distances, membership, sums per 64-point tile), fp64 M-step */
+    TDLO_PREC_F64 = 1        /* fp64 everywhere */
+};
+
+typedef struct tdlo_ctx tdlo_ctx;
+
+typedef struct {
+    int device;              /* HIP device ordinal */
+    int max_frames;          /* number of frame slots (>= 1); slots are independent clouds/trackers */
+    int max_points;          /* initial per-slot capacity in points (grown on demand) */
+    int max_nodes;           /* initial capacity in nodes (grown on demand) */
+    int use_graph;           /* 1: replay the EM loop from a captured hipGraph (default 1) */
+    int estep_blocks;        /* 0 = auto; otherwise workgroups per frame for the E-step */
+} tdlo_config;
+
+/* Arguments of trackdlo::cpd_lle after (X_orig, Y, sigma2): trackdlo/include/trackdlo.h:80-94. */
+typedef struct {
+    double beta;
+    double lambda;
+    double lle_weight;
+    double mu;
+    int max_iter;                 /* reference default 30 */
+    double tol;                   /* reference default 1e-4 */
+    int include_lle;              /* reference default true */
+    double alpha;                 /* reference default 0 */
+    double k_vis;                 /* reference default 0 */
+    double visibility_threshold;  /* reference default 0.01 */
+    int precision;                /* TDLO_PREC_*; not in the reference (which is fp64 on the CPU) */
+} tdlo_params;
+
+typedef struct {
+    int iters;            /* EM iterations executed (the reference only logs this, trackdlo.cpp:426) */
+    int converged;        /* return value of trackdlo::cpd_lle */
+    int n_kept;           /* N after the prune, trackdlo.cpp:195 */
+    int status;           /* 0, or TDLO_E_NUMERIC / TDLO_E_EMPTY */
+    double sigma2;        /* final sigma2 (also written through the in/out pointer) */
+    float loop_ms;        /* HIP-event time of the EM loop body on the context's stream (trackdlo.cpp:275-438) */
+    float total_ms;       /* HIP-event time of the whole device-side call (prune + setup + loop + readback) */
+    double host_ms;       /* host wall time of the call including uploads and the final synchronise */
+} tdlo_stats;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int tdlo_abi_version(void);
+int tdlo_device_count(void);
+void tdlo_default_config(tdlo_config *cfg);
+/* Creates a context on cfg->device.  Replaces nothing in the reference (it has no device state);
+ * it owns what `class trackdlo`'s members own (trackdlo/include/trackdlo.h:104-121) plus device buffers. */
+tdlo_ctx *tdlo_create(const tdlo_config *cfg, int *err);
+void tdlo_destroy(tdlo_ctx *ctx);
+const char *tdlo_last_error(const tdlo_ctx *ctx);
+/* raw hipStream_t of the context (for callers that time or order work on it) */
+void *tdlo_stream(tdlo_ctx *ctx);
+int tdlo_synchronize(tdlo_ctx *ctx);
+
+/* ---- EM registration ----------------------------------------------------------------------- */
+/* Uploads a point cloud into frame slot `slot` (H2D copy, stays resident in HBM).
+ * Replaces the by-value `MatrixXd X_orig` argument of cpd_lle / tracking_step (trackdlo.h:80, :96). */
+int tdlo_set_cloud(tdlo_ctx *ctx, int slot, const double *X, int N);
+
+/* trackdlo::cpd_lle (trackdlo/src/trackdlo.cpp:161-441) on the cloud resident in `slot`.
+ *   Y        in/out  M x 3 column-major           (MatrixXd& Y)
+ *   sigma2   in/out                                (double& sigma2; 0 => initialised as at :271-273)
+ *   priors   K x 4 row-major [idx, x, y, z]        (std::vector<MatrixXd> correspondence_priors)
+ *   visible_nodes, n_vis                           (std::vector<int> visible_nodes)
+ *   H_override optional M x M column-major matrix used in place of the LLE regulariser
+ *              H = (I-L)^T (I-L) of :236-237 (whose weights are numerically ill-defined).
+ * Returns 0 or an error; stats->converged carries the reference's bool result. */
+int tdlo_cpd_lle_resident(tdlo_ctx *ctx, int slot, double *Y, int M, double *sigma2,
+                          const tdlo_params *params, const double *priors, int K,
+                          const int *visible_nodes, int n_vis, const double *H_override,
+                          tdlo_stats *stats);
+
+/* Same, taking the cloud from host memory like the reference signature does:
+ * tdlo_set_cloud(slot 0) followed by tdlo_cpd_lle_resident. */
+int tdlo_cpd_lle(tdlo_ctx *ctx, const double *X, int N, double *Y, int M, double *sigma2,
+                 const tdlo_params *params, const double *priors, int K,
+                 const int *visible_nodes, int n_vis, const double *H_override,
+                 tdlo_stats *stats);
+
+/* Batched form: F independent registrations (slots 0..F-1, clouds already resident), executed
+ * concurrently on the GPU.  Arrays are indexed by frame; Y is F consecutive M x 3 blocks; priors/
+ * visible_nodes are shared by all frames (pass K = 0 / n_vis = 0 for none).  No reference
+ * counterpart: the reference processes one frame per call (BASELINE.json configs[2]). */
+int tdlo_cpd_lle_batch(tdlo_ctx *ctx, int F, double *Y, int M, double *sigma2,
+                       const tdlo_params *params, const double *priors, int K,
+                       const int *visible_nodes, int n_vis, const double *H_override,
+                       tdlo_stats *stats /* F entries */);
+
+/* ---- N-split building blocks (BASELINE.json configs[3]) --------------------------------------- */
+/* When one frame's cloud is split over several GPUs, each rank holds a shard in slot 0 and the
+ * host interleaves these calls with an all-reduce (SUM) of the packed buffer
+ *   sums[0..M) = P1, sums[M..4M) = PX (column-major M x 3, centred), sums[4M] = Q, sums[4M+1] = N_kept
+ * and, when visibility weighting is active, an all-reduce (MIN) of dmin[M].
+ * They expose the halves of one iteration of trackdlo.cpp:275-438. */
+int tdlo_split_begin(tdlo_ctx *ctx, const double *Y, int M, double sigma2, const tdlo_params *params,
+                     const double *priors, int K, const int *visible_nodes, int n_vis,
+                     const double *H_override, double *init /* out: [n_kept_local, sum_d2_local] */);
+int tdlo_split_set_global(tdlo_ctx *ctx, double n_kept_global, double sum_d2_global);
+int tdlo_split_dmin(tdlo_ctx *ctx, double *dmin_sq /* out M, local */);
+int tdlo_split_estep(tdlo_ctx *ctx, const double *dmin_sq_global /* in M or NULL */, double *sums /* out 4M+2 */);
+int tdlo_split_mstep(tdlo_ctx *ctx, const double *sums_global /* in 4M+2 */, int *done /* out */);
+int tdlo_split_end(tdlo_ctx *ctx, double *Y, double *sigma2, tdlo_stats *stats);
+
+/* ---- tracker object: class trackdlo (trackdlo/include/trackdlo.h:53-130) ---------------------- */
+typedef struct tdlo_tracker tdlo_tracker;
+
+/* trackdlo::trackdlo(int num_of_nodes, double visibility_threshold, double beta, double lambda,
+ *   double alpha, double k_vis, double mu, int max_iter, double tol, double beta_pre_proc,
+ *   double lambda_pre_proc, double lle_weight)  -- trackdlo.cpp:30-59.  Uses slot `slot` of ctx. */
+tdlo_tracker *tdlo_tracker_create(tdlo_ctx *ctx, int slot, int num_of_nodes, double visibility_threshold,
+                                  double beta, double lambda, double alpha, double k_vis, double mu,
+                                  int max_iter, double tol, double beta_pre_proc,
+                                  double lambda_pre_proc, double lle_weight);
+/* trackdlo::trackdlo(int num_of_nodes) defaults -- trackdlo.cpp:10-28 */
+tdlo_tracker *tdlo_tracker_create_default(tdlo_ctx *ctx, int slot, int num_of_nodes);
+void tdlo_tracker_destroy(tdlo_tracker *t);
+int tdlo_tracker_set_precision(tdlo_tracker *t, int precision);
+/* trackdlo::initialize_nodes (trackdlo.cpp:83-86) */
+int tdlo_tracker_initialize_nodes(tdlo_tracker *t, const double *Y_init /* M x 3 */);
+/* trackdlo::initialize_geodesic_coord (trackdlo.cpp:77-81; appends, like the reference) */
+int tdlo_tracker_initialize_geodesic_coord(tdlo_tracker *t, const double *coord, int n);
+/* trackdlo::get_sigma2 / set_sigma2 (trackdlo.cpp:61-63, :88-90) */
+double tdlo_tracker_get_sigma2(const tdlo_tracker *t);
+void tdlo_tracker_set_sigma2(tdlo_tracker *t, double sigma2);
+/* trackdlo::get_tracking_result (trackdlo.cpp:65-67): copies M x 3 */
+int tdlo_tracker_get_tracking_result(const tdlo_tracker *t, double *Y_out);
+/* trackdlo::get_guide_nodes (trackdlo.cpp:69-71): returns row count, copies rows x 3 */
+int tdlo_tracker_get_guide_nodes(const tdlo_tracker *t, double *out, int max_rows);
+/* trackdlo::get_correspondence_pairs (trackdlo.cpp:73-75): returns K, copies K x 4 row-major */
+int tdlo_tracker_get_correspondence_pairs(const tdlo_tracker *t, double *out, int max_rows);
+/* trackdlo::tracking_step (trackdlo.cpp:900-999).  proj_matrix/img_rows/img_cols of the reference
+ * signature are unused by its body and therefore not part of the ABI.  H_pre: optional override of
+ * the pre-processing registration's LLE matrix (n_vis_ext x n_vis_ext).  stats may be NULL;
+ * otherwise stats[0] = pre-processing registration (:927), stats[1] = main registration (:998). */
+int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N,
+                               const int *visible_nodes, int n_vis,
+                               const int *visible_nodes_extended, int n_vis_ext,
+                               const double *H_pre, tdlo_stats *stats);
+
+/* ---- host helpers on the path (exported so the parity tests can address them directly) -------- */
+/* trackdlo::calc_LLE_weights (trackdlo.cpp:119-159), k as passed at :236 (6). L: M x M col-major out. */
+int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L);
+/* line_sphere_intersection (trackdlo/src/utils.cpp:185-241): returns number of points (0..2) */
+int tdlo_line_sphere_intersection(const double A[3], const double B[3], const double C[3],
+                                  double radius, double out[6]);
+/* trackdlo::traverse_euclidean (trackdlo.cpp:584-898): returns number of pairs or TDLO_E_TRAVERSE */
+int tdlo_traverse_euclidean(const double *geodesic_coord, int n_coord, const double *guide_nodes, int Mg,
+                            const int *visible_nodes, int n_vis, int alignment, int alignment_node_idx,
+                            double *out /* (n_coord + 2) x 4 row-major */);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Launches the E-step kernel `reps` times back to back on the context's stream for the state left
+ * by the last cpd_lle call on `slot` and returns the HIP-event average per launch (microseconds).
+ * kind: 0 = membership/E-step kernel, 1 = per-node min-distance kernel, 2 = M-step kernel. */
+int tdlo_profile_kernel(tdlo_ctx *ctx, int slot, int kind, int reps, float *avg_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

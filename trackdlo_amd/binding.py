@@ -1,0 +1,313 @@
+"""ctypes binding of libtrackdlo_hip.so (include/trackdlo_hip.h).
+
+This is plumbing only: every call goes straight to the C ABI.  There is NO CPU fallback -- if the
+shared library or a gfx950 device is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrackdlo_hip.so")
+
+TDLO_OK = 0
+TDLO_E_NO_DEVICE, TDLO_E_INVALID, TDLO_E_HIP, TDLO_E_EMPTY, TDLO_E_NUMERIC, TDLO_E_TRAVERSE = -1, -2, -3, -4, -5, -6
+PREC_F32, PREC_F64 = 0, 1
+
+
+class TdloError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"trackdlo_hip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("max_frames", C.c_int), ("max_points", C.c_int), ("max_nodes", C.c_int),
+                ("use_graph", C.c_int), ("estep_blocks", C.c_int)]
+
+
+class Params(C.Structure):
+    _fields_ = [("beta", C.c_double), ("lambda_", C.c_double), ("lle_weight", C.c_double), ("mu", C.c_double),
+                ("max_iter", C.c_int), ("tol", C.c_double), ("include_lle", C.c_int), ("alpha", C.c_double),
+                ("k_vis", C.c_double), ("visibility_threshold", C.c_double), ("precision", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iters", C.c_int), ("converged", C.c_int), ("n_kept", C.c_int), ("status", C.c_int),
+                ("sigma2", C.c_double), ("loop_ms", C.c_float), ("total_ms", C.c_float), ("host_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/trackdlo_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "tdlo_abi_version", "tdlo_device_count", "tdlo_default_config", "tdlo_create", "tdlo_destroy", "tdlo_last_error",
+    "tdlo_stream", "tdlo_synchronize", "tdlo_set_cloud", "tdlo_cpd_lle_resident", "tdlo_cpd_lle", "tdlo_cpd_lle_batch",
+    "tdlo_split_begin", "tdlo_split_set_global", "tdlo_split_dmin", "tdlo_split_estep", "tdlo_split_mstep", "tdlo_split_end",
+    "tdlo_tracker_create", "tdlo_tracker_create_default", "tdlo_tracker_destroy", "tdlo_tracker_set_precision",
+    "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_get_sigma2",
+    "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
+    "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel",
+]
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Loads libtrackdlo_hip.so.  Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not built: run `make -C trackdlo_amd/csrc` (needs hipcc); there is no CPU fallback")
+    lib = C.CDLL(p)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    lib.tdlo_abi_version.restype = ci
+    lib.tdlo_device_count.restype = ci
+    lib.tdlo_default_config.argtypes = [C.POINTER(Config)]
+    lib.tdlo_create.restype = vp
+    lib.tdlo_create.argtypes = [C.POINTER(Config), C.POINTER(ci)]
+    lib.tdlo_destroy.argtypes = [vp]
+    lib.tdlo_last_error.restype = C.c_char_p
+    lib.tdlo_last_error.argtypes = [vp]
+    lib.tdlo_stream.restype = vp
+    lib.tdlo_stream.argtypes = [vp]
+    lib.tdlo_synchronize.argtypes = [vp]
+    lib.tdlo_set_cloud.argtypes = [vp, ci, vp, ci]
+    lib.tdlo_cpd_lle_resident.argtypes = [vp, ci, vp, ci, C.POINTER(cd), C.POINTER(Params), vp, ci, vp, ci, vp, C.POINTER(Stats)]
+    lib.tdlo_cpd_lle.argtypes = [vp, vp, ci, vp, ci, C.POINTER(cd), C.POINTER(Params), vp, ci, vp, ci, vp, C.POINTER(Stats)]
+    lib.tdlo_cpd_lle_batch.argtypes = [vp, ci, vp, ci, vp, C.POINTER(Params), vp, ci, vp, ci, vp, vp]
+    lib.tdlo_split_begin.argtypes = [vp, vp, ci, cd, C.POINTER(Params), vp, ci, vp, ci, vp, vp]
+    lib.tdlo_split_set_global.argtypes = [vp, cd, cd]
+    lib.tdlo_split_dmin.argtypes = [vp, vp]
+    lib.tdlo_split_estep.argtypes = [vp, vp, vp]
+    lib.tdlo_split_mstep.argtypes = [vp, vp, C.POINTER(ci)]
+    lib.tdlo_split_end.argtypes = [vp, vp, C.POINTER(cd), C.POINTER(Stats)]
+    lib.tdlo_tracker_create.restype = vp
+    lib.tdlo_tracker_create.argtypes = [vp, ci, ci, cd, cd, cd, cd, cd, cd, ci, cd, cd, cd, cd]
+    lib.tdlo_tracker_create_default.restype = vp
+    lib.tdlo_tracker_create_default.argtypes = [vp, ci, ci]
+    lib.tdlo_tracker_destroy.argtypes = [vp]
+    lib.tdlo_tracker_set_precision.argtypes = [vp, ci]
+    lib.tdlo_tracker_initialize_nodes.argtypes = [vp, vp]
+    lib.tdlo_tracker_initialize_geodesic_coord.argtypes = [vp, vp, ci]
+    lib.tdlo_tracker_get_sigma2.restype = cd
+    lib.tdlo_tracker_get_sigma2.argtypes = [vp]
+    lib.tdlo_tracker_set_sigma2.argtypes = [vp, cd]
+    lib.tdlo_tracker_get_tracking_result.argtypes = [vp, vp]
+    lib.tdlo_tracker_get_guide_nodes.argtypes = [vp, vp, ci]
+    lib.tdlo_tracker_get_correspondence_pairs.argtypes = [vp, vp, ci]
+    lib.tdlo_tracker_tracking_step.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp]
+    lib.tdlo_calc_lle_weights.argtypes = [ci, vp, ci, vp]
+    lib.tdlo_line_sphere_intersection.argtypes = [vp, vp, vp, cd, vp]
+    lib.tdlo_traverse_euclidean.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
+    lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_params(beta, lambda_, lle_weight, mu, max_iter=30, tol=1e-4, include_lle=True, alpha=0.0, k_vis=0.0,
+                visibility_threshold=0.01, precision=PREC_F32) -> Params:
+    return Params(beta, lambda_, lle_weight, mu, int(max_iter), tol, int(bool(include_lle)), alpha, k_vis,
+                  visibility_threshold, int(precision))
+
+
+class Context:
+    """Owns one tdlo_ctx (one GPU, one HIP stream)."""
+
+    def __init__(self, device=0, max_frames=1, max_points=65536, max_nodes=64, estep_blocks=0, use_graph=1):
+        self.lib = load_library()
+        cfg = Config(device, max_frames, max_points, max_nodes, use_graph, estep_blocks)
+        err = C.c_int(0)
+        self.h = self.lib.tdlo_create(C.byref(cfg), C.byref(err))
+        if not self.h:
+            raise TdloError(err.value, "tdlo_create failed (no usable gfx950 device? there is no CPU fallback)")
+        self.max_frames = max_frames
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tdlo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise TdloError(rc, self.lib.tdlo_last_error(self.h).decode())
+
+    def synchronize(self):
+        self._chk(self.lib.tdlo_synchronize(self.h))
+
+    def set_cloud(self, slot, X):
+        X = _f64(X)
+        assert X.ndim == 2 and X.shape[1] == 3
+        self._chk(self.lib.tdlo_set_cloud(self.h, slot, _ptr(X), X.shape[0]))
+
+    @staticmethod
+    def _opt(priors, visible_nodes, H):
+        pri = None; K = 0
+        if priors is not None and len(priors):
+            pri = np.ascontiguousarray(np.asarray(priors, dtype=np.float64).reshape(-1, 4)); K = pri.shape[0]
+        vis = None; nv = 0
+        if visible_nodes is not None and len(visible_nodes):
+            vis = np.ascontiguousarray(np.asarray(visible_nodes, dtype=np.int32)); nv = len(vis)
+        Hm = _f64(H) if H is not None else None
+        return pri, K, vis, nv, Hm
+
+    def cpd_lle_resident(self, slot, Y, sigma2, params: Params, priors=None, visible_nodes=None, H=None, check=True):
+        Y = _f64(Y).copy(order="F")
+        M = Y.shape[0]
+        pri, K, vis, nv, Hm = self._opt(priors, visible_nodes, H)
+        s2 = C.c_double(float(sigma2)); st = Stats()
+        rc = self.lib.tdlo_cpd_lle_resident(self.h, slot, _ptr(Y), M, C.byref(s2), C.byref(params), _ptr(pri), K,
+                                            _ptr(vis), nv, _ptr(Hm), C.byref(st))
+        if check:
+            self._chk(rc)
+        return dict(Y=Y, sigma2=s2.value, converged=bool(st.converged), iters=st.iters, n_kept=st.n_kept, rc=rc,
+                    status=st.status, loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms)
+
+    def cpd_lle(self, X, Y, sigma2, params: Params, priors=None, visible_nodes=None, H=None, check=True):
+        """trackdlo::cpd_lle (trackdlo.cpp:161-441): returns dict(Y, sigma2, converged, ...)."""
+        self.set_cloud(0, X)
+        return self.cpd_lle_resident(0, Y, sigma2, params, priors, visible_nodes, H, check)
+
+    def cpd_lle_batch(self, Ys, sigma2s, params: Params, priors=None, visible_nodes=None, H=None):
+        Ys = [np.asarray(y, dtype=np.float64) for y in Ys]
+        F = len(Ys); M = Ys[0].shape[0]
+        Yb = np.empty((F, 3, M), dtype=np.float64)
+        for i, y in enumerate(Ys):
+            Yb[i] = y.T
+        s2 = np.ascontiguousarray(np.asarray(sigma2s, dtype=np.float64)).copy()
+        st = (Stats * F)()
+        pri, K, vis, nv, Hm = self._opt(priors, visible_nodes, H)
+        self._chk(self.lib.tdlo_cpd_lle_batch(self.h, F, _ptr(Yb), M, _ptr(s2), C.byref(params), _ptr(pri), K, _ptr(vis), nv,
+                                              _ptr(Hm), C.cast(st, C.c_void_p)))
+        return dict(Y=[Yb[i].T.copy() for i in range(F)], sigma2=s2, stats=[s.as_dict() for s in st])
+
+    def profile_kernel(self, kind, reps=200, slot=0):
+        us = C.c_float(0)
+        self._chk(self.lib.tdlo_profile_kernel(self.h, slot, kind, reps, C.byref(us)))
+        return us.value
+
+
+class trackdlo:
+    """Mirror of the reference's `class trackdlo` (trackdlo/include/trackdlo.h:53-130): same method names,
+    argument order and meaning.  Matrices are numpy arrays (M x 3, N x 3)."""
+
+    def __init__(self, num_of_nodes, visibility_threshold=None, beta=None, lambda_=None, alpha=None, k_vis=None, mu=None,
+                 max_iter=None, tol=None, beta_pre_proc=None, lambda_pre_proc=None, lle_weight=None, *, ctx: Context = None,
+                 slot=0, precision=PREC_F32):
+        self.ctx = ctx or Context()
+        lib = self.ctx.lib
+        self.M = int(num_of_nodes)
+        if visibility_threshold is None:
+            self.h = lib.tdlo_tracker_create_default(self.ctx.h, slot, self.M)
+        else:
+            self.h = lib.tdlo_tracker_create(self.ctx.h, slot, self.M, visibility_threshold, beta, lambda_, alpha, k_vis, mu,
+                                             int(max_iter), tol, beta_pre_proc, lambda_pre_proc, lle_weight)
+        if not self.h:
+            raise TdloError(TDLO_E_INVALID, "tdlo_tracker_create failed")
+        lib.tdlo_tracker_set_precision(self.h, precision)
+        self.last_stats = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.tdlo_tracker_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def get_sigma2(self):
+        return self.ctx.lib.tdlo_tracker_get_sigma2(self.h)
+
+    def set_sigma2(self, sigma2):
+        self.ctx.lib.tdlo_tracker_set_sigma2(self.h, float(sigma2))
+
+    def initialize_nodes(self, Y_init):
+        Y = _f64(Y_init)
+        assert Y.shape == (self.M, 3)
+        self.ctx._chk(self.ctx.lib.tdlo_tracker_initialize_nodes(self.h, _ptr(Y)))
+
+    def initialize_geodesic_coord(self, geodesic_coord):
+        c = np.ascontiguousarray(geodesic_coord, dtype=np.float64)
+        self.ctx._chk(self.ctx.lib.tdlo_tracker_initialize_geodesic_coord(self.h, _ptr(c), len(c)))
+
+    def get_tracking_result(self):
+        out = np.zeros((self.M, 3), order="F")
+        self.ctx.lib.tdlo_tracker_get_tracking_result(self.h, _ptr(out))
+        return out
+
+    def get_guide_nodes(self):
+        buf = np.zeros(3 * self.M)
+        n = self.ctx.lib.tdlo_tracker_get_guide_nodes(self.h, _ptr(buf), self.M)
+        return buf[:3 * n].reshape(3, n).T.copy()
+
+    def get_correspondence_pairs(self):
+        buf = np.zeros((2 * self.M + 2, 4))
+        n = self.ctx.lib.tdlo_tracker_get_correspondence_pairs(self.h, _ptr(buf), buf.shape[0])
+        return buf[:n].copy()
+
+    def tracking_step(self, X_orig, visible_nodes, visible_nodes_extended, proj_matrix=None, img_rows=0, img_cols=0, *,
+                      H_pre=None):
+        """trackdlo::tracking_step (trackdlo.cpp:900-999). proj_matrix/img_rows/img_cols are accepted and ignored, as in
+        the reference body."""
+        X = _f64(X_orig)
+        v = np.ascontiguousarray(visible_nodes, dtype=np.int32)
+        ve = np.ascontiguousarray(visible_nodes_extended, dtype=np.int32)
+        Hm = _f64(H_pre) if H_pre is not None else None
+        st = (Stats * 2)()
+        rc = self.ctx.lib.tdlo_tracker_tracking_step(self.h, _ptr(X), X.shape[0], _ptr(v), len(v), _ptr(ve), len(ve), _ptr(Hm),
+                                                     C.cast(st, C.c_void_p))
+        self.last_stats = [s.as_dict() for s in st]
+        self.ctx._chk(rc)
+
+
+def calc_LLE_weights(k, Y):
+    lib = load_library()
+    Y = _f64(Y); M = Y.shape[0]
+    L = np.zeros((M, M), order="F")
+    rc = lib.tdlo_calc_lle_weights(int(k), _ptr(Y), M, _ptr(L))
+    if rc:
+        raise TdloError(rc, "tdlo_calc_lle_weights")
+    return L
+
+
+def line_sphere_intersection(point_A, point_B, sphere_center, radius):
+    lib = load_library()
+    A = np.ascontiguousarray(point_A, dtype=np.float64).ravel(); B = np.ascontiguousarray(point_B, dtype=np.float64).ravel()
+    Cc = np.ascontiguousarray(sphere_center, dtype=np.float64).ravel()
+    out = np.zeros(6)
+    n = lib.tdlo_line_sphere_intersection(_ptr(A), _ptr(B), _ptr(Cc), float(radius), _ptr(out))
+    return out.reshape(2, 3)[:n].copy()
+
+
+def traverse_euclidean(geodesic_coord, guide_nodes, visible_nodes, alignment, alignment_node_idx=-1):
+    lib = load_library()
+    coord = np.ascontiguousarray(geodesic_coord, dtype=np.float64); guide = _f64(guide_nodes)
+    vis = np.ascontiguousarray(visible_nodes, dtype=np.int32)
+    out = np.zeros((len(coord) + 2, 4))
+    n = lib.tdlo_traverse_euclidean(_ptr(coord), len(coord), _ptr(guide), guide.shape[0], _ptr(vis), len(vis), int(alignment),
+                                    int(alignment_node_idx), _ptr(out))
+    if n < 0:
+        raise TdloError(n, "traverse_euclidean: out-of-bounds in the reference")
+    return out[:n].copy()

@@ -1,0 +1,727 @@
+// tdlo_api.cpp -- C ABI (include/trackdlo_hip.h): context, frame slots, the cpd_lle driver, the
+// batched and N-split forms, and the tracker object mirroring class trackdlo
+// (trackdlo/include/trackdlo.h:53-130, trackdlo/src/trackdlo.cpp:8-90, :900-999).
+#include "../../include/trackdlo_hip.h"
+#include "tdlo_internal.h"
+#include "tdlo_host.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tdlo;
+
+namespace {
+
+constexpr int kMaxEstepBlocks = 1024;
+
+struct Slot {
+    // cloud-sized
+    int cap_points = 0;
+    int N0 = 0;
+    double *Xraw = nullptr;
+    void *Xs = nullptr;
+    unsigned char *keep = nullptr;
+    int *blkcnt = nullptr;
+    double *blksum = nullptr;
+    // node-sized (one allocation, carved)
+    int cap_nodes = 0;
+    double *nodeblk = nullptr;
+    size_t nodeblk_doubles = 0;
+};
+
+struct NodeCarve {
+    // offsets in doubles into Slot::nodeblk for a given M; the first `upload` doubles are the
+    // host-supplied block [Yin | aJ | aYd | H] uploaded with one copy, and [Yout | IterState] is read
+    // back with one copy.
+    size_t Yin, aJ, aYd, H, upload;
+    size_t Yout, st, readback;
+    size_t ctr, Y, Y0, nodes, coord, G, HG, HY0, dmin, sums, Ascr, part, total;
+    explicit NodeCarve(int M) {
+        const size_t m = (size_t)M, mm = m * m;
+        size_t o = 0;
+        auto take = [&](size_t n) { size_t r = o; o += (n + 1) & ~(size_t)1; return r; };   // keep 16-byte alignment
+        Yin = take(3 * m); aJ = take(m); aYd = take(3 * m); H = take(mm); upload = o;
+        Yout = take(3 * m); st = take((sizeof(IterState) + 7) / 8); readback = o - Yout;
+        ctr = take(4); Y = take(3 * m); Y0 = take(3 * m); nodes = take(4 * m); coord = take(m);
+        G = take(mm); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2);
+        Ascr = take((size_t)(M | 1) * (m + 3));
+        part = take((size_t)kMaxEstepBlocks * (4 * m + 1));
+        total = o;
+    }
+};
+
+}  // namespace
+
+struct tdlo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    tdlo_config cfg{};
+    std::vector<Slot> slots;
+    std::vector<FrameDev> fh;        // host copies of the frame descriptors of the last call
+    FrameDev *fd = nullptr;          // device array [max_frames]
+    double *pin = nullptr;           // pinned staging
+    size_t pin_doubles = 0;
+    std::string err;
+    int last_F = 0;
+    // split-mode scratch
+    int split_active = 0;
+    std::vector<double> split_Y;
+};
+
+namespace {
+
+int fail(tdlo_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), TDLO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+int ensure_pin(tdlo_ctx *c, size_t doubles) {
+    if (doubles <= c->pin_doubles) return 0;
+    if (c->pin) hipHostFree(c->pin);
+    c->pin = nullptr; c->pin_doubles = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->pin, doubles * sizeof(double), hipHostMallocDefault));
+    c->pin_doubles = doubles;
+    return 0;
+}
+
+int ensure_points(tdlo_ctx *c, Slot &s, int n) {
+    if (n <= s.cap_points) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.keep); hipFree(s.blkcnt); hipFree(s.blksum); }
+    s.cap_points = 0;
+    const size_t cap = ((size_t)n + 1023) & ~(size_t)1023;
+    const size_t nb = cap / kBlock + 1;
+    HIPCHK(c, hipMalloc((void **)&s.Xraw, 3 * cap * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&s.Xs, 3 * cap * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&s.keep, cap));
+    HIPCHK(c, hipMalloc((void **)&s.blkcnt, nb * sizeof(int)));
+    HIPCHK(c, hipMalloc((void **)&s.blksum, nb * sizeof(double)));
+    s.cap_points = (int)cap;
+    return 0;
+}
+
+int ensure_nodes(tdlo_ctx *c, Slot &s, int M) {
+    if (M <= s.cap_nodes) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (s.nodeblk) hipFree(s.nodeblk);
+    s.nodeblk = nullptr; s.cap_nodes = 0;
+    const int cap = std::max(M, 16);
+    NodeCarve nc(cap);
+    HIPCHK(c, hipMalloc((void **)&s.nodeblk, nc.total * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(s.nodeblk, 0, nc.total * sizeof(double), c->stream));
+    s.nodeblk_doubles = nc.total;
+    s.cap_nodes = cap;
+    return 0;
+}
+
+int check_params(tdlo_ctx *c, int M, const tdlo_params *p) {
+    if (!p) return fail(c, TDLO_E_INVALID, "params is null");
+    if (M < 4) return fail(c, TDLO_E_INVALID, "M < 4: the reference's neighbour clamps (trackdlo.cpp:313-321) need at least 4 nodes");
+    if (M > kMaxNodes) return fail(c, TDLO_E_INVALID, "M > 512 is not supported by the E-step tiling");
+    if (p->max_iter < 0) return fail(c, TDLO_E_INVALID, "max_iter < 0");
+    if (p->precision != TDLO_PREC_F32 && p->precision != TDLO_PREC_F64) return fail(c, TDLO_E_INVALID, "bad precision");
+    return 0;
+}
+
+// Fills the host-side upload block [Yin | aJ | aYd | H] for one frame and its FrameDev.
+int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, const tdlo_params *p,
+                  const double *priors, int K, const int *vis, int n_vis, const double *H_override,
+                  double *stage, FrameDev &f) {
+    Slot &s = c->slots[slot];
+    if (s.N0 <= 0) return fail(c, TDLO_E_INVALID, "no cloud resident in slot (call tdlo_set_cloud)");
+    int rc = ensure_nodes(c, s, M);
+    if (rc) return rc;
+    NodeCarve nc(M);
+    double *blk = s.nodeblk;
+    std::memcpy(stage + nc.Yin, Y, sizeof(double) * 3 * M);
+    // J / Y_extended (trackdlo.cpp:240-260): aJ = alpha * diag(J), aYd = alpha * (Y_extended - Y0)
+    double *aJ = stage + nc.aJ, *aYd = stage + nc.aYd;
+    std::fill(aJ, aJ + M, 0.0);
+    std::fill(aYd, aYd + 3 * M, 0.0);
+    for (int i = 0; i < K; ++i) {
+        const int idx = (int)priors[4 * i];
+        if (idx < 0 || idx >= M) return fail(c, TDLO_E_INVALID, "correspondence prior index out of range");
+        aJ[idx] = p->alpha;
+        for (int d = 0; d < 3; ++d) aYd[d * M + idx] = p->alpha * (priors[4 * i + 1 + d] - Y[d * M + idx]);
+    }
+    size_t upload = nc.H;            // doubles to upload
+    if (p->include_lle) {
+        double *H = stage + nc.H;
+        if (H_override) std::memcpy(H, H_override, sizeof(double) * (size_t)M * M);
+        else {
+            std::vector<double> L((size_t)M * M);
+            lle_weights(6, Y, M, L.data());                  // trackdlo.cpp:236
+            lle_regulariser(L.data(), M, H);                 // :237
+        }
+        upload = nc.upload;
+    }
+    (void)upload;
+
+    std::memset(&f, 0, sizeof f);
+    f.N0 = s.N0; f.M = M; f.ldx = s.cap_points;
+    const int nbatch = (s.N0 + 63) / 64;
+    int nblk = (nbatch + 3) / 4;
+    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : 256;
+    cap = std::min(cap, kMaxEstepBlocks);
+    f.nblkE = std::max(1, std::min(nblk, cap));
+    f.max_iter = p->max_iter; f.include_lle = p->include_lle ? 1 : 0; f.has_priors = K > 0 ? 1 : 0;
+    // trackdlo.cpp:358: visible_nodes.size() != Y.rows() && !visible_nodes.empty() && k_vis != 0
+    f.vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0) ? 1 : 0;
+    (void)vis;
+    f.precision = p->precision;
+    f.nprune_blocks = (s.N0 + kBlock - 1) / kBlock;
+    f.tol = p->tol; f.beta = p->beta; f.lambda = p->lambda; f.lle_weight = p->lle_weight; f.mu = p->mu;
+    f.alpha = p->alpha; f.k_vis = p->k_vis; f.vis_thr = p->visibility_threshold; f.sigma2_in = sigma2;
+    f.Xraw = s.Xraw; f.Xs = s.Xs; f.keep = s.keep; f.blkcnt = s.blkcnt; f.blksum = s.blksum;
+    f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
+    f.coord = blk + nc.coord; f.G = blk + nc.G; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
+    f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
+    f.part = blk + nc.part; f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout;
+    f.st = (IterState *)(blk + nc.st);
+    return 0;
+}
+
+size_t upload_doubles(const NodeCarve &nc, const tdlo_params *p) { return p->include_lle ? nc.upload : nc.H; }
+
+void fill_stats(tdlo_stats *st, const IterState &is) {
+    st->iters = is.it; st->converged = is.converged; st->n_kept = is.N; st->status = is.status; st->sigma2 = is.sigma2;
+}
+
+// Shared driver of tdlo_cpd_lle_resident / _batch.
+int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *sigma2, const tdlo_params *p,
+               const double *priors, int K, const int *vis, int n_vis, const double *H_override, tdlo_stats *stats) {
+    const auto t_host0 = std::chrono::steady_clock::now();
+    int rc = check_params(c, M, p);
+    if (rc) return rc;
+    if (F < 1 || F > c->cfg.max_frames) return fail(c, TDLO_E_INVALID, "bad frame count");
+    NodeCarve nc(M);
+    const size_t up = upload_doubles(nc, p);
+    rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2));
+    if (rc) return rc;
+    c->fh.assign(F, FrameDev{});
+    for (int i = 0; i < F; ++i) {
+        rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
+                           c->pin + (size_t)i * nc.upload, c->fh[i]);
+        if (rc) return rc;
+    }
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    for (int i = 0; i < F; ++i)
+        HIPCHK(c, hipMemcpyAsync(c->slots[slots[i]].nodeblk, c->pin + (size_t)i * nc.upload, up * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
+    HIPCHK(c, launch_prune_and_setup(c->fd, c->fh.data(), F, s));
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    for (int it = 0; it < p->max_iter; ++it) HIPCHK(c, launch_iteration(c->fd, c->fh.data(), F, s));
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
+    for (int i = 0; i < F; ++i)
+        HIPCHK(c, hipMemcpyAsync(c->pin + (size_t)i * nc.upload, c->slots[slots[i]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->last_F = F;
+    float loop_ms = 0, total_ms = 0;
+    hipEventElapsedTime(&loop_ms, c->ev[1], c->ev[2]);
+    hipEventElapsedTime(&total_ms, c->ev[0], c->ev[3]);
+    const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    int worst = 0;
+    for (int i = 0; i < F; ++i) {
+        const double *rb = c->pin + (size_t)i * nc.upload;
+        IterState is;
+        std::memcpy(&is, rb + (nc.st - nc.Yout), sizeof is);
+        if (is.status == 0 || is.status == TDLO_E_NUMERIC) {
+            if (p->max_iter > 0 && is.it > 0) std::memcpy(Y + (size_t)i * 3 * M, rb, sizeof(double) * 3 * M);
+            sigma2[i] = is.sigma2;
+        }
+        if (p->max_iter == 0) { is.converged = 1; }
+        if (stats) {
+            fill_stats(&stats[i], is);
+            stats[i].loop_ms = loop_ms; stats[i].total_ms = total_ms; stats[i].host_ms = host_ms;
+        }
+        if (is.status != 0 && worst == 0) worst = is.status;
+    }
+    if (worst == TDLO_E_EMPTY) return fail(c, worst, "every point was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
+    if (worst == TDLO_E_NUMERIC) return fail(c, worst, "non-finite or non-positive sigma2, or singular M-step system");
+    return TDLO_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int tdlo_abi_version(void) { return TDLO_ABI_VERSION; }
+
+int tdlo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void tdlo_default_config(tdlo_config *cfg) {
+    if (!cfg) return;
+    cfg->device = 0; cfg->max_frames = 1; cfg->max_points = 65536; cfg->max_nodes = 64; cfg->use_graph = 1; cfg->estep_blocks = 0;
+}
+
+tdlo_ctx *tdlo_create(const tdlo_config *cfg_in, int *err) {
+    tdlo_config cfg;
+    if (cfg_in) cfg = *cfg_in; else tdlo_default_config(&cfg);
+    auto bail = [&](int code) -> tdlo_ctx * { if (err) *err = code; return nullptr; };
+    int n = 0;
+    hipError_t he = hipGetDeviceCount(&n);
+    if (he != hipSuccess || n <= 0 || cfg.device < 0 || cfg.device >= n) {
+        fprintf(stderr, "trackdlo_hip: hipGetDeviceCount -> %s, %d device(s), requested %d\n", hipGetErrorString(he), n, cfg.device);
+        return bail(TDLO_E_NO_DEVICE);
+    }
+    he = hipSetDevice(cfg.device);
+    if (he != hipSuccess) { fprintf(stderr, "trackdlo_hip: hipSetDevice -> %s\n", hipGetErrorString(he)); return bail(TDLO_E_NO_DEVICE); }
+    if (check_device_image() != 0) return bail(TDLO_E_NO_DEVICE);     // no gfx950 code object for this device
+    if (cfg.max_frames < 1) cfg.max_frames = 1;
+    tdlo_ctx *c = new tdlo_ctx();
+    c->device = cfg.device; c->cfg = cfg;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
+    for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
+    c->slots.resize(cfg.max_frames);
+    if (hipMalloc((void **)&c->fd, sizeof(FrameDev) * cfg.max_frames) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
+    for (auto &s : c->slots) {
+        if (ensure_points(c, s, std::max(cfg.max_points, 1024)) || ensure_nodes(c, s, std::max(cfg.max_nodes, 16))) {
+            if (err) *err = TDLO_E_HIP;
+            tdlo_destroy(c);
+            return nullptr;
+        }
+    }
+    if (err) *err = TDLO_OK;
+    return c;
+}
+
+void tdlo_destroy(tdlo_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &s : c->slots) {
+        if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.keep); hipFree(s.blkcnt); hipFree(s.blksum); }
+        if (s.nodeblk) hipFree(s.nodeblk);
+    }
+    if (c->fd) hipFree(c->fd);
+    if (c->pin) hipHostFree(c->pin);
+    for (auto &e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *tdlo_last_error(const tdlo_ctx *c) { return c ? c->err.c_str() : "no context (no usable HIP device?)"; }
+void *tdlo_stream(tdlo_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int tdlo_synchronize(tdlo_ctx *c) {
+    if (!c) return TDLO_E_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TDLO_OK;
+}
+
+int tdlo_set_cloud(tdlo_ctx *c, int slot, const double *X, int N) {
+    if (!c) return TDLO_E_INVALID;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
+    if (!X || N <= 0) return fail(c, TDLO_E_INVALID, "empty cloud");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot &s = c->slots[slot];
+    int rc = ensure_points(c, s, N);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(s.Xraw, X, 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // caller may free X on return (by-value semantics)
+    s.N0 = N;
+    return TDLO_OK;
+}
+
+int tdlo_cpd_lle_resident(tdlo_ctx *c, int slot, double *Y, int M, double *sigma2, const tdlo_params *p,
+                          const double *priors, int K, const int *vis, int n_vis, const double *H_override,
+                          tdlo_stats *stats) {
+    if (!c) return TDLO_E_INVALID;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
+    if (!Y || !sigma2) return fail(c, TDLO_E_INVALID, "null Y / sigma2");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_frames(c, 1, &slot, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+}
+
+int tdlo_cpd_lle(tdlo_ctx *c, const double *X, int N, double *Y, int M, double *sigma2, const tdlo_params *p,
+                 const double *priors, int K, const int *vis, int n_vis, const double *H_override, tdlo_stats *stats) {
+    int rc = tdlo_set_cloud(c, 0, X, N);
+    if (rc) return rc;
+    return tdlo_cpd_lle_resident(c, 0, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+}
+
+int tdlo_cpd_lle_batch(tdlo_ctx *c, int F, double *Y, int M, double *sigma2, const tdlo_params *p,
+                       const double *priors, int K, const int *vis, int n_vis, const double *H_override,
+                       tdlo_stats *stats) {
+    if (!c) return TDLO_E_INVALID;
+    if (F < 1 || F > (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad frame count");
+    if (!Y || !sigma2) return fail(c, TDLO_E_INVALID, "null Y / sigma2");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int> slots(F);
+    for (int i = 0; i < F; ++i) slots[i] = i;
+    return run_frames(c, F, slots.data(), Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+}
+
+// ---- N-split -------------------------------------------------------------------------------------
+int tdlo_split_begin(tdlo_ctx *c, const double *Y, int M, double sigma2, const tdlo_params *p,
+                     const double *priors, int K, const int *vis, int n_vis, const double *H_override, double *init) {
+    if (!c) return TDLO_E_INVALID;
+    int rc = check_params(c, M, p);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    NodeCarve nc(M);
+    rc = ensure_pin(c, std::max(nc.upload, nc.readback + 2) + 8 * (size_t)M + 16);
+    if (rc) return rc;
+    c->fh.assign(1, FrameDev{});
+    rc = prepare_frame(c, 0, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, c->pin, c->fh[0]);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev), hipMemcpyHostToDevice, s));
+    HIPCHK(c, launch_split_setup(c->fd, c->fh.data(), s));
+    HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[0].nodeblk + nc.st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    IterState is;
+    std::memcpy(&is, c->pin, sizeof is);
+    if (init) { init[0] = (double)is.N; init[1] = is.sum_d2; }
+    c->split_active = 1;
+    c->last_F = 1;
+    return TDLO_OK;
+}
+
+int tdlo_split_set_global(tdlo_ctx *c, double n_kept_global, double sum_d2_global) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, launch_split_set_global(c->fd, n_kept_global, sum_d2_global, c->stream));
+    return TDLO_OK;
+}
+
+int tdlo_split_dmin(tdlo_ctx *c, double *dmin_sq) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    const FrameDev &f = c->fh[0];
+    const int M = f.M;
+    if (!f.vis_branch) { for (int m = 0; m < M; ++m) dmin_sq[m] = 0; return TDLO_OK; }
+    hipStream_t s = c->stream;
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 1, s));
+    HIPCHK(c, hipMemcpyAsync(c->pin, f.dminbits, sizeof(double) * M, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const unsigned long long *b = (const unsigned long long *)c->pin;
+    for (int m = 0; m < M; ++m) {
+        if (b[m] == ~0ull) { dmin_sq[m] = 1e300; continue; }
+        if (f.precision == TDLO_PREC_F64) { double v; std::memcpy(&v, &b[m], 8); dmin_sq[m] = v; }
+        else { unsigned u = (unsigned)b[m]; float v; std::memcpy(&v, &u, 4); dmin_sq[m] = (double)v; }
+    }
+    return TDLO_OK;
+}
+
+int tdlo_split_estep(tdlo_ctx *c, const double *dmin_sq_global, double *sums) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    const FrameDev &f = c->fh[0];
+    const int M = f.M;
+    hipStream_t s = c->stream;
+    if (f.vis_branch && dmin_sq_global) {
+        unsigned long long *b = (unsigned long long *)c->pin;
+        for (int m = 0; m < M; ++m) {
+            if (f.precision == TDLO_PREC_F64) { double v = dmin_sq_global[m]; std::memcpy(&b[m], &v, 8); }
+            else { float v = (float)dmin_sq_global[m]; unsigned u; std::memcpy(&u, &v, 4); b[m] = u; }
+        }
+        HIPCHK(c, hipMemcpyAsync(f.dminbits, c->pin, sizeof(double) * M, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));        // reduce block partials -> sums
+    HIPCHK(c, hipMemcpyAsync(c->pin + M, f.sums, sizeof(double) * (4 * M + 2), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::memcpy(sums, c->pin + M, sizeof(double) * (4 * M + 2));
+    return TDLO_OK;
+}
+
+int tdlo_split_mstep(tdlo_ctx *c, const double *sums_global, int *done) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    const FrameDev &f = c->fh[0];
+    const int M = f.M;
+    hipStream_t s = c->stream;
+    std::memcpy(c->pin, sums_global, sizeof(double) * (4 * M + 2));
+    HIPCHK(c, hipMemcpyAsync(f.sums, c->pin, sizeof(double) * (4 * M + 2), hipMemcpyHostToDevice, s));
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 4, s));
+    HIPCHK(c, hipMemcpyAsync(c->pin + 4 * M + 4, f.st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    IterState is;
+    std::memcpy(&is, c->pin + 4 * M + 4, sizeof is);
+    if (done) *done = is.done;
+    return TDLO_OK;
+}
+
+int tdlo_split_end(tdlo_ctx *c, double *Y, double *sigma2, tdlo_stats *stats) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    const FrameDev &f = c->fh[0];
+    const int M = f.M;
+    NodeCarve nc(M);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[0].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    IterState is;
+    std::memcpy(&is, c->pin + (nc.st - nc.Yout), sizeof is);
+    if (Y && is.it > 0) std::memcpy(Y, c->pin, sizeof(double) * 3 * M);
+    if (sigma2) *sigma2 = is.sigma2;
+    if (stats) { std::memset(stats, 0, sizeof *stats); fill_stats(stats, is); }
+    c->split_active = 0;
+    return is.status;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------
+int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us) {
+    if (!c || c->last_F < 1 || c->fh.empty()) return TDLO_E_INVALID;
+    if (kind < 0 || kind > 2 || reps < 1) return fail(c, TDLO_E_INVALID, "bad kind / reps");
+    (void)slot;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int F = c->last_F;
+    // the loop left done = 1; clear it so the kernels do their work (state is scratch from here on)
+    std::vector<IterState> saved(F);
+    for (int i = 0; i < F; ++i) {
+        HIPCHK(c, hipMemcpyAsync(&saved[i], c->fh[i].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int i = 0; i < F; ++i) {
+        IterState is = saved[i];
+        is.done = 0; is.it = 0;
+        std::memcpy(c->pin + i * 16, &is, sizeof is);
+        HIPCHK(c, hipMemcpyAsync(c->fh[i].st, c->pin + i * 16, sizeof(IterState), hipMemcpyHostToDevice, s));
+    }
+    std::vector<FrameDev> fh = c->fh;
+    for (auto &f : fh) f.max_iter = 1 << 30;
+    for (auto &f : fh) f.tol = -1.0;
+    HIPCHK(c, hipMemcpyAsync(c->fd, fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
+    for (int w = 0; w < 3; ++w) HIPCHK(c, launch_estep_only(c->fd, fh.data(), F, kind, s));
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    for (int r = 0; r < reps; ++r) HIPCHK(c, launch_estep_only(c->fd, fh.data(), F, kind, s));
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    if (avg_us) *avg_us = ms * 1000.0f / (float)reps;
+    // restore
+    for (int i = 0; i < F; ++i) {
+        std::memcpy(c->pin + i * 16, &saved[i], sizeof(IterState));
+        HIPCHK(c, hipMemcpyAsync(c->fh[i].st, c->pin + i * 16, sizeof(IterState), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return TDLO_OK;
+}
+
+// ---- host helpers --------------------------------------------------------------------------------
+int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L) {
+    if (!Y || !L || M < 1 || k < 2 || k > 13) return TDLO_E_INVALID;
+    lle_weights(k, Y, M, L);
+    return TDLO_OK;
+}
+
+int tdlo_line_sphere_intersection(const double A[3], const double B[3], const double C[3], double radius, double out[6]) {
+    Vec3 o[2];
+    const int n = line_sphere(Vec3{A[0], A[1], A[2]}, Vec3{B[0], B[1], B[2]}, Vec3{C[0], C[1], C[2]}, radius, o);
+    for (int i = 0; i < n; ++i) { out[3 * i] = o[i].x; out[3 * i + 1] = o[i].y; out[3 * i + 2] = o[i].z; }
+    return n;
+}
+
+int tdlo_traverse_euclidean(const double *coord, int n_coord, const double *guide, int Mg, const int *vis, int n_vis,
+                            int alignment, int anchor, double *out) {
+    if (!coord || !guide || !vis || !out) return TDLO_E_INVALID;
+    std::vector<double> cv(coord, coord + n_coord), res;
+    std::vector<int> vv(vis, vis + n_vis);
+    const int n = traverse_euclidean(cv, guide, Mg, vv, alignment, anchor, res);
+    if (n < 0) return TDLO_E_TRAVERSE;
+    std::memcpy(out, res.data(), sizeof(double) * res.size());
+    return n;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// class trackdlo (trackdlo/include/trackdlo.h:53-130)
+// =================================================================================================
+struct tdlo_tracker {
+    tdlo_ctx *ctx;
+    int slot;
+    int M;
+    int precision = TDLO_PREC_F32;
+    // members of the reference class, trackdlo.h:104-121
+    std::vector<double> Y;              // M x 3 column-major
+    std::vector<double> guide_nodes;    // Mg x 3 column-major
+    int Mg;
+    double sigma2, beta, beta_pre_proc, lambda, lambda_pre_proc, alpha, k_vis, mu, tol, lle_weight;
+    int max_iter;
+    std::vector<double> geodesic_coord;
+    std::vector<double> priors;         // K x 4 row-major
+    double visibility_threshold;
+};
+
+extern "C" {
+
+tdlo_tracker *tdlo_tracker_create(tdlo_ctx *ctx, int slot, int M, double visibility_threshold, double beta, double lambda,
+                                  double alpha, double k_vis, double mu, int max_iter, double tol, double beta_pre_proc,
+                                  double lambda_pre_proc, double lle_weight) {
+    if (!ctx || slot < 0 || slot >= (int)ctx->slots.size() || M < 1) return nullptr;
+    tdlo_tracker *t = new tdlo_tracker();
+    t->ctx = ctx; t->slot = slot; t->M = M;
+    t->Y.assign(3 * (size_t)M, 0.0);                       // trackdlo.cpp:43
+    t->guide_nodes = t->Y; t->Mg = M;                      // :45
+    t->sigma2 = 0.0;                                       // :46
+    t->visibility_threshold = visibility_threshold; t->beta = beta; t->beta_pre_proc = beta_pre_proc;
+    t->lambda = lambda; t->lambda_pre_proc = lambda_pre_proc; t->alpha = alpha; t->lle_weight = lle_weight;
+    t->k_vis = k_vis; t->mu = mu; t->max_iter = max_iter; t->tol = tol;
+    return t;
+}
+
+tdlo_tracker *tdlo_tracker_create_default(tdlo_ctx *ctx, int slot, int M) {
+    // trackdlo.cpp:10-28
+    return tdlo_tracker_create(ctx, slot, M, /*visibility_threshold*/ 0.02, /*beta*/ 5.0, /*lambda*/ 1.0, /*alpha*/ 0.0,
+                               /*k_vis*/ 0.0, /*mu*/ 0.05, /*max_iter*/ 50, /*tol*/ 0.00001, /*beta_pre_proc*/ 3.0,
+                               /*lambda_pre_proc*/ 1.0, /*lle_weight*/ 1.0);
+}
+
+void tdlo_tracker_destroy(tdlo_tracker *t) { delete t; }
+
+int tdlo_tracker_set_precision(tdlo_tracker *t, int precision) {
+    if (!t || (precision != TDLO_PREC_F32 && precision != TDLO_PREC_F64)) return TDLO_E_INVALID;
+    t->precision = precision;
+    return TDLO_OK;
+}
+
+int tdlo_tracker_initialize_nodes(tdlo_tracker *t, const double *Y_init) {
+    if (!t || !Y_init) return TDLO_E_INVALID;
+    t->Y.assign(Y_init, Y_init + 3 * (size_t)t->M);
+    t->guide_nodes = t->Y; t->Mg = t->M;
+    return TDLO_OK;
+}
+
+int tdlo_tracker_initialize_geodesic_coord(tdlo_tracker *t, const double *coord, int n) {
+    if (!t || !coord || n < 0) return TDLO_E_INVALID;
+    t->geodesic_coord.insert(t->geodesic_coord.end(), coord, coord + n);
+    return TDLO_OK;
+}
+
+double tdlo_tracker_get_sigma2(const tdlo_tracker *t) { return t ? t->sigma2 : 0.0; }
+void tdlo_tracker_set_sigma2(tdlo_tracker *t, double s) { if (t) t->sigma2 = s; }
+
+int tdlo_tracker_get_tracking_result(const tdlo_tracker *t, double *out) {
+    if (!t || !out) return TDLO_E_INVALID;
+    std::memcpy(out, t->Y.data(), sizeof(double) * t->Y.size());
+    return t->M;
+}
+
+int tdlo_tracker_get_guide_nodes(const tdlo_tracker *t, double *out, int max_rows) {
+    if (!t || !out) return TDLO_E_INVALID;
+    if (max_rows < t->Mg) return TDLO_E_INVALID;
+    std::memcpy(out, t->guide_nodes.data(), sizeof(double) * 3 * (size_t)t->Mg);
+    return t->Mg;
+}
+
+int tdlo_tracker_get_correspondence_pairs(const tdlo_tracker *t, double *out, int max_rows) {
+    if (!t || !out) return TDLO_E_INVALID;
+    const int K = (int)(t->priors.size() / 4);
+    if (max_rows < K) return TDLO_E_INVALID;
+    std::memcpy(out, t->priors.data(), sizeof(double) * t->priors.size());
+    return K;
+}
+
+int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const int *vis, int n_vis,
+                               const int *vis_ext, int n_ext, const double *H_pre, tdlo_stats *stats) {
+    if (!t || !X || !vis_ext) return TDLO_E_INVALID;
+    tdlo_ctx *c = t->ctx;
+    const int M = t->M;
+    if (n_ext <= 0 || n_ext > M) return fail(c, TDLO_E_INVALID, "visible_nodes_extended must hold 1..M indices (empty is undefined in the reference, trackdlo_node.cpp:351)");
+    for (int i = 0; i < n_ext; ++i) if (vis_ext[i] < 0 || vis_ext[i] >= M) return fail(c, TDLO_E_INVALID, "visible_nodes_extended index out of range");
+    for (int i = 0; i < n_vis; ++i) if (vis[i] < 0 || vis[i] >= M) return fail(c, TDLO_E_INVALID, "visible_nodes index out of range");
+    t->priors.clear();                                                   // :908
+    int rc = tdlo_set_cloud(c, t->slot, X, N);                           // X_orig by value: one upload for both registrations
+    if (rc) return rc;
+
+    // guide nodes = visible sub-chain (:913-921)
+    const int Mg = n_ext;
+    t->Mg = Mg;
+    t->guide_nodes.assign(3 * (size_t)Mg, 0.0);
+    if (Mg != M) { for (int i = 0; i < Mg; ++i) for (int d = 0; d < 3; ++d) t->guide_nodes[d * Mg + i] = t->Y[d * M + vis_ext[i]]; }
+    else t->guide_nodes = t->Y;
+
+    // pre-processing registration (:925-927): sigma2 copy, beta/lambda_pre_proc, include_lle = true
+    tdlo_params pp{};
+    pp.beta = t->beta_pre_proc; pp.lambda = t->lambda_pre_proc; pp.lle_weight = t->lle_weight; pp.mu = t->mu;
+    pp.max_iter = t->max_iter; pp.tol = t->tol; pp.include_lle = 1; pp.alpha = 0; pp.k_vis = 0; pp.visibility_threshold = 0.01;
+    pp.precision = t->precision;
+    double sigma2_pre = t->sigma2;
+    tdlo_stats st_pre{}, st_main{};
+    rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
+    if (stats) stats[0] = st_pre;
+    if (rc) return rc;
+
+    std::vector<int> ve(vis_ext, vis_ext + n_ext);
+    std::vector<double> p1, p2;
+    const double *guide = t->guide_nodes.data();
+    auto trav = [&](int alignment, int anchor, std::vector<double> &out) {
+        return traverse_euclidean(t->geodesic_coord, guide, Mg, ve, alignment, anchor, out);
+    };
+    const char *oob = "traverse_euclidean: the reference would index out of bounds for these visible nodes";
+    if (Mg == M) {                                                       // all visible / minor occlusion (:929-957)
+        const int n1 = trav(0, -1, p1), n2 = trav(1, -1, p2);
+        if (n1 <= 0 || n2 <= 0) return fail(c, TDLO_E_TRAVERSE, oob);
+        // p2 runs tail -> head; bring it to ascending order (:942)
+        std::vector<double> r2(p2.size());
+        for (int i = 0; i < n2; ++i) std::memcpy(&r2[4 * i], &p2[4 * (n2 - 1 - i)], 4 * sizeof(double));
+        for (int i = 0; i < M; ++i) {
+            const long long j2 = (long long)i - ((long long)M - n2);     // unsigned in the reference: negative == huge
+            const bool j2_ok = j2 >= 0 && j2 < n2;
+            if ((double)i < r2[0] && i < n1) {
+                t->priors.insert(t->priors.end(), &p1[4 * i], &p1[4 * i] + 4);
+            } else if ((double)i > p1[4 * (n1 - 1)] && j2_ok) {
+                t->priors.insert(t->priors.end(), &r2[4 * j2], &r2[4 * j2] + 4);
+            } else {
+                if (i >= n1 || !j2_ok) return fail(c, TDLO_E_TRAVERSE, oob);
+                for (int k = 0; k < 4; ++k) t->priors.push_back((p1[4 * i + k] + r2[4 * j2 + k]) / 2.0);    // :954
+            }
+        }
+    } else if (ve.front() == 0 && ve.back() == M - 1) {                  // mid-section occluded (:958-967)
+        if (trav(0, -1, p1) < 0 || trav(1, -1, p2) < 0) return fail(c, TDLO_E_TRAVERSE, oob);
+        t->priors = p1;
+        t->priors.insert(t->priors.end(), p2.begin(), p2.end());
+    } else if (ve.front() == 0) {                                        // tail occluded (:968-973)
+        if (trav(0, -1, p1) < 0) return fail(c, TDLO_E_TRAVERSE, oob);
+        t->priors = p1;
+    } else if (ve.back() == M - 1) {                                     // head occluded (:974-979)
+        if (trav(1, -1, p1) < 0) return fail(c, TDLO_E_TRAVERSE, oob);
+        t->priors = p1;
+    } else {                                                             // both ends occluded (:980-995)
+        int anchor = -1; double moved = 999999;
+        for (int i = 0; i < n_vis && i < Mg; ++i) {                      // reference pairs visible_nodes[i] with guide row i
+            double s = 0;
+            for (int d = 0; d < 3; ++d) { const double e = t->Y[d * M + vis[i]] - t->guide_nodes[d * Mg + i]; s += e * e; }
+            const double dd = std::sqrt(s);
+            if (dd < moved) { moved = dd; anchor = i; }
+        }
+        if (trav(2, anchor, p1) < 0) return fail(c, TDLO_E_TRAVERSE, oob);
+        t->priors = p1;
+    }
+
+    // main registration (:998): include_lle = false, priors, alpha, visible_nodes_extended, k_vis
+    tdlo_params mp{};
+    mp.beta = t->beta; mp.lambda = t->lambda; mp.lle_weight = t->lle_weight; mp.mu = t->mu; mp.max_iter = t->max_iter;
+    mp.tol = t->tol; mp.include_lle = 0; mp.alpha = t->alpha; mp.k_vis = t->k_vis; mp.visibility_threshold = t->visibility_threshold;
+    mp.precision = t->precision;
+    // prior indices may be fractional after the averaging at :954; the reference truncates (:247)
+    rc = tdlo_cpd_lle_resident(c, t->slot, t->Y.data(), M, &t->sigma2, &mp, t->priors.data(), (int)(t->priors.size() / 4),
+                               vis_ext, n_ext, nullptr, &st_main);
+    if (stats) stats[1] = st_main;
+    return rc;
+}
+
+}  // extern "C"

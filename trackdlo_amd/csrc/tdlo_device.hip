@@ -1,0 +1,741 @@
+// tdlo_device.hip -- gfx950 (CDNA4, wave64) kernels for TrackDLO's EM registration loop.
+//
+// Reference path: trackdlo/src/trackdlo.cpp:161-441 (trackdlo::cpd_lle).  Nothing here is a
+// translation of that code: the reference materialises five dense M x N fp64 matrices per
+// iteration on one CPU thread; here no M x N matrix ever exists.
+//
+// Kernels (one EM iteration = [k_dmin] -> k_estep -> k_mstep, all on one stream, no host sync):
+//   k_prune_pass1 / k_setup / k_prune_scatter   once per call   (:177-273)
+//   k_dmin    per-node minimum distance to the cloud (visibility weighting only, :278-296, :358-372)
+//   k_estep   fused distances + nearest-node + geodesic membership + normalisation + column sums
+//             (:278-389): thread = point, nodes via scalar loads, 64x64 lane-transposed LDS tile so
+//             that lane = node accumulates P1 / PX without cross-lane reductions
+//   k_mstep   block-partial reduction, A/B assembly, dense solve, T, sigma2, convergence (:392-437)
+//
+// Numerics: all device geometry lives in a frame centred on the centroid of the incoming nodes
+// (every formula of the path is translation invariant).  In TDLO_PREC_F32 the E-step works in fp32
+// on fp32-rounded centred coordinates; sums leave each 64-point tile in fp32 and are accumulated in
+// fp64 from there on.  sigma2 uses the algebraically identical residual form
+//   sum_mn P_mn |x_n - T_m|^2 = Q - 2 sum_m d_m.R_m + sum_m P1_m |d_m|^2,
+//   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m,  d_m = T_m - y_m
+// instead of :418-422's difference of three large traces, which would cancel catastrophically in fp32.
+#include "tdlo_internal.h"
+#include "../../include/trackdlo_hip.h"
+#include <cstdio>
+
+namespace tdlo {
+
+template <typename T> struct alignas(16) V4 { T x, y, z, w; };
+
+__device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double tmin(double a, double b) { return ::fmin(a, b); }
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+    static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+    static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    static __device__ __forceinline__ unsigned long long bits(float x) { return (unsigned long long)__float_as_uint(x); }
+    static __device__ __forceinline__ double from_bits(unsigned long long b) { return (double)__uint_as_float((unsigned)b); }
+};
+template <> struct Num<double> {
+    static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ unsigned long long bits(double x) { return (unsigned long long)__double_as_longlong(x); }
+    static __device__ __forceinline__ double from_bits(unsigned long long b) { return __longlong_as_double((long long)b); }
+};
+
+// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the
+// compiler has to be kept from reordering across the point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum for kBlock threads; scratch holds >= 4 doubles; result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
+    // c of trackdlo.cpp:300 (or c' of :378 when visibility weighting is active)
+    double c = pow(2.0 * M_PI * sigma2, 1.5) * f.mu / (1.0 - f.mu);
+    c = f.vis_branch ? c / Nc : c * (double)f.M / Nc;
+    st->sigma2 = sigma2;
+    st->Nc = Nc;
+    st->k2 = -1.4426950408889634 / (2.0 * sigma2);
+    st->c_norm = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prune, trackdlo.cpp:177-195, fused with the sigma2 initialisation sum of :263-273
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restrict__ frames) {
+    const FrameDev &f = frames[blockIdx.y];
+    if ((int)blockIdx.x >= f.nprune_blocks) return;
+    __shared__ double scratch[4];
+    const int N0 = f.N0, M = f.M;
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = n < N0;
+    double x = 0, y = 0, z = 0;
+    if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
+    const double *__restrict__ Yi = f.Yin;
+    double best = 1e300, sum = 0;
+    for (int m = 0; m < M; ++m) {
+        const double dx = Yi[m] - x, dy = Yi[M + m] - y, dz = Yi[2 * M + m] - z;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        best = fmin(best, d2);
+        sum += d2;
+    }
+    const bool keep = valid && (::sqrt(best) < 0.1);
+    if (valid) f.keep[n] = keep ? 1 : 0;
+    const int cnt = __syncthreads_count(keep);
+    const double s = block_sum(keep ? sum : 0.0, scratch);
+    if (threadIdx.x == 0) { f.blkcnt[blockIdx.x] = cnt; f.blksum[blockIdx.x] = s; }
+}
+
+// One workgroup per frame: scan of the prune counts, centring, chain coordinate + kernel G
+// (:214-233), H*G / H*Y0 (:396-401), iteration-0 constants.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ frames, int split_mode) {
+    const FrameDev &f = frames[blockIdx.x];
+    IterState *st = f.st;
+    __shared__ double sd[kBlock];
+    __shared__ int si[kBlock];
+    __shared__ double sctr[3];
+    __shared__ int sN;
+    __shared__ double sS;
+    const int t = threadIdx.x, M = f.M;
+    // exclusive scan of per-block kept counts (deterministic order)
+    const int nb = f.nprune_blocks;
+    const int per = (nb + kBlock - 1) / kBlock;
+    const int b0 = min(nb, t * per), b1 = min(nb, b0 + per);
+    int c = 0; double s = 0;
+    for (int b = b0; b < b1; ++b) { c += f.blkcnt[b]; s += f.blksum[b]; }
+    si[t] = c; sd[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0; double tot = 0;
+        for (int i = 0; i < kBlock; ++i) { const int v = si[i]; si[i] = run; run += v; tot += sd[i]; }
+        sN = run; sS = tot;
+    }
+    __syncthreads();
+    {
+        int run = si[t];
+        for (int b = b0; b < b1; ++b) { const int v = f.blkcnt[b]; f.blkcnt[b] = run; run += v; }
+    }
+    // centring offset
+    if (t < 3) {
+        double a = 0;
+        for (int m = 0; m < M; ++m) a += f.Yin[t * M + m];
+        sctr[t] = a / M; f.ctr[t] = a / M;
+    }
+    __syncthreads();
+    for (int i = t; i < 3 * M; i += kBlock) { const double v = f.Yin[i] - sctr[i / M]; f.Y[i] = v; f.Y0[i] = v; f.Yout[i] = f.Yin[i]; }
+    for (int i = t; i < M - 1; i += kBlock) {
+        const double dx = f.Yin[i + 1] - f.Yin[i], dy = f.Yin[M + i + 1] - f.Yin[M + i], dz = f.Yin[2 * M + i + 1] - f.Yin[2 * M + i];
+        f.coord[i + 1] = ::sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    __syncthreads();
+    if (t == 0) {   // same left-to-right running sum as :219-223
+        double cur = 0; f.coord[0] = 0;
+        for (int i = 0; i < M - 1; ++i) { cur += f.coord[i + 1]; f.coord[i + 1] = cur; }
+    }
+    __syncthreads();
+    V4<T> *nodes = (V4<T> *)f.nodes;
+    for (int m = t; m < M; m += kBlock) {
+        V4<T> q; q.x = (T)f.Y[m]; q.y = (T)f.Y[M + m]; q.z = (T)f.Y[2 * M + m]; q.w = (T)f.coord[m];
+        nodes[m] = q;
+        f.dminbits[m] = ~0ull;
+    }
+    const double beta = f.beta;
+    for (int e = t; e < M * M; e += kBlock) {
+        const int i = e % M, j = e / M;
+        const double dd = fabs(f.coord[i] - f.coord[j]);
+        f.G[e] = 1.0 / (2 * beta * 2 * beta) * ::exp(-::sqrt(2.0) * dd / beta) * (2 * dd + ::sqrt(2.0) * beta);
+    }
+    __syncthreads();
+    if (f.include_lle) {
+        for (int e = t; e < M * M; e += kBlock) {
+            const int i = e % M, j = e / M;
+            double a = 0;
+            for (int k = 0; k < M; ++k) a += f.H[(size_t)k * M + i] * f.G[(size_t)j * M + k];
+            f.HG[e] = a;
+        }
+        for (int e = t; e < 3 * M; e += kBlock) {
+            const int i = e % M, d = e / M;
+            double a = 0;
+            for (int k = 0; k < M; ++k) a += f.H[(size_t)k * M + i] * f.Yin[d * M + k];
+            f.HY0[e] = a;
+        }
+    }
+    if (t == 0) {
+        const int N = sN;
+        st->N = N; st->sum_d2 = sS;
+        st->it = 0; st->converged = 1; st->crit = 0; st->Np = 0;
+        st->status = 0; st->done = 0;
+        if (!split_mode) {
+            if (N == 0) { st->status = TDLO_E_EMPTY; st->done = 1; st->sigma2 = f.sigma2_in; }
+            else {
+                double sigma2 = f.sigma2_in;
+                if (sigma2 == 0) sigma2 = sS / (3.0 * (double)M * (double)N);     // :271-273
+                set_iter_consts(f, st, sigma2, (double)N);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_prune_scatter(const FrameDev *__restrict__ frames) {
+    const FrameDev &f = frames[blockIdx.y];
+    if ((int)blockIdx.x >= f.nprune_blocks) return;
+    __shared__ int wc[4];
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    const bool keep = (n < f.N0) && f.keep[n];
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wc[w] = __popcll(bal);
+    __syncthreads();
+    int off = f.blkcnt[blockIdx.x];
+    for (int i = 0; i < w; ++i) off += wc[i];
+    if (keep) {
+        const int dst = off + pre;
+        T *xs = (T *)f.Xs;
+        const size_t N0 = f.N0, ld = f.ldx;
+        xs[dst] = (T)(f.Xraw[n] - f.ctr[0]);
+        xs[ld + dst] = (T)(f.Xraw[N0 + n] - f.ctr[1]);
+        xs[2 * ld + dst] = (T)(f.Xraw[2 * N0 + n] - f.ctr[2]);
+    }
+}
+
+// split mode: global N and sum_d2 arrive from the all-reduce
+__global__ void k_split_set_global(const FrameDev *__restrict__ frames, double Nglob, double Sglob) {
+    const FrameDev &f = frames[0];
+    IterState *st = f.st;
+    if (threadIdx.x == 0) {
+        if (Nglob <= 0) { st->status = TDLO_E_EMPTY; st->done = 1; return; }
+        double sigma2 = f.sigma2_in;
+        if (sigma2 == 0) sigma2 = Sglob / (3.0 * (double)f.M * Nglob);
+        set_iter_consts(f, st, sigma2, Nglob);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-node shortest distance to the cloud, trackdlo.cpp:278-296 (only consumed by :358-372)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(kBlock) void k_dmin(const FrameDev *__restrict__ frames, int nblk) {
+    const FrameDev &f = frames[blockIdx.y];
+    IterState *st = f.st;
+    if (!f.vis_branch || st->done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = st->N, M = f.M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rows = M < kChunk ? M : kChunk;
+    T *pb = (T *)smem + (size_t)wave * rows * kPStride;
+    const V4<T> *__restrict__ nodes = (const V4<T> *)f.nodes;
+    const T *__restrict__ xs = (const T *)f.Xs;
+    const size_t ld = f.ldx;
+    T rmin[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) rmin[c] = Num<T>::inf();
+    const int nbatch = (N + 63) >> 6;
+    for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += nblk * 4) {
+        const int n = batch * 64 + lane;
+        const bool valid = n < N;
+        T x = 0, y = 0, z = 0;
+        if (valid) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int m0 = c * kChunk, m1 = min(M, m0 + kChunk);
+            for (int m = m0; m < m1; ++m) {
+                const V4<T> q = nodes[m];
+                const T dx = x - q.x, dy = y - q.y, dz = z - q.z;
+                const T d2 = dx * dx + dy * dy + dz * dz;
+                pb[(m - m0) * kPStride + lane] = valid ? d2 : Num<T>::inf();
+            }
+            wave_lds_sync();
+            if (m0 + lane < m1) {
+                T r = rmin[c];
+#pragma unroll 16
+                for (int j = 0; j < 64; ++j) r = tmin(r, pb[lane * kPStride + j]);
+                rmin[c] = r;
+            }
+            wave_lds_sync();
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int m = c * kChunk + lane;
+        if (m < M && rmin[c] < Num<T>::inf()) atomicMin(&f.dminbits[m], Num<T>::bits(rmin[c]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// E-step, trackdlo.cpp:278-389
+// ------------------------------------------------------------------------------------------------
+// Geodesic membership of node m for a point whose nearest pair is (lo, hi):
+//   m <= lo : (coord_lo - coord_m + |x - y_lo|)^2      m >= hi : (coord_m - coord_hi + |x - y_hi|)^2
+//   lo < m < hi (only when hi - lo == 2, the reference's end-node quirk): 0            (:332-350)
+template <typename T>
+__device__ __forceinline__ T geo_arg(int m, int lo, int hi, T cm, T c_lo, T d_lo, T c_hi, T d_hi) {
+    const T t_lo = (c_lo - cm) + d_lo;
+    const T t_hi = (cm - c_hi) + d_hi;
+    T t = (m <= lo) ? t_lo : T(0);
+    t = (m >= hi) ? t_hi : t;
+    return t * t;
+}
+
+template <typename T, int NCH, bool VIS>
+__global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ frames) {
+    const FrameDev &f = frames[blockIdx.y];
+    IterState *st = f.st;
+    if ((int)blockIdx.x >= f.nblkE || st->done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = st->N, M = f.M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = M < kChunk ? M : kChunk;
+    // LDS carve (every offset a multiple of 16 bytes)
+    V4<T> *nodesL = (V4<T> *)smem;                                    // M
+    V4<T> *pts = nodesL + M;                                          // 4 x 64
+    T *lvL = (T *)(pts + 4 * 64);                                     // M rounded up to 4
+    T *pbase = lvL + ((M + 3) & ~3);
+    T *pb = pbase + (size_t)wave * rows * kPStride;
+    double *scratch = (double *)(pbase + (size_t)4 * rows * kPStride + 4);   // 8-byte aligned
+    scratch = (double *)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
+
+    const V4<T> *__restrict__ nodes = (const V4<T> *)f.nodes;
+    const T *__restrict__ xs = (const T *)f.Xs;
+    const size_t ld = f.ldx;
+    for (int m = tid; m < M; m += kBlock) nodesL[m] = nodes[m];
+    if (VIS) {
+        // P_vis rows, :362-372: v_m = exp(-k_vis * dmin_m) / sum, folded into the exponent as log2 v_m
+        double tot = 0;
+        for (int m = tid; m < M; m += kBlock) {
+            double d = ::sqrt(Num<T>::from_bits(f.dminbits[m]));
+            if (d > 10000.0) d = 10000.0;                        // initial value of :282
+            if (d <= f.vis_thr) d = 0;                           // :291-293
+            tot += ::exp(-f.k_vis * d);
+        }
+        tot = block_sum(tot, scratch);
+        for (int m = tid; m < M; m += kBlock) {
+            double d = ::sqrt(Num<T>::from_bits(f.dminbits[m]));
+            if (d > 10000.0) d = 10000.0;
+            if (d <= f.vis_thr) d = 0;
+            lvL[m] = (T)(-f.k_vis * d * 1.4426950408889634 - ::log2(tot));
+        }
+    }
+    __syncthreads();
+
+    const T k2 = (T)st->k2;
+    const T cn = (T)st->c_norm;
+    double accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { accP[c] = 0; accX[c] = 0; accY[c] = 0; accZ[c] = 0; }
+    double accQ = 0;
+
+    const int nbatch = (N + 63) >> 6;
+    for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += f.nblkE * 4) {
+        const int n = batch * 64 + lane;
+        const bool valid = n < N;
+        T x = 0, y = 0, z = 0;
+        if (valid) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }
+        // ---- nearest node: argmax of the Euclidean membership (:298-310) == argmin of d2, first index
+        T best = Num<T>::inf();
+        int a = 0;
+        for (int m = 0; m < M; ++m) {
+            const V4<T> q = nodes[m];
+            const T dx = x - q.x, dy = y - q.y, dz = z - q.z;
+            const T d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) { best = d2; a = m; }
+        }
+        // ---- second node by distance (:313-329)
+        const int c1 = (a == 0) ? 2 : a - 1;
+        const int c2 = (a == M - 1) ? M - 3 : a + 1;
+        const V4<T> q1 = nodesL[c1], q2 = nodesL[c2], qa = nodesL[a];
+        T dx = x - q1.x, dy = y - q1.y, dz = z - q1.z;
+        const T e1 = Num<T>::sqrt(dx * dx + dy * dy + dz * dz);
+        dx = x - q2.x; dy = y - q2.y; dz = z - q2.z;
+        const T e2 = Num<T>::sqrt(dx * dx + dy * dy + dz * dz);
+        const bool first = e1 < e2;
+        const int b = first ? c1 : c2;
+        const T eb = first ? e1 : e2, cb = first ? q1.w : q2.w;
+        const T ea = Num<T>::sqrt(best);
+        const bool a_lo = a < b;
+        const int lo = a_lo ? a : b, hi = a_lo ? b : a;
+        const T d_lo = a_lo ? ea : eb, d_hi = a_lo ? eb : ea;
+        const T c_lo = a_lo ? qa.w : cb, c_hi = a_lo ? cb : qa.w;
+
+        // ---- unnormalised membership, column sum, Q (:354-383)
+        T sum = 0, qs = 0;
+        for (int m = 0; m < M; ++m) {
+            const V4<T> q = nodes[m];
+            T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
+            if (VIS) e += lvL[m];
+            const T p = Num<T>::exp2(e);
+            const T ddx = x - q.x, ddy = y - q.y, ddz = z - q.z;
+            const T d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            sum += p;
+            qs += p * d2;
+            if (NCH == 1) pb[m * kPStride + lane] = p;
+        }
+        const T inv = valid ? T(1) / (sum + cn) : T(0);
+        accQ += (double)(inv * qs);
+        V4<T> pw; pw.x = inv * x; pw.y = inv * y; pw.z = inv * z; pw.w = inv;
+        pts[wave * 64 + lane] = pw;
+
+        // ---- column sums with lane = node (:386-389)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int m0 = c * kChunk, m1 = min(M, m0 + kChunk);
+            if (NCH > 1) {
+                for (int m = m0; m < m1; ++m) {
+                    const V4<T> q = nodes[m];
+                    T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
+                    if (VIS) e += lvL[m];
+                    pb[(m - m0) * kPStride + lane] = Num<T>::exp2(e);
+                }
+            }
+            wave_lds_sync();
+            if (m0 + lane < m1) {
+                T s0 = 0, sx = 0, sy = 0, sz = 0;
+                const T *prow = pb + lane * kPStride;
+                const V4<T> *pw_ = pts + wave * 64;
+#pragma unroll 8
+                for (int j = 0; j < 64; ++j) {
+                    const T p = prow[j];
+                    const V4<T> w = pw_[j];
+                    s0 += p * w.w; sx += p * w.x; sy += p * w.y; sz += p * w.z;
+                }
+                accP[c] += (double)s0; accX[c] += (double)sx; accY[c] += (double)sy; accZ[c] += (double)sz;
+            }
+            wave_lds_sync();
+        }
+    }
+
+    // ---- block partial: sum the 4 waves, write [P1 | PXx | PXy | PXz | Q]
+    __syncthreads();
+    double *red = (double *)pbase;      // reuse the tile area: 4 waves x 64 lanes x 4 values per chunk
+    double *part = f.part + (size_t)blockIdx.x * (4 * M + 1);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        red[(wave * 64 + lane) * 4 + 0] = accP[c];
+        red[(wave * 64 + lane) * 4 + 1] = accX[c];
+        red[(wave * 64 + lane) * 4 + 2] = accY[c];
+        red[(wave * 64 + lane) * 4 + 3] = accZ[c];
+        __syncthreads();
+        {
+            const int l = tid >> 2, k = tid & 3;     // 64 lanes x 4 values
+            const int m = c * kChunk + l;
+            if (m < M) {
+                const double v = red[(0 * 64 + l) * 4 + k] + red[(1 * 64 + l) * 4 + k] + red[(2 * 64 + l) * 4 + k] + red[(3 * 64 + l) * 4 + k];
+                part[k * M + m] = v;
+            }
+        }
+        __syncthreads();
+    }
+    const double q = block_sum(accQ, scratch);
+    if (tid == 0) part[4 * M] = q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M-step, trackdlo.cpp:392-437.  One workgroup per frame.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool LDSA>
+__global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ frames, int from_sums) {
+    const FrameDev &f = frames[blockIdx.x];
+    IterState *st = f.st;
+    if (st->done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = f.M, t = threadIdx.x, lane = t & 63;
+    const int nS = 4 * M + 1;
+    const int ld = M | 1;                     // odd leading dimension
+    double *S = (double *)smem;               // nS (+pad)
+    double *W = S + ((nS + 1) & ~1);          // 3M
+    double *Tn = W + 3 * M;                   // 3M
+    double *scratch = Tn + 3 * M;             // 8
+    int *piv = (int *)(scratch + 8);          // M
+    int *used = piv + M;                      // M
+    double *A = LDSA ? (double *)(((uintptr_t)(used + M) + 15) & ~(uintptr_t)15) : f.Ascr;   // ld x (M+3)
+
+    // ---- 1. reduce the E-step block partials in a fixed order
+    if (!from_sums) {
+        const int nb = f.nblkE;
+        for (int e = t; e < nS; e += kBlock) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int b = 0;
+            for (; b + 3 < nb; b += 4) {
+                a0 += f.part[(size_t)b * nS + e]; a1 += f.part[(size_t)(b + 1) * nS + e];
+                a2 += f.part[(size_t)(b + 2) * nS + e]; a3 += f.part[(size_t)(b + 3) * nS + e];
+            }
+            for (; b < nb; ++b) a0 += f.part[(size_t)b * nS + e];
+            S[e] = (a0 + a1) + (a2 + a3);
+        }
+    } else {
+        for (int e = t; e < nS; e += kBlock) S[e] = f.sums[e];
+    }
+    __syncthreads();
+    if (from_sums == 2) {       // split mode, export only: publish local sums and stop
+        for (int e = t; e < nS; e += kBlock) f.sums[e] = S[e];
+        if (t == 0) f.sums[nS] = (double)st->N;
+        return;
+    }
+
+    // ---- 2. assemble [A | B] (:392-413)
+    const double sigma2 = st->sigma2;
+    const double c2 = f.lambda * sigma2, sg = sigma2 * f.lle_weight;
+    for (int e = t; e < M * M; e += kBlock) {
+        const int i = e % M, j = e / M;
+        const double g = f.G[e];
+        double a = S[i] * g + (i == j ? c2 : 0.0);
+        if (f.include_lle) a += sg * f.HG[e];
+        if (f.has_priors) a += f.aJ[i] * g;
+        A[(size_t)j * ld + i] = a;
+    }
+    for (int e = t; e < 3 * M; e += kBlock) {
+        const int i = e % M, d = e / M;
+        double b = S[M + e] - S[i] * f.Y0[e];
+        if (f.include_lle) b -= sg * f.HY0[e];
+        if (f.has_priors) b += f.aYd[e];
+        A[(size_t)(M + d) * ld + i] = b;
+    }
+    for (int i = t; i < M; i += kBlock) used[i] = 0;
+    __syncthreads();
+
+    // ---- 3. Gauss-Jordan elimination with partial pivoting, rows permuted implicitly (:415)
+    int singular = 0;
+    for (int k = 0; k < M; ++k) {
+        // every wave finds the pivot row redundantly (no hand-off needed)
+        double bv = -1.0; int bi = 0x7fffffff;
+        for (int i = lane; i < M; i += 64) {
+            if (!used[i]) {
+                const double v = fabs(A[(size_t)k * ld + i]);
+                if (v > bv) { bv = v; bi = i; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const int p = bi;
+        const double pv = A[(size_t)k * ld + p];
+        if (!(bv > 0.0)) singular = 1;
+        const double rp = (bv > 0.0) ? 1.0 / pv : 0.0;
+        const int ncol = M + 2 - k;          // columns k+1 .. M+2
+        for (int e = t; e < ncol * M; e += kBlock) {
+            const int i = e % M, j = k + 1 + e / M;
+            if (i != p) {
+                const double l = A[(size_t)k * ld + i] * rp;
+                A[(size_t)j * ld + i] -= l * A[(size_t)j * ld + p];
+            }
+        }
+        if (t == 0) { piv[k] = p; used[p] = 1; }
+        __syncthreads();
+    }
+    for (int e = t; e < 3 * M; e += kBlock) {
+        const int k = e % M, d = e / M;
+        const int p = piv[k];
+        W[e] = A[(size_t)(M + d) * ld + p] / A[(size_t)k * ld + p];
+    }
+    __syncthreads();
+
+    // ---- 4. T = Y0 + G W (:417)
+    for (int e = t; e < 3 * M; e += kBlock) {
+        const int i = e % M, d = e / M;
+        double a = 0;
+        for (int k = 0; k < M; ++k) a += f.G[(size_t)k * M + i] * W[d * M + k];
+        Tn[e] = f.Y0[e] + a;
+    }
+    __syncthreads();
+
+    // ---- 5. sigma2 (residual form of :418-422) and the convergence criterion (:424)
+    const V4<T> *nodes = (const V4<T> *)f.nodes;
+    double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
+    for (int m = t; m < M; m += kBlock) {
+        const V4<T> q = nodes[m];
+        const double yx = (double)q.x, yy = (double)q.y, yz = (double)q.z;    // nodes as the E-step saw them
+        const double p1 = S[m];
+        const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
+        const double rx = S[M + m] - p1 * yx, ry = S[2 * M + m] - p1 * yy, rz = S[3 * M + m] - p1 * yz;
+        s_np += p1;
+        s_dr += dx * rx + dy * ry + dz * rz;
+        s_pd += p1 * (dx * dx + dy * dy + dz * dz);
+        const double ex = f.Y[m] - Tn[m], ey = f.Y[M + m] - Tn[M + m], ez = f.Y[2 * M + m] - Tn[2 * M + m];
+        s_cr += ::sqrt(ex * ex + ey * ey + ez * ez);
+    }
+    s_np = block_sum(s_np, scratch);
+    s_dr = block_sum(s_dr, scratch);
+    s_pd = block_sum(s_pd, scratch);
+    s_cr = block_sum(s_cr, scratch);
+    const double new_sigma2 = (S[4 * M] - 2.0 * s_dr + s_pd) / (s_np * 3.0);
+    const double crit = s_cr / (double)M;
+
+    // ---- 6. publish Y, nodes, iteration state
+    V4<T> *nodes_w = (V4<T> *)f.nodes;
+    for (int m = t; m < M; m += kBlock) {
+        V4<T> q; q.x = (T)Tn[m]; q.y = (T)Tn[M + m]; q.z = (T)Tn[2 * M + m]; q.w = (T)f.coord[m];
+        nodes_w[m] = q;
+        f.dminbits[m] = ~0ull;
+    }
+    for (int e = t; e < 3 * M; e += kBlock) {
+        f.Y[e] = Tn[e];
+        f.Yout[e] = Tn[e] + f.ctr[e / M];
+    }
+    if (t == 0) {
+        const int it = st->it + 1;
+        st->it = it; st->crit = crit; st->Np = s_np;
+        const double Nc = st->Nc;
+        const bool finite_ok = (new_sigma2 == new_sigma2) && (fabs(new_sigma2) < 1e300) && (new_sigma2 > 0) && !singular;
+        if (finite_ok) set_iter_consts(f, st, new_sigma2, Nc);
+        else { st->sigma2 = new_sigma2; st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
+        if (crit < f.tol) st->done = 1;                                   // :424-428
+        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int nch_for(int M) { const int c = (M + kChunk - 1) / kChunk; return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }
+
+template <typename T> static size_t estep_lds_bytes(int M) {
+    const int rows = M < kChunk ? M : kChunk;
+    size_t b = sizeof(V4<T>) * (size_t)M + sizeof(V4<T>) * 256 + sizeof(T) * (size_t)((M + 3) & ~3) +
+               sizeof(T) * ((size_t)4 * rows * kPStride + 4) + 16 + 64;
+    const size_t red = 4 * 64 * 4 * sizeof(double) + sizeof(T) * 4;     // block-combine area must fit in the tile area
+    const size_t tile = sizeof(T) * (size_t)4 * rows * kPStride;
+    if (tile < red) b += red - tile;
+    return b;
+}
+template <typename T> static size_t dmin_lds_bytes(int M) {
+    const int rows = M < kChunk ? M : kChunk;
+    return sizeof(T) * (size_t)4 * rows * kPStride;
+}
+size_t mstep_lds_bytes(int M) {
+    const int nS = 4 * M + 1, ld = M | 1;
+    size_t b = sizeof(double) * (size_t)(((nS + 1) & ~1) + 6 * M + 8) + sizeof(int) * 2 * (size_t)M + 16;
+    if (M <= kLdsSolveMaxM) b += sizeof(double) * (size_t)ld * (M + 3);
+    return b;
+}
+
+template <typename K> static hipError_t set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+
+#define TDLO_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+template <typename T> static hipError_t launch_estep_T(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+    const int M = fh[0].M, nch = nch_for(M);
+    const bool vis = fh[0].vis_branch != 0;
+    int gx = 0;
+    for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
+    const dim3 grid(gx, F), block(kBlock);
+    const size_t lds = estep_lds_bytes<T>(M);
+#define TDLO_E(NCH, VIS) do { TDLO_TRY(set_lds(k_estep<T, NCH, VIS>, lds)); hipLaunchKernelGGL((k_estep<T, NCH, VIS>), grid, block, lds, s, fd); } while (0)
+    if (vis) { switch (nch) { case 1: TDLO_E(1, true); break; case 2: TDLO_E(2, true); break; case 4: TDLO_E(4, true); break; default: TDLO_E(8, true); } }
+    else     { switch (nch) { case 1: TDLO_E(1, false); break; case 2: TDLO_E(2, false); break; case 4: TDLO_E(4, false); break; default: TDLO_E(8, false); } }
+#undef TDLO_E
+    return hipGetLastError();
+}
+
+static inline int dmin_blocks(const FrameDev *fh, int F) {
+    int gx = 0;
+    for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
+    return gx < 64 ? gx : 64;
+}
+
+template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+    const int M = fh[0].M, nch = nch_for(M);
+    const int gx = dmin_blocks(fh, F);
+    const dim3 grid(gx, F), block(kBlock);
+    const size_t lds = dmin_lds_bytes<T>(M);
+#define TDLO_D(NCH) do { TDLO_TRY(set_lds(k_dmin<T, NCH>, lds)); hipLaunchKernelGGL((k_dmin<T, NCH>), grid, block, lds, s, fd, gx); } while (0)
+    switch (nch) { case 1: TDLO_D(1); break; case 2: TDLO_D(2); break; case 4: TDLO_D(4); break; default: TDLO_D(8); }
+#undef TDLO_D
+    return hipGetLastError();
+}
+
+template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
+    const int M = fh[0].M;
+    const size_t lds = mstep_lds_bytes(M);
+    if (M <= kLdsSolveMaxM) {
+        TDLO_TRY(set_lds(k_mstep<T, true>, lds));
+        hipLaunchKernelGGL((k_mstep<T, true>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
+    } else {
+        hipLaunchKernelGGL((k_mstep<T, false>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+    int gx = 0;
+    for (int i = 0; i < F; ++i) gx = fh[i].nprune_blocks > gx ? fh[i].nprune_blocks : gx;
+    const bool f64 = fh[0].precision == TDLO_PREC_F64;
+    hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), 0, s, fd);
+    if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(F), dim3(kBlock), 0, s, fd, 0);
+    else hipLaunchKernelGGL((k_setup<float>), dim3(F), dim3(kBlock), 0, s, fd, 0);
+    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), 0, s, fd);
+    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), 0, s, fd);
+    return hipGetLastError();
+}
+
+hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+    const bool f64 = fh[0].precision == TDLO_PREC_F64;
+    if (fh[0].vis_branch) TDLO_TRY(f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s));
+    TDLO_TRY(f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s));
+    TDLO_TRY(f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s));
+    return hipSuccess;
+}
+
+// kind: 0 E-step, 1 dmin, 2 M-step (from block partials), 3 M-step export-only (split), 4 M-step from global sums (split)
+hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int kind, hipStream_t s) {
+    const bool f64 = fh[0].precision == TDLO_PREC_F64;
+    switch (kind) {
+        case 0: return f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s);
+        case 1: return f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s);
+        case 2: return f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s);
+        case 3: return f64 ? launch_mstep_T<double>(fd, fh, F, 2, s) : launch_mstep_T<float>(fd, fh, F, 2, s);
+        case 4: return f64 ? launch_mstep_T<double>(fd, fh, F, 1, s) : launch_mstep_T<float>(fd, fh, F, 1, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_split_setup(const FrameDev *fd, const FrameDev *fh, hipStream_t s) {
+    const bool f64 = fh[0].precision == TDLO_PREC_F64;
+    hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), 0, s, fd);
+    if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(1), dim3(kBlock), 0, s, fd, 1);
+    else hipLaunchKernelGGL((k_setup<float>), dim3(1), dim3(kBlock), 0, s, fd, 1);
+    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), 0, s, fd);
+    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), 0, s, fd);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_set_global(const FrameDev *fd, double Nglob, double Sglob, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_set_global, dim3(1), dim3(64), 0, s, fd, Nglob, Sglob);
+    return hipGetLastError();
+}
+
+int check_device_image() {
+    hipFuncAttributes attr;
+    const hipError_t e = hipFuncGetAttributes(&attr, (const void *)k_prune_pass1);
+    if (e != hipSuccess) fprintf(stderr, "trackdlo_hip: no gfx950 kernel image usable on this device: %s\n", hipGetErrorString(e));
+    return e == hipSuccess ? 0 : -1;
+}
+
+}  // namespace tdlo

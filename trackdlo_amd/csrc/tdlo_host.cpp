@@ -1,0 +1,281 @@
+// tdlo_host.cpp -- host-side (CPU, fp64) pieces of the path that stay on the host by design:
+// they are O(M) .. O(M^2), serial and branchy.
+//
+//   LLE weights            trackdlo/src/trackdlo.cpp:92-159
+//   line/sphere intersect  trackdlo/src/utils.cpp:172-241
+//   traverse_euclidean     trackdlo/src/trackdlo.cpp:584-898
+//
+// Written against the behaviour of those functions, not their text: chain traversal is expressed
+// as one "pursuit" routine parameterised by direction instead of four unrolled copies.
+#include "tdlo_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace tdlo {
+
+// ---------------------------------------------------------------------------------------------
+// LLE weights.  Local Gram matrices are at most 6 x 6; they are inverted by LU with partial
+// pivoting, the algorithm Eigen's dynamic-size inverse()/determinant() use (trackdlo.cpp:136-137).
+// For the 4..6-neighbour rows the Gram matrix of 3-D differences has rank <= 3, so -- exactly as in
+// the reference -- the resulting weights are dominated by rounding noise; callers
+// that need reproducible registrations pass H explicitly.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct SmallLU {
+    int n = 0;
+    double a[36];
+    int perm[6];
+    double det = 1.0;
+
+    void factor(const double *src, int n_) {
+        n = n_;
+        std::memcpy(a, src, sizeof(double) * n * n);
+        det = 1.0;
+        for (int i = 0; i < n; ++i) perm[i] = i;
+        for (int k = 0; k < n; ++k) {
+            int p = k;
+            for (int i = k + 1; i < n; ++i) if (std::fabs(a[i * n + k]) > std::fabs(a[p * n + k])) p = i;
+            if (p != k) {
+                for (int j = 0; j < n; ++j) std::swap(a[k * n + j], a[p * n + j]);
+                std::swap(perm[k], perm[p]);
+                det = -det;
+            }
+            const double piv = a[k * n + k];
+            det *= piv;
+            if (piv == 0.0) continue;
+            for (int i = k + 1; i < n; ++i) {
+                const double l = a[i * n + k] / piv;
+                a[i * n + k] = l;
+                for (int j = k + 1; j < n; ++j) a[i * n + j] -= l * a[k * n + j];
+            }
+        }
+    }
+    // solves A x = b
+    void solve(const double *b, double *x) const {
+        double y[6];
+        for (int i = 0; i < n; ++i) {
+            double s = b[perm[i]];
+            for (int j = 0; j < i; ++j) s -= a[i * n + j] * y[j];
+            y[i] = s;
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < n; ++j) s -= a[i * n + j] * x[j];
+            x[i] = s / a[i * n + i];
+        }
+    }
+};
+
+std::vector<int> chain_neighbours(int half, int M, int idx) {   // trackdlo.cpp:92-117 (truncated at the ends)
+    int first = idx - half, last = idx + half;
+    if (idx - half < 0) first = 0;
+    else if (idx + half >= M) last = M - 1;
+    std::vector<int> out;
+    for (int i = first; i <= last; ++i) if (i != idx) out.push_back(i);
+    return out;
+}
+
+}  // namespace
+
+void lle_weights(int k, const double *Y, int M, double *L) {
+    std::fill(L, L + (size_t)M * M, 0.0);
+    for (int i = 0; i < M; ++i) {
+        const std::vector<int> nb = chain_neighbours(k / 2, M, i);
+        const int n = (int)nb.size();
+        if (n == 0 || n > 6) continue;
+        double gram[36];
+        for (int r = 0; r < n; ++r)
+            for (int s = 0; s < n; ++s) {
+                double acc = 0;
+                for (int d = 0; d < 3; ++d) acc += (Y[d * M + i] - Y[d * M + nb[r]]) * (Y[d * M + i] - Y[d * M + nb[s]]);
+                gram[r * n + s] = acc;
+            }
+        SmallLU lu;
+        lu.factor(gram, n);
+        if (lu.det == 0.0) {                                     // trackdlo.cpp:139-144
+            for (int r = 0; r < n; ++r) gram[r * n + r] += 0.00001;
+            lu.factor(gram, n);
+        }
+        // w = Gi^-1 1 / (1^T Gi^-1 1) (:146-150); Gi^-1 1 is obtained as the solution of Gi w = 1
+        double ones[6] = {1, 1, 1, 1, 1, 1}, w[6];
+        lu.solve(ones, w);
+        double tot = 0;
+        for (int r = 0; r < n; ++r) tot += w[r];
+        for (int r = 0; r < n; ++r) L[(size_t)nb[r] * M + i] = w[r] / tot;
+    }
+}
+
+void lle_regulariser(const double *L, int M, double *H) {        // H = (I-L)^T (I-L), trackdlo.cpp:237
+    std::vector<double> IL((size_t)M * M);
+    for (int j = 0; j < M; ++j)
+        for (int i = 0; i < M; ++i) IL[(size_t)j * M + i] = (i == j ? 1.0 : 0.0) - L[(size_t)j * M + i];
+    for (int j = 0; j < M; ++j)
+        for (int i = 0; i < M; ++i) {
+            double s = 0;
+            for (int k = 0; k < M; ++k) s += IL[(size_t)i * M + k] * IL[(size_t)j * M + k];
+            H[(size_t)j * M + i] = s;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// line segment / sphere intersection, utils.cpp:172-241
+// ---------------------------------------------------------------------------------------------
+static inline double dist(const Vec3 &a, const Vec3 &b) {
+    const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return std::sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+static bool within_box(const Vec3 &p, const Vec3 &a, const Vec3 &b) {   // isBetween, 0.1 mm slack per axis
+    const double tol = 0.0001;
+    const double pv[3] = {p.x, p.y, p.z}, av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+        const bool fwd = (av[i] - tol <= pv[i]) && (pv[i] <= bv[i] + tol);
+        const bool rev = (bv[i] - tol <= pv[i]) && (pv[i] <= av[i] + tol);
+        if (!fwd && !rev) ok = false;
+    }
+    return ok;
+}
+
+int line_sphere(const Vec3 &A, const Vec3 &B, const Vec3 &C, double radius, Vec3 out[2]) {
+    const Vec3 u{B.x - A.x, B.y - A.y, B.z - A.z};
+    const Vec3 w{A.x - C.x, A.y - C.y, A.z - C.z};
+    const double qa = (A.x - B.x) * (A.x - B.x) + (A.y - B.y) * (A.y - B.y) + (A.z - B.z) * (A.z - B.z);
+    const double qb = 2 * (u.x * w.x + u.y * w.y + u.z * w.z);
+    const double qc = (w.x * w.x + w.y * w.y + w.z * w.z) - radius * radius;
+    const double disc = qb * qb - 4 * qa * qc;
+    int n = 0;
+    if (disc < 0) return 0;
+    auto at = [&](double s) { return Vec3{A.x + s * u.x, A.y + s * u.y, A.z + s * u.z}; };
+    if (disc > 0) {
+        const double r = std::sqrt(disc);
+        const Vec3 p1 = at((-qb + r) / (2 * qa)), p2 = at((-qb - r) / (2 * qa));
+        if (within_box(p1, A, B)) out[n++] = p1;
+        if (within_box(p2, A, B)) out[n++] = p2;
+    } else {
+        const Vec3 p1 = at(-qb / (2 * qa));
+        if (within_box(p1, A, B)) out[n++] = p1;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// traverse_euclidean, trackdlo.cpp:584-898: re-space the registered guide nodes at the original
+// inter-node arc lengths by repeatedly intersecting a sphere (radius = next arc length) with the
+// guide polyline ("pure pursuit"), starting from the head (0), the tail (1) or a middle node (2).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Pursuit {
+    const double *guide; int Mg;
+    Vec3 centre;
+    int last_found;
+    bool oob = false;
+
+    Vec3 row(int i) const { return Vec3{guide[i], guide[Mg + i], guide[2 * Mg + i]}; }
+
+    // Scans segments (i, i+dir) from last_found while `more(i)`; accepts the first usable hit.
+    template <class More> bool step(int dir, double look, More more, Vec3 &hit) {
+        for (int i = last_found; more(i); i += dir) {
+            const int j = i + dir;
+            if (i < 0 || i >= Mg || j < 0 || j >= Mg) { oob = true; return false; }
+            const Vec3 a = row(i), b = row(j);
+            Vec3 cand[2];
+            const int n = line_sphere(a, b, centre, look, cand);
+            if (n == 0) continue;
+            if (n == 1 && dist(cand[0], b) > dist(centre, b)) continue;      // lone hit behind us
+            last_found = i;
+            hit = (n == 2 && !(dist(cand[0], b) <= dist(cand[1], b))) ? cand[1] : cand[0];
+            centre = hit;
+            return true;
+        }
+        return false;
+    }
+};
+
+inline void push_pair(std::vector<double> &out, int idx, const Vec3 &p) {
+    out.push_back((double)idx); out.push_back(p.x); out.push_back(p.y); out.push_back(p.z);
+}
+
+}  // namespace
+
+int traverse_euclidean(const std::vector<double> &coord, const double *guide, int Mg,
+                       const std::vector<int> &vis, int alignment, int anchor, std::vector<double> &out) {
+    out.clear();
+    const int nvis = (int)vis.size(), ncoord = (int)coord.size();
+    if (nvis <= 0 || Mg <= 0) return -1;
+    Pursuit pu{guide, Mg, Vec3{0, 0, 0}, 0};
+    if (Mg == 1) { push_pair(out, vis[0], pu.row(0)); return 1; }               // :590-595
+    Vec3 hit{0, 0, 0};
+
+    if (alignment == 0) {                                                        // head -> tail, :597-671
+        pu.centre = pu.row(0);
+        push_pair(out, vis[0], pu.centre);
+        int run = 0;                                   // leading run of visible nodes 0,1,2,...
+        while (run < nvis && vis[run] == run) ++run;
+        if (run == 0) return -1;                       // reference: size()-1 wraps, out-of-bounds reads
+        pu.last_found = 0;
+        int seg = 0;
+        while (pu.last_found + 1 <= run - 1 && seg + 1 <= ncoord - 1) {
+            const double look = std::fabs(coord[seg + 1] - coord[seg]);
+            if (!pu.step(+1, look, [&](int i) { return i + 1 <= run - 1; }, hit)) break;
+            push_pair(out, ++seg, hit);
+        }
+    } else if (alignment == 1) {                                                 // tail -> head, :672-748
+        pu.centre = pu.row(Mg - 1);
+        push_pair(out, vis[nvis - 1], pu.centre);
+        int run = 0;                                   // trailing run ..., ncoord-2, ncoord-1
+        while (run < nvis && vis[nvis - 1 - run] == ncoord - 1 - run) ++run;
+        pu.last_found = Mg - 1;
+        int seg = ncoord - 1;
+        const long long floor_row = (long long)Mg - run;     // lowest guide row that belongs to the run
+        // the reference compares (size_t)(last_found-1) >= Mg-run: a wrapped -1 passes, then the
+        // inner scan is empty and the loop ends -- same outcome as stopping here.
+        while ((pu.last_found - 1 >= floor_row || pu.last_found - 1 < 0) && seg - 1 >= 0) {
+            const double look = std::fabs(coord[seg] - coord[seg - 1]);
+            if (!pu.step(-1, look, [&](int i) { return (long long)i >= floor_row + 1; }, hit)) break;
+            push_pair(out, --seg, hit);
+        }
+    } else {                                                                     // from a middle anchor, :749-895
+        if (anchor < 0 || anchor >= nvis || anchor >= Mg) return -1;
+        pu.centre = pu.row(anchor);
+        push_pair(out, vis[anchor], pu.centre);
+        int fwd = 1;                                   // consecutive run starting at the anchor
+        while (anchor + fwd < nvis && vis[anchor + fwd] - vis[anchor + fwd - 1] == 1) ++fwd;
+        pu.last_found = anchor;
+        int seg = vis[anchor];
+        while (pu.last_found + 1 <= anchor + fwd - 1 && seg + 1 <= ncoord - 1) {
+            const double look = std::fabs(coord[seg + 1] - coord[seg]);
+            if (!pu.step(+1, look, [&](int i) { return i + 1 <= anchor + fwd - 1; }, hit)) break;
+            push_pair(out, ++seg, hit);
+        }
+        // Head-ward part.  The reference counts this run with a loop that walks TOWARDS THE TAIL
+        // (its index is incremented, :828) and stops at the first non-consecutive pair; reading past
+        // the end of visible_nodes is undefined there and is taken as "stop" here.  The resulting
+        // count enters an unsigned comparison (:842): when it exceeds the anchor index the
+        // subtraction wraps and the head-ward pursuit is skipped altogether.
+        int back = 1;
+        if (anchor - 1 >= 0)
+            for (int i = anchor - 1; i + 1 < nvis && vis[i + 1] - vis[i] == 1; ++i) ++back;
+        pu.last_found = anchor;
+        seg = vis[anchor];
+        pu.centre = pu.row(anchor);
+        const bool wraps = back > anchor;              // (size_t)(anchor - back) is astronomically large
+        auto gate = [&]() {
+            if (wraps) return pu.last_found - 1 < 0;   // only a wrapped left-hand side can pass
+            return pu.last_found - 1 < 0 || pu.last_found - 1 >= anchor - back;
+        };
+        while (gate() && seg - 1 >= 0) {
+            const double look = std::fabs(coord[seg] - coord[seg - 1]);
+            if (!pu.step(-1, look, [&](int i) { return i - 1 >= 0; }, hit)) break;
+            push_pair(out, --seg, hit);
+        }
+    }
+    if (pu.oob) return -1;
+    return (int)(out.size() / 4);
+}
+
+}  // namespace tdlo

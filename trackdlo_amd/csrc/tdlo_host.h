@@ -1,0 +1,20 @@
+// tdlo_host.h -- host-side helpers of the path (see tdlo_host.cpp).
+#pragma once
+#include <vector>
+
+namespace tdlo {
+
+struct Vec3 { double x, y, z; };
+
+// trackdlo::calc_LLE_weights (trackdlo.cpp:119-159); Y is M x 3 column-major, L is M x M column-major.
+void lle_weights(int k, const double *Y, int M, double *L);
+// H = (I - L)^T (I - L) (trackdlo.cpp:237)
+void lle_regulariser(const double *L, int M, double *H);
+// line_sphere_intersection (utils.cpp:185-241)
+int line_sphere(const Vec3 &A, const Vec3 &B, const Vec3 &C, double radius, Vec3 out[2]);
+// trackdlo::traverse_euclidean (trackdlo.cpp:584-898); out receives rows [idx, x, y, z].
+// Returns the number of rows or -1 where the reference would index out of bounds.
+int traverse_euclidean(const std::vector<double> &coord, const double *guide, int Mg,
+                       const std::vector<int> &vis, int alignment, int anchor, std::vector<double> &out);
+
+}  // namespace tdlo

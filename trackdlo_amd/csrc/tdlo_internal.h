@@ -1,0 +1,75 @@
+// tdlo_internal.h -- structures shared by the host driver and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tdlo {
+
+constexpr int kBlock = 256;          // workgroup size of the point-parallel kernels (4 wave64)
+constexpr int kWave = 64;
+constexpr int kChunk = 64;           // nodes handled per lane-transposed tile
+constexpr int kPStride = 65;         // LDS row stride of the 64 x 64 transposition tile (conflict-free)
+constexpr int kMaxNodes = 512;       // E-step template covers ceil(M/64) in {1,2,4,8}
+constexpr int kLdsSolveMaxM = 128;   // M-step keeps [A|B] in LDS up to this M
+
+// Mutable per-iteration state of one registration, device resident (trackdlo.cpp:275-438 loop state).
+struct IterState {
+    double sigma2;      // current sigma2
+    double k2;          // -log2(e) / (2 sigma2): membership exponent scale (:354)
+    double c_norm;      // denominator constant c (:300) or c' (:378) for the current sigma2 and N
+    double crit;        // last value of sum_m |dY_m| / M (:424)
+    double Np;          // last Np (:388)
+    double sum_d2;      // sum over kept points and nodes of |Y0_m - x_n|^2 (:263-273)
+    double Nc;          // N used in the denominator constant c (global N when the cloud is split)
+    int N;              // points kept by the prune (:195)
+    int it;             // iterations completed
+    int done;           // 1: remaining kernels of the loop are no-ops
+    int converged;      // value cpd_lle returns (:440)
+    int status;         // 0 or TDLO_E_*
+    int pad;
+};
+
+// Immutable-after-setup description of one frame's registration.
+struct FrameDev {
+    // sizes / parameters (trackdlo.h:80-94)
+    int N0, M, ldx, nblkE;
+    int max_iter, include_lle, has_priors, vis_branch;
+    int precision, nprune_blocks, pad0, pad1;
+    double tol, beta, lambda, lle_weight, mu, alpha, k_vis, vis_thr, sigma2_in;
+    // cloud
+    const double *Xraw;     // N0 x 3 column-major as uploaded
+    void *Xs;               // pruned, centred SoA in compute precision: x[ldx] y[ldx] z[ldx]
+    unsigned char *keep;    // N0
+    int *blkcnt;            // per prune block kept count -> exclusive offsets after setup
+    double *blksum;         // per prune block sum of d2 over kept points
+    // nodes
+    const double *Yin;      // M x 3 as given by the caller
+    double *ctr;            // 3: centring offset (centroid of Yin)
+    double *Y;              // M x 3 centred, current (fp64)
+    double *Y0;             // M x 3 centred, start of call
+    void *nodes;            // M x {x,y,z,coord} in compute precision (float4 / double4)
+    double *coord;          // M cumulative arc length (:214-223)
+    double *G;              // M x M kernel (:233)
+    const double *H;        // M x M LLE regulariser (host supplied) or nullptr
+    double *HG;             // M x M  H*G   (include_lle)
+    double *HY0;            // M x 3  H*Yin (include_lle)
+    const double *aJ;       // M: alpha * J_mm (:240-260, :406)
+    const double *aYd;      // M x 3: alpha * (Y_extended - Y0) (:407)
+    unsigned long long *dminbits;  // M: per-node min squared distance, as ordered bits
+    double *part;           // nblkE x (4M+1) block partials [P1 | PXx | PXy | PXz | Q]
+    double *sums;           // 4M+2 reduced sums (N-split interface)
+    double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
+    double *Yout;           // M x 3 uncentred result
+    IterState *st;
+};
+
+// launchers implemented in tdlo_device.hip
+hipError_t launch_prune_and_setup(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
+hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
+hipError_t launch_estep_only(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int kind, hipStream_t s);
+hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames_host, hipStream_t s);
+hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
+size_t mstep_lds_bytes(int M);
+int check_device_image();
+
+}  // namespace tdlo
