@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""bench.py -- EM iterations/s of TrackDLO's registration loop on MI355X (BASELINE.json metric).
+
+Workload at N=1 (BASELINE.json configs[1], "C2"): ONE frame, N = 50 000 cloud points, M = 50 nodes,
+50 EM iterations with tol = 0 (so exactly 50 run), launch/trackdlo.launch parameter values, fp32
+E-step + fp64 M-step.  A "step" is one complete trackdlo::cpd_lle call (trackdlo.cpp:161-441: prune,
+setup, 50 iterations, read-back of Y / sigma2) on a cloud that is already resident in HBM.
+    value = steps * frames * 50 / wall time         [EM iterations / s, whole job, all ranks]
+With --gpus N (torch.distributed.run, one rank per GPU, RCCL only for the barrier and the max-over-ranks
+of the time) every rank registers its own frame(s): frames are independent, so scaling is "weak" and
+there is no data-path collective (BASELINE.json configs[2]).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel (the fused E-step): algorithmic bytes per launch (3 * 4 B * N, one read of
+               the cloud) / its HIP-event average launch time vs the 8 TB/s HBM peak
+  cpu_baseline the CPU oracle (a plain-C port of the reference loop; the reference's own Eigen build
+               cannot be produced here) timed on this box's host, single thread like the reference
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS, M_NODES, EM_ITERS = 50000, 50, 50
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=1, help="independent frames registered concurrently per rank (C2: 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-repeats", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    F = args.frames
+    ctx = B.Context(device=local_rank, max_frames=F, max_points=N_POINTS, max_nodes=M_NODES)   # raises without a GPU
+    params = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
+                           alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
+    Ys = []
+    for f in range(F):
+        X, Y0, _ = synth.scene(N_POINTS, M_NODES, config=2, frame=rank * F + f)
+        ctx.set_cloud(f, X)                      # inputs resident in HBM before the timed region
+        Ys.append(Y0)
+    X0, Y00, _ = synth.scene(N_POINTS, M_NODES, config=2, frame=rank * F)
+
+    def step():
+        if F == 1:
+            return ctx.cpd_lle_resident(0, Ys[0], 0.0, params)
+        return ctx.cpd_lle_batch(Ys, [0.0] * F, params)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    loop_ms = 0.0
+    for _ in range(args.steps):
+        r = step()
+        loop_ms += (r["loop_ms"] if F == 1 else r["stats"][0]["loop_ms"])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    iters_total = args.steps * F * EM_ITERS * world
+    value = iters_total / dt
+
+    out = None
+    if rank == 0:
+        # ---- dominant kernel: fused E-step, HIP-event average over back-to-back launches on the ctx stream
+        ctx.cpd_lle_resident(0, Ys[0], 0.0, params) if F == 1 else ctx.cpd_lle_batch(Ys, [0.0] * F, params)
+        est_us = ctx.profile_kernel(0, 300)
+        mst_us = ctx.profile_kernel(2, 100)
+        alg_bytes = 3 * 4 * N_POINTS * F
+        achieved = alg_bytes / (est_us * 1e-6) / 1e9
+        roof = dict(bound="hbm", kernel="k_estep<float,1,false>", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, avg_launch_us=round(est_us, 3),
+                    algorithmic_bytes_per_launch=alg_bytes, mstep_avg_launch_us=round(mst_us, 3),
+                    note="E-step is VALU/latency-bound at this size (about 100 flop per byte); HBM fraction reported as the metric requires")
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ref_cpu
+            kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
+                      include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+            rates = []
+            o = None
+            for _ in range(args.cpu_repeats):
+                o = ref_cpu.cpd_lle(X0, Y00, 0.0, **kw)
+                rates.append(o["iters"] / o["loop_seconds"])
+            g = ctx.cpd_lle_resident(0, Ys[0], 0.0, params) if F == 1 else None
+            cpu = dict(value=round(float(np.median(rates)), 3), unit="EM iterations/s", cores=1, kind="port",
+                       sample=f"the full C2 workload (N={N_POINTS}, M={M_NODES}, {EM_ITERS} iterations), median of {args.cpu_repeats} runs of the loop body",
+                       note="oracle/ref_cpu.c: plain-C fp64 restatement of trackdlo.cpp:275-438, -O3, single thread like the reference")
+            if g is not None:
+                cpu["max_abs_dY_vs_gpu_m"] = float(np.abs(g["Y"] - o["Y"]).max())
+        out = dict(metric="EM iterations/sec at N=50k cloud pts, M=50 nodes", value=round(value, 2), unit="EM iterations/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt * 1e3 / args.steps, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"C2: {F} frame(s) per GPU, N={N_POINTS} points, M={M_NODES} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, trackdlo.launch parameters, fp32 E-step + fp64 M-step",
+                               frames_per_gpu=F, parallelism=f"frames sharded, {world} rank(s), no data-path collective"),
+                   frames_per_s=round(args.steps * F * world / dt, 2),
+                   em_loop_only_iters_per_s=round(args.steps * F * EM_ITERS / (loop_ms * 1e-3), 2),
+                   roofline=roof, cpu_baseline=cpu)
+        if cpu:
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

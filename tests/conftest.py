@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import ref_cpu
+    ref_cpu.lib()
+    return ref_cpu
+
+
+@pytest.fixture(scope="session")
+def hip_ctx():
+    """A context on cuda:0.  No skip and no fallback: on a box without the built library or without a
+    gfx950 device this raises, so a GPU run can never pass on a silent CPU path."""
+    from trackdlo_amd import binding
+    ctx = binding.Context(device=0, max_frames=8, max_points=1 << 16, max_nodes=64)
+    yield ctx
+    ctx.close()
+
+
+def load_cases(name="oracle_cases.npz"):
+    z = np.load(os.path.join(GOLDEN, name))
+    cases = {}
+    for k in z.files:
+        c, f = k.split("__", 1)
+        cases.setdefault(c, {})[f] = z[k]
+    return cases
+
+
+def case_kwargs(c):
+    kw = {k[3:]: float(v) for k, v in c.items() if k.startswith("kw_")}
+    kw["max_iter"] = int(kw["max_iter"]); kw["include_lle"] = bool(kw["include_lle"])
+    return kw

@@ -1,0 +1,307 @@
+"""GPU suite: the HIP path (through the C ABI, include/trackdlo_hip.h) against the CPU oracle.
+
+Stated tolerances, after an equal, fixed number of EM iterations:
+  TDLO_PREC_F32 (fp32 E-step, fp64 M-step):  max |dY| <= 1e-5 m,  |d sigma2| / sigma2 <= 1e-3
+  TDLO_PREC_F64:                              max |dY| <= 1e-9 m,  |d sigma2| / sigma2 <= 1e-7
+Iteration counts, the converged flag and the kept-point count must match exactly.
+"""
+import numpy as np
+import pytest
+
+from conftest import case_kwargs, load_cases
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: (1e-5, 1e-3), 1: (1e-9, 1e-7)}
+
+
+def _params(kw, prec):
+    from trackdlo_amd import binding as B
+    return B.make_params(kw["beta"], kw["lambda_"], kw["lle_weight"], kw["mu"], kw["max_iter"], kw["tol"], kw["include_lle"],
+                         kw["alpha"], kw["k_vis"], kw["visibility_threshold"], prec)
+
+
+def _check(g, o, prec):
+    ty, ts = TOL[prec]
+    assert g["rc"] == 0
+    assert g["iters"] == o["iters"] and g["converged"] == o["converged"] and g["n_kept"] == o["n_kept"]
+    assert np.abs(g["Y"] - o["Y"]).max() <= ty
+    assert abs(g["sigma2"] - o["sigma2"]) <= ts * o["sigma2"]
+
+
+CASES = sorted(load_cases())
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+@pytest.mark.parametrize("name", CASES)
+def test_committed_golden_cases(hip_ctx, name, prec):
+    """HIP vs the committed per-branch fixtures (tests/golden/oracle_cases.npz)."""
+    c = load_cases()[name]
+    kw = case_kwargs(c)
+    g = hip_ctx.cpd_lle(c["X"], c["Y0"], float(c["sigma2_in"]), _params(kw, prec), priors=c.get("priors"),
+                        visible_nodes=c.get("vis"), H=c.get("H"))
+    o = dict(Y=c["Y"], sigma2=float(c["sigma2"]), iters=int(c["iters"]), converged=bool(c["converged"]), n_kept=int(c["n_kept"]))
+    _check(g, o, prec)
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_per_iteration_trajectory(hip_ctx, prec):
+    """The whole trajectory is pinned, not just the end point: max_iter = 1..6 against the dumped Y / sigma2."""
+    for name in ("plain", "vis_priors", "lle"):
+        c = load_cases()[name]
+        kw = case_kwargs(c)
+        for it in range(1, int(c["iters"]) + 1):
+            kw["max_iter"] = it
+            g = hip_ctx.cpd_lle(c["X"], c["Y0"], float(c["sigma2_in"]), _params(kw, prec), priors=c.get("priors"),
+                                visible_nodes=c.get("vis"), H=c.get("H"))
+            ty, ts = TOL[prec]
+            assert np.abs(g["Y"] - c["trace_Y"][it - 1]).max() <= ty
+            assert abs(g["sigma2"] - c["trace_sigma2"][it - 1]) <= ts * c["trace_sigma2"][it - 1]
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+@pytest.mark.parametrize("N,M,iters,opts", [
+    (2000, 30, 20, {}),                                    # BASELINE.json configs[0] (C1)
+    (2000, 30, 20, dict(vis=True)),
+    (2000, 30, 20, dict(priors=True)),
+    (2000, 30, 20, dict(vis=True, priors=True, sigma2=1e-4)),
+    (2000, 30, 20, dict(lle=True)),
+    (1999, 45, 10, {}),                                    # ragged: N not a multiple of 64, production M
+    (63, 4, 5, {}),                                        # smallest legal chain, less than one wave of points
+    (5000, 64, 6, {}),                                     # exactly one node tile
+    (5000, 65, 6, {}),                                     # first size needing a second node tile
+    (4000, 100, 8, dict(vis=True)),
+    (3000, 130, 4, {}),                                    # M-step leaves LDS (M > 128)
+], ids=lambda v: str(v).replace(" ", ""))
+def test_live_oracle_small(hip_ctx, oracle, N, M, iters, opts, prec):
+    from trackdlo_amd import synth
+    P = synth.LAUNCH_PARAMS
+    vis = opts.get("vis", False)
+    X, Y0, v = synth.scene(N, M, config=40 + M, occlude=(0.4, 0.6) if vis else None, outliers=5)
+    vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0)) if vis else None
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=iters, tol=0.0,
+              include_lle=False, alpha=0.0, k_vis=P["k_vis"] if vis else 0.0, visibility_threshold=P["visibility_threshold"])
+    pri = None; H = None
+    if opts.get("priors"):
+        idx = np.arange(0, M, 3)
+        pri = np.concatenate([idx[:, None].astype(float), Y0[idx] + np.array([0, 0.004, 0.0])], axis=1)
+        kw["alpha"] = P["alpha"]
+    if opts.get("lle"):
+        L = oracle.calc_lle_weights(Y0, 6); H = (np.eye(M) - L).T @ (np.eye(M) - L)
+        kw.update(include_lle=True, beta=P["beta_pre_proc"], lambda_=P["lambda_pre_proc"])
+    s2 = opts.get("sigma2", 0.0)
+    o = oracle.cpd_lle(X, Y0, s2, priors=pri, visible_nodes=vext, H=H, **kw)
+    g = hip_ctx.cpd_lle(X, Y0, s2, _params(kw, prec), priors=pri, visible_nodes=vext, H=H)
+    _check(g, o, prec)
+
+
+def test_c2_full_size_against_oracle(hip_ctx, oracle):
+    """BASELINE.json configs[1]: N = 50 000, M = 50, 50 EM iterations, fp32 E-step, tolerance-checked."""
+    from trackdlo_amd import synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, _ = synth.scene(50000, 50, config=2)
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=50, tol=0.0, include_lle=False,
+              alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+    o = oracle.cpd_lle(X, Y0, 0.0, **kw)
+    g = hip_ctx.cpd_lle(X, Y0, 0.0, _params(kw, 0))
+    _check(g, o, 0)
+    # production stopping rule (tol = 2e-4): same iteration count and flag
+    kw["tol"] = P["tol"]
+    o = oracle.cpd_lle(X, Y0, 0.0, **kw)
+    g = hip_ctx.cpd_lle(X, Y0, 0.0, _params(kw, 0))
+    _check(g, o, 0)
+    assert g["converged"]
+
+
+def test_early_exit_and_max_iter_flags(hip_ctx, oracle):
+    from trackdlo_amd import synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, _ = synth.scene(3000, 30, config=7)
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=50, tol=P["tol"], include_lle=False,
+              alpha=0.0, k_vis=0.0, visibility_threshold=0.01)
+    o = oracle.cpd_lle(X, Y0, 0.0, **kw)
+    g = hip_ctx.cpd_lle(X, Y0, 0.0, _params(kw, 0))
+    assert o["converged"] and g["converged"] and g["iters"] == o["iters"] < 50
+    kw["max_iter"] = 3                       # reached without convergence -> cpd_lle returns false (:433-437)
+    o = oracle.cpd_lle(X, Y0, 0.0, **kw)
+    g = hip_ctx.cpd_lle(X, Y0, 0.0, _params(kw, 0))
+    assert (not o["converged"]) and (not g["converged"]) and g["iters"] == 3
+
+
+def test_error_paths(hip_ctx):
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, _ = synth.scene(500, 10, config=8)
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 5, 0.0, False)
+    # every point pruned: nothing within 0.1 m of any node
+    g = hip_ctx.cpd_lle(X + np.array([0, 0, 5.0]), Y0, 0.0, pr, check=False)
+    assert g["rc"] == B.TDLO_E_EMPTY
+    np.testing.assert_array_equal(g["Y"], Y0)                 # Y untouched
+    # M < 4 is undefined in the reference (clamps at :313-321) -> rejected
+    g = hip_ctx.cpd_lle(X, Y0[:3], 0.0, pr, check=False)
+    assert g["rc"] == B.TDLO_E_INVALID
+    with pytest.raises(B.TdloError):
+        hip_ctx.cpd_lle(X, Y0, 0.0, pr, priors=[[99, 0, 0, 0]])
+    # the context stays usable after errors
+    g = hip_ctx.cpd_lle(X, Y0, 0.0, pr)
+    assert g["rc"] == 0 and g["iters"] == 5
+
+
+def test_bitwise_repeatable(hip_ctx):
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, v = synth.scene(20000, 50, config=9, occlude=(0.3, 0.5))
+    vext = synth.extend_visible(v, 50, synth.geodesic_coord(Y0))
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 15, 0.0, False, 0.0, P["k_vis"], P["visibility_threshold"])
+    a = hip_ctx.cpd_lle(X, Y0, 0.0, pr, visible_nodes=vext)
+    b = hip_ctx.cpd_lle(X, Y0, 0.0, pr, visible_nodes=vext)
+    np.testing.assert_array_equal(a["Y"], b["Y"])
+    assert a["sigma2"] == b["sigma2"]
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_full_size_invariances(hip_ctx, prec):
+    """Size-independent properties at N = 200 000 (oracle would take minutes): the registration is
+    invariant under a permutation of the cloud and equivariant under a rigid translation."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 200000, 50
+    X, Y0, _ = synth.scene(N, M, config=4)
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 10, 0.0, False, precision=prec)
+    a = hip_ctx.cpd_lle(X, Y0, 0.0, pr)
+    perm = np.random.default_rng(1).permutation(N)
+    b = hip_ctx.cpd_lle(X[perm], Y0, 0.0, pr)
+    ty, ts = TOL[prec]
+    assert np.abs(a["Y"] - b["Y"]).max() <= ty * 0.1
+    assert abs(a["sigma2"] - b["sigma2"]) <= ts * a["sigma2"]
+    sh = np.array([0.25, -0.125, 0.5])        # exactly representable shift
+    c = hip_ctx.cpd_lle(X + sh, Y0 + sh, 0.0, pr)
+    assert np.abs((c["Y"] - sh) - a["Y"]).max() <= ty
+    assert abs(c["sigma2"] - a["sigma2"]) <= ts * a["sigma2"]
+    assert a["n_kept"] == N and a["iters"] == 10
+
+
+def test_batch_equals_single(hip_ctx):
+    """BASELINE.json configs[2] per GPU: frames registered concurrently give exactly the single-frame results."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    F, N, M = 6, 8000, 50
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 12, 0.0, False)
+    Xs, Ys = [], []
+    for f in range(F):
+        X, Y0, _ = synth.scene(N - 37 * f, M, config=3, frame=f)       # ragged frame sizes
+        Xs.append(X); Ys.append(Y0)
+    single = [hip_ctx.cpd_lle(Xs[f], Ys[f], 0.0, pr) for f in range(F)]
+    for f in range(F):
+        hip_ctx.set_cloud(f, Xs[f])
+    out = hip_ctx.cpd_lle_batch(Ys, [0.0] * F, pr)
+    for f in range(F):
+        np.testing.assert_array_equal(out["Y"][f], single[f]["Y"])
+        assert out["sigma2"][f] == single[f]["sigma2"]
+        assert out["stats"][f]["iters"] == 12 and out["stats"][f]["n_kept"] == single[f]["n_kept"]
+
+
+def test_nsplit_single_rank_equals_plain(hip_ctx):
+    """The N-split entry points with one rank (identity collectives) reproduce the plain call."""
+    from trackdlo_amd import binding as B, nsplit, synth
+    P = synth.LAUNCH_PARAMS
+
+    class Identity:
+        def all_reduce_sum(self, a): return np.array(a, dtype=np.float64)
+        def all_reduce_min(self, a): return np.array(a, dtype=np.float64)
+
+    for vis in (False, True):
+        X, Y0, v = synth.scene(6000, 40, config=6, occlude=(0.4, 0.6) if vis else None, outliers=11)
+        vext = synth.extend_visible(v, 40, synth.geodesic_coord(Y0)) if vis else None
+        pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 10, 0.0, False, 0.0, P["k_vis"] if vis else 0.0,
+                           P["visibility_threshold"])
+        a = hip_ctx.cpd_lle(X, Y0, 0.0, pr, visible_nodes=vext)
+        b = nsplit.cpd_lle_nsplit(nsplit.HipShard(hip_ctx, X), Identity(), Y0, 0.0, pr, visible_nodes=vext)
+        assert np.abs(a["Y"] - b["Y"]).max() <= 1e-12
+        assert abs(a["sigma2"] - b["sigma2"]) <= 1e-12 * a["sigma2"]
+        assert b["iters"] == 10 and b["n_kept"] == a["n_kept"]
+
+
+def test_nsplit_two_shards_on_one_gpu(hip_ctx, oracle):
+    """Two shards (two contexts on the same GPU) exchanging sums through the N-split driver equal the oracle."""
+    import threading, queue
+    from trackdlo_amd import binding as B, nsplit, synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, v = synth.scene(9000, 40, config=12, occlude=(0.4, 0.6))
+    vext = synth.extend_visible(v, 40, synth.geodesic_coord(Y0))
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 8, 0.0, False, 0.0, P["k_vis"], P["visibility_threshold"])
+
+    class Pair:      # in-process 2-rank "communicator"
+        def __init__(self):
+            self.b = threading.Barrier(2); self.slots = [None, None]
+        def comm(self, rank):
+            outer = self
+            class C_:
+                def _x(self, a, op):
+                    outer.slots[rank] = np.array(a, dtype=np.float64); outer.b.wait()
+                    r = op(outer.slots[0], outer.slots[1]); outer.b.wait(); return r
+                def all_reduce_sum(self, a): return self._x(a, np.add)
+                def all_reduce_min(self, a): return self._x(a, np.minimum)
+            return C_()
+
+    pair = Pair(); res = queue.Queue()
+    ctxs = [hip_ctx, B.Context(device=0, max_points=1 << 14, max_nodes=64)]
+    n = X.shape[0]
+
+    def work(r):
+        try:
+            out = nsplit.cpd_lle_nsplit(nsplit.HipShard(ctxs[r], X[r * n // 2:(r + 1) * n // 2]), pair.comm(r), Y0, 0.0, pr,
+                                        visible_nodes=vext)
+            res.put((r, out))
+        except Exception as e:      # pragma: no cover
+            res.put((r, e)); pair.b.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    outs = dict(res.get() for _ in range(2))
+    ctxs[1].close()
+    o = oracle.cpd_lle(X, Y0, 0.0, beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=8, tol=0.0,
+                       include_lle=False, k_vis=P["k_vis"], visibility_threshold=P["visibility_threshold"], visible_nodes=vext)
+    for r in range(2):
+        assert not isinstance(outs[r], Exception), outs[r]
+        assert np.abs(outs[r]["Y"] - o["Y"]).max() <= 1e-5
+        assert abs(outs[r]["sigma2"] - o["sigma2"]) <= 1e-3 * o["sigma2"]
+    np.testing.assert_array_equal(outs[0]["Y"], outs[1]["Y"])
+
+
+@pytest.mark.parametrize("occl", [None, (0.45, 0.5), (0.35, 0.65), (0.0, 0.3), (0.7, 1.0), (0.0, 0.2, 0.8, 1.0)],
+                         ids=["all", "minor", "mid", "head", "tail", "both-ends"])
+def test_tracking_step_against_oracle(hip_ctx, oracle, occl):
+    """trackdlo::tracking_step (trackdlo.cpp:900-999) through the tracker object, all five occlusion states.
+    The pre-processing registration's LLE matrix is injected on both sides (its weights are ill-conditioned)."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M = 30
+    Y0 = synth.nodes(M); coord = synth.geodesic_coord(Y0)
+    if occl is None:
+        X, _, _ = synth.scene(3000, M, config=20); vis = np.arange(M)
+    elif len(occl) == 2:
+        X, _, vis = synth.scene(3000, M, config=20, occlude=occl)
+    else:
+        X, _, _ = synth.scene(3000, M, config=20)
+        s = np.linspace(0, 1, M)
+        vis = np.nonzero((s > occl[1]) & (s < occl[2]))[0].astype(np.int32)
+        d = np.linalg.norm(X[:, None, :] - Y0[None, vis, :], axis=2).min(axis=1)
+        X = np.asfortranarray(X[d < 0.012])
+    vext = synth.extend_visible(vis, M, coord)
+    Lg = oracle.calc_lle_weights(Y0[vext], 6)
+    Hpre = (np.eye(len(vext)) - Lg).T @ (np.eye(len(vext)) - Lg)
+    args = (M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+            P["lambda_pre_proc"], P["lle_weight"])
+    ref = oracle.Tracker(*args); ref.initialize_nodes(Y0); ref.initialize_geodesic_coord(coord)
+    trk = B.trackdlo(*args, ctx=hip_ctx); trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+    for step in range(2):        # two consecutive frames: state (Y_, sigma2_) carries over
+        ref.tracking_step(X, vis, vext, H_pre=Hpre)
+        trk.tracking_step(X, vis, vext, None, 0, 0, H_pre=Hpre)
+        assert trk.last_stats[0]["iters"] == ref.stats_pre.iters and trk.last_stats[1]["iters"] == ref.stats_main.iters
+        np.testing.assert_allclose(trk.get_guide_nodes(), ref.get_guide_nodes(), rtol=0, atol=1e-5)
+        kp, kr = trk.get_correspondence_pairs(), ref.get_correspondence_pairs()
+        assert kp.shape == kr.shape
+        np.testing.assert_allclose(kp, kr, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(trk.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=1e-5)
+        assert abs(trk.get_sigma2() - ref.get_sigma2()) <= 1e-3 * ref.get_sigma2()

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     double *A = LDSA ? (double *)(((uintptr_t)(used + M) + 15) & ~(uintptr_t)15) : f.Ascr;   // ld x (M+3)
 
     // ---- 1. reduce the E-step block partials in a fixed order
-    if (!from_sums) {
+    if (from_sums != 1) {
         const int nb = f.nblkE;
         for (int e = t; e < nS; e += kBlock) {
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
