@@ -196,6 +196,9 @@ int tdlo_traverse_euclidean(const double *geodesic_coord, int n_coord, const dou
  * by the last cpd_lle call on `slot` and returns the HIP-event average per launch (microseconds).
  * kind: 0 = membership/E-step kernel, 1 = per-node min-distance kernel, 2 = M-step kernel. */
 int tdlo_profile_kernel(tdlo_ctx *ctx, int slot, int kind, int reps, float *avg_us);
+/* Development aid: copies the first n (<= 64) shader-clock stamps that the M-step kernel of the last
+ * launch wrote at its phase boundaries (reduce / assemble / eliminate / update / publish). */
+int tdlo_debug_stamps(tdlo_ctx *ctx, int slot, unsigned long long *out, int n);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,16 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from trackdlo_amd import binding as B, synth
+P = synth.LAUNCH_PARAMS
+ctx = B.Context(max_points=1 << 16)
+X, Y0, _ = synth.scene(50000, 50, config=2)
+pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], 50, 0.0, False)
+g = ctx.cpd_lle(X, Y0, 0.0, pr)
+g = ctx.cpd_lle_resident(0, Y0, 0.0, pr)
+print('loop_ms', g['loop_ms'], 'total', g['total_ms'], 'host', g['host_ms'])
+st = ctx.debug_stamps(24).astype(np.int64)
+print('stamps', st[:8] - st[0])
+print('loop wave0 ', st[8:13] - st[8])
+print('loop waveL ', st[16:21] - st[8])
+print('estep', ctx.profile_kernel(0, 300), 'mstep', ctx.profile_kernel(2, 300))

@@ -52,7 +52,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps",
 ]
 
 _lib = None
@@ -108,6 +108,7 @@ def load_library(path: str | None = None):
     lib.tdlo_line_sphere_intersection.argtypes = [vp, vp, vp, cd, vp]
     lib.tdlo_traverse_euclidean.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
     lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
+    lib.tdlo_debug_stamps.argtypes = [vp, ci, vp, ci]
     if path is None:
         _lib = lib
     return lib
@@ -202,6 +203,11 @@ class Context:
         self._chk(self.lib.tdlo_cpd_lle_batch(self.h, F, _ptr(Yb), M, _ptr(s2), C.byref(params), _ptr(pri), K, _ptr(vis), nv,
                                               _ptr(Hm), C.cast(st, C.c_void_p)))
         return dict(Y=[Yb[i].T.copy() for i in range(F)], sigma2=s2, stats=[s.as_dict() for s in st])
+
+    def debug_stamps(self, n=16, slot=0):
+        out = np.zeros(n, dtype=np.uint64)
+        self._chk(self.lib.tdlo_debug_stamps(self.h, slot, _ptr(out), n))
+        return out
 
     def profile_kernel(self, kind, reps=200, slot=0):
         us = C.c_float(0)

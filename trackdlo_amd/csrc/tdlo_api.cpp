@@ -40,7 +40,7 @@ struct NodeCarve {
     // back with one copy.
     size_t Yin, aJ, aYd, H, upload;
     size_t Yout, st, readback;
-    size_t ctr, Y, Y0, nodes, coord, G, HG, HY0, dmin, sums, Ascr, part, total;
+    size_t ctr, Y, Y0, nodes, coord, G, HG, HY0, dmin, sums, dbg, Ascr, part, total;
     explicit NodeCarve(int M) {
         const size_t m = (size_t)M, mm = m * m;
         size_t o = 0;
@@ -48,9 +48,9 @@ struct NodeCarve {
         Yin = take(3 * m); aJ = take(m); aYd = take(3 * m); H = take(mm); upload = o;
         Yout = take(3 * m); st = take((sizeof(IterState) + 7) / 8); readback = o - Yout;
         ctr = take(4); Y = take(3 * m); Y0 = take(3 * m); nodes = take(4 * m); coord = take(m);
-        G = take(mm); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2);
+        G = take(mm); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2); dbg = take(64);
         Ascr = take((size_t)(M | 1) * (m + 3));
-        part = take((size_t)kMaxEstepBlocks * (4 * m + 1));
+        part = take((size_t)kMaxEstepBlocks * (4 * m + 2));
         total = o;
     }
 };
@@ -189,7 +189,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
     f.coord = blk + nc.coord; f.G = blk + nc.G; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
     f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
-    f.part = blk + nc.part; f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout;
+    f.part = blk + nc.part; f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
     f.st = (IterState *)(blk + nc.st);
     return 0;
 }
@@ -517,6 +517,14 @@ int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us
     }
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    return TDLO_OK;
+}
+
+int tdlo_debug_stamps(tdlo_ctx *c, int slot, unsigned long long *out, int n) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || !out || n < 1 || n > 64 || c->fh.empty()) return TDLO_E_INVALID;
+    HIPCHK(c, hipMemcpyAsync(c->pin, c->fh[0].dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out, c->pin, sizeof(unsigned long long) * n);
     return TDLO_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "tdlo_internal.h"
 #include "../../include/trackdlo_hip.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace tdlo {
 
@@ -29,6 +30,13 @@ template <typename T> struct alignas(16) V4 { T x, y, z, w; };
 
 __device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double tmin(double a, double b) { return ::fmin(a, b); }
+
+// Address-space casts.  Pointers reach the kernels through the FrameDev descriptor, so the compiler
+// only sees generic (flat) pointers and would emit flat_load + full waits.  Node data and parameters
+// are never written by the kernel that reads them, so they are read through the constant address
+// space (wave-uniform index => s_load into SGPRs, no VALU/LDS/VMEM cost); the cloud through global.
+#define TDLO_AS_CONST(TYPE, p) ((const __attribute__((address_space(4))) TYPE *)(uintptr_t)(p))
+#define TDLO_AS_GLOBAL(TYPE, p) ((const __attribute__((address_space(1))) TYPE *)(uintptr_t)(p))
 
 template <typename T> struct Num;
 template <> struct Num<float> {
@@ -68,6 +76,9 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     __syncthreads();
     return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
+
+// partial rows written by the E-step have an even stride so that the M-step can fetch them 16 bytes at a time
+__host__ __device__ inline int part_stride(int M) { return 4 * M + 2; }
 
 __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
     // c of trackdlo.cpp:300 (or c' of :378 when visibility weighting is active)
@@ -246,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void k_dmin(const FrameDev *__restrict__ fr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rows = M < kChunk ? M : kChunk;
     T *pb = (T *)smem + (size_t)wave * rows * kPStride;
-    const V4<T> *__restrict__ nodes = (const V4<T> *)f.nodes;
-    const T *__restrict__ xs = (const T *)f.Xs;
+    const auto nodes = TDLO_AS_CONST(V4<T>, f.nodes);
+    const auto xs = TDLO_AS_GLOBAL(T, f.Xs);
     const size_t ld = f.ldx;
     T rmin[NCH];
 #pragma unroll
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_dmin(const FrameDev *__restrict__ fr
         for (int c = 0; c < NCH; ++c) {
             const int m0 = c * kChunk, m1 = min(M, m0 + kChunk);
             for (int m = m0; m < m1; ++m) {
-                const V4<T> q = nodes[m];
+                V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
                 const T dx = x - q.x, dy = y - q.y, dz = z - q.z;
                 const T d2 = dx * dx + dy * dy + dz * dz;
                 pb[(m - m0) * kPStride + lane] = valid ? d2 : Num<T>::inf();
@@ -314,13 +325,12 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
     T *lvL = (T *)(pts + 4 * 64);                                     // M rounded up to 4
     T *pbase = lvL + ((M + 3) & ~3);
     T *pb = pbase + (size_t)wave * rows * kPStride;
-    double *scratch = (double *)(pbase + (size_t)4 * rows * kPStride + 4);   // 8-byte aligned
-    scratch = (double *)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
+    double *scratch = (double *)(pbase + (((size_t)4 * rows * kPStride + 7) & ~(size_t)3));   // 16-byte aligned, stays an LDS pointer
 
-    const V4<T> *__restrict__ nodes = (const V4<T> *)f.nodes;
-    const T *__restrict__ xs = (const T *)f.Xs;
+    const auto nodes = TDLO_AS_CONST(V4<T>, f.nodes);
+    const auto xs = TDLO_AS_GLOBAL(T, f.Xs);
     const size_t ld = f.ldx;
-    for (int m = tid; m < M; m += kBlock) nodesL[m] = nodes[m];
+    for (int m = tid; m < M; m += kBlock) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
     if (VIS) {
         // P_vis rows, :362-372: v_m = exp(-k_vis * dmin_m) / sum, folded into the exponent as log2 v_m
         double tot = 0;
@@ -356,8 +366,9 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
         // ---- nearest node: argmax of the Euclidean membership (:298-310) == argmin of d2, first index
         T best = Num<T>::inf();
         int a = 0;
+#pragma unroll 8
         for (int m = 0; m < M; ++m) {
-            const V4<T> q = nodes[m];
+            V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
             const T dx = x - q.x, dy = y - q.y, dz = z - q.z;
             const T d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < best) { best = d2; a = m; }
@@ -381,8 +392,9 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
 
         // ---- unnormalised membership, column sum, Q (:354-383)
         T sum = 0, qs = 0;
+#pragma unroll 8
         for (int m = 0; m < M; ++m) {
-            const V4<T> q = nodes[m];
+            V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
             T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
             if (VIS) e += lvL[m];
             const T p = Num<T>::exp2(e);
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
             const int m0 = c * kChunk, m1 = min(M, m0 + kChunk);
             if (NCH > 1) {
                 for (int m = m0; m < m1; ++m) {
-                    const V4<T> q = nodes[m];
+                    V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
                     T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
                     if (VIS) e += lvL[m];
                     pb[(m - m0) * kPStride + lane] = Num<T>::exp2(e);
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
     // ---- block partial: sum the 4 waves, write [P1 | PXx | PXy | PXz | Q]
     __syncthreads();
     double *red = (double *)pbase;      // reuse the tile area: 4 waves x 64 lanes x 4 values per chunk
-    double *part = f.part + (size_t)blockIdx.x * (4 * M + 1);
+    double *part = f.part + (size_t)blockIdx.x * part_stride(M);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         red[(wave * 64 + lane) * 4 + 0] = accP[c];
@@ -467,21 +479,22 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     double *W = S + ((nS + 1) & ~1);          // 3M
     double *Tn = W + 3 * M;                   // 3M
     double *scratch = Tn + 3 * M;             // 8
-    int *piv = (int *)(scratch + 8);          // M
-    int *used = piv + M;                      // M
-    double *A = LDSA ? (double *)(((uintptr_t)(used + M) + 15) & ~(uintptr_t)15) : f.Ascr;   // ld x (M+3)
+    int *piv = (int *)(scratch + 8);          // M (rounded to a multiple of 4 ints)
+    int *used = piv + ((M + 3) & ~3);         // M (rounded)
+    double *Alds = (double *)(used + ((M + 3) & ~3));
+    double *A = LDSA ? Alds : f.Ascr;         // ld x (M+3)
 
     // ---- 1. reduce the E-step block partials in a fixed order
     if (from_sums != 1) {
-        const int nb = f.nblkE;
+        const int nb = f.nblkE, nSp = part_stride(M);
         for (int e = t; e < nS; e += kBlock) {
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int b = 0;
             for (; b + 3 < nb; b += 4) {
-                a0 += f.part[(size_t)b * nS + e]; a1 += f.part[(size_t)(b + 1) * nS + e];
-                a2 += f.part[(size_t)(b + 2) * nS + e]; a3 += f.part[(size_t)(b + 3) * nS + e];
+                a0 += f.part[(size_t)b * nSp + e]; a1 += f.part[(size_t)(b + 1) * nSp + e];
+                a2 += f.part[(size_t)(b + 2) * nSp + e]; a3 += f.part[(size_t)(b + 3) * nSp + e];
             }
-            for (; b < nb; ++b) a0 += f.part[(size_t)b * nS + e];
+            for (; b < nb; ++b) a0 += f.part[(size_t)b * nSp + e];
             S[e] = (a0 + a1) + (a2 + a3);
         }
     } else {
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     const V4<T> *nodes = (const V4<T> *)f.nodes;
     double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
     for (int m = t; m < M; m += kBlock) {
-        const V4<T> q = nodes[m];
+        V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
         const double yx = (double)q.x, yy = (double)q.y, yz = (double)q.z;    // nodes as the E-step saw them
         const double p1 = S[m];
         const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
@@ -608,6 +621,258 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// M-step, fast path (M <= 128): [A | B] and G live in LDS; MB threads arranged as
+// (row = t % RS, column slot = t / RS).  Elimination is Gauss-Jordan on [A | B].
+//   * include_lle == 0:  A = c I + D G with D >= 0 diagonal and G symmetric positive definite.
+//     Row scaling does not change Gaussian elimination, so eliminating A without pivoting is the
+//     elimination of the SPD matrix (G + c D^-1) (rows with D_i = 0 stay c e_i): unconditionally
+//     stable, no pivot search.  One barrier per column; the reciprocal of the next pivot is
+//     produced by the thread that updates it, so no division sits between barrier and update.
+//   * include_lle == 1:  A = c I + (D + s H) G is not of that form -> partial pivoting (row
+//     permutation kept implicit), pivot found redundantly by every wave.
+// SINGLE: the frame descriptor arrives by value in the kernarg segment (no pointer chasing).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {     // src_lane must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double fast_rcp(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
+template <typename T, int NW, int MC, bool SINGLE>
+__global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
+    constexpr int MB = NW * 64, NSLOT = NW;
+    const FrameDev &f = SINGLE ? f0 : frames[blockIdx.x];
+    IterState *st = f.st;
+    const int M = f.M, t = threadIdx.x, lane = t & 63;
+    const int slot = __builtin_amdgcn_readfirstlane(t >> 6);      // wave index, wave-uniform
+    const int row = lane;
+    const bool rowok = row < M;
+    const int nS = 4 * M + 1, nSp = part_stride(M), npair = nSp / 2;
+    const int ncol = M + 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *S = (double *)smem;                       // nSp
+    double *W = S + nSp;                              // 3M (+pad)
+    double *Tn = W + ((3 * M + 1) & ~1);              // 3M (+pad)
+    double *red = Tn + ((3 * M + 1) & ~1);            // 8
+    double *colb = red + 8;                           // 2 x 64: pivot column ping-pong
+    double *tmp = colb + 128;                         // 6 x 64: G W slices
+    double *Gs = tmp + 6 * 64;                        // M x M (column-major, ld = M)
+    double *Sg = Gs + (((size_t)M * M + 1) & ~(size_t)1);   // NG x nSp partial-sum groups
+
+#define TDLO_STAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    TDLO_STAMP(0);
+    const auto stg = TDLO_AS_GLOBAL(IterState, st);
+    const int done = stg->done;
+    const auto Gg = TDLO_AS_GLOBAL(double, f.G);
+    // ---- 1. everything that comes from memory is requested up front: block partials (16 B per load,
+    //         NG thread groups striding over the blocks, fixed summation order), G
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int NG = MB / npair;                        // >= 1 for M <= 64
+    const int pe = t % npair, g = t / npair;
+    d2 acc = {0.0, 0.0};
+    if (from_sums != 1 && g < NG) {
+        const auto part = TDLO_AS_GLOBAL(d2, f.part);
+        const int nb = f.nblkE;
+        int b = g;
+        for (; b + 9 * NG < nb; b += 10 * NG) {
+            d2 v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v[u] = part[(size_t)(b + u * NG) * npair + pe];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) acc += v[u];
+        }
+        for (; b < nb; b += NG) acc += part[(size_t)b * npair + pe];
+    }
+    for (int i = t; i < M * M; i += MB) Gs[i] = Gg[i];
+    if (done) return;
+    if (from_sums != 1) { if (g < NG) { Sg[g * nSp + 2 * pe] = acc.x; Sg[g * nSp + 2 * pe + 1] = acc.y; } }
+    TDLO_STAMP(1);
+    __syncthreads();
+    if (from_sums != 1) {
+        for (int i = t; i < nS; i += MB) { double a = 0; for (int q = 0; q < NG; ++q) a += Sg[q * nSp + i]; S[i] = a; }
+    } else {
+        const auto sums = TDLO_AS_GLOBAL(double, f.sums);
+        for (int i = t; i < nS; i += MB) S[i] = sums[i];
+    }
+    __syncthreads();
+    if (from_sums == 2) {       // split mode, export only
+        for (int i = t; i < nS; i += MB) f.sums[i] = S[i];
+        if (t == 0) f.sums[nS] = (double)stg->N;
+        return;
+    }
+
+    // ---- 2. assemble [A | B] (:392-413) straight into registers: wave = column slot, lane = row,
+    //         a[c] = element (row, slot + 8 c)
+    TDLO_STAMP(2);
+    const double sigma2 = stg->sigma2;
+    const double c2 = f.lambda * sigma2, sg = sigma2 * f.lle_weight;
+    const int lle = f.include_lle, pri = f.has_priors;
+    const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
+    double a[MC];
+    {
+        const double p1 = rowok ? S[row] : 0.0;
+        const double aj = (pri && rowok) ? f.aJ[row] : 0.0;
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            const int j = slot + c * NSLOT;           // wave-uniform
+            double v = 0.0;
+            if (rowok && j < M) {
+                const double gv = Gs[(size_t)j * M + row];
+                v = (p1 + aj) * gv + (row == j ? c2 : 0.0);
+                if (lle) v += sg * f.HG[(size_t)j * M + row];
+            } else if (rowok && j < ncol) {
+                const int i = (j - M) * M + row;
+                v = S[M + i] - p1 * Y0g[i];
+                if (lle) v -= sg * f.HY0[i];
+                if (pri) v += f.aYd[i];
+            }
+            a[c] = v;
+        }
+    }
+    if (slot == 0) colb[row] = a[0];                  // column 0 (rows >= M hold 0)
+    __syncthreads();
+
+    // ---- 3. Gauss-Jordan elimination on [A | B], one barrier per column, straight-line code.
+    //   * pivot ROW: the entries a wave needs are exactly those its own lane `pw` holds -> v_readlane
+    //     into SGPRs (an LDS-broadcast version was LDS-bandwidth bound);
+    //   * pivot COLUMN (multipliers): the only data crossing waves, 512 bytes through LDS (ping-pong).
+    // The row operation is division-free: row_i <- (p s) row_i - (a_ik s) row_k, s = 2^-exponent(p): no
+    // reciprocal on the dependency chain.  Eliminated columns keep being updated (straight-line code;
+    // they only feed themselves); each row's pivot entry and accumulated scale are tracked exactly in
+    // `dgv`, and x = b / dgv at the end.
+    //   include_lle == 0: A = c I + D G, D >= 0 diagonal, G SPD.  Row scaling does not change Gaussian
+    //     elimination, so this is the elimination of the SPD matrix G + c D^-1 (rows with D_i = 0 are
+    //     c e_i): stable without pivoting.
+    //   include_lle == 1: A = c I + (D + s H) G has no such structure -> partial pivoting, the row
+    //     permutation stays implicit (`mine`).
+    TDLO_STAMP(3);
+    int singular = 0;
+    int mine = -1;                                    // unknown this row ends up solving
+    double dgv = 1.0;                                 // a(row, mine) times the row's later scalings (exact bookkeeping)
+    unsigned long long usedmask = 0;
+    for (int k = 0; k < M; ++k) {
+        const int cur = (k & 1), nxt = cur ^ 1;
+        const double aik = colb[cur * 64 + row];
+        int pw = k;
+        if (lle) {
+            double bv = (rowok && !((usedmask >> row) & 1ull)) ? fabs(aik) : -1.0;
+            double mx = bv;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+            const unsigned long long hit = __ballot(bv == mx);
+            pw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+            usedmask |= 1ull << pw;
+        }
+        const double pv = readlane_f64(aik, pw);
+        const int e = (__double2hiint(pv) >> 20) & 0x7ff;
+        if (e == 0 || e == 0x7ff) singular = 1;       // zero / denormal / non-finite pivot
+        const double sc = __hiloint2double((2046 - e) << 20, 0);           // 2^-(exponent of pv)
+        const bool self = (row == pw);
+        const double ps = self ? 1.0 : pv * sc;
+        const double ls = self ? 0.0 : aik * sc;
+        dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
+        mine = self ? k : mine;
+        double pr[MC];
+#pragma unroll
+        for (int c = 0; c < MC; ++c) pr[c] = readlane_f64(a[c], pw);
+#pragma unroll
+        for (int c = 0; c < MC; ++c) a[c] = fma(ps, a[c], -(ls * pr[c]));
+        const int kn = k + 1;
+        if (slot == (kn & (NSLOT - 1))) {             // wave-uniform: this wave owns column k+1
+            const int cn = kn / NSLOT;
+            double v = a[0];
+#pragma unroll
+            for (int c = 1; c < MC; ++c) v = (c == cn) ? a[c] : v;
+            colb[nxt * 64 + row] = v;
+        }
+        __syncthreads();
+    }
+    if (rowok && mine >= 0) {                         // x = b / (pivot entry with the row's accumulated scale)
+#pragma unroll
+        for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dgv; }
+    }
+    __syncthreads();
+
+    // ---- 4. T = Y0 + G W (:417): waves 0..5 = (coordinate d, half of the k range), lane = node
+    TDLO_STAMP(4);
+    if (NW >= 6) {
+        if (slot < 6 && rowok) {
+            const int d = slot % 3, ks = slot / 3;
+            double v = 0;
+            for (int k = ks; k < M; k += 2) v += Gs[(size_t)k * M + row] * W[d * M + k];
+            tmp[slot * 64 + row] = v;
+        }
+        __syncthreads();
+        if (slot < 3 && rowok) Tn[slot * M + row] = Y0g[slot * M + row] + (tmp[slot * 64 + row] + tmp[(slot + 3) * 64 + row]);
+    } else {
+        if (slot < 3 && rowok) {
+            double v0 = 0, v1 = 0;
+            for (int k = 0; k + 1 < M; k += 2) { v0 += Gs[(size_t)k * M + row] * W[slot * M + k]; v1 += Gs[(size_t)(k + 1) * M + row] * W[slot * M + k + 1]; }
+            if (M & 1) v0 += Gs[(size_t)(M - 1) * M + row] * W[slot * M + M - 1];
+            Tn[slot * M + row] = Y0g[slot * M + row] + (v0 + v1);
+        }
+    }
+    __syncthreads();
+
+    // ---- 5. sigma2 (residual form of :418-422) and the convergence criterion (:424): waves 0..3 each
+    //         reduce one of the four sums over the nodes
+    TDLO_STAMP(5);
+    if (slot < 4) {
+        double v = 0;
+        if (rowok) {
+            const int m = row;
+            const auto nodes = TDLO_AS_GLOBAL(V4<T>, f.nodes);
+            const auto Yg = TDLO_AS_GLOBAL(double, f.Y);
+            const double yx = (double)nodes[m].x, yy = (double)nodes[m].y, yz = (double)nodes[m].z;   // nodes as the E-step saw them
+            const double p1 = S[m];
+            const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
+            if (slot == 0) v = p1;
+            else if (slot == 1) v = dx * (S[M + m] - p1 * yx) + dy * (S[2 * M + m] - p1 * yy) + dz * (S[3 * M + m] - p1 * yz);
+            else if (slot == 2) v = p1 * (dx * dx + dy * dy + dz * dz);
+            else { const double ex = Yg[m] - Tn[m], ey = Yg[M + m] - Tn[M + m], ez = Yg[2 * M + m] - Tn[2 * M + m]; v = ::sqrt(ex * ex + ey * ey + ez * ez); }
+        }
+        v = wave_sum(v);
+        if (lane == 0) red[slot] = v;
+    }
+    __syncthreads();
+    const double s_np = red[0], s_dr = red[1], s_pd = red[2], s_cr = red[3];
+    const double new_sigma2 = (S[4 * M] - 2.0 * s_dr + s_pd) / (s_np * 3.0);
+    const double crit = s_cr / (double)M;
+
+    // ---- 6. publish Y, nodes, iteration state
+    TDLO_STAMP(6);
+    V4<T> *nodes_w = (V4<T> *)f.nodes;
+    for (int m = t; m < M; m += MB) {
+        V4<T> q; q.x = (T)Tn[m]; q.y = (T)Tn[M + m]; q.z = (T)Tn[2 * M + m]; q.w = (T)f.coord[m];
+        nodes_w[m] = q;
+        f.dminbits[m] = ~0ull;
+    }
+    for (int i = t; i < 3 * M; i += MB) {
+        f.Y[i] = Tn[i];
+        f.Yout[i] = Tn[i] + f.ctr[i / M];
+    }
+    TDLO_STAMP(7);
+    if (t == 0) {
+        const int it = stg->it + 1;
+        st->it = it; st->crit = crit; st->Np = s_np;
+        const double Nc = stg->Nc;
+        const bool finite_ok = (new_sigma2 == new_sigma2) && (fabs(new_sigma2) < 1e300) && (new_sigma2 > 0) && !singular;
+        if (finite_ok) set_iter_consts(f, st, new_sigma2, Nc);
+        else { st->sigma2 = new_sigma2; st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
+        if (crit < f.tol) st->done = 1;                                   // :424-428
+        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -628,7 +893,7 @@ template <typename T> static size_t dmin_lds_bytes(int M) {
 }
 size_t mstep_lds_bytes(int M) {
     const int nS = 4 * M + 1, ld = M | 1;
-    size_t b = sizeof(double) * (size_t)(((nS + 1) & ~1) + 6 * M + 8) + sizeof(int) * 2 * (size_t)M + 16;
+    size_t b = sizeof(double) * (size_t)(((nS + 1) & ~1) + 6 * M + 8) + sizeof(int) * 2 * (size_t)((M + 3) & ~3) + 16;
     if (M <= kLdsSolveMaxM) b += sizeof(double) * (size_t)ld * (M + 3);
     return b;
 }
@@ -671,13 +936,52 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
     return hipGetLastError();
 }
 
+static size_t mstep_fast_lds_bytes(int M, int NW) {
+    const int nSp = part_stride(M), npair = nSp / 2, NG = (NW * 64) / npair;
+    size_t d = (size_t)nSp + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 128 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
+    return d * sizeof(double);
+}
+
+template <typename T, int NW, int MC> static hipError_t launch_mstep_fast(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
+    const size_t lds = mstep_fast_lds_bytes(fh[0].M, NW);
+    if (F == 1) {
+        TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true>, lds));
+        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
+    } else {
+        TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, false>, lds));
+        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, false>), dim3(F), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
+    }
+    return hipGetLastError();
+}
+
+static int mstep_waves() {
+    static int v = 0;
+    if (!v) { const char *e = getenv("TDLO_MSTEP_WAVES"); v = e ? atoi(e) : 8; if (v != 4 && v != 8) v = 8; }
+    return v;
+}
+
 template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
     const int M = fh[0].M;
-    const size_t lds = mstep_lds_bytes(M);
-    if (M <= kLdsSolveMaxM) {
+    if (M <= 64) {
+        if (mstep_waves() == 8) {
+            const int mc = (M + 3 + 7) / 8;           // columns per wave
+            if (mc <= 3) return launch_mstep_fast<T, 8, 3>(fd, fh, F, from_sums, s);
+            if (mc <= 5) return launch_mstep_fast<T, 8, 5>(fd, fh, F, from_sums, s);
+            if (mc <= 7) return launch_mstep_fast<T, 8, 7>(fd, fh, F, from_sums, s);
+            return launch_mstep_fast<T, 8, 9>(fd, fh, F, from_sums, s);
+        } else {
+            const int mc = (M + 3 + 3) / 4;
+            if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
+            if (mc <= 10) return launch_mstep_fast<T, 4, 10>(fd, fh, F, from_sums, s);
+            if (mc <= 14) return launch_mstep_fast<T, 4, 14>(fd, fh, F, from_sums, s);
+            return launch_mstep_fast<T, 4, 17>(fd, fh, F, from_sums, s);
+        }
+    } else if (M <= kLdsSolveMaxM) {
+        const size_t lds = mstep_lds_bytes(M);
         TDLO_TRY(set_lds(k_mstep<T, true>, lds));
         hipLaunchKernelGGL((k_mstep<T, true>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
     } else {
+        const size_t lds = mstep_lds_bytes(M);
         hipLaunchKernelGGL((k_mstep<T, false>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
     }
     return hipGetLastError();

@@ -60,6 +60,7 @@ struct FrameDev {
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
+    unsigned long long *dbg; // 64 shader-clock stamps written by the M-step (tdlo_debug_stamps)
     IterState *st;
 };
 
