@@ -9,8 +9,11 @@ pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], 50, 0.0, F
 g = ctx.cpd_lle(X, Y0, 0.0, pr)
 g = ctx.cpd_lle_resident(0, Y0, 0.0, pr)
 print('loop_ms', g['loop_ms'], 'total', g['total_ms'], 'host', g['host_ms'])
-st = ctx.debug_stamps(24).astype(np.int64)
+st = ctx.debug_stamps(64).astype(np.int64)
+print('estep stamps', st[32:40] - st[32])
 print('stamps', st[:8] - st[0])
-print('loop wave0 ', st[8:13] - st[8])
-print('loop waveL ', st[16:21] - st[8])
+for w in (0,1):
+    for kk in range(4):
+        b = 8 + w*24 + kk*6
+        print('wave',w,'k',16+kk, st[b:b+5] - st[8])
 print('estep', ctx.profile_kernel(0, 300), 'mstep', ctx.profile_kernel(2, 300))

@@ -310,59 +310,87 @@ __device__ __forceinline__ T geo_arg(int m, int lo, int hi, T cm, T c_lo, T d_lo
     return t * t;
 }
 
-template <typename T, int NCH, bool VIS>
-__global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ frames) {
-    const FrameDev &f = frames[blockIdx.y];
-    IterState *st = f.st;
-    if ((int)blockIdx.x >= f.nblkE || st->done) return;
+template <int NW> __device__ __forceinline__ double block_sum_n(double v, double *scratch) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r += scratch[w];
+    return r;
+}
+
+// EB = threads per workgroup (256 or 512); SINGLE: the frame descriptor arrives by value in the
+// kernarg segment (no dependent loads before the first useful one).
+template <typename T, int NCH, bool VIS, int EB, bool SINGLE>
+__global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frames, const FrameDev f0) {
+    constexpr int NWE = EB / 64;
+    const FrameDev &f = SINGLE ? f0 : frames[blockIdx.y];
+    if ((int)blockIdx.x >= f.nblkE) return;
+    const auto stg = TDLO_AS_GLOBAL(IterState, f.st);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = st->N, M = f.M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = f.M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = M < kChunk ? M : kChunk;
+#define TDLO_ESTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); f.dbg[32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    TDLO_ESTAMP(0);
     // LDS carve (every offset a multiple of 16 bytes)
     V4<T> *nodesL = (V4<T> *)smem;                                    // M
-    V4<T> *pts = nodesL + M;                                          // 4 x 64
-    T *lvL = (T *)(pts + 4 * 64);                                     // M rounded up to 4
+    V4<T> *pts = nodesL + M;                                          // NWE x 64
+    T *lvL = (T *)(pts + NWE * 64);                                   // M rounded up to 4
     T *pbase = lvL + ((M + 3) & ~3);
     T *pb = pbase + (size_t)wave * rows * kPStride;
-    double *scratch = (double *)(pbase + (((size_t)4 * rows * kPStride + 7) & ~(size_t)3));   // 16-byte aligned, stays an LDS pointer
+    double *scratch = (double *)(pbase + (((size_t)NWE * rows * kPStride + 7) & ~(size_t)3));   // 16-byte aligned, stays an LDS pointer
 
     const auto nodes = TDLO_AS_CONST(V4<T>, f.nodes);
     const auto xs = TDLO_AS_GLOBAL(T, f.Xs);
     const size_t ld = f.ldx;
-    for (int m = tid; m < M; m += kBlock) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
+    // first wave of loads: iteration state, this wave's first points, nodes for the LDS copy
+    const int done = stg->done;
+    const int N = stg->N;
+    const T k2 = (T)stg->k2;
+    const T cn = (T)stg->c_norm;
+    const int batch0 = blockIdx.x * NWE + wave;
+    T x = 0, y = 0, z = 0;
+    {
+        const int n = batch0 * 64 + lane;
+        if (n < f.N0) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }     // N <= N0: always in bounds
+    }
+    for (int m = tid; m < M; m += EB) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
+    if (done) return;
     if (VIS) {
         // P_vis rows, :362-372: v_m = exp(-k_vis * dmin_m) / sum, folded into the exponent as log2 v_m
         double tot = 0;
-        for (int m = tid; m < M; m += kBlock) {
+        for (int m = tid; m < M; m += EB) {
             double d = ::sqrt(Num<T>::from_bits(f.dminbits[m]));
             if (d > 10000.0) d = 10000.0;                        // initial value of :282
             if (d <= f.vis_thr) d = 0;                           // :291-293
             tot += ::exp(-f.k_vis * d);
         }
-        tot = block_sum(tot, scratch);
-        for (int m = tid; m < M; m += kBlock) {
+        tot = block_sum_n<NWE>(tot, scratch);
+        for (int m = tid; m < M; m += EB) {
             double d = ::sqrt(Num<T>::from_bits(f.dminbits[m]));
             if (d > 10000.0) d = 10000.0;
             if (d <= f.vis_thr) d = 0;
             lvL[m] = (T)(-f.k_vis * d * 1.4426950408889634 - ::log2(tot));
         }
     }
+    TDLO_ESTAMP(1);
     __syncthreads();
+    TDLO_ESTAMP(2);
 
-    const T k2 = (T)st->k2;
-    const T cn = (T)st->c_norm;
     double accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { accP[c] = 0; accX[c] = 0; accY[c] = 0; accZ[c] = 0; }
     double accQ = 0;
 
     const int nbatch = (N + 63) >> 6;
-    for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += f.nblkE * 4) {
+    for (int batch = batch0; batch < nbatch; batch += f.nblkE * NWE) {
         const int n = batch * 64 + lane;
         const bool valid = n < N;
-        T x = 0, y = 0, z = 0;
-        if (valid) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }
+        if (batch != batch0) { x = 0; y = 0; z = 0; if (valid) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; } }
         // ---- nearest node: argmax of the Euclidean membership (:298-310) == argmin of d2, first index
         T best = Num<T>::inf();
         int a = 0;
@@ -373,6 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
             const T d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < best) { best = d2; a = m; }
         }
+        TDLO_ESTAMP(3);
         // ---- second node by distance (:313-329)
         const int c1 = (a == 0) ? 2 : a - 1;
         const int c2 = (a == M - 1) ? M - 3 : a + 1;
@@ -404,6 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
             qs += p * d2;
             if (NCH == 1) pb[m * kPStride + lane] = p;
         }
+        TDLO_ESTAMP(4);
         const T inv = valid ? T(1) / (sum + cn) : T(0);
         accQ += (double)(inv * qs);
         V4<T> pw; pw.x = inv * x; pw.y = inv * y; pw.z = inv * z; pw.w = inv;
@@ -438,9 +468,11 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
         }
     }
 
-    // ---- block partial: sum the 4 waves, write [P1 | PXx | PXy | PXz | Q]
+    // ---- block partial: sum the waves in a fixed order, write [P1 | PXx | PXy | PXz | Q]
+    TDLO_ESTAMP(5);
     __syncthreads();
-    double *red = (double *)pbase;      // reuse the tile area: 4 waves x 64 lanes x 4 values per chunk
+    TDLO_ESTAMP(6);
+    double *red = (double *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
     double *part = f.part + (size_t)blockIdx.x * part_stride(M);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -449,18 +481,21 @@ __global__ __launch_bounds__(kBlock) void k_estep(const FrameDev *__restrict__ f
         red[(wave * 64 + lane) * 4 + 2] = accY[c];
         red[(wave * 64 + lane) * 4 + 3] = accZ[c];
         __syncthreads();
-        {
+        if (tid < 256) {
             const int l = tid >> 2, k = tid & 3;     // 64 lanes x 4 values
             const int m = c * kChunk + l;
             if (m < M) {
-                const double v = red[(0 * 64 + l) * 4 + k] + red[(1 * 64 + l) * 4 + k] + red[(2 * 64 + l) * 4 + k] + red[(3 * 64 + l) * 4 + k];
+                double v = 0;
+#pragma unroll
+                for (int w = 0; w < NWE; ++w) v += red[(w * 64 + l) * 4 + k];
                 part[k * M + m] = v;
             }
         }
         __syncthreads();
     }
-    const double q = block_sum(accQ, scratch);
+    const double q = block_sum_n<NWE>(accQ, scratch);
     if (tid == 0) part[4 * M] = q;
+    TDLO_ESTAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -663,8 +698,8 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     double *W = S + nSp;                              // 3M (+pad)
     double *Tn = W + ((3 * M + 1) & ~1);              // 3M (+pad)
     double *red = Tn + ((3 * M + 1) & ~1);            // 8
-    double *colb = red + 8;                           // 2 x 64: pivot column ping-pong
-    double *tmp = colb + 128;                         // 6 x 64: G W slices
+    double *colb = red + 8;                           // 16 x 64 x {value, tag}: ring of pivot columns
+    double *tmp = colb + 2 * 16 * 64;                 // 6 x 64: G W slices
     double *Gs = tmp + 6 * 64;                        // M x M (column-major, ld = M)
     double *Sg = Gs + (((size_t)M * M + 1) & ~(size_t)1);   // NG x nSp partial-sum groups
 
@@ -738,10 +773,16 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             a[c] = v;
         }
     }
-    if (slot == 0) colb[row] = a[0];                  // column 0 (rows >= M hold 0)
+    {   // ring: clear every tag, then publish column 0 (rows >= M hold 0) with tag 1
+        typedef double d2i __attribute__((ext_vector_type(2)));
+        d2i *rg = (d2i *)colb;
+        for (int i = t; i < 16 * 64; i += MB) { d2i z = {0.0, 0.0}; rg[i] = z; }
+        __syncthreads();
+        if (slot == 0) { d2i g0 = {a[0], 1.0}; rg[row] = g0; }
+    }
     __syncthreads();
 
-    // ---- 3. Gauss-Jordan elimination on [A | B], one barrier per column, straight-line code.
+    // ---- 3. Gauss-Jordan elimination on [A | B], straight-line code, no barrier inside the loop.
     //   * pivot ROW: the entries a wave needs are exactly those its own lane `pw` holds -> v_readlane
     //     into SGPRs (an LDS-broadcast version was LDS-bandwidth bound);
     //   * pivot COLUMN (multipliers): the only data crossing waves, 512 bytes through LDS (ping-pong).
@@ -755,47 +796,75 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     //   include_lle == 1: A = c I + (D + s H) G has no such structure -> partial pivoting, the row
     //     permutation stays implicit (`mine`).
     TDLO_STAMP(3);
+    // Waves are NOT barrier-synchronised per column.  The owner of column k+1 updates that column
+    // first and publishes it as 16-byte {value, tag = k+1} granules (one ds_write_b128 per lane, so a
+    // reader can never see a torn pair); every wave spins on the tag of ITS OWN granule before starting
+    // column k+1 and does the bulk of its updates in the shadow of the next hand-off.  A wave owns
+    // every NSLOT-th column, so no wave can run more than NSLOT columns ahead of the slowest one and a
+    // ring of kRing > NSLOT + 1 buffers is never overwritten while still being read.  Spins are bounded.
+    constexpr int kRing = 16;
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v *ring = (d2v *)colb;                          // kRing x 64 granules
     int singular = 0;
     int mine = -1;                                    // unknown this row ends up solving
     double dgv = 1.0;                                 // a(row, mine) times the row's later scalings (exact bookkeeping)
     unsigned long long usedmask = 0;
-    for (int k = 0; k < M; ++k) {
-        const int cur = (k & 1), nxt = cur ^ 1;
-        const double aik = colb[cur * 64 + row];
-        int pw = k;
-        if (lle) {
-            double bv = (rowok && !((usedmask >> row) & 1ull)) ? fabs(aik) : -1.0;
-            double mx = bv;
+    // Columns are walked in groups of NSLOT (outer loop unrolled): inside group q every register
+    // column c < q is already eliminated for every wave, so the update loop is the static range
+    // [q, MC) -- about half the work of updating everything, without a single data-dependent branch.
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-            const unsigned long long hit = __ballot(bv == mx);
-            pw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
-            usedmask |= 1ull << pw;
+    for (int q = 0; q < MC; ++q) {
+        for (int kk = 0; kk < NSLOT; ++kk) {
+            const int k = q * NSLOT + kk;
+            if (k >= M) break;                        // wave-uniform
+            const int kn = k + 1;
+            const bool own = (kn < M) && (slot == (kn & (NSLOT - 1)));    // wave-uniform
+            // column kn lives in register q (kn < (q+1) NSLOT) or q+1 (kn == (q+1) NSLOT)
+            double vown = 0.0;
+            if (own) vown = (kk == NSLOT - 1) ? a[q + 1 < MC ? q + 1 : q] : a[q];
+            double aik;
+            {
+                const volatile d2v *slotp = (const volatile d2v *)&ring[(k & (kRing - 1)) * 64 + row];
+                const double want = (double)(k + 1);
+                int spins = 0;
+                d2v g;
+                do { g = *slotp; } while (!__all(g.y == want) && ++spins < (1 << 22));
+                if (spins >= (1 << 22)) singular = 1; // never expected; keeps a broken run from hanging
+                aik = g.x;
+            }
+            int pw = k;
+            if (lle) {
+                double bv = (rowok && !((usedmask >> row) & 1ull)) ? fabs(aik) : -1.0;
+                double mx = bv;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+                const unsigned long long hit = __ballot(bv == mx);
+                pw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+                usedmask |= 1ull << pw;
+            }
+            const double pv = readlane_f64(aik, pw);
+            const int e = (__double2hiint(pv) >> 20) & 0x7ff;
+            if (e == 0 || e == 0x7ff) singular = 1;   // zero / denormal / non-finite pivot
+            const double sc = __hiloint2double((2046 - e) << 20, 0);       // 2^-(exponent of pv)
+            const bool self = (row == pw);
+            const double ps = self ? 1.0 : pv * sc;
+            const double ls = self ? 0.0 : aik * sc;
+            if (own) {                                // hand column k+1 off first
+                d2v g;
+                g.x = fma(ps, vown, -(ls * readlane_f64(vown, pw)));
+                g.y = (double)(kn + 1);
+                ring[(kn & (kRing - 1)) * 64 + row] = g;
+            }
+            dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
+            mine = self ? k : mine;
+            double pr[MC];
+#pragma unroll
+            for (int c = q; c < MC; ++c) pr[c] = readlane_f64(a[c], pw);
+#pragma unroll
+            for (int c = q; c < MC; ++c) a[c] = fma(ps, a[c], -(ls * pr[c]));
         }
-        const double pv = readlane_f64(aik, pw);
-        const int e = (__double2hiint(pv) >> 20) & 0x7ff;
-        if (e == 0 || e == 0x7ff) singular = 1;       // zero / denormal / non-finite pivot
-        const double sc = __hiloint2double((2046 - e) << 20, 0);           // 2^-(exponent of pv)
-        const bool self = (row == pw);
-        const double ps = self ? 1.0 : pv * sc;
-        const double ls = self ? 0.0 : aik * sc;
-        dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
-        mine = self ? k : mine;
-        double pr[MC];
-#pragma unroll
-        for (int c = 0; c < MC; ++c) pr[c] = readlane_f64(a[c], pw);
-#pragma unroll
-        for (int c = 0; c < MC; ++c) a[c] = fma(ps, a[c], -(ls * pr[c]));
-        const int kn = k + 1;
-        if (slot == (kn & (NSLOT - 1))) {             // wave-uniform: this wave owns column k+1
-            const int cn = kn / NSLOT;
-            double v = a[0];
-#pragma unroll
-            for (int c = 1; c < MC; ++c) v = (c == cn) ? a[c] : v;
-            colb[nxt * 64 + row] = v;
-        }
-        __syncthreads();
     }
+    __syncthreads();
     if (rowok && mine >= 0) {                         // x = b / (pivot entry with the row's accumulated scale)
 #pragma unroll
         for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dgv; }
@@ -878,15 +947,6 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
 // ------------------------------------------------------------------------------------------------
 static inline int nch_for(int M) { const int c = (M + kChunk - 1) / kChunk; return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }
 
-template <typename T> static size_t estep_lds_bytes(int M) {
-    const int rows = M < kChunk ? M : kChunk;
-    size_t b = sizeof(V4<T>) * (size_t)M + sizeof(V4<T>) * 256 + sizeof(T) * (size_t)((M + 3) & ~3) +
-               sizeof(T) * ((size_t)4 * rows * kPStride + 4) + 16 + 64;
-    const size_t red = 4 * 64 * 4 * sizeof(double) + sizeof(T) * 4;     // block-combine area must fit in the tile area
-    const size_t tile = sizeof(T) * (size_t)4 * rows * kPStride;
-    if (tile < red) b += red - tile;
-    return b;
-}
 template <typename T> static size_t dmin_lds_bytes(int M) {
     const int rows = M < kChunk ? M : kChunk;
     return sizeof(T) * (size_t)4 * rows * kPStride;
@@ -905,18 +965,35 @@ template <typename K> static hipError_t set_lds(K kernel, size_t bytes) {
 
 #define TDLO_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-template <typename T> static hipError_t launch_estep_T(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+template <typename T, int EB> static size_t estep_lds_bytes(int M) {
+    const int rows = M < kChunk ? M : kChunk;
+    constexpr int NWE = EB / 64;
+    const size_t tile = sizeof(T) * (((size_t)NWE * rows * kPStride + 7) & ~(size_t)3);
+    const size_t red = (size_t)NWE * 64 * 4 * sizeof(double);
+    size_t b = sizeof(V4<T>) * (size_t)M + sizeof(V4<T>) * NWE * 64 + sizeof(T) * (size_t)((M + 3) & ~3);
+    b += (tile > red ? tile : red) + 16 * sizeof(double) + 64;
+    return b;
+}
+
+template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
     const int M = fh[0].M, nch = nch_for(M);
     const bool vis = fh[0].vis_branch != 0;
     int gx = 0;
     for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
-    const dim3 grid(gx, F), block(kBlock);
-    const size_t lds = estep_lds_bytes<T>(M);
-#define TDLO_E(NCH, VIS) do { TDLO_TRY(set_lds(k_estep<T, NCH, VIS>, lds)); hipLaunchKernelGGL((k_estep<T, NCH, VIS>), grid, block, lds, s, fd); } while (0)
+    const dim3 grid(gx, F), block(EB);
+    const size_t lds = estep_lds_bytes<T, EB>(M);
+#define TDLO_E2(NCH, VIS, SINGLE) do { TDLO_TRY(set_lds(k_estep<T, NCH, VIS, EB, SINGLE>, lds)); hipLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, fd, fh[0]); } while (0)
+#define TDLO_E(NCH, VIS) do { if (F == 1) TDLO_E2(NCH, VIS, true); else TDLO_E2(NCH, VIS, false); } while (0)
     if (vis) { switch (nch) { case 1: TDLO_E(1, true); break; case 2: TDLO_E(2, true); break; case 4: TDLO_E(4, true); break; default: TDLO_E(8, true); } }
     else     { switch (nch) { case 1: TDLO_E(1, false); break; case 2: TDLO_E(2, false); break; case 4: TDLO_E(4, false); break; default: TDLO_E(8, false); } }
 #undef TDLO_E
+#undef TDLO_E2
     return hipGetLastError();
+}
+
+template <typename T> static hipError_t launch_estep_T(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+    if (fh[0].eb == 512) return launch_estep_TE<T, 512>(fd, fh, F, s);
+    return launch_estep_TE<T, 256>(fd, fh, F, s);
 }
 
 static inline int dmin_blocks(const FrameDev *fh, int F) {
@@ -938,7 +1015,7 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
 
 static size_t mstep_fast_lds_bytes(int M, int NW) {
     const int nSp = part_stride(M), npair = nSp / 2, NG = (NW * 64) / npair;
-    size_t d = (size_t)nSp + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 128 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
+    size_t d = (size_t)nSp + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 16 * 64 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
     return d * sizeof(double);
 }
 
