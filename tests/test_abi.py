@@ -99,3 +99,11 @@ def test_lle_weights_structure_and_oracle(oracle):
         np.testing.assert_allclose(L[0], Lo[0], atol=1e-9); np.testing.assert_allclose(L[M - 1], Lo[M - 1], atol=1e-9)
         # 2-neighbour weights are well conditioned everywhere
         np.testing.assert_allclose(B.calc_LLE_weights(2, Y), oracle.calc_lle_weights(Y, 2), atol=1e-9)
+
+
+def test_cpp_shim_header_compiles():
+    """The drop-in class template compiles against a minimal Eigen-like matrix (no GPU needed)."""
+    import subprocess
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ROOT, "tests", "cpp", "shim_test.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

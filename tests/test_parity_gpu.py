@@ -305,3 +305,15 @@ def test_tracking_step_against_oracle(hip_ctx, oracle, occl):
         np.testing.assert_allclose(kp, kr, rtol=0, atol=1e-5)
         np.testing.assert_allclose(trk.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=1e-5)
         assert abs(trk.get_sigma2() - ref.get_sigma2()) <= 1e-3 * ref.get_sigma2()
+
+
+def test_cpp_drop_in_class():
+    """include/trackdlo_shim.hpp (`class trackdlo`, reference signatures) used like trackdlo_node.cpp:131-143/:366-369,
+    compared with the oracle inside the C++ program (tests/cpp/shim_test.cpp, built by __graft_entry__.build())."""
+    import os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "shim_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         const int n = batch * 64 + lane;
         const bool valid = n < N;
         if (batch != batch0) { x = 0; y = 0; z = 0; if (valid) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; } }
+        else if (!valid) { x = 0; y = 0; z = 0; }     // the speculative first load may have read past the kept points
         // ---- nearest node: argmax of the Euclidean membership (:298-310) == argmin of d2, first index
         T best = Num<T>::inf();
         int a = 0;
