@@ -102,8 +102,14 @@ def main():
         mst_us = ctx.profile_kernel(2, 100)
         alg_bytes = 3 * 4 * N_POINTS * F
         achieved = alg_bytes / (est_us * 1e-6) / 1e9
+        traffic = None
+        try:        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE calibrated, + WRITE_SIZE), see profiles/r01_pmc_hbm.json
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
+                traffic = round(json.load(fh)["estep"]["traffic_bytes_per_launch"] * F)
+        except Exception:
+            traffic = None
         roof = dict(bound="hbm", kernel="k_estep<float,1,false>", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, avg_launch_us=round(est_us, 3),
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, avg_launch_us=round(est_us, 3),
                     algorithmic_bytes_per_launch=alg_bytes, mstep_avg_launch_us=round(mst_us, 3),
                     note="E-step is VALU/latency-bound at this size (about 100 flop per byte); HBM fraction reported as the metric requires")
         cpu = None

@@ -334,8 +334,6 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = M < kChunk ? M : kChunk;
-#define TDLO_ESTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); f.dbg[32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
-    TDLO_ESTAMP(0);
     // LDS carve (every offset a multiple of 16 bytes)
     V4<T> *nodesL = (V4<T> *)smem;                                    // M
     V4<T> *pts = nodesL + M;                                          // NWE x 64
@@ -377,9 +375,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             lvL[m] = (T)(-f.k_vis * d * 1.4426950408889634 - ::log2(tot));
         }
     }
-    TDLO_ESTAMP(1);
     __syncthreads();
-    TDLO_ESTAMP(2);
 
     double accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
 #pragma unroll
@@ -402,7 +398,6 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const T d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < best) { best = d2; a = m; }
         }
-        TDLO_ESTAMP(3);
         // ---- second node by distance (:313-329)
         const int c1 = (a == 0) ? 2 : a - 1;
         const int c2 = (a == M - 1) ? M - 3 : a + 1;
@@ -434,7 +429,6 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             qs += p * d2;
             if (NCH == 1) pb[m * kPStride + lane] = p;
         }
-        TDLO_ESTAMP(4);
         const T inv = valid ? T(1) / (sum + cn) : T(0);
         accQ += (double)(inv * qs);
         V4<T> pw; pw.x = inv * x; pw.y = inv * y; pw.z = inv * z; pw.w = inv;
@@ -470,9 +464,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
 
     // ---- block partial: sum the waves in a fixed order, write [P1 | PXx | PXy | PXz | Q]
-    TDLO_ESTAMP(5);
     __syncthreads();
-    TDLO_ESTAMP(6);
     double *red = (double *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
     double *part = f.part + (size_t)blockIdx.x * part_stride(M);
 #pragma unroll
@@ -496,7 +488,6 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     const double q = block_sum_n<NWE>(accQ, scratch);
     if (tid == 0) part[4 * M] = q;
-    TDLO_ESTAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -821,8 +812,11 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             const int kn = k + 1;
             const bool own = (kn < M) && (slot == (kn & (NSLOT - 1)));    // wave-uniform
             // column kn lives in register q (kn < (q+1) NSLOT) or q+1 (kn == (q+1) NSLOT)
-            double vown = 0.0;
-            if (own) vown = (kk == NSLOT - 1) ? a[q + 1 < MC ? q + 1 : q] : a[q];
+            double vown = 0.0, prv = 0.0;
+            if (own) {
+                vown = (kk == NSLOT - 1) ? a[q + 1 < MC ? q + 1 : q] : a[q];
+                if (!lle) prv = readlane_f64(vown, k);
+            }
             double aik;
             {
                 const volatile d2v *slotp = (const volatile d2v *)&ring[(k & (kRing - 1)) * 64 + row];
@@ -842,20 +836,25 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                 const unsigned long long hit = __ballot(bv == mx);
                 pw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
                 usedmask |= 1ull << pw;
+                if (own) prv = readlane_f64(vown, pw);
             }
             const double pv = readlane_f64(aik, pw);
+            // s = 2^-exponent(p): p s lies in [1, 2), so every row grows by less than 2x per column and
+            // the elimination cannot overflow (a scale taken from the PREVIOUS pivot does not have this
+            // property: the pivots themselves carry the accumulated row scale)
             const int e = (__double2hiint(pv) >> 20) & 0x7ff;
-            if (e == 0 || e == 0x7ff) singular = 1;   // zero / denormal / non-finite pivot
-            const double sc = __hiloint2double((2046 - e) << 20, 0);       // 2^-(exponent of pv)
+            const double sc = __hiloint2double((2046 - e) << 20, 0);
             const bool self = (row == pw);
             const double ps = self ? 1.0 : pv * sc;
             const double ls = self ? 0.0 : aik * sc;
             if (own) {                                // hand column k+1 off first
                 d2v g;
-                g.x = fma(ps, vown, -(ls * readlane_f64(vown, pw)));
+                g.x = fma(ps, vown, -(ls * prv));
                 g.y = (double)(kn + 1);
                 ring[(kn & (kRing - 1)) * 64 + row] = g;
             }
+            // bookkeeping, off the hand-off chain
+            if (e == 0 || e == 0x7ff) singular = 1;   // zero / denormal / non-finite pivot
             dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
             mine = self ? k : mine;
             double pr[MC];
