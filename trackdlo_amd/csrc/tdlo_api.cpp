@@ -19,6 +19,7 @@ using namespace tdlo;
 namespace {
 
 constexpr int kMaxEstepBlocks = 1024;
+constexpr int kChunkIters = 6;          // EM iterations per early-exit polling chunk
 
 struct Slot {
     // cloud-sized
@@ -61,7 +62,7 @@ struct NodeCarve {
 struct tdlo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0..3 timing, 4..5 early-exit polling
     tdlo_config cfg{};
     std::vector<Slot> slots;
     std::vector<FrameDev> fh;        // host copies of the frame descriptors of the last call
@@ -215,7 +216,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (F < 1 || F > c->cfg.max_frames) return fail(c, TDLO_E_INVALID, "bad frame count");
     NodeCarve nc(M);
     const size_t up = upload_doubles(nc, p);
-    rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2));
+    rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2) + 2 * (size_t)F * ((sizeof(IterState) + 7) / 8) + 4);
     if (rc) return rc;
     c->fh.assign(F, FrameDev{});
     for (int i = 0; i < F; ++i) {
@@ -230,7 +231,34 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
     HIPCHK(c, launch_prune_and_setup(c->fd, c->fh.data(), F, s));
     HIPCHK(c, hipEventRecord(c->ev[1], s));
-    for (int it = 0; it < p->max_iter; ++it) HIPCHK(c, launch_iteration(c->fd, c->fh.data(), F, s));
+    if (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) {
+        // fixed iteration count: enqueue everything, no host involvement
+        for (int it = 0; it < p->max_iter; ++it) HIPCHK(c, launch_iteration(c->fd, c->fh.data(), F, s));
+    } else {
+        // early exit (trackdlo.cpp:424-428) is decided on the device; kernels of finished frames are
+        // no-ops.  To avoid enqueueing up to max_iter of them, iterations go out in chunks and the
+        // `done` flags of chunk i are inspected while chunk i+1 is already running (the GPU never idles).
+        IterState *flags = (IterState *)(c->pin + (size_t)F * nc.upload);     // pinned, 2 x F entries
+        int launched = 0, chunk = 0;
+        bool stop = false;
+        while (launched < p->max_iter && !stop) {
+            const int n = std::min(kChunkIters, p->max_iter - launched);
+            for (int it = 0; it < n; ++it) HIPCHK(c, launch_iteration(c->fd, c->fh.data(), F, s));
+            launched += n;
+            const int slotp = chunk & 1;
+            for (int i = 0; i < F; ++i)
+                HIPCHK(c, hipMemcpyAsync(&flags[slotp * F + i], c->fh[i].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipEventRecord(c->ev[4 + slotp], s));
+            if (chunk > 0) {
+                const int prev = (chunk - 1) & 1;
+                HIPCHK(c, hipEventSynchronize(c->ev[4 + prev]));
+                bool all = true;
+                for (int i = 0; i < F; ++i) all = all && flags[prev * F + i].done != 0;
+                stop = all;
+            }
+            ++chunk;
+        }
+    }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
     for (int i = 0; i < F; ++i)
