@@ -180,6 +180,17 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N,
                                const int *visible_nodes_extended, int n_vis_ext,
                                const double *H_pre, tdlo_stats *stats);
 
+/* ---- caller-side visibility pre-pass ----------------------------------- */
+/* What the ROS node computes right before tracking_step (trackdlo/src/trackdlo_node.cpp:257-277, :345-360):
+ * each node's shortest distance to the cloud resident in `slot` (M x N distances on the GPU, fp64),
+ *   visible_nodes          = { m : dist_m <= visibility_threshold }, ascending          (:316, :326, :346)
+ *   visible_nodes_extended = visible_nodes with occluded runs shorter than d_vis (in geodesic_coord) filled in (:350-360)
+ * The OpenCV painter's-algorithm self-occlusion test (:279-343, cv::line rasterisation) is NOT part of it.
+ * Output arrays need room for M entries; any output pointer may be NULL. */
+int tdlo_visibility_prepass(tdlo_ctx *ctx, int slot, const double *Y, int M, double visibility_threshold, double d_vis,
+                            const double *geodesic_coord, double *node_dist, int *visible_nodes, int *n_vis,
+                            int *visible_nodes_extended, int *n_vis_ext);
+
 /* ---- host helpers on the path (exported so the parity tests can address them directly) -------- */
 /* trackdlo::calc_LLE_weights (trackdlo.cpp:119-159), k as passed at :236 (6). L: M x M col-major out. */
 int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L);

@@ -795,3 +795,29 @@ done:
     free(pv1); free(pv2);
     return ret;
 }
+
+/* ---------------------------------------------------------------- trackdlo_node.cpp:257-277, :345-360 */
+
+int ref_visibility_prepass(const double *X, int N, const double *Y, int M, double visibility_threshold, double d_vis,
+                           const double *coord, double *node_dist, int *vis, int *vis_ext, int *n_ext) {
+    int nv = 0, ne = 0;
+    for (int m = 0; m < M; m++) {
+        double shortest = 100000;                       /* :261 */
+        for (int n = 0; n < N; n++) {
+            double dist = sqrt(sqdist3(Y, M, m, X[n], X[(size_t)N + n], X[2 * (size_t)N + n]));
+            if (dist < shortest) shortest = dist;
+        }
+        if (node_dist) node_dist[m] = shortest;
+        if (shortest <= visibility_threshold) vis[nv++] = m;      /* :316 / :326; ascending == the sort of :346 */
+    }
+    if (nv > 0) {
+        for (int i = 0; i < nv - 1; i++) {                           /* :351-359 */
+            vis_ext[ne++] = vis[i];
+            if (fabs(coord[vis[i + 1]] - coord[vis[i]]) <= d_vis)
+                for (int j = 1; j < vis[i + 1] - vis[i]; j++) vis_ext[ne++] = vis[i] + j;
+        }
+        vis_ext[ne++] = vis[nv - 1];                                  /* :360 */
+    }
+    if (n_ext) *n_ext = ne;
+    return nv;
+}

@@ -124,6 +124,12 @@ int ref_tracking_step(ref_tracker *t, const double *X, int N, const int *vis, in
                       const int *vis_ext, int n_vis_ext, const double *H_pre,
                       ref_stats *stats_pre, ref_stats *stats_main);
 
+/* Caller-side visibility pre-pass, trackdlo/src/trackdlo_node.cpp:257-277 (per-node shortest distance),
+ * :316/:326 (distance test; the OpenCV painter test of :279-343 is not restated), :345-360 (sort + gap fill).
+ * Returns n_vis; *n_ext receives the size of vis_ext. Arrays need room for M ints / doubles. */
+int ref_visibility_prepass(const double *X, int N, const double *Y, int M, double visibility_threshold, double d_vis,
+                           const double *coord, double *node_dist, int *vis, int *vis_ext, int *n_ext);
+
 /* dense helper exposed for tests: solve A x = B (A n x n col-major, B n x nrhs col-major)
  * by Householder QR with column pivoting (what completeOrthogonalDecomposition reduces to for
  * full-rank A, trackdlo.cpp:415). A and B are overwritten; solution returned in X (n x nrhs). */

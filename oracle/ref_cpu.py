@@ -53,6 +53,7 @@ def lib():
         _LIB.ref_solve_qrcp.restype = C.c_int
         _LIB.ref_tracker_create.restype = C.c_void_p
         _LIB.ref_tracking_step.restype = C.c_int
+        _LIB.ref_visibility_prepass.restype = C.c_int
     return _LIB
 
 
@@ -132,6 +133,15 @@ def traverse_euclidean(coord, guide, vis, alignment, alignment_node_idx=-1):
     if n < 0:
         raise ValueError(f"ref_traverse_euclidean rc={n}")
     return out[:n].copy()
+
+
+def visibility_prepass(X, Y, visibility_threshold, d_vis, coord):
+    X = _f(X); Y = _f(Y); M = Y.shape[0]
+    coord = np.ascontiguousarray(coord, dtype=np.float64)
+    dist = np.zeros(M); vis = np.zeros(M, dtype=np.int32); ext = np.zeros(M, dtype=np.int32); ne = C.c_int(0)
+    nv = lib().ref_visibility_prepass(_dp(X), C.c_int(X.shape[0]), _dp(Y), C.c_int(M), C.c_double(visibility_threshold), C.c_double(d_vis),
+                                      _dp(coord), _dp(dist), _dp(vis), _dp(ext), C.byref(ne))
+    return dist, vis[:nv].copy(), ext[:ne.value].copy()
 
 
 def solve_qrcp(A, B):

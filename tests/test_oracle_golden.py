@@ -162,3 +162,16 @@ def test_oracle_tracking_step_runs_all_occlusion_states(oracle):
         assert np.abs(Y - Y0).max() < 0.03
         K = t.get_correspondence_pairs()
         assert len(K) >= 1 and (K[:, 0] >= 0).all() and (K[:, 0] < M).all()
+
+
+def test_visibility_prepass_oracle(oracle):
+    from trackdlo_amd import synth
+    M = 30
+    X, Y0, vis_true = synth.scene(4000, M, config=31, occlude=(0.4, 0.6))
+    coord = synth.geodesic_coord(Y0)
+    d, vis, ext = oracle.visibility_prepass(X, Y0, 0.008, 0.06, coord)
+    dn = np.linalg.norm(X[:, None, :] - Y0[None, :, :], axis=2).min(axis=0)
+    np.testing.assert_allclose(d, dn, rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(vis, np.nonzero(dn <= 0.008)[0])
+    np.testing.assert_array_equal(ext, synth.extend_visible(vis, M, coord, 0.06))
+    assert set(vis.tolist()) <= set(ext.tolist())

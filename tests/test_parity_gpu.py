@@ -317,3 +317,21 @@ def test_cpp_drop_in_class():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+@pytest.mark.parametrize("occl", [None, (0.45, 0.5), (0.3, 0.6), (0.0, 0.25)], ids=["all", "minor", "mid", "head"])
+def test_visibility_prepass(hip_ctx, oracle, occl):
+    """the node<->cloud distance pre-pass of trackdlo_node.cpp:257-277 and the gap fill of :345-360."""
+    from trackdlo_amd import synth
+    P = synth.LAUNCH_PARAMS
+    M = 45
+    X, Y0, _ = synth.scene(30000, M, config=30, occlude=occl, outliers=7)
+    coord = synth.geodesic_coord(Y0)
+    hip_ctx.set_cloud(0, X)
+    d, vis, ext = hip_ctx.visibility_prepass(0, Y0, P["visibility_threshold"], 0.06, coord)
+    do, viso, exto = oracle.visibility_prepass(X, Y0, P["visibility_threshold"], 0.06, coord)
+    np.testing.assert_allclose(d, do, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(vis, viso)
+    np.testing.assert_array_equal(ext, exto)
+    assert len(vis) >= 1 and (occl is not None or len(vis) >= M - 2)
+    np.testing.assert_array_equal(ext, synth.extend_visible(vis, M, coord, 0.06))

@@ -52,7 +52,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_visibility_prepass",
 ]
 
 _lib = None
@@ -109,6 +109,7 @@ def load_library(path: str | None = None):
     lib.tdlo_traverse_euclidean.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
     lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     lib.tdlo_debug_stamps.argtypes = [vp, ci, vp, ci]
+    lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
     if path is None:
         _lib = lib
     return lib
@@ -203,6 +204,16 @@ class Context:
         self._chk(self.lib.tdlo_cpd_lle_batch(self.h, F, _ptr(Yb), M, _ptr(s2), C.byref(params), _ptr(pri), K, _ptr(vis), nv,
                                               _ptr(Hm), C.cast(st, C.c_void_p)))
         return dict(Y=[Yb[i].T.copy() for i in range(F)], sigma2=s2, stats=[s.as_dict() for s in st])
+
+    def visibility_prepass(self, slot, Y, visibility_threshold, d_vis, geodesic_coord):
+        """trackdlo_node.cpp:257-277 + :345-360 (distance test and gap fill; no painter test)."""
+        Y = _f64(Y); M = Y.shape[0]
+        coord = np.ascontiguousarray(geodesic_coord, dtype=np.float64)
+        dist = np.zeros(M); vis = np.zeros(M, dtype=np.int32); ext = np.zeros(M, dtype=np.int32)
+        nv = C.c_int(0); ne = C.c_int(0)
+        self._chk(self.lib.tdlo_visibility_prepass(self.h, slot, _ptr(Y), M, float(visibility_threshold), float(d_vis), _ptr(coord),
+                                                   _ptr(dist), _ptr(vis), C.byref(nv), _ptr(ext), C.byref(ne)))
+        return dist, vis[:nv.value].copy(), ext[:ne.value].copy()
 
     def debug_stamps(self, n=16, slot=0):
         out = np.zeros(n, dtype=np.uint64)

@@ -512,6 +512,55 @@ int tdlo_split_end(tdlo_ctx *c, double *Y, double *sigma2, tdlo_stats *stats) {
     return is.status;
 }
 
+// ---- caller-side visibility pre-pass ------------------------------------------------------------
+int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, double visibility_threshold, double d_vis,
+                            const double *geodesic_coord, double *node_dist, int *visible_nodes, int *n_vis,
+                            int *visible_nodes_extended, int *n_vis_ext) {
+    if (!c) return TDLO_E_INVALID;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
+    if (!Y || M < 1 || !geodesic_coord) return fail(c, TDLO_E_INVALID, "null Y / geodesic_coord");
+    Slot &s = c->slots[slot];
+    if (s.N0 <= 0) return fail(c, TDLO_E_INVALID, "no cloud resident in slot (call tdlo_set_cloud)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_nodes(c, s, M);
+    if (rc) return rc;
+    rc = ensure_pin(c, 4 * (size_t)M + 8);
+    if (rc) return rc;
+    NodeCarve nc(M);
+    hipStream_t st = c->stream;
+    double *dY = s.nodeblk + nc.Yin;                                  // reuse the node upload area
+    unsigned long long *dbits = (unsigned long long *)(s.nodeblk + nc.dmin);
+    std::memcpy(c->pin, Y, sizeof(double) * 3 * M);
+    for (int m = 0; m < M; ++m) { const unsigned long long inf = 0x7ff0000000000000ull; std::memcpy(c->pin + 3 * M + m, &inf, 8); }
+    HIPCHK(c, hipMemcpyAsync(dY, c->pin, sizeof(double) * 3 * M, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dbits, c->pin + 3 * M, sizeof(double) * M, hipMemcpyHostToDevice, st));
+    HIPCHK(c, launch_node_min_dist(s.Xraw, s.N0, dY, M, dbits, st));
+    HIPCHK(c, hipMemcpyAsync(c->pin, dbits, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // thresholding and gap fill on the host (O(M)): trackdlo_node.cpp:316/:326 (distance test only, the OpenCV
+    // painter test of :279-343 is out of scope), :345-360
+    std::vector<int> vis;
+    for (int m = 0; m < M; ++m) {
+        const double d = std::sqrt(c->pin[m]);
+        if (node_dist) node_dist[m] = d;
+        if (d <= visibility_threshold) vis.push_back(m);
+    }
+    if (n_vis) *n_vis = (int)vis.size();
+    if (visible_nodes) std::copy(vis.begin(), vis.end(), visible_nodes);
+    std::vector<int> ext;
+    if (!vis.empty()) {
+        for (size_t i = 0; i + 1 < vis.size(); ++i) {
+            ext.push_back(vis[i]);
+            if (std::fabs(geodesic_coord[vis[i + 1]] - geodesic_coord[vis[i]]) <= d_vis)
+                for (int j = 1; j < vis[i + 1] - vis[i]; ++j) ext.push_back(vis[i] + j);
+        }
+        ext.push_back(vis.back());
+    }
+    if (n_vis_ext) *n_vis_ext = (int)ext.size();
+    if (visible_nodes_extended) std::copy(ext.begin(), ext.end(), visible_nodes_extended);
+    return TDLO_OK;      // an empty visible set is reported as n_vis = 0 (the reference underflows at :351)
+}
+
 // ---- measurement ---------------------------------------------------------------------------------
 int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us) {
     if (!c || c->last_F < 1 || c->fh.empty()) return TDLO_E_INVALID;

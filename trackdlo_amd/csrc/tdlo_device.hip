@@ -943,6 +943,38 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Caller-side visibility pre-pass: per-node shortest distance to the RAW cloud,
+// trackdlo/src/trackdlo_node.cpp:257-277.  fp64 on the uploaded fp64 points so that the `<=
+// visibility_threshold` decision at :316 is taken on the same numbers as the reference.
+// thread = point, grid-stride; per node a wave-level min, then one atomicMin per wave on ordered bits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_node_min_dist(const double *__restrict__ X, int N, const double *__restrict__ Y, int M,
+                                                         unsigned long long *__restrict__ out_bits) {
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * kBlock; base < N; base += gridDim.x * kBlock) {
+        const int n = base + threadIdx.x;
+        const bool valid = n < N;
+        double x = 0, y = 0, z = 0;
+        if (valid) { x = X[n]; y = X[(size_t)N + n]; z = X[2 * (size_t)N + n]; }
+        for (int m = 0; m < M; ++m) {
+            const double dx = Y[m] - x, dy = Y[M + m] - y, dz = Y[2 * M + m] - z;
+            double d2 = valid ? dx * dx + dy * dy + dz * dz : __builtin_huge_val();
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d2 = ::fmin(d2, __shfl_xor(d2, o));
+            if (lane == 0) atomicMin(&out_bits[m], (unsigned long long)__double_as_longlong(d2));
+        }
+    }
+}
+
+hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s) {
+    int blocks = (N + kBlock - 1) / kBlock;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_node_min_dist, dim3(blocks), dim3(kBlock), 0, s, X, N, Y, M, out_bits);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline int nch_for(int M) { const int c = (M + kChunk - 1) / kChunk; return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }

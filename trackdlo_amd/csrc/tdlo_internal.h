@@ -70,6 +70,7 @@ hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_h
 hipError_t launch_estep_only(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int kind, hipStream_t s);
 hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames_host, hipStream_t s);
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
+hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s);
 size_t mstep_lds_bytes(int M);
 int check_device_image();
 
