@@ -690,8 +690,8 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     double *W = S + nSp;                              // 3M (+pad)
     double *Tn = W + ((3 * M + 1) & ~1);              // 3M (+pad)
     double *red = Tn + ((3 * M + 1) & ~1);            // 8
-    double *colb = red + 8;                           // 16 x 64 x {value, tag}: ring of pivot columns
-    double *tmp = colb + 2 * 16 * 64;                 // 6 x 64: G W slices
+    double *colb = red + 8;                           // 2 x 8 x 64: panel exchange buffers (double-buffered)
+    double *tmp = colb + 2 * 8 * 64;                  // 6 x 64: G W slices
     double *Gs = tmp + 6 * 64;                        // M x M (column-major, ld = M)
     double *Sg = Gs + (((size_t)M * M + 1) & ~(size_t)1);   // NG x nSp partial-sum groups
 
@@ -765,103 +765,82 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             a[c] = v;
         }
     }
-    {   // ring: clear every tag, then publish column 0 (rows >= M hold 0) with tag 1
-        typedef double d2i __attribute__((ext_vector_type(2)));
-        d2i *rg = (d2i *)colb;
-        for (int i = t; i < 16 * 64; i += MB) { d2i z = {0.0, 0.0}; rg[i] = z; }
-        __syncthreads();
-        if (slot == 0) { d2i g0 = {a[0], 1.0}; rg[row] = g0; }
-    }
-    __syncthreads();
-
-    // ---- 3. Gauss-Jordan elimination on [A | B], straight-line code, no barrier inside the loop.
-    //   * pivot ROW: the entries a wave needs are exactly those its own lane `pw` holds -> v_readlane
-    //     into SGPRs (an LDS-broadcast version was LDS-bandwidth bound);
-    //   * pivot COLUMN (multipliers): the only data crossing waves, 512 bytes through LDS (ping-pong).
-    // The row operation is division-free: row_i <- (p s) row_i - (a_ik s) row_k, s = 2^-exponent(p): no
-    // reciprocal on the dependency chain.  Eliminated columns keep being updated (straight-line code;
-    // they only feed themselves); each row's pivot entry and accumulated scale are tracked exactly in
-    // `dgv`, and x = b / dgv at the end.
+    // ---- 3. Gauss-Jordan elimination on [A | B]: straight-line code, ONE barrier per 8 columns.
+    // wave = column slot, lane = row; a lane keeps its row's entries of the columns j = slot + 8 c in
+    // registers.  Columns are eliminated in panels of 8 (one column from every wave):
+    //   * at the start of a panel the 8 columns are exchanged through LDS (4 KB, one barrier) and EVERY
+    //     wave keeps a private copy `pc[]` which it updates redundantly while the panel is eliminated --
+    //     the pivot column is therefore always local: no per-column hand-off, no spin, no chain of LDS
+    //     round trips (the VALU has room: two waves per SIMD run this at full speed each);
+    //   * the pivot ROW entries a wave needs are the ones its own lane `pw` holds -> v_readlane.
+    // Row operation, division-free: row_i <- (p s) row_i - (a_ik s) row_k with s = 2^-exponent(p), so
+    // p s is in [1, 2): rows grow by < 2x per column, no reciprocal on the dependency chain.  A row's
+    // pivot entry and accumulated scale are tracked exactly in `dgv`; x = b / dgv at the end.
     //   include_lle == 0: A = c I + D G, D >= 0 diagonal, G SPD.  Row scaling does not change Gaussian
     //     elimination, so this is the elimination of the SPD matrix G + c D^-1 (rows with D_i = 0 are
     //     c e_i): stable without pivoting.
     //   include_lle == 1: A = c I + (D + s H) G has no such structure -> partial pivoting, the row
-    //     permutation stays implicit (`mine`).
+    //     permutation stays implicit (`mine`); every wave takes the same decision on its own copy.
     TDLO_STAMP(3);
-    // Waves are NOT barrier-synchronised per column.  The owner of column k+1 updates that column
-    // first and publishes it as 16-byte {value, tag = k+1} granules (one ds_write_b128 per lane, so a
-    // reader can never see a torn pair); every wave spins on the tag of ITS OWN granule before starting
-    // column k+1 and does the bulk of its updates in the shadow of the next hand-off.  A wave owns
-    // every NSLOT-th column, so no wave can run more than NSLOT columns ahead of the slowest one and a
-    // ring of kRing > NSLOT + 1 buffers is never overwritten while still being read.  Spins are bounded.
-    constexpr int kRing = 16;
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    d2v *ring = (d2v *)colb;                          // kRing x 64 granules
+    constexpr int NB = NSLOT;                         // panel width
+    static_assert(NB == 8 || NB == 4, "panel width");
+    double *pan = colb;                               // 2 x NB x 64 doubles
     int singular = 0;
     int mine = -1;                                    // unknown this row ends up solving
     double dgv = 1.0;                                 // a(row, mine) times the row's later scalings (exact bookkeeping)
     unsigned long long usedmask = 0;
-    // Columns are walked in groups of NSLOT (outer loop unrolled): inside group q every register
-    // column c < q is already eliminated for every wave, so the update loop is the static range
-    // [q, MC) -- about half the work of updating everything, without a single data-dependent branch.
+    bool has_rhs = false;
 #pragma unroll
-    for (int q = 0; q < MC; ++q) {
-        for (int kk = 0; kk < NSLOT; ++kk) {
-            const int k = q * NSLOT + kk;
-            if (k >= M) break;                        // wave-uniform
-            const int kn = k + 1;
-            const bool own = (kn < M) && (slot == (kn & (NSLOT - 1)));    // wave-uniform
-            // column kn lives in register q (kn < (q+1) NSLOT) or q+1 (kn == (q+1) NSLOT)
-            double vown = 0.0, prv = 0.0;
-            if (own) {
-                vown = (kk == NSLOT - 1) ? a[q + 1 < MC ? q + 1 : q] : a[q];
-                if (!lle) prv = readlane_f64(vown, k);
+    for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; has_rhs = has_rhs || (j >= M && j < ncol); }
+#pragma unroll
+    for (int p = 0; p < MC; ++p) {                    // panel p = columns p NB .. p NB + NB - 1; mine is register p
+        if (p * NB < M) {                             // wave-uniform
+            double *buf = pan + (p & 1) * NB * 64;
+            buf[slot * 64 + row] = a[p];
+            __syncthreads();
+            double pc[NB];
+#pragma unroll
+            for (int s2 = 0; s2 < NB; ++s2) pc[s2] = buf[s2 * 64 + row];
+#pragma unroll
+            for (int sI = 0; sI < NB; ++sI) {
+                const int k = p * NB + sI;
+                if (k < M) {                          // wave-uniform
+                    const double aik = pc[sI];
+                    int pw = k;
+                    if (lle) {
+                        double bv = (rowok && !((usedmask >> row) & 1ull)) ? fabs(aik) : -1.0;
+                        double mx = bv;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+                        const unsigned long long hit = __ballot(bv == mx);
+                        pw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+                        usedmask |= 1ull << pw;
+                    }
+                    const double pv = readlane_f64(aik, pw);
+                    const int e = (__double2hiint(pv) >> 20) & 0x7ff;
+                    if (e == 0 || e == 0x7ff) singular = 1;          // zero / denormal / non-finite pivot
+                    const double sc = __hiloint2double((2046 - e) << 20, 0);
+                    const bool self = (row == pw);
+                    const double ps = self ? 1.0 : pv * sc;
+                    const double ls = self ? 0.0 : aik * sc;
+                    if (has_rhs) {                    // wave-uniform: only waves holding right-hand-side columns need the scale
+                        dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
+                        mine = self ? k : mine;
+                    }
+#pragma unroll
+                    for (int s2 = sI + 1; s2 < NB; ++s2) pc[s2] = fma(ps, pc[s2], -(ls * readlane_f64(pc[s2], pw)));
+#pragma unroll
+                    for (int c = p + 1; c < MC; ++c) a[c] = fma(ps, a[c], -(ls * readlane_f64(a[c], pw)));
+                }
             }
-            double aik;
+            // this wave's own column of the panel goes back to its register (matters for right-hand-side
+            // columns that share the last panel with matrix columns)
             {
-                const volatile d2v *slotp = (const volatile d2v *)&ring[(k & (kRing - 1)) * 64 + row];
-                const double want = (double)(k + 1);
-                int spins = 0;
-                d2v g;
-                do { g = *slotp; } while (!__all(g.y == want) && ++spins < (1 << 22));
-                if (spins >= (1 << 22)) singular = 1; // never expected; keeps a broken run from hanging
-                aik = g.x;
-            }
-            int pw = k;
-            if (lle) {
-                double bv = (rowok && !((usedmask >> row) & 1ull)) ? fabs(aik) : -1.0;
-                double mx = bv;
+                double v = pc[0];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-                const unsigned long long hit = __ballot(bv == mx);
-                pw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
-                usedmask |= 1ull << pw;
-                if (own) prv = readlane_f64(vown, pw);
+                for (int s2 = 1; s2 < NB; ++s2) v = (s2 == slot) ? pc[s2] : v;
+                a[p] = v;
             }
-            const double pv = readlane_f64(aik, pw);
-            // s = 2^-exponent(p): p s lies in [1, 2), so every row grows by less than 2x per column and
-            // the elimination cannot overflow (a scale taken from the PREVIOUS pivot does not have this
-            // property: the pivots themselves carry the accumulated row scale)
-            const int e = (__double2hiint(pv) >> 20) & 0x7ff;
-            const double sc = __hiloint2double((2046 - e) << 20, 0);
-            const bool self = (row == pw);
-            const double ps = self ? 1.0 : pv * sc;
-            const double ls = self ? 0.0 : aik * sc;
-            if (own) {                                // hand column k+1 off first
-                d2v g;
-                g.x = fma(ps, vown, -(ls * prv));
-                g.y = (double)(kn + 1);
-                ring[(kn & (kRing - 1)) * 64 + row] = g;
-            }
-            // bookkeeping, off the hand-off chain
-            if (e == 0 || e == 0x7ff) singular = 1;   // zero / denormal / non-finite pivot
-            dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
-            mine = self ? k : mine;
-            double pr[MC];
-#pragma unroll
-            for (int c = q; c < MC; ++c) pr[c] = readlane_f64(a[c], pw);
-#pragma unroll
-            for (int c = q; c < MC; ++c) a[c] = fma(ps, a[c], -(ls * pr[c]));
         }
     }
     __syncthreads();
@@ -1047,7 +1026,7 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
 
 static size_t mstep_fast_lds_bytes(int M, int NW) {
     const int nSp = part_stride(M), npair = nSp / 2, NG = (NW * 64) / npair;
-    size_t d = (size_t)nSp + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 16 * 64 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
+    size_t d = (size_t)nSp + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
     return d * sizeof(double);
 }
 
