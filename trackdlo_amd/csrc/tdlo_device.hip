@@ -78,7 +78,8 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 }
 
 // partial rows written by the E-step have an even stride so that the M-step can fetch them 16 bytes at a time
-__host__ __device__ inline int part_stride(int M) { return 4 * M + 2; }
+// (fp32 mode: fp32 partials, stride a multiple of 4 floats; fp64 mode: fp64 partials, even stride)
+template <typename PT> __host__ __device__ inline int part_stride(int M) { return sizeof(PT) == 4 ? ((4 * M + 1 + 3) & ~3) : (4 * M + 2); }
 
 __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
     // c of trackdlo.cpp:300 (or c' of :378 when visibility weighting is active)
@@ -288,10 +289,19 @@ __global__ __launch_bounds__(kBlock) void k_dmin(const FrameDev *__restrict__ fr
             wave_lds_sync();
         }
     }
+    // block-level min over the 4 waves, then one atomicMin per node and workgroup
+    __syncthreads();
+    T *red = (T *)smem;                                   // 4 x 64 (the tiles are dead)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int m = c * kChunk + lane;
-        if (m < M && rmin[c] < Num<T>::inf()) atomicMin(&f.dminbits[m], Num<T>::bits(rmin[c]));
+        red[wave * 64 + lane] = rmin[c];
+        __syncthreads();
+        if (wave == 0) {
+            const T r = tmin(tmin(red[lane], red[64 + lane]), tmin(red[128 + lane], red[192 + lane]));
+            const int m = c * kChunk + lane;
+            if (m < M && r < Num<T>::inf()) atomicMin(&f.dminbits[m], Num<T>::bits(r));
+        }
+        __syncthreads();
     }
 }
 
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     // ---- block partial: sum the waves in a fixed order, write [P1 | PXx | PXy | PXz | Q]
     __syncthreads();
     double *red = (double *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
-    double *part = f.part + (size_t)blockIdx.x * part_stride(M);
+    T *part = (T *)f.part + (size_t)blockIdx.x * part_stride<T>(M);      // partials leave in the compute precision
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         red[(wave * 64 + lane) * 4 + 0] = accP[c];
@@ -481,13 +491,13 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 double v = 0;
 #pragma unroll
                 for (int w = 0; w < NWE; ++w) v += red[(w * 64 + l) * 4 + k];
-                part[k * M + m] = v;
+                part[k * M + m] = (T)v;
             }
         }
         __syncthreads();
     }
     const double q = block_sum_n<NWE>(accQ, scratch);
-    if (tid == 0) part[4 * M] = q;
+    if (tid == 0) part[4 * M] = (T)q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,15 +523,16 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
 
     // ---- 1. reduce the E-step block partials in a fixed order
     if (from_sums != 1) {
-        const int nb = f.nblkE, nSp = part_stride(M);
+        const int nb = f.nblkE, nSp = part_stride<T>(M);
+        const T *partT = (const T *)f.part;
         for (int e = t; e < nS; e += kBlock) {
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int b = 0;
             for (; b + 3 < nb; b += 4) {
-                a0 += f.part[(size_t)b * nSp + e]; a1 += f.part[(size_t)(b + 1) * nSp + e];
-                a2 += f.part[(size_t)(b + 2) * nSp + e]; a3 += f.part[(size_t)(b + 3) * nSp + e];
+                a0 += (double)partT[(size_t)b * nSp + e]; a1 += (double)partT[(size_t)(b + 1) * nSp + e];
+                a2 += (double)partT[(size_t)(b + 2) * nSp + e]; a3 += (double)partT[(size_t)(b + 3) * nSp + e];
             }
-            for (; b < nb; ++b) a0 += f.part[(size_t)b * nSp + e];
+            for (; b < nb; ++b) a0 += (double)partT[(size_t)b * nSp + e];
             S[e] = (a0 + a1) + (a2 + a3);
         }
     } else {
@@ -683,11 +694,12 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     const int slot = __builtin_amdgcn_readfirstlane(t >> 6);      // wave index, wave-uniform
     const int row = lane;
     const bool rowok = row < M;
-    const int nS = 4 * M + 1, nSp = part_stride(M), npair = nSp / 2;
+    constexpr int VEC = 16 / (int)sizeof(T);          // partial elements per 16-byte load
+    const int nS = 4 * M + 1, nSp = part_stride<T>(M), npair = nSp / VEC;
     const int ncol = M + 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *S = (double *)smem;                       // nSp
-    double *W = S + nSp;                              // 3M (+pad)
+    double *W = S + ((nSp + 1) & ~1);                 // 3M (+pad)
     double *Tn = W + ((3 * M + 1) & ~1);              // 3M (+pad)
     double *red = Tn + ((3 * M + 1) & ~1);            // 8
     double *colb = red + 8;                           // 2 x 8 x 64: panel exchange buffers (double-buffered)
@@ -702,26 +714,39 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
     // ---- 1. everything that comes from memory is requested up front: block partials (16 B per load,
     //         NG thread groups striding over the blocks, fixed summation order), G
-    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef T pvec __attribute__((ext_vector_type(VEC)));
     const int NG = MB / npair;                        // >= 1 for M <= 64
     const int pe = t % npair, g = t / npair;
-    d2 acc = {0.0, 0.0};
+    double acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
     if (from_sums != 1 && g < NG) {
-        const auto part = TDLO_AS_GLOBAL(d2, f.part);
+        const auto part = TDLO_AS_GLOBAL(pvec, f.part);
         const int nb = f.nblkE;
         int b = g;
         for (; b + 9 * NG < nb; b += 10 * NG) {
-            d2 v[10];
+            pvec v[10];
 #pragma unroll
             for (int u = 0; u < 10; ++u) v[u] = part[(size_t)(b + u * NG) * npair + pe];
 #pragma unroll
-            for (int u = 0; u < 10; ++u) acc += v[u];
+            for (int u = 0; u < 10; ++u)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += (double)v[u][i];
         }
-        for (; b < nb; b += NG) acc += part[(size_t)b * npair + pe];
+        for (; b < nb; b += NG) {
+            const pvec v = part[(size_t)b * npair + pe];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += (double)v[i];
+        }
     }
     for (int i = t; i < M * M; i += MB) Gs[i] = Gg[i];
     if (done) return;
-    if (from_sums != 1) { if (g < NG) { Sg[g * nSp + 2 * pe] = acc.x; Sg[g * nSp + 2 * pe + 1] = acc.y; } }
+    if (from_sums != 1) {
+        if (g < NG) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) Sg[g * nSp + VEC * pe + i] = acc[i];
+        }
+    }
     TDLO_STAMP(1);
     __syncthreads();
     if (from_sums != 1) {
@@ -960,7 +985,8 @@ static inline int nch_for(int M) { const int c = (M + kChunk - 1) / kChunk; retu
 
 template <typename T> static size_t dmin_lds_bytes(int M) {
     const int rows = M < kChunk ? M : kChunk;
-    return sizeof(T) * (size_t)4 * rows * kPStride;
+    const size_t tile = sizeof(T) * (size_t)4 * rows * kPStride, red = sizeof(T) * 256;
+    return tile > red ? tile : red;
 }
 size_t mstep_lds_bytes(int M) {
     const int nS = 4 * M + 1, ld = M | 1;
@@ -1010,7 +1036,7 @@ template <typename T> static hipError_t launch_estep_T(const FrameDev *fd, const
 static inline int dmin_blocks(const FrameDev *fh, int F) {
     int gx = 0;
     for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
-    return gx < 64 ? gx : 64;
+    return gx;
 }
 
 template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
@@ -1024,14 +1050,15 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
     return hipGetLastError();
 }
 
-static size_t mstep_fast_lds_bytes(int M, int NW) {
-    const int nSp = part_stride(M), npair = nSp / 2, NG = (NW * 64) / npair;
-    size_t d = (size_t)nSp + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
+template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW) {
+    const int VEC = 16 / (int)sizeof(T);
+    const int nSp = part_stride<T>(M), npair = nSp / VEC, NG = (NW * 64) / npair;
+    size_t d = (size_t)((nSp + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
     return d * sizeof(double);
 }
 
 template <typename T, int NW, int MC> static hipError_t launch_mstep_fast(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
-    const size_t lds = mstep_fast_lds_bytes(fh[0].M, NW);
+    const size_t lds = mstep_fast_lds_bytes<T>(fh[0].M, NW);
     if (F == 1) {
         TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true>, lds));
         hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
