@@ -46,17 +46,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
+    backend = "nccl"
+    dev_index = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL (backend "nccl") over xGMI on a real multi-GPU node; TDLO_BENCH_BACKEND=gloo exists only so that the
+        # multi-rank code path can be exercised on a box with fewer GPUs than ranks
+        backend = os.environ.get("TDLO_BENCH_BACKEND", "nccl")
+        ngpu = torch.cuda.device_count()
+        dev_index = local_rank % max(ngpu, 1)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
     F = args.frames
-    ctx = B.Context(device=local_rank, max_frames=F, max_points=N_POINTS, max_nodes=M_NODES)   # raises without a GPU
+    ctx = B.Context(device=dev_index, max_frames=F, max_points=N_POINTS, max_nodes=M_NODES)   # raises without a GPU
     params = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
                            alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
     Ys = []
@@ -88,7 +98,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     iters_total = args.steps * F * EM_ITERS * world
