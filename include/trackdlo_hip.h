@@ -132,7 +132,8 @@ int tdlo_cpd_lle_batch(tdlo_ctx *ctx, int F, double *Y, int M, double *sigma2,
 /* ---- N-split building blocks (BASELINE.json configs[3]) --------------------------------------- */
 /* When one frame's cloud is split over several GPUs, each rank holds a shard in slot 0 and the
  * host interleaves these calls with an all-reduce (SUM) of the packed buffer
- *   sums[0..M) = P1, sums[M..4M) = PX (column-major M x 3, centred), sums[4M] = Q, sums[4M+1] = N_kept
+ *   sums[0..M) = P1, sums[M..4M) = R = PX - P1 y (column-major M x 3, residual w.r.t. the current nodes,
+ *   which are identical on every rank), sums[4M] = Q, sums[4M+1] = N_kept
  * and, when visibility weighting is active, an all-reduce (MIN) of dmin[M].
  * They expose the halves of one iteration of trackdlo.cpp:275-438. */
 int tdlo_split_begin(tdlo_ctx *ctx, const double *Y, int M, double sigma2, const tdlo_params *params,
@@ -210,6 +211,9 @@ int tdlo_profile_kernel(tdlo_ctx *ctx, int slot, int kind, int reps, float *avg_
 /* Development aid: copies the first n (<= 64) shader-clock stamps that the M-step kernel of the last
  * launch wrote at its phase boundaries (reduce / assemble / eliminate / update / publish). */
 int tdlo_debug_stamps(tdlo_ctx *ctx, int slot, unsigned long long *out, int n);
+/* Development aid: copies the pruned, centred, node-sorted cloud of the last call (N x 3 column-major, widened to
+ * double) and the centring offset; returns N. */
+int tdlo_debug_read_cloud(tdlo_ctx *ctx, int slot, double *out, int max_points, double *ctr);
 
 #ifdef __cplusplus
 }

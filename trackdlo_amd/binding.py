@@ -52,7 +52,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_visibility_prepass",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass",
 ]
 
 _lib = None
@@ -109,6 +109,7 @@ def load_library(path: str | None = None):
     lib.tdlo_traverse_euclidean.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
     lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     lib.tdlo_debug_stamps.argtypes = [vp, ci, vp, ci]
+    lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
     lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
     if path is None:
         _lib = lib
@@ -214,6 +215,13 @@ class Context:
         self._chk(self.lib.tdlo_visibility_prepass(self.h, slot, _ptr(Y), M, float(visibility_threshold), float(d_vis), _ptr(coord),
                                                    _ptr(dist), _ptr(vis), C.byref(nv), _ptr(ext), C.byref(ne)))
         return dist, vis[:nv.value].copy(), ext[:ne.value].copy()
+
+    def debug_read_cloud(self, max_points, slot=0):
+        out = np.zeros((3, max_points)); ctr = np.zeros(3)
+        n = self.lib.tdlo_debug_read_cloud(self.h, slot, _ptr(out), max_points, _ptr(ctr))
+        if n < 0:
+            raise TdloError(n, "tdlo_debug_read_cloud")
+        return out.reshape(-1)[:3 * n].reshape(3, n).T.copy(), ctr
 
     def debug_stamps(self, n=16, slot=0):
         out = np.zeros(n, dtype=np.uint64)

@@ -27,8 +27,9 @@ struct Slot {
     int N0 = 0;
     double *Xraw = nullptr;
     void *Xs = nullptr;
-    unsigned char *keep = nullptr;
-    int *blkcnt = nullptr;
+    unsigned short *bucket = nullptr;
+    int *hist = nullptr;
+    size_t hist_ints = 0;
     double *blksum = nullptr;
     // node-sized (one allocation, carved)
     int cap_nodes = 0;
@@ -102,14 +103,13 @@ int ensure_pin(tdlo_ctx *c, size_t doubles) {
 int ensure_points(tdlo_ctx *c, Slot &s, int n) {
     if (n <= s.cap_points) return 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.keep); hipFree(s.blkcnt); hipFree(s.blksum); }
+    if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.bucket); hipFree(s.blksum); }
     s.cap_points = 0;
     const size_t cap = ((size_t)n + 1023) & ~(size_t)1023;
     const size_t nb = cap / kBlock + 1;
     HIPCHK(c, hipMalloc((void **)&s.Xraw, 3 * cap * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&s.Xs, 3 * cap * sizeof(double)));
-    HIPCHK(c, hipMalloc((void **)&s.keep, cap));
-    HIPCHK(c, hipMalloc((void **)&s.blkcnt, nb * sizeof(int)));
+    HIPCHK(c, hipMalloc((void **)&s.bucket, cap * sizeof(unsigned short)));
     HIPCHK(c, hipMalloc((void **)&s.blksum, nb * sizeof(double)));
     s.cap_points = (int)cap;
     return 0;
@@ -189,10 +189,21 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0) ? 1 : 0;
     (void)vis;
     f.precision = p->precision;
+    { const char *e = getenv("TDLO_NOSORT"); f.pad1 = e ? atoi(e) : 0; }
     f.nprune_blocks = (s.N0 + kBlock - 1) / kBlock;
     f.tol = p->tol; f.beta = p->beta; f.lambda = p->lambda; f.lle_weight = p->lle_weight; f.mu = p->mu;
     f.alpha = p->alpha; f.k_vis = p->k_vis; f.vis_thr = p->visibility_threshold; f.sigma2_in = sigma2;
-    f.Xraw = s.Xraw; f.Xs = s.Xs; f.keep = s.keep; f.blkcnt = s.blkcnt; f.blksum = s.blksum;
+    {   // per (prune block, node) histogram of the counting sort
+        const size_t need = (size_t)f.nprune_blocks * M;
+        if (need > s.hist_ints) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (s.hist) hipFree(s.hist);
+            s.hist = nullptr; s.hist_ints = 0;
+            HIPCHK(c, hipMalloc((void **)&s.hist, need * sizeof(int)));
+            s.hist_ints = need;
+        }
+    }
+    f.Xraw = s.Xraw; f.Xs = s.Xs; f.bucket = s.bucket; f.hist = s.hist; f.blksum = s.blksum;
     f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
     f.coord = blk + nc.coord; f.G = blk + nc.G; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
     f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
@@ -345,7 +356,8 @@ void tdlo_destroy(tdlo_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &s : c->slots) {
-        if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.keep); hipFree(s.blkcnt); hipFree(s.blksum); }
+        if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.bucket); hipFree(s.blksum); }
+        if (s.hist) hipFree(s.hist);
         if (s.nodeblk) hipFree(s.nodeblk);
     }
     if (c->fd) hipFree(c->fd);
@@ -601,6 +613,23 @@ int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return TDLO_OK;
+}
+
+int tdlo_debug_read_cloud(tdlo_ctx *c, int slot, double *out, int max_points, double *ctr) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || !out || c->fh.empty()) return TDLO_E_INVALID;
+    const FrameDev &f = c->fh[0];
+    IterState is;
+    HIPCHK(c, hipMemcpy(&is, f.st, sizeof is, hipMemcpyDeviceToHost));
+    const int N = is.N;
+    if (N > max_points) return TDLO_E_INVALID;
+    const size_t es = f.precision == TDLO_PREC_F64 ? 8 : 4;
+    std::vector<char> buf(es * (size_t)N);
+    for (int d = 0; d < 3; ++d) {
+        HIPCHK(c, hipMemcpy(buf.data(), (const char *)f.Xs + es * (size_t)f.ldx * d, es * (size_t)N, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) out[(size_t)d * N + n] = es == 8 ? ((const double *)buf.data())[n] : (double)((const float *)buf.data())[n];
+    }
+    if (ctr) HIPCHK(c, hipMemcpy(ctr, f.ctr, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return N;
 }
 
 int tdlo_debug_stamps(tdlo_ctx *c, int slot, unsigned long long *out, int n) {

@@ -17,7 +17,7 @@
 // on fp32-rounded centred coordinates; sums leave each 64-point tile in fp32 and are accumulated in
 // fp64 from there on.  sigma2 uses the algebraically identical residual form
 //   sum_mn P_mn |x_n - T_m|^2 = Q - 2 sum_m d_m.R_m + sum_m P1_m |d_m|^2,
-//   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m,  d_m = T_m - y_m
+//   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m (accumulated directly by the E-step),  d_m = T_m - y_m
 // instead of :418-422's difference of three large traces, which would cancel catastrophically in fp32.
 #include "tdlo_internal.h"
 #include "../../include/trackdlo_hip.h"
@@ -79,6 +79,8 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 
 // partial rows written by the E-step have an even stride so that the M-step can fetch them 16 bytes at a time
 // (fp32 mode: fp32 partials, stride a multiple of 4 floats; fp64 mode: fp64 partials, even stride)
+// block partial element type for compute precision T
+template <typename T> struct PartOf { typedef T type; };     // fp32 mode: fp32 partials (half the M-step's load); fp64 mode: fp64
 template <typename PT> __host__ __device__ inline int part_stride(int M) { return sizeof(PT) == 4 ? ((4 * M + 1 + 3) & ~3) : (4 * M + 2); }
 
 __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
@@ -98,24 +100,34 @@ __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restri
     const FrameDev &f = frames[blockIdx.y];
     if ((int)blockIdx.x >= f.nprune_blocks) return;
     __shared__ double scratch[4];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *lh = (int *)smem;                            // M: kept points of this block per nearest node
     const int N0 = f.N0, M = f.M;
+    for (int m = threadIdx.x; m < M; m += kBlock) lh[m] = 0;
+    __syncthreads();
     const int n = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = n < N0;
     double x = 0, y = 0, z = 0;
     if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
     const double *__restrict__ Yi = f.Yin;
     double best = 1e300, sum = 0;
+    int a0 = 0;
     for (int m = 0; m < M; ++m) {
         const double dx = Yi[m] - x, dy = Yi[M + m] - y, dz = Yi[2 * M + m] - z;
         const double d2 = dx * dx + dy * dy + dz * dz;
-        best = fmin(best, d2);
+        if (d2 < best) { best = d2; a0 = m; }
         sum += d2;
     }
     const bool keep = valid && (::sqrt(best) < 0.1);
-    if (valid) f.keep[n] = keep ? 1 : 0;
-    const int cnt = __syncthreads_count(keep);
+    // the kept points are stored sorted by their nearest node (stable), which makes the points of a
+    // wave spatially coherent: the E-step then only touches the few nodes with non-zero membership
+    if (f.pad1 == 1) a0 = 0;                            // TDLO_NOSORT=1 (experiments): keep the original point order
+    if (valid) f.bucket[n] = keep ? (unsigned short)a0 : (unsigned short)0xffff;
+    if (keep) atomicAdd(&lh[a0], 1);
     const double s = block_sum(keep ? sum : 0.0, scratch);
-    if (threadIdx.x == 0) { f.blkcnt[blockIdx.x] = cnt; f.blksum[blockIdx.x] = s; }
+    __syncthreads();
+    for (int m = threadIdx.x; m < M; m += kBlock) f.hist[(size_t)blockIdx.x * M + m] = lh[m];
+    if (threadIdx.x == 0) f.blksum[blockIdx.x] = s;
 }
 
 // One workgroup per frame: scan of the prune counts, centring, chain coordinate + kernel G
@@ -125,28 +137,37 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     const FrameDev &f = frames[blockIdx.x];
     IterState *st = f.st;
     __shared__ double sd[kBlock];
-    __shared__ int si[kBlock];
     __shared__ double sctr[3];
     __shared__ int sN;
     __shared__ double sS;
     const int t = threadIdx.x, M = f.M;
-    // exclusive scan of per-block kept counts (deterministic order)
+    // counting sort by nearest node: hist[block][node] -> start offset of that (node, block) run.
+    // pass A: per-node totals and per-thread chunk sums of blksum; pass B: offsets.
     const int nb = f.nprune_blocks;
-    const int per = (nb + kBlock - 1) / kBlock;
-    const int b0 = min(nb, t * per), b1 = min(nb, b0 + per);
-    int c = 0; double s = 0;
-    for (int b = b0; b < b1; ++b) { c += f.blkcnt[b]; s += f.blksum[b]; }
-    si[t] = c; sd[t] = s;
+    __shared__ int stot[kMaxNodes];
+    for (int m = t; m < M; m += kBlock) {
+        int run = 0;
+        for (int b = 0; b < nb; ++b) { const int v = f.hist[(size_t)b * M + m]; f.hist[(size_t)b * M + m] = run; run += v; }
+        stot[m] = run;
+    }
+    {
+        const int per = (nb + kBlock - 1) / kBlock;
+        const int b0 = min(nb, t * per), b1 = min(nb, b0 + per);
+        double s = 0;
+        for (int b = b0; b < b1; ++b) s += f.blksum[b];
+        sd[t] = s;
+    }
     __syncthreads();
     if (t == 0) {
         int run = 0; double tot = 0;
-        for (int i = 0; i < kBlock; ++i) { const int v = si[i]; si[i] = run; run += v; tot += sd[i]; }
+        for (int m = 0; m < M; ++m) { const int v = stot[m]; stot[m] = run; run += v; }
+        for (int i = 0; i < kBlock; ++i) tot += sd[i];
         sN = run; sS = tot;
     }
     __syncthreads();
-    {
-        int run = si[t];
-        for (int b = b0; b < b1; ++b) { const int v = f.blkcnt[b]; f.blkcnt[b] = run; run += v; }
+    for (int m = t; m < M; m += kBlock) {
+        const int base = stot[m];
+        for (int b = 0; b < nb; ++b) f.hist[(size_t)b * M + m] += base;
     }
     // centring offset
     if (t < 3) {
@@ -213,18 +234,30 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_prune_scatter(const FrameDev *__restrict__ frames) {
     const FrameDev &f = frames[blockIdx.y];
     if ((int)blockIdx.x >= f.nprune_blocks) return;
-    __shared__ int wc[4];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *wcnt = (int *)smem;                          // 4 x M: kept points per (wave, nearest node)
+    const int M = f.M;
     const int n = blockIdx.x * kBlock + threadIdx.x;
-    const bool keep = (n < f.N0) && f.keep[n];
-    const unsigned long long bal = __ballot(keep);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wc[w] = __popcll(bal);
+    for (int i = threadIdx.x; i < 4 * M; i += kBlock) wcnt[i] = 0;
     __syncthreads();
-    int off = f.blkcnt[blockIdx.x];
-    for (int i = 0; i < w; ++i) off += wc[i];
+    const int b = (n < f.N0) ? (int)f.bucket[n] : 0xffff;
+    const bool keep = b != 0xffff;
+    // rank of this point among the earlier points of the wave with the same nearest node (stable order)
+    int rank = 0;
+    unsigned long long remaining = __ballot(keep);
+    while (remaining) {
+        const int leader = (int)__builtin_ctzll(remaining);
+        const int b0 = __builtin_amdgcn_readlane(b, leader);
+        const unsigned long long mask = __ballot(keep && b == b0);
+        if (keep && b == b0) rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == leader) wcnt[w * M + b0] = __popcll(mask);
+        remaining &= ~mask;
+    }
+    __syncthreads();
     if (keep) {
-        const int dst = off + pre;
+        int dst = f.hist[(size_t)blockIdx.x * M + b] + rank;
+        for (int i = 0; i < w; ++i) dst += wcnt[i * M + b];
         T *xs = (T *)f.Xs;
         const size_t N0 = f.N0, ld = f.ldx;
         xs[dst] = (T)(f.Xraw[n] - f.ctr[0]);
@@ -391,6 +424,16 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { accP[c] = 0; accX[c] = 0; accY[c] = 0; accZ[c] = 0; }
     double accQ = 0;
+    // NCH == 1 (M <= 64): windowed variant.  The cloud is sorted by nearest node, so the 64 points of a
+    // wave sit on a short piece of the chain, and every membership whose exponent is below -151 (fp32;
+    // -1080 in fp64) is EXACTLY zero: only the nodes inside an arc-length window around the wave's
+    // nearest-pair range can contribute, the others are skipped -- same sums, bit for bit.
+    double *accL = scratch + 16 + (size_t)wave * M * 4;    // per-wave [M][4] accumulators (NCH == 1)
+    if (NCH == 1) {
+        for (int i = lane; i < M * 4; i += 64) accL[i] = 0.0;
+    }
+    constexpr double kCut = sizeof(T) == 4 ? 151.0 : 1080.0;
+    const T Rwin = (T)(1.01 * ::sqrt(kCut / fabs((double)k2)));
 
     const int nbatch = (N + 63) >> 6;
     for (int batch = batch0; batch < nbatch; batch += f.nblkE * NWE) {
@@ -425,10 +468,22 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         const T d_lo = a_lo ? ea : eb, d_hi = a_lo ? eb : ea;
         const T c_lo = a_lo ? qa.w : cb, c_hi = a_lo ? cb : qa.w;
 
+        // ---- node window of this wave (NCH == 1)
+        int wlo = 0, whi = M - 1;
+        if (NCH == 1) {
+            T amin = valid ? c_lo : Num<T>::inf(), amax = valid ? c_hi : -Num<T>::inf();
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { amin = tmin(amin, __shfl_xor(amin, o)); amax = -tmin(-amax, -__shfl_xor(amax, o)); }
+            const T cm = (lane < M) ? nodesL[lane].w : Num<T>::inf();
+            const unsigned long long inw = __ballot(lane < M && cm > amin - Rwin && cm < amax + Rwin);
+            if (inw && f.pad1 != 3) { wlo = (int)__builtin_ctzll(inw); whi = 63 - (int)__builtin_clzll(inw); }
+            wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
+        }
+
         // ---- unnormalised membership, column sum, Q (:354-383)
         T sum = 0, qs = 0;
-#pragma unroll 8
-        for (int m = 0; m < M; ++m) {
+#pragma unroll 4
+        for (int m = wlo; m <= whi; ++m) {
             V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
             T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
             if (VIS) e += lvL[m];
@@ -437,24 +492,57 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const T d2 = ddx * ddx + ddy * ddy + ddz * ddz;
             sum += p;
             qs += p * d2;
-            if (NCH == 1) pb[m * kPStride + lane] = p;
+            if (NCH == 1) pb[(m - wlo) * kPStride + lane] = p;
         }
         const T inv = valid ? T(1) / (sum + cn) : T(0);
         accQ += (double)(inv * qs);
-        V4<T> pw; pw.x = inv * x; pw.y = inv * y; pw.z = inv * z; pw.w = inv;
+        // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
+        // wave's points within centimetres) and leave as the residual R_m = sum_n P_mn (x_n - y_m):
+        // small numbers, so fp32 tile sums and fp32 block partials lose nothing that matters
+        const T ox = f.pad1 == 2 ? T(0) : __shfl(x, 0), oy = f.pad1 == 2 ? T(0) : __shfl(y, 0), oz = f.pad1 == 2 ? T(0) : __shfl(z, 0);
+        V4<T> pw; pw.x = inv * (x - ox); pw.y = inv * (y - oy); pw.z = inv * (z - oz); pw.w = inv;
         pts[wave * 64 + lane] = pw;
 
+        if (NCH == 1) {
+            // ---- column sums (:386-389): lane = (node of the window, slice of the 64 points)
+            wave_lds_sync();
+            const int Wn = whi - wlo + 1;
+            const int shift = Wn <= 16 ? 4 : (Wn <= 32 ? 5 : 6);         // wave-uniform
+            const int wl = lane & ((1 << shift) - 1), sl = lane >> shift;
+            const int nj = 1 << shift;                                   // points per slice: 16 / 32 / 64
+            T s0 = 0, sx = 0, sy = 0, sz = 0;
+            if (wl < Wn) {
+                const T *prow = pb + wl * kPStride + sl * nj;
+                const V4<T> *pw_ = pts + wave * 64 + sl * nj;
+#pragma unroll 8
+                for (int j = 0; j < nj; ++j) {
+                    const T p = prow[j];
+                    const V4<T> w = pw_[j];
+                    s0 += p * w.w; sx += p * w.x; sy += p * w.y; sz += p * w.z;
+                }
+            }
+            if (shift <= 5) { s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32); }
+            if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
+            if (lane < Wn) {
+                double *ac = accL + (size_t)(wlo + lane) * 4;
+                const V4<T> ym = nodesL[wlo + lane];
+                const double w0 = (double)s0;
+                ac[0] += w0;
+                ac[1] += (double)sx + ((double)ox - (double)ym.x) * w0;
+                ac[2] += (double)sy + ((double)oy - (double)ym.y) * w0;
+                ac[3] += (double)sz + ((double)oz - (double)ym.z) * w0;
+            }
+            wave_lds_sync();
+        } else {
         // ---- column sums with lane = node (:386-389)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int m0 = c * kChunk, m1 = min(M, m0 + kChunk);
-            if (NCH > 1) {
-                for (int m = m0; m < m1; ++m) {
-                    V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
-                    T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
-                    if (VIS) e += lvL[m];
-                    pb[(m - m0) * kPStride + lane] = Num<T>::exp2(e);
-                }
+            for (int m = m0; m < m1; ++m) {
+                V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
+                T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
+                if (VIS) e += lvL[m];
+                pb[(m - m0) * kPStride + lane] = Num<T>::exp2(e);
             }
             wave_lds_sync();
             if (m0 + lane < m1) {
@@ -467,16 +555,33 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                     const V4<T> w = pw_[j];
                     s0 += p * w.w; sx += p * w.x; sy += p * w.y; sz += p * w.z;
                 }
-                accP[c] += (double)s0; accX[c] += (double)sx; accY[c] += (double)sy; accZ[c] += (double)sz;
+                const V4<T> ym = nodesL[m0 + lane];
+                const double w0 = (double)s0;
+                accP[c] += w0;
+                accX[c] += (double)sx + ((double)ox - (double)ym.x) * w0;
+                accY[c] += (double)sy + ((double)oy - (double)ym.y) * w0;
+                accZ[c] += (double)sz + ((double)oz - (double)ym.z) * w0;
             }
             wave_lds_sync();
+        }
         }
     }
 
     // ---- block partial: sum the waves in a fixed order, write [P1 | PXx | PXy | PXz | Q]
     __syncthreads();
+    typedef typename PartOf<T>::type PT;
+    PT *part = (PT *)f.part + (size_t)blockIdx.x * part_stride<PT>(M);
+    if (NCH == 1) {
+        const double *accAll = scratch + 16;
+        for (int i = tid; i < 4 * M; i += EB) {
+            const int m = i >> 2, k = i & 3;
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < NWE; ++w) v += accAll[(size_t)w * M * 4 + i];
+            part[k * M + m] = (PT)v;
+        }
+    } else {
     double *red = (double *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
-    T *part = (T *)f.part + (size_t)blockIdx.x * part_stride<T>(M);      // partials leave in the compute precision
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         red[(wave * 64 + lane) * 4 + 0] = accP[c];
@@ -491,13 +596,14 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 double v = 0;
 #pragma unroll
                 for (int w = 0; w < NWE; ++w) v += red[(w * 64 + l) * 4 + k];
-                part[k * M + m] = (T)v;
+                part[k * M + m] = (PT)v;
             }
         }
         __syncthreads();
     }
+    }
     const double q = block_sum_n<NWE>(accQ, scratch);
-    if (tid == 0) part[4 * M] = (T)q;
+    if (tid == 0) part[4 * M] = (PT)q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -523,8 +629,9 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
 
     // ---- 1. reduce the E-step block partials in a fixed order
     if (from_sums != 1) {
-        const int nb = f.nblkE, nSp = part_stride<T>(M);
-        const T *partT = (const T *)f.part;
+        typedef typename PartOf<T>::type PT;
+        const int nb = f.nblkE, nSp = part_stride<PT>(M);
+        const PT *partT = (const PT *)f.part;
         for (int e = t; e < nS; e += kBlock) {
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int b = 0;
@@ -558,7 +665,9 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     }
     for (int e = t; e < 3 * M; e += kBlock) {
         const int i = e % M, d = e / M;
-        double b = S[M + e] - S[i] * f.Y0[e];
+        const V4<T> *ndq = (const V4<T> *)f.nodes;
+        const double yd = d == 0 ? (double)ndq[i].x : (d == 1 ? (double)ndq[i].y : (double)ndq[i].z);
+        double b = S[M + e] + S[i] * (yd - f.Y0[e]);     // B = R + P1 (y - Y0), R = PX - P1 y from the E-step
         if (f.include_lle) b -= sg * f.HY0[e];
         if (f.has_priors) b += f.aYd[e];
         A[(size_t)(M + d) * ld + i] = b;
@@ -622,7 +731,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
         const double yx = (double)q.x, yy = (double)q.y, yz = (double)q.z;    // nodes as the E-step saw them
         const double p1 = S[m];
         const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
-        const double rx = S[M + m] - p1 * yx, ry = S[2 * M + m] - p1 * yy, rz = S[3 * M + m] - p1 * yz;
+        const double rx = S[M + m], ry = S[2 * M + m], rz = S[3 * M + m];
         s_np += p1;
         s_dr += dx * rx + dy * ry + dz * rz;
         s_pd += p1 * (dx * dx + dy * dy + dz * dz);
@@ -694,8 +803,9 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     const int slot = __builtin_amdgcn_readfirstlane(t >> 6);      // wave index, wave-uniform
     const int row = lane;
     const bool rowok = row < M;
-    constexpr int VEC = 16 / (int)sizeof(T);          // partial elements per 16-byte load
-    const int nS = 4 * M + 1, nSp = part_stride<T>(M), npair = nSp / VEC;
+    typedef typename PartOf<T>::type PT;
+    constexpr int VEC = 16 / (int)sizeof(PT);         // partial elements per 16-byte load
+    const int nS = 4 * M + 1, nSp = part_stride<PT>(M), npair = nSp / VEC;
     const int ncol = M + 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *S = (double *)smem;                       // nSp
@@ -714,7 +824,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
     // ---- 1. everything that comes from memory is requested up front: block partials (16 B per load,
     //         NG thread groups striding over the blocks, fixed summation order), G
-    typedef T pvec __attribute__((ext_vector_type(VEC)));
+    typedef PT pvec __attribute__((ext_vector_type(VEC)));
     const int NG = MB / npair;                        // >= 1 for M <= 64
     const int pe = t % npair, g = t / npair;
     double acc[VEC];
@@ -782,8 +892,11 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                 v = (p1 + aj) * gv + (row == j ? c2 : 0.0);
                 if (lle) v += sg * f.HG[(size_t)j * M + row];
             } else if (rowok && j < ncol) {
-                const int i = (j - M) * M + row;
-                v = S[M + i] - p1 * Y0g[i];
+                // B = PX - P1 Y0 = R + P1 (y - Y0): the E-step delivers R = PX - P1 y (y = nodes as it saw them)
+                const int i = (j - M) * M + row, d = j - M;
+                const auto ndg = TDLO_AS_GLOBAL(V4<T>, f.nodes);
+                const double yd = d == 0 ? (double)ndg[row].x : (d == 1 ? (double)ndg[row].y : (double)ndg[row].z);
+                v = S[M + i] + p1 * (yd - Y0g[i]);
                 if (lle) v -= sg * f.HY0[i];
                 if (pri) v += f.aYd[i];
             }
@@ -909,7 +1022,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             const double p1 = S[m];
             const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
             if (slot == 0) v = p1;
-            else if (slot == 1) v = dx * (S[M + m] - p1 * yx) + dy * (S[2 * M + m] - p1 * yy) + dz * (S[3 * M + m] - p1 * yz);
+            else if (slot == 1) v = dx * S[M + m] + dy * S[2 * M + m] + dz * S[3 * M + m];
             else if (slot == 2) v = p1 * (dx * dx + dy * dy + dz * dz);
             else { const double ex = Yg[m] - Tn[m], ey = Yg[M + m] - Tn[M + m], ez = Yg[2 * M + m] - Tn[2 * M + m]; v = ::sqrt(ex * ex + ey * ey + ez * ez); }
         }
@@ -1009,6 +1122,7 @@ template <typename T, int EB> static size_t estep_lds_bytes(int M) {
     const size_t red = (size_t)NWE * 64 * 4 * sizeof(double);
     size_t b = sizeof(V4<T>) * (size_t)M + sizeof(V4<T>) * NWE * 64 + sizeof(T) * (size_t)((M + 3) & ~3);
     b += (tile > red ? tile : red) + 16 * sizeof(double) + 64;
+    if (M <= kChunk) b += sizeof(double) * (size_t)NWE * M * 4;     // per-wave accumulators of the windowed variant
     return b;
 }
 
@@ -1051,8 +1165,9 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
 }
 
 template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW) {
-    const int VEC = 16 / (int)sizeof(T);
-    const int nSp = part_stride<T>(M), npair = nSp / VEC, NG = (NW * 64) / npair;
+    typedef typename PartOf<T>::type PT;
+    const int VEC = 16 / (int)sizeof(PT);
+    const int nSp = part_stride<PT>(M), npair = nSp / VEC, NG = (NW * 64) / npair;
     size_t d = (size_t)((nSp + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
     return d * sizeof(double);
 }
@@ -1106,11 +1221,11 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     int gx = 0;
     for (int i = 0; i < F; ++i) gx = fh[i].nprune_blocks > gx ? fh[i].nprune_blocks : gx;
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
-    hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), 0, s, fd);
+    hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * fh[0].M, s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(F), dim3(kBlock), 0, s, fd, 0);
     else hipLaunchKernelGGL((k_setup<float>), dim3(F), dim3(kBlock), 0, s, fd, 0);
-    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), 0, s, fd);
-    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), 0, s, fd);
+    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
+    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
     return hipGetLastError();
 }
 
@@ -1137,11 +1252,11 @@ hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int 
 
 hipError_t launch_split_setup(const FrameDev *fd, const FrameDev *fh, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
-    hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), 0, s, fd);
+    hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * fh[0].M, s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(1), dim3(kBlock), 0, s, fd, 1);
     else hipLaunchKernelGGL((k_setup<float>), dim3(1), dim3(kBlock), 0, s, fd, 1);
-    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), 0, s, fd);
-    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), 0, s, fd);
+    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
+    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
     return hipGetLastError();
 }
 

@@ -39,8 +39,8 @@ struct FrameDev {
     // cloud
     const double *Xraw;     // N0 x 3 column-major as uploaded
     void *Xs;               // pruned, centred SoA in compute precision: x[ldx] y[ldx] z[ldx]
-    unsigned char *keep;    // N0
-    int *blkcnt;            // per prune block kept count -> exclusive offsets after setup
+    unsigned short *bucket; // N0: nearest node of a kept point, 0xffff = pruned
+    int *hist;              // nprune_blocks x M: kept points per (block, nearest node) -> start offsets after setup
     double *blksum;         // per prune block sum of d2 over kept points
     // nodes
     const double *Yin;      // M x 3 as given by the caller
