@@ -175,10 +175,10 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     std::memset(&f, 0, sizeof f);
     f.N0 = s.N0; f.M = M; f.ldx = s.cap_points;
     const int nbatch = (s.N0 + 63) / 64;
-    // 4 waves per workgroup; an 8-wave variant (half as many block partials for the M-step, fp32 only:
-    // fp64 tiles are twice as large) measured the same end to end and can be selected for experiments
-    f.eb = 256;
-    { const char *e = getenv("TDLO_ESTEP_THREADS"); if (e && atoi(e) == 512 && p->precision == TDLO_PREC_F32) f.eb = 512; }
+    // fp32: 8 waves per workgroup (half as many block partials for the M-step to add up); fp64 tiles are
+    // twice as large, so 4 waves.  TDLO_ESTEP_THREADS=256 forces the small variant (experiments).
+    f.eb = (p->precision == TDLO_PREC_F32 && M <= 64) ? 512 : 256;
+    { const char *e = getenv("TDLO_ESTEP_THREADS"); if (e && atoi(e) == 256) f.eb = 256; }
     const int wpb = f.eb / 64;
     int nblk = (nbatch + wpb - 1) / wpb;
     int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : 256;

@@ -142,13 +142,28 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     __shared__ double sS;
     const int t = threadIdx.x, M = f.M;
     // counting sort by nearest node: hist[block][node] -> start offset of that (node, block) run.
-    // pass A: per-node totals and per-thread chunk sums of blksum; pass B: offsets.
+    // 256 threads = 64 nodes x 4 chunks of blocks; per node an exclusive scan over the blocks in block order.
     const int nb = f.nprune_blocks;
     __shared__ int stot[kMaxNodes];
-    for (int m = t; m < M; m += kBlock) {
-        int run = 0;
-        for (int b = 0; b < nb; ++b) { const int v = f.hist[(size_t)b * M + m]; f.hist[(size_t)b * M + m] = run; run += v; }
-        stot[m] = run;
+    __shared__ int csum[4][64];
+    {
+        const int ml = t & 63, ch = t >> 6;
+        const int cb0 = (int)((long long)nb * ch / 4), cb1 = (int)((long long)nb * (ch + 1) / 4);
+        for (int mg = 0; mg < M; mg += 64) {
+            const int m = mg + ml;
+            int run = 0;
+            if (m < M) for (int b = cb0; b < cb1; ++b) run += f.hist[(size_t)b * M + m];
+            csum[ch][ml] = run;
+            __syncthreads();
+            int start = 0;
+            for (int c2 = 0; c2 < ch; ++c2) start += csum[c2][ml];
+            if (ch == 3 && m < M) stot[m] = start + run;
+            if (m < M) {
+                int r2 = start;
+                for (int b = cb0; b < cb1; ++b) { const int v = f.hist[(size_t)b * M + m]; f.hist[(size_t)b * M + m] = r2; r2 += v; }
+            }
+            __syncthreads();
+        }
     }
     {
         const int per = (nb + kBlock - 1) / kBlock;
@@ -165,10 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         sN = run; sS = tot;
     }
     __syncthreads();
-    for (int m = t; m < M; m += kBlock) {
-        const int base = stot[m];
-        for (int b = 0; b < nb; ++b) f.hist[(size_t)b * M + m] += base;
-    }
+    for (int i = t; i < nb * M; i += kBlock) f.hist[i] += stot[i % M];
     // centring offset
     if (t < 3) {
         double a = 0;
