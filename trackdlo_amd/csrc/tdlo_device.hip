@@ -915,6 +915,25 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             a[c] = v;
         }
     }
+    {   // tracer column j = M + 3: t = A 1 (row sums).  Its solution is the all-ones vector, so after the
+        // elimination it holds each row's pivot entry times the row's accumulated scale: x = b / t with no
+        // per-column bookkeeping at all.
+        double rs = 0.0;
+#pragma unroll
+        for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j < M) rs += a[c]; }
+        colb[slot * 64 + row] = rs;                   // (the panel buffers are free until the elimination starts)
+        __syncthreads();
+        const int jt = M + 3;
+        if (slot == (jt & (NSLOT - 1))) {
+            const int ct = jt / NSLOT;
+            double tsum = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < NSLOT; ++s2) tsum += colb[s2 * 64 + row];      // fixed order: deterministic
+#pragma unroll
+            for (int c = 0; c < MC; ++c) if (c == ct) a[c] = rowok ? tsum : 0.0;
+        }
+        __syncthreads();
+    }
     // ---- 3. Gauss-Jordan elimination on [A | B]: straight-line code, ONE barrier per 8 columns.
     // wave = column slot, lane = row; a lane keeps its row's entries of the columns j = slot + 8 c in
     // registers.  Columns are eliminated in panels of 8 (one column from every wave):
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     //   * the pivot ROW entries a wave needs are the ones its own lane `pw` holds -> v_readlane.
     // Row operation, division-free: row_i <- (p s) row_i - (a_ik s) row_k with s = 2^-exponent(p), so
     // p s is in [1, 2): rows grow by < 2x per column, no reciprocal on the dependency chain.  A row's
-    // pivot entry and accumulated scale are tracked exactly in `dgv`; x = b / dgv at the end.
+    // pivot entry times its accumulated scale is read off the tracer column at the end: x = b / t.
     //   include_lle == 0: A = c I + D G, D >= 0 diagonal, G SPD.  Row scaling does not change Gaussian
     //     elimination, so this is the elimination of the SPD matrix G + c D^-1 (rows with D_i = 0 are
     //     c e_i): stable without pivoting.
@@ -936,12 +955,13 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     static_assert(NB == 8 || NB == 4, "panel width");
     double *pan = colb;                               // 2 x NB x 64 doubles
     int singular = 0;
-    int mine = -1;                                    // unknown this row ends up solving
-    double dgv = 1.0;                                 // a(row, mine) times the row's later scalings (exact bookkeeping)
+    int mine = lle ? -1 : row;                        // unknown this row ends up solving (row itself without pivoting)
     unsigned long long usedmask = 0;
-    bool has_rhs = false;
-#pragma unroll
-    for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; has_rhs = has_rhs || (j >= M && j < ncol); }
+    double dgv = 1.0;                                 // pivoting path only: pivot entry times later row scalings
+    // Panels are unrolled so that inside panel p the update loop is the static register range (p, MC):
+    // finished columns are skipped without a single data-dependent branch.  (A rolled panel loop that
+    // updates every register was measured slower: the extra column updates cost more than the
+    // instruction fetches saved.)
 #pragma unroll
     for (int p = 0; p < MC; ++p) {                    // panel p = columns p NB .. p NB + NB - 1; mine is register p
         if (p * NB < M) {                             // wave-uniform
@@ -973,7 +993,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                     const bool self = (row == pw);
                     const double ps = self ? 1.0 : pv * sc;
                     const double ls = self ? 0.0 : aik * sc;
-                    if (has_rhs) {                    // wave-uniform: only waves holding right-hand-side columns need the scale
+                    if (lle) {                        // ill-conditioned system: exact bookkeeping instead of the tracer
                         dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
                         mine = self ? k : mine;
                     }
@@ -994,9 +1014,19 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         }
     }
     __syncthreads();
-    if (rowok && mine >= 0) {                         // x = b / (pivot entry with the row's accumulated scale)
+    {   // x = b / t: the tracer column now holds (pivot entry x accumulated row scale)
+        const int jt = M + 3;
+        if (slot == (jt & (NSLOT - 1))) {
+            const int ct = jt / NSLOT;
 #pragma unroll
-        for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dgv; }
+            for (int c = 0; c < MC; ++c) if (c == ct) colb[row] = a[c];
+        }
+        __syncthreads();
+        const double dg = lle ? dgv : colb[row];
+        if (rowok && mine >= 0) {
+#pragma unroll
+            for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dg; }
+        }
     }
     __syncthreads();
 
@@ -1198,7 +1228,7 @@ template <typename T, int NW, int MC> static hipError_t launch_mstep_fast(const 
 
 static int mstep_waves() {
     static int v = 0;
-    if (!v) { const char *e = getenv("TDLO_MSTEP_WAVES"); v = e ? atoi(e) : 8; if (v != 4 && v != 8) v = 8; }
+    if (!v) { const char *e = getenv("TDLO_MSTEP_WAVES"); v = e ? atoi(e) : 4; if (v != 4 && v != 8) v = 4; }
     return v;
 }
 
@@ -1206,13 +1236,13 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
     const int M = fh[0].M;
     if (M <= 64) {
         if (mstep_waves() == 8) {
-            const int mc = (M + 3 + 7) / 8;           // columns per wave
+            const int mc = (M + 4 + 7) / 8;           // columns per wave: M matrix + 3 right-hand sides + 1 tracer
             if (mc <= 3) return launch_mstep_fast<T, 8, 3>(fd, fh, F, from_sums, s);
             if (mc <= 5) return launch_mstep_fast<T, 8, 5>(fd, fh, F, from_sums, s);
             if (mc <= 7) return launch_mstep_fast<T, 8, 7>(fd, fh, F, from_sums, s);
             return launch_mstep_fast<T, 8, 9>(fd, fh, F, from_sums, s);
         } else {
-            const int mc = (M + 3 + 3) / 4;
+            const int mc = (M + 4 + 3) / 4;
             if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
             if (mc <= 10) return launch_mstep_fast<T, 4, 10>(fd, fh, F, from_sums, s);
             if (mc <= 14) return launch_mstep_fast<T, 4, 14>(fd, fh, F, from_sums, s);
