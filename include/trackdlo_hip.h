@@ -203,6 +203,13 @@ int tdlo_traverse_euclidean(const double *geodesic_coord, int n_coord, const dou
                             const int *visible_nodes, int n_vis, int alignment, int alignment_node_idx,
                             double *out /* (n_coord + 2) x 4 row-major */);
 
+/* ---- frame-level accuracy metric ------------------------------------------ */
+/* evaluator::get_piecewise_error (trackdlo/src/evaluator.cpp:258-283, with calc_min_distance :233-256): mean over the
+ * nodes of Y_track of the distance to the polyline through Y_true.  Chains are n x 3 column-major.  < 0 on bad input. */
+double tdlo_piecewise_error(const double *Y_track, int n_track, const double *Y_true, int n_true);
+/* evaluator::compute_error (evaluator.cpp:333-341): the symmetrised mean (E(track,true) + E(true,track)) / 2. */
+double tdlo_compute_error(const double *Y_track, int n_track, const double *Y_true, int n_true);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Launches the E-step kernel `reps` times back to back on the context's stream for the state left
  * by the last cpd_lle call on `slot` and returns the HIP-event average per launch (microseconds).

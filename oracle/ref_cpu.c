@@ -821,3 +821,47 @@ int ref_visibility_prepass(const double *X, int N, const double *Y, int M, doubl
     if (n_ext) *n_ext = ne;
     return nv;
 }
+
+/* ---------------------------------------------------------------- evaluator.cpp:233-283, :333-341 */
+
+static double calc_min_distance(const double A[3], const double B[3], const double E[3]) {
+    double AB[3], AE[3], cr[3];
+    for (int i = 0; i < 3; i++) { AB[i] = B[i] - A[i]; AE[i] = E[i] - A[i]; }
+    cr[0] = AE[1] * AB[2] - AE[2] * AB[1];                       /* utils.cpp:477-486 */
+    cr[1] = -(AE[0] * AB[2] - AE[2] * AB[0]);
+    cr[2] = AE[0] * AB[1] - AE[1] * AB[0];
+    double nAB = sqrt(AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2]);
+    double distance = sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]) / nAB;     /* :237 */
+    double dAEAB = AE[0] * AB[0] + AE[1] * AB[1] + AE[2] * AB[2];
+    double dABAB = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+    double P[3], AP[3];
+    for (int i = 0; i < 3; i++) { P[i] = A[i] + AB[i] * dAEAB / dABAB; AP[i] = P[i] - A[i]; }   /* :238-240 */
+    double dAPAB = AP[0] * AB[0] + AP[1] * AB[1] + AP[2] * AB[2];
+    if (dAPAB < 0 || dAPAB > dABAB) {                             /* :241-252 */
+        double BE[3];
+        for (int i = 0; i < 3; i++) BE[i] = E[i] - B[i];
+        double dAE = sqrt(AE[0] * AE[0] + AE[1] * AE[1] + AE[2] * AE[2]);
+        double dBE = sqrt(BE[0] * BE[0] + BE[1] * BE[1] + BE[2] * BE[2]);
+        distance = (dAE > dBE) ? dBE : dAE;
+    }
+    return distance;
+}
+
+double ref_piecewise_error(const double *Yt, int n1, const double *Yr, int n2) {
+    double total = 0.0;
+    for (int idx = 0; idx < n1; idx++) {
+        double dist = -1;
+        double E[3] = {Yt[idx], Yt[n1 + idx], Yt[2 * n1 + idx]};
+        for (int i = 0; i < n2 - 1; i++) {
+            double A[3] = {Yr[i], Yr[n2 + i], Yr[2 * n2 + i]}, B[3] = {Yr[i + 1], Yr[n2 + i + 1], Yr[2 * n2 + i + 1]};
+            double di = calc_min_distance(A, B, E);
+            if (dist == -1 || di < dist) dist = di;
+        }
+        total += dist;
+    }
+    return total / n1;                                             /* :280 */
+}
+
+double ref_compute_error(const double *Yt, int n1, const double *Yr, int n2) {
+    return (ref_piecewise_error(Yt, n1, Yr, n2) + ref_piecewise_error(Yr, n2, Yt, n1)) / 2;     /* :335-339 */
+}

@@ -130,6 +130,11 @@ int ref_tracking_step(ref_tracker *t, const double *X, int N, const int *vis, in
 int ref_visibility_prepass(const double *X, int N, const double *Y, int M, double visibility_threshold, double d_vis,
                            const double *coord, double *node_dist, int *vis, int *vis_ext, int *n_ext);
 
+/* evaluator::get_piecewise_error / compute_error, trackdlo/src/evaluator.cpp:233-283, :333-341 (with
+ * cross_product / dot_product of utils.cpp:477-489).  Chains n x 3 column-major. */
+double ref_piecewise_error(const double *Y_track, int n1, const double *Y_true, int n2);
+double ref_compute_error(const double *Y_track, int n1, const double *Y_true, int n2);
+
 /* dense helper exposed for tests: solve A x = B (A n x n col-major, B n x nrhs col-major)
  * by Householder QR with column pivoting (what completeOrthogonalDecomposition reduces to for
  * full-rank A, trackdlo.cpp:415). A and B are overwritten; solution returned in X (n x nrhs). */

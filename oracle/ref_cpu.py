@@ -54,6 +54,8 @@ def lib():
         _LIB.ref_tracker_create.restype = C.c_void_p
         _LIB.ref_tracking_step.restype = C.c_int
         _LIB.ref_visibility_prepass.restype = C.c_int
+        _LIB.ref_piecewise_error.restype = C.c_double
+        _LIB.ref_compute_error.restype = C.c_double
     return _LIB
 
 
@@ -142,6 +144,16 @@ def visibility_prepass(X, Y, visibility_threshold, d_vis, coord):
     nv = lib().ref_visibility_prepass(_dp(X), C.c_int(X.shape[0]), _dp(Y), C.c_int(M), C.c_double(visibility_threshold), C.c_double(d_vis),
                                       _dp(coord), _dp(dist), _dp(vis), _dp(ext), C.byref(ne))
     return dist, vis[:nv].copy(), ext[:ne.value].copy()
+
+
+def piecewise_error(Y_track, Y_true):
+    a = _f(Y_track); b = _f(Y_true)
+    return lib().ref_piecewise_error(_dp(a), C.c_int(a.shape[0]), _dp(b), C.c_int(b.shape[0]))
+
+
+def compute_error(Y_track, Y_true):
+    a = _f(Y_track); b = _f(Y_true)
+    return lib().ref_compute_error(_dp(a), C.c_int(a.shape[0]), _dp(b), C.c_int(b.shape[0]))
 
 
 def solve_qrcp(A, B):

@@ -107,3 +107,28 @@ def test_cpp_shim_header_compiles():
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ROOT, "tests", "cpp", "shim_test.cpp")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_piecewise_error_metric(oracle):
+    """SURVEY 8(f) row 3: evaluator::get_piecewise_error / compute_error (evaluator.cpp:233-283, :333-341)."""
+    from trackdlo_amd import binding as B, synth
+    # analytic: a chain shifted by h perpendicular to a straight polyline is at distance h everywhere
+    n = 12
+    Yt = np.stack([np.linspace(0, 1, n), np.zeros(n), np.zeros(n)], axis=1)
+    Ys = Yt + np.array([0.0, 0.03, 0.0])
+    assert abs(B.get_piecewise_error(Ys, Yt) - 0.03) < 1e-15 and abs(B.compute_error(Ys, Yt) - 0.03) < 1e-15
+    # a point beyond the end of the polyline measures to the end point
+    P = np.array([[1.5, 0.0, 0.0]])
+    assert abs(B.get_piecewise_error(P, Yt) - 0.5) < 1e-15
+    rng = np.random.default_rng(5)
+    for M1, M2 in ((30, 30), (45, 37), (5, 60)):
+        A = synth.nodes(M1) + rng.normal(scale=0.004, size=(M1, 3))
+        Bm = synth.nodes(M2) + rng.normal(scale=0.004, size=(M2, 3)) + np.array([0.0, 0.003, 0.0])
+        assert abs(B.get_piecewise_error(A, Bm) - oracle.piecewise_error(A, Bm)) < 1e-15
+        assert abs(B.compute_error(A, Bm) - oracle.compute_error(A, Bm)) < 1e-15
+        assert B.compute_error(A, Bm) == B.compute_error(Bm, A)
+        # brute-force check of the definition on a dense resampling of the polyline
+        s = np.linspace(0, 1, 400)[:, None]
+        seg = np.concatenate([(1 - s) * Bm[i] + s * Bm[i + 1] for i in range(M2 - 1)])
+        brute = np.mean([np.linalg.norm(seg - a, axis=1).min() for a in A])
+        assert abs(B.get_piecewise_error(A, Bm) - brute) < 2e-5

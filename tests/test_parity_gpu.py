@@ -335,3 +335,29 @@ def test_visibility_prepass(hip_ctx, oracle, occl):
     np.testing.assert_array_equal(ext, exto)
     assert len(vis) >= 1 and (occl is not None or len(vis) >= M - 2)
     np.testing.assert_array_equal(ext, synth.extend_visible(vis, M, coord, 0.06))
+
+
+def test_tracking_sequence_in_evaluation_units(hip_ctx, oracle):
+    """A short synthetic sequence tracked by the HIP tracker and by the oracle tracker, compared in the reference's
+    own evaluation unit: evaluator::compute_error (evaluator.cpp:333-341), metres of mean node-to-curve distance."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M = 40
+    Y0 = synth.nodes(M); coord = synth.geodesic_coord(Y0)
+    args = (M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+            P["lambda_pre_proc"], P["lle_weight"])
+    ref = oracle.Tracker(*args); ref.initialize_nodes(Y0); ref.initialize_geodesic_coord(coord)
+    trk = B.trackdlo(*args, ctx=hip_ctx); trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+    Lg = oracle.calc_lle_weights(Y0, 6)
+    Hpre = (np.eye(M) - Lg).T @ (np.eye(M) - Lg)
+    vis = np.arange(M)
+    for frame in range(5):
+        shift = np.array([0.0, 0.004 * (frame + 1), 0.002 * frame])
+        X, _, _ = synth.scene(4000, M, config=21, frame=frame, shift=shift)
+        truth = Y0 + shift
+        ref.tracking_step(X, vis, vis, H_pre=Hpre)
+        trk.tracking_step(X, vis, vis, None, 0, 0, H_pre=Hpre)
+        Yg, Yr = trk.get_tracking_result(), ref.get_tracking_result()
+        assert B.compute_error(Yg, Yr) <= 1e-5                      # HIP vs oracle, in evaluation units
+        assert abs(B.compute_error(Yg, truth) - oracle.compute_error(Yr, truth)) <= 1e-5
+        assert B.compute_error(Yg, truth) < 0.004                   # and it actually tracks the moving rope

@@ -52,7 +52,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
 ]
 
 _lib = None
@@ -110,6 +110,10 @@ def load_library(path: str | None = None):
     lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     lib.tdlo_debug_stamps.argtypes = [vp, ci, vp, ci]
     lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
+    lib.tdlo_piecewise_error.restype = cd
+    lib.tdlo_piecewise_error.argtypes = [vp, ci, vp, ci]
+    lib.tdlo_compute_error.restype = cd
+    lib.tdlo_compute_error.argtypes = [vp, ci, vp, ci]
     lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
     if path is None:
         _lib = lib
@@ -336,3 +340,17 @@ def traverse_euclidean(geodesic_coord, guide_nodes, visible_nodes, alignment, al
     if n < 0:
         raise TdloError(n, "traverse_euclidean: out-of-bounds in the reference")
     return out[:n].copy()
+
+
+def get_piecewise_error(Y_track, Y_true):
+    """evaluator::get_piecewise_error (evaluator.cpp:258-283)."""
+    lib = load_library()
+    a = _f64(Y_track); b = _f64(Y_true)
+    return lib.tdlo_piecewise_error(_ptr(a), a.shape[0], _ptr(b), b.shape[0])
+
+
+def compute_error(Y_track, Y_true):
+    """evaluator::compute_error (evaluator.cpp:333-341)."""
+    lib = load_library()
+    a = _f64(Y_track); b = _f64(Y_true)
+    return lib.tdlo_compute_error(_ptr(a), a.shape[0], _ptr(b), b.shape[0])

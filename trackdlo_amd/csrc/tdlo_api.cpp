@@ -654,6 +654,16 @@ int tdlo_line_sphere_intersection(const double A[3], const double B[3], const do
     return n;
 }
 
+double tdlo_piecewise_error(const double *Y_track, int n_track, const double *Y_true, int n_true) {
+    if (!Y_track || !Y_true || n_track < 1 || n_true < 2) return -1.0;
+    return piecewise_error(Y_track, n_track, Y_true, n_true);
+}
+
+double tdlo_compute_error(const double *Y_track, int n_track, const double *Y_true, int n_true) {
+    if (!Y_track || !Y_true || n_track < 2 || n_true < 2) return -1.0;
+    return 0.5 * (piecewise_error(Y_track, n_track, Y_true, n_true) + piecewise_error(Y_true, n_true, Y_track, n_track));
+}
+
 int tdlo_traverse_euclidean(const double *coord, int n_coord, const double *guide, int Mg, const int *vis, int n_vis,
                             int alignment, int anchor, double *out) {
     if (!coord || !guide || !vis || !out) return TDLO_E_INVALID;

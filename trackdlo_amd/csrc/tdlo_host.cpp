@@ -278,4 +278,42 @@ int traverse_euclidean(const std::vector<double> &coord, const double *guide, in
     return (int)(out.size() / 4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frame-level accuracy metric of the reference's evaluator:
+// mean distance from each node of one chain to the other chain's polyline
+// (evaluator::calc_min_distance / get_piecewise_error, trackdlo/src/evaluator.cpp:233-283) and its
+// symmetrised form (compute_error, :333-341).  O(M^2) on the host.
+// ---------------------------------------------------------------------------------------------
+static double point_segment_distance(const Vec3 &A, const Vec3 &B, const Vec3 &E) {
+    const Vec3 ab{B.x - A.x, B.y - A.y, B.z - A.z}, ae{E.x - A.x, E.y - A.y, E.z - A.z};
+    const Vec3 cr{ae.y * ab.z - ae.z * ab.y, -(ae.x * ab.z - ae.z * ab.x), ae.x * ab.y - ae.y * ab.x};
+    const double ab2 = ab.x * ab.x + ab.y * ab.y + ab.z * ab.z;
+    double d = std::sqrt(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z) / std::sqrt(ab2);      // distance to the infinite line
+    const double tpar = (ae.x * ab.x + ae.y * ab.y + ae.z * ab.z) / ab2;                   // foot point parameter
+    const Vec3 ap{ab.x * tpar, ab.y * tpar, ab.z * tpar};
+    const double proj = ap.x * ab.x + ap.y * ab.y + ap.z * ab.z;
+    if (proj < 0 || proj > ab2) {                       // foot point outside the segment: nearer end point
+        const double da = std::sqrt(ae.x * ae.x + ae.y * ae.y + ae.z * ae.z);
+        const Vec3 be{E.x - B.x, E.y - B.y, E.z - B.z};
+        const double db = std::sqrt(be.x * be.x + be.y * be.y + be.z * be.z);
+        d = (da > db) ? db : da;
+    }
+    return d;
+}
+
+double piecewise_error(const double *Ytrack, int n1, const double *Ytrue, int n2) {
+    double total = 0.0;
+    for (int i = 0; i < n1; ++i) {
+        const Vec3 E{Ytrack[i], Ytrack[n1 + i], Ytrack[2 * n1 + i]};
+        double best = -1;
+        for (int j = 0; j + 1 < n2; ++j) {
+            const Vec3 A{Ytrue[j], Ytrue[n2 + j], Ytrue[2 * n2 + j]}, B{Ytrue[j + 1], Ytrue[n2 + j + 1], Ytrue[2 * n2 + j + 1]};
+            const double d = point_segment_distance(A, B, E);
+            if (best == -1 || d < best) best = d;
+        }
+        total += best;
+    }
+    return total / n1;
+}
+
 }  // namespace tdlo

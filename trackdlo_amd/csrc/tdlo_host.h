@@ -17,4 +17,7 @@ int line_sphere(const Vec3 &A, const Vec3 &B, const Vec3 &C, double radius, Vec3
 int traverse_euclidean(const std::vector<double> &coord, const double *guide, int Mg,
                        const std::vector<int> &vis, int alignment, int anchor, std::vector<double> &out);
 
+// evaluator::get_piecewise_error (evaluator.cpp:258-283); chains are n x 3 column-major.
+double piecewise_error(const double *Ytrack, int n1, const double *Ytrue, int n2);
+
 }  // namespace tdlo
