@@ -12,11 +12,5 @@ print('loop_ms', g['loop_ms'], 'total', g['total_ms'], 'host', g['host_ms'])
 st = ctx.debug_stamps(64).astype(np.int64)
 print('estep stamps', st[32:40] - st[32])
 print('stamps', st[:8] - st[0])
-import numpy as _np
-_np.set_printoptions(linewidth=250)
-print('panel stamps', (st[8:24] - st[3]).tolist())
-for w in (0,1):
-    for kk in range(4):
-        b = 8 + w*24 + kk*6
-        print('wave',w,'k',16+kk, st[b:b+5] - st[8])
+print('wave load-done stamps', (st[8:12] - st[0]).tolist())
 print('estep', ctx.profile_kernel(0, 300), 'mstep', ctx.profile_kernel(2, 300))

@@ -20,6 +20,7 @@
 //   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m (accumulated directly by the E-step),  d_m = T_m - y_m
 // instead of :418-422's difference of three large traces, which would cancel catastrophically in fp32.
 #include "tdlo_internal.h"
+#include <type_traits>
 #include "../../include/trackdlo_hip.h"
 #include <cstdio>
 #include <cstdlib>
@@ -806,8 +807,26 @@ __device__ __forceinline__ double fast_rcp(double v) {
     return r;
 }
 
-template <typename T, int NW, int MC, bool SINGLE>
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+// value of lane group g = lane >> 4 out of four wave-uniform-per-group candidates.  v_cndmask with the
+// four constant lane masks; written as inline asm because a ?: chain over array elements is turned into
+// a dynamically indexed scratch array by the compiler.
+__device__ __forceinline__ double sel_by_group(double a0, double a1, double a2, double a3) {
+    int lo = __double2loint(a0), hi = __double2hiint(a0);
+    const unsigned long long m1 = 0x00000000ffff0000ull, m2 = 0x0000ffff00000000ull, m3 = 0xffff000000000000ull;
+    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(__double2loint(a1)), "s"(m1));
+    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(hi) : "v"(__double2hiint(a1)), "s"(m1));
+    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(__double2loint(a2)), "s"(m2));
+    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(hi) : "v"(__double2hiint(a2)), "s"(m2));
+    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(__double2loint(a3)), "s"(m3));
+    asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(hi) : "v"(__double2hiint(a3)), "s"(m3));
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T, int NW, int MC, bool SINGLE, bool MFMA>
 __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
+    static_assert(!MFMA || NW == 4, "the MFMA elimination maps one 16-column block to each of 4 waves");
     constexpr int MB = NW * 64, NSLOT = NW;
     const FrameDev &f = SINGLE ? f0 : frames[blockIdx.x];
     IterState *st = f.st;
@@ -842,26 +861,30 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     double acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
+    constexpr int GQ = (64 * 64 + MB - 1) / MB;       // G (M <= 64) goes through registers: requested before the partials
+    double gq[GQ];
+#pragma unroll
+    for (int u = 0; u < GQ; ++u) { const int i = t + u * MB; gq[u] = i < M * M ? Gg[i] : 0.0; }
     if (from_sums != 1 && g < NG) {
         const auto part = TDLO_AS_GLOBAL(pvec, f.part);
         const int nb = f.nblkE;
-        int b = g;
-        for (; b + 9 * NG < nb; b += 10 * NG) {
-            pvec v[10];
+        constexpr int UL = 20;                        // loads in flight per thread; no scalar remainder loop (a
+        for (int b = g; b < nb; b += UL * NG) {       // dependent load per trip costs a full memory latency each)
+            pvec v[UL];
 #pragma unroll
-            for (int u = 0; u < 10; ++u) v[u] = part[(size_t)(b + u * NG) * npair + pe];
+            for (int u = 0; u < UL; ++u) { const int bb = b + u * NG; v[u] = part[(size_t)(bb < nb ? bb : nb - 1) * npair + pe]; }
 #pragma unroll
-            for (int u = 0; u < 10; ++u)
+            for (int u = 0; u < UL; ++u) {
+                if (b + u * NG < nb) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] += (double)v[u][i];
-        }
-        for (; b < nb; b += NG) {
-            const pvec v = part[(size_t)b * npair + pe];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] += (double)v[i];
+                    for (int i = 0; i < VEC; ++i) acc[i] += (double)v[u][i];
+                }
+            }
         }
     }
-    for (int i = t; i < M * M; i += MB) Gs[i] = Gg[i];
+    if (slot < 4) f.dbg[8 + slot] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int u = 0; u < GQ; ++u) { const int i = t + u * MB; if (i < M * M) Gs[i] = gq[u]; }
     if (done) return;
     if (from_sums != 1) {
         if (g < NG) {
@@ -891,6 +914,136 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     const double c2 = f.lambda * sigma2, sg = sigma2 * f.lle_weight;
     const int lle = f.include_lle, pri = f.has_priors;
     const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
+    int singular = 0;
+    if constexpr (MFMA) {
+    // ---- 2+3 (MFMA variant, include_lle == 0, M <= 60): blocked Gauss-Jordan on the 64 x 64 tableau
+    //   [A (cols 0..59, identity-padded) | - | B (cols 61..63)]  held in v_mfma_f64_16x16x4 accumulators:
+    //   wave w = columns 16 w .. 16 w + 15, lane (c = lane & 15, g = lane >> 4), C[rb][r] = element
+    //   (row 16 rb + 4 r + g, column 16 w + c).  Per panel of 4 pivot columns k0 .. k0 + 3:
+    //     a. the owner wave publishes the 4 columns (64 x 4, 2 KB) in LDS; one barrier;
+    //     b. the 4 pivot rows are the accumulator register C[k0 / 16][(k0 % 16) / 4]: row k0 + g sits in
+    //        lane group g, i.e. they ARE the MFMA B operand.  They are reduced among themselves by 4
+    //        division-free row operations (row_i <- p row_i - a_ik row_k; the 4 x 4 pivot block is
+    //        tracked redundantly by every lane, the partner row arrives by one cross-lane read) and
+    //        then normalised by ONE reciprocal per row -- no reciprocal inside the 4-step chain;
+    //     c. every other row:  row_i -= sum_k a_ik U_k  =  4 MFMAs per wave (A operand = the published
+    //        columns with the pivot rows zeroed); the pivot rows are replaced by U.
+    //   Applying the 4 row operations sequentially (instead of multiplying by an explicit inverse of
+    //   the pivot block) keeps the accuracy of the unblocked elimination (measured: 1e-13 vs 1e-12).
+    //   A = c I + D G with D >= 0 diagonal, G SPD: elimination without pivoting is stable (see below).
+        const int w = slot, cL = lane & 15, gL = lane >> 4;
+        const int col = 16 * w + cL;
+        const int np4 = (M + 3) >> 2;                 // panels
+        mfma_d4 C[4];
+        {
+            const auto ndg = TDLO_AS_GLOBAL(V4<T>, f.nodes);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = 16 * rb + 4 * r + gL;
+                    double v = 0.0;
+                    if (rw < M) {
+                        const double p1 = S[rw];
+                        if (col < M) {
+                            const double dd = p1 + (pri ? f.aJ[rw] : 0.0);
+                            v = dd * Gs[(size_t)rw * M + col] + (rw == col ? c2 : 0.0);     // G is symmetric: row-major read, conflict-free
+                        } else if (col >= 61) {
+                            const int d = col - 61, i = d * M + rw;
+                            const double yd = d == 0 ? (double)ndg[rw].x : (d == 1 ? (double)ndg[rw].y : (double)ndg[rw].z);
+                            v = S[M + i] + p1 * (yd - Y0g[i]);
+                            if (pri) v += f.aYd[i];
+                        }
+                    } else if (rw == col) v = 1.0;
+                    C[rb][r] = v;
+                }
+            }
+        }
+        TDLO_STAMP(3);
+        double *pan = colb;                           // 2 x (64 rows x 4) doubles
+        double *strip = colb + 512 + 64 * w;          // per wave: 16 columns x 4 pivot rows
+        strip[cL * 4 + gL] = C[0][0];
+        if (w == 0 && cL < 4) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pan[(16 * rb + 4 * r + gL) * 4 + cL] = C[rb][r];
+        }
+        auto panel = [&](auto PC) __attribute__((always_inline)) {
+            constexpr int p = decltype(PC)::value;
+            // (waves left of the panel hold finished columns only; they run the same code -- a branch around it
+            //  would cost a copy of all accumulators at the join and they are not on the critical path)
+            const int k0 = 4 * p, rb0 = k0 >> 4, r0 = (k0 & 15) >> 2, rr = k0 & 15;
+            const double *buf = pan + (p & 1) * 256;
+            __syncthreads();
+            double ak[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ak[i][j] = buf[(k0 + i) * 4 + j];
+            double aop[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const double v = buf[(16 * rb + cL) * 4 + gL];
+                aop[rb] = (rb == rb0 && cL >= rr && cL < rr + 4) ? 0.0 : -v;
+            }
+            // all four pivot-row entries of this lane's column (published to the wave's private LDS strip right
+            // after the previous panel's update, i.e. off the critical path)
+            double Rall[4];
+            {
+                const double2 q0 = *(const double2 *)(strip + cL * 4), q1 = *(const double2 *)(strip + cL * 4 + 2);
+                Rall[0] = q0.x; Rall[1] = q0.y; Rall[2] = q1.x; Rall[3] = q1.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double pv = ak[k][k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i == k) continue;
+                    const double m = ak[i][k];
+                    Rall[i] = fma(pv, Rall[i], -(m * Rall[k]));
+#pragma unroll
+                    for (int j = k + 1; j < 4; ++j) ak[i][j] = fma(pv, ak[i][j], -(m * ak[k][j]));
+                    if (i < k) ak[i][i] *= pv;
+                }
+            }
+            const double R = sel_by_group(Rall[0], Rall[1], Rall[2], Rall[3]);
+            const double dg = sel_by_group(ak[0][0], ak[1][1], ak[2][2], ak[3][3]);
+            {
+                const int e = (__double2hiint(dg) >> 20) & 0x7ff;
+                if (e == 0 || e == 0x7ff) singular = 1;      // zero / denormal / non-finite pivot
+            }
+            const double U = R * fast_rcp(dg);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) C[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[rb], U, C[rb], 0, 0, 0);
+            C[rb0][r0] = U;
+            // next panel: its pivot rows go to this wave's strip, its columns are published by the wave that owns them
+            {
+                const int k1 = k0 + 4, c1 = k1 & 15;
+                if (k1 < 64) strip[cL * 4 + gL] = C[k1 >> 4][(k1 & 15) >> 2];
+                if (w == (k1 >> 4) && cL >= c1 && cL < c1 + 4) {
+                    double *nb = pan + ((p + 1) & 1) * 256;
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) nb[(16 * rb + 4 * r + gL) * 4 + (cL - c1)] = C[rb][r];
+                }
+            }
+        };
+        // straight-line panels with static register indices; nested so that leaving early (np4 is block-uniform)
+        // never merges accumulator values back into a common path
+#define TDLO_P(P) if (np4 > P) { panel(std::integral_constant<int, P>());
+        TDLO_P(0) TDLO_P(1) TDLO_P(2) TDLO_P(3) TDLO_P(4) TDLO_P(5) TDLO_P(6) TDLO_P(7) TDLO_P(8) TDLO_P(9) TDLO_P(10) TDLO_P(11)
+        TDLO_P(12) TDLO_P(13) TDLO_P(14) }}}}} }}}}} }}}}}
+#undef TDLO_P
+        if (w == 3 && cL >= 13) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int rw = 16 * rb + 4 * r + gL; if (rw < M) W[(cL - 13) * M + rw] = C[rb][r]; }
+        }
+        singular = __syncthreads_or(singular);
+    } else {
     double a[MC];
     {
         const double p1 = rowok ? S[row] : 0.0;
@@ -954,7 +1107,6 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     constexpr int NB = NSLOT;                         // panel width
     static_assert(NB == 8 || NB == 4, "panel width");
     double *pan = colb;                               // 2 x NB x 64 doubles
-    int singular = 0;
     int mine = lle ? -1 : row;                        // unknown this row ends up solving (row itself without pivoting)
     unsigned long long usedmask = 0;
     double dgv = 1.0;                                 // pivoting path only: pivot entry times later row scalings
@@ -1028,7 +1180,8 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dg; }
         }
     }
-    __syncthreads();
+    singular = __syncthreads_or(singular);
+    }   // !MFMA
 
     // ---- 4. T = Y0 + G W (:417): waves 0..5 = (coordinate d, half of the k range), lane = node
     TDLO_STAMP(4);
@@ -1214,16 +1367,22 @@ template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW) {
     return d * sizeof(double);
 }
 
-template <typename T, int NW, int MC> static hipError_t launch_mstep_fast(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
+template <typename T, int NW, int MC, bool MFMA = false> static hipError_t launch_mstep_fast(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
     const size_t lds = mstep_fast_lds_bytes<T>(fh[0].M, NW);
     if (F == 1) {
-        TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true>, lds));
-        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
+        TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true, MFMA>, lds));
+        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
     } else {
-        TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, false>, lds));
-        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, false>), dim3(F), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
+        TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, false, MFMA>, lds));
+        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, false, MFMA>), dim3(F), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
     }
     return hipGetLastError();
+}
+
+static int mstep_mfma_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("TDLO_MSTEP_MFMA"); v = e ? atoi(e) : 1; }
+    return v;
 }
 
 static int mstep_waves() {
@@ -1234,6 +1393,9 @@ static int mstep_waves() {
 
 template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
     const int M = fh[0].M;
+    bool any_lle = false;
+    for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
+    if (M <= 60 && !any_lle && mstep_mfma_enabled()) return launch_mstep_fast<T, 4, 1, true>(fd, fh, F, from_sums, s);
     if (M <= 64) {
         if (mstep_waves() == 8) {
             const int mc = (M + 4 + 7) / 8;           // columns per wave: M matrix + 3 right-hand sides + 1 tracer
