@@ -844,15 +844,35 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     double *Tn = W + ((3 * M + 1) & ~1);              // 3M (+pad)
     double *red = Tn + ((3 * M + 1) & ~1);            // 8
     double *colb = red + 8;                           // 2 x 8 x 64: panel exchange buffers (double-buffered)
-    double *tmp = colb + 2 * 8 * 64;                  // 6 x 64: G W slices
-    double *Gs = tmp + 6 * 64;                        // M x M (column-major, ld = M)
+    double *tmp = colb + 2 * 8 * 64;                  // 12 x 64: G W slices
+    double *aux = tmp + 12 * 64;                      // 7 x 64: node - Y0 (3), alpha (Y_ext - Y0) (3), alpha J (1)
+    double *Gs = aux + 7 * 64;                        // M x M (column-major, ld = M)
     double *Sg = Gs + (((size_t)M * M + 1) & ~(size_t)1);   // NG x nSp partial-sum groups
 
 #define TDLO_STAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     TDLO_STAMP(0);
     const auto stg = TDLO_AS_GLOBAL(IterState, st);
     const int done = stg->done;
+    const double sigma2 = stg->sigma2;
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
+    const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
+    const int lle = f.include_lle, pri = f.has_priors;
+    // per-node quantities the later phases need (lane = node): requested now, used after the elimination
+    V4<T> nq; nq.x = nq.y = nq.z = nq.w = (T)0;
+    double yq[3] = {0, 0, 0}, y0q[3] = {0, 0, 0}, ayq[3] = {0, 0, 0}, ajq = 0;
+    if (rowok) {
+        const auto ndg = TDLO_AS_GLOBAL(V4<T>, f.nodes);
+        const auto Yg = TDLO_AS_GLOBAL(double, f.Y);
+        nq.x = ndg[row].x; nq.y = ndg[row].y; nq.z = ndg[row].z; nq.w = ndg[row].w;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { yq[d] = Yg[d * M + row]; y0q[d] = Y0g[d * M + row]; }
+        if (pri && slot == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) ayq[d] = f.aYd[d * M + row];
+            ajq = f.aJ[row];
+        }
+    }
+    const double ctr0 = f.ctr[0], ctr1 = f.ctr[1], ctr2 = f.ctr[2];
     // ---- 1. everything that comes from memory is requested up front: block partials (16 B per load,
     //         NG thread groups striding over the blocks, fixed summation order), G
     typedef PT pvec __attribute__((ext_vector_type(VEC)));
@@ -886,6 +906,10 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
 #pragma unroll
     for (int u = 0; u < GQ; ++u) { const int i = t + u * MB; if (i < M * M) Gs[i] = gq[u]; }
     if (done) return;
+    if (slot == 0) {
+        aux[row] = (double)nq.x - y0q[0]; aux[64 + row] = (double)nq.y - y0q[1]; aux[128 + row] = (double)nq.z - y0q[2];
+        aux[192 + row] = ayq[0]; aux[256 + row] = ayq[1]; aux[320 + row] = ayq[2]; aux[384 + row] = ajq;
+    }
     if (from_sums != 1) {
         if (g < NG) {
 #pragma unroll
@@ -910,10 +934,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     // ---- 2. assemble [A | B] (:392-413) straight into registers: wave = column slot, lane = row,
     //         a[c] = element (row, slot + 8 c)
     TDLO_STAMP(2);
-    const double sigma2 = stg->sigma2;
     const double c2 = f.lambda * sigma2, sg = sigma2 * f.lle_weight;
-    const int lle = f.include_lle, pri = f.has_priors;
-    const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
     int singular = 0;
     if constexpr (MFMA) {
     // ---- 2+3 (MFMA variant, include_lle == 0, M <= 60): blocked Gauss-Jordan on the 64 x 64 tableau
@@ -936,26 +957,21 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         const int np4 = (M + 3) >> 2;                 // panels
         mfma_d4 C[4];
         {
-            const auto ndg = TDLO_AS_GLOBAL(V4<T>, f.nodes);
+            // B = PX - P1 Y0 = R + P1 (y - Y0): the E-step delivers R = PX - P1 y (y = nodes as it saw them)
+            // (branch-free: every LDS read is issued unconditionally on a clamped index, the result is selected)
+            const int dcol = col >= 61 ? col - 61 : 0, colc = col < M ? col : M - 1;
+            const bool isA = col < M, isB = col >= 61;
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int rw = 16 * rb + 4 * r + gL;
-                    double v = 0.0;
-                    if (rw < M) {
-                        const double p1 = S[rw];
-                        if (col < M) {
-                            const double dd = p1 + (pri ? f.aJ[rw] : 0.0);
-                            v = dd * Gs[(size_t)rw * M + col] + (rw == col ? c2 : 0.0);     // G is symmetric: row-major read, conflict-free
-                        } else if (col >= 61) {
-                            const int d = col - 61, i = d * M + rw;
-                            const double yd = d == 0 ? (double)ndg[rw].x : (d == 1 ? (double)ndg[rw].y : (double)ndg[rw].z);
-                            v = S[M + i] + p1 * (yd - Y0g[i]);
-                            if (pri) v += f.aYd[i];
-                        }
-                    } else if (rw == col) v = 1.0;
-                    C[rb][r] = v;
+                    const int rw = 16 * rb + 4 * r + gL, rwc = rw < M ? rw : M - 1;
+                    const double p1 = S[rwc];
+                    const double gv = Gs[rwc * M + colc];                              // G symmetric: row-major read, conflict-free
+                    const double va = (p1 + aux[384 + rwc]) * gv + (rw == col ? c2 : 0.0);
+                    const double vb = S[M + dcol * M + rwc] + p1 * aux[dcol * 64 + rwc] + aux[192 + dcol * 64 + rwc];
+                    const double vin = isA ? va : (isB ? vb : 0.0);
+                    C[rb][r] = rw < M ? vin : (rw == col ? 1.0 : 0.0);
                 }
             }
         }
@@ -1193,14 +1209,24 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             tmp[slot * 64 + row] = v;
         }
         __syncthreads();
-        if (slot < 3 && rowok) Tn[slot * M + row] = Y0g[slot * M + row] + (tmp[slot * 64 + row] + tmp[(slot + 3) * 64 + row]);
+        if (slot < 3 && rowok) Tn[slot * M + row] = y0q[slot] + (tmp[slot * 64 + row] + tmp[(slot + 3) * 64 + row]);
     } else {
-        if (slot < 3 && rowok) {
-            double v0 = 0, v1 = 0;
-            for (int k = 0; k + 1 < M; k += 2) { v0 += Gs[(size_t)k * M + row] * W[slot * M + k]; v1 += Gs[(size_t)(k + 1) * M + row] * W[slot * M + k + 1]; }
-            if (M & 1) v0 += Gs[(size_t)(M - 1) * M + row] * W[slot * M + M - 1];
-            Tn[slot * M + row] = Y0g[slot * M + row] + (v0 + v1);
+        // wave = quarter of the k range, lane = node, three coordinates at once; fixed-order sum of the quarters
+        const int kq = (M + 3) >> 2, kb = slot * kq, ke = (kb + kq) < M ? (kb + kq) : M;
+        double v0 = 0, v1 = 0, v2 = 0;
+        {
+            const int rc = rowok ? row : 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {            // kq <= 16; straight-line so that the LDS reads are batched
+                const int k = kb + u, kc = k < M ? k : M - 1;
+                const double gk = (k < ke) ? Gs[kc * M + rc] : 0.0;
+                v0 += gk * W[kc]; v1 += gk * W[M + kc]; v2 += gk * W[2 * M + kc];
+            }
         }
+        tmp[(slot * 3 + 0) * 64 + row] = v0; tmp[(slot * 3 + 1) * 64 + row] = v1; tmp[(slot * 3 + 2) * 64 + row] = v2;
+        __syncthreads();
+        if (slot < 3 && rowok)
+            Tn[slot * M + row] = y0q[slot] + (((tmp[slot * 64 + row] + tmp[(3 + slot) * 64 + row]) + tmp[(6 + slot) * 64 + row]) + tmp[(9 + slot) * 64 + row]);
     }
     __syncthreads();
 
@@ -1211,15 +1237,13 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         double v = 0;
         if (rowok) {
             const int m = row;
-            const auto nodes = TDLO_AS_GLOBAL(V4<T>, f.nodes);
-            const auto Yg = TDLO_AS_GLOBAL(double, f.Y);
-            const double yx = (double)nodes[m].x, yy = (double)nodes[m].y, yz = (double)nodes[m].z;   // nodes as the E-step saw them
+            const double yx = (double)nq.x, yy = (double)nq.y, yz = (double)nq.z;   // nodes as the E-step saw them
             const double p1 = S[m];
             const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
             if (slot == 0) v = p1;
             else if (slot == 1) v = dx * S[M + m] + dy * S[2 * M + m] + dz * S[3 * M + m];
             else if (slot == 2) v = p1 * (dx * dx + dy * dy + dz * dz);
-            else { const double ex = Yg[m] - Tn[m], ey = Yg[M + m] - Tn[M + m], ez = Yg[2 * M + m] - Tn[2 * M + m]; v = ::sqrt(ex * ex + ey * ey + ez * ez); }
+            else { const double ex = yq[0] - Tn[m], ey = yq[1] - Tn[M + m], ez = yq[2] - Tn[2 * M + m]; v = ::sqrt(ex * ex + ey * ey + ez * ez); }
         }
         v = wave_sum(v);
         if (lane == 0) red[slot] = v;
@@ -1232,14 +1256,15 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     // ---- 6. publish Y, nodes, iteration state
     TDLO_STAMP(6);
     V4<T> *nodes_w = (V4<T> *)f.nodes;
-    for (int m = t; m < M; m += MB) {
-        V4<T> q; q.x = (T)Tn[m]; q.y = (T)Tn[M + m]; q.z = (T)Tn[2 * M + m]; q.w = (T)f.coord[m];
-        nodes_w[m] = q;
-        f.dminbits[m] = ~0ull;
+    if (slot == 3 && rowok) {
+        V4<T> q; q.x = (T)Tn[row]; q.y = (T)Tn[M + row]; q.z = (T)Tn[2 * M + row]; q.w = nq.w;      // .w = chain coordinate, unchanged
+        nodes_w[row] = q;
+        f.dminbits[row] = ~0ull;
     }
-    for (int i = t; i < 3 * M; i += MB) {
+    if (slot < 3 && rowok) {
+        const int i = slot * M + row;
         f.Y[i] = Tn[i];
-        f.Yout[i] = Tn[i] + f.ctr[i / M];
+        f.Yout[i] = Tn[i] + (slot == 0 ? ctr0 : (slot == 1 ? ctr1 : ctr2));
     }
     TDLO_STAMP(7);
     if (t == 0) {
@@ -1363,7 +1388,7 @@ template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW) {
     typedef typename PartOf<T>::type PT;
     const int VEC = 16 / (int)sizeof(PT);
     const int nSp = part_stride<PT>(M), npair = nSp / VEC, NG = (NW * 64) / npair;
-    size_t d = (size_t)((nSp + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 6 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
+    size_t d = (size_t)((nSp + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 12 * 64 + 7 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
     return d * sizeof(double);
 }
 
