@@ -176,10 +176,27 @@ int tdlo_tracker_get_correspondence_pairs(const tdlo_tracker *t, double *out, in
  * signature are unused by its body and therefore not part of the ABI.  H_pre: optional override of
  * the pre-processing registration's LLE matrix (n_vis_ext x n_vis_ext).  stats may be NULL;
  * otherwise stats[0] = pre-processing registration (:927), stats[1] = main registration (:998). */
+/* X == NULL: use the cloud already resident in the tracker's slot (tdlo_set_cloud / tdlo_depth_to_cloud); N ignored. */
 int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N,
                                const int *visible_nodes, int n_vis,
                                const int *visible_nodes_extended, int n_vis_ext,
                                const double *H_pre, tdlo_stats *stats);
+
+/* ---- depth image -> cloud -> voxel-grid down-sample ------------------------ */
+/* The step right upstream of tracking_step in the ROS node (trackdlo/src/trackdlo_node.cpp:195-241): every pixel
+ * with mask != 0 is back-projected ((u - cx) z / fx, (v - cy) z / fy, z = depth / 1000; float storage like
+ * pcl::PointXYZRGB, :212-232) and the points are down-sampled by pcl::VoxelGrid with a cubic leaf of `leaf_size`
+ * metres (:235-239; PCL 1.10 algorithm: one centroid per occupied cell, ascending cell index; when the cell count
+ * overflows int32 the cloud is passed through unchanged, as PCL does).  depth: rows x cols uint16 millimetres, mask:
+ * rows x cols uint8, both row-major (cv::Mat layout).  The result becomes the cloud resident in `slot` -- what
+ * tdlo_set_cloud would have uploaded (:241) -- so tdlo_cpd_lle_resident, tdlo_visibility_prepass and
+ * tdlo_tracker_tracking_step (with X == NULL) run on it without the cloud ever visiting the host.
+ * X_out (optional): n x 3 column-major, leading dimension n, needs x_capacity >= n rows (else TDLO_E_INVALID after
+ * the cloud has been made resident); *n_out = n, *n_raw_out = number of masked pixels.  n == 0 is not an error here
+ * (the registration calls report TDLO_E_INVALID for an empty cloud). */
+int tdlo_depth_to_cloud(tdlo_ctx *ctx, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                        double fx, double fy, double cx, double cy, double leaf_size,
+                        double *X_out, int x_capacity, int *n_out, int *n_raw_out);
 
 /* ---- caller-side visibility pre-pass ----------------------------------- */
 /* What the ROS node computes right before tracking_step (trackdlo/src/trackdlo_node.cpp:257-277, :345-360):

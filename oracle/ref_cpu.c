@@ -865,3 +865,91 @@ double ref_piecewise_error(const double *Yt, int n1, const double *Yr, int n2) {
 double ref_compute_error(const double *Yt, int n1, const double *Yr, int n2) {
     return (ref_piecewise_error(Yt, n1, Yr, n2) + ref_piecewise_error(Yr, n2, Yt, n1)) / 2;     /* :335-339 */
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Depth image -> cloud -> voxel-grid down-sample.
+ * Back-projection: trackdlo/src/trackdlo_node.cpp:195-232 (row-major pixel scan, double arithmetic,
+ * result stored in the float fields of pcl::PointXYZRGB).  Down-sample: :235-241 call
+ * pcl::VoxelGrid<pcl::PointXYZRGB>::filter with leaf = downsample_leaf_size on all three axes.  PCL is a
+ * third-party dependency that is not under /root/reference (ROS Noetic ships PCL 1.10); this restates the
+ * published algorithm of pcl/filters/impl/voxel_grid.hpp (applyFilter, downsample_all_data_ = true,
+ * min_points_per_voxel_ = 0, no filter field):
+ *   bounding box (getMinMax3D, float) -> min_b = floor(min * inv_leaf), div_b = max_b - min_b + 1
+ *   -> cell index idx = ijk0 + ijk1 div_b0 + ijk2 div_b0 div_b1, ijk = (int)(floor(p * inv_leaf) - (float)min_b)
+ *   -> sort by idx -> one output point per occupied cell in ascending idx: float sum / (float) count
+ *   (CentroidPoint / AccumulatorXYZ), and `output = input` when the cell count overflows int32.
+ * PARITY UNPINNED against PCL itself.  One known implementation-defined detail: PCL sorts with std::sort,
+ * which is not stable, so the order in which a cell's points are added (fp32, ulp-level effect) is
+ * unspecified there; this restatement adds them in input (pixel) order.
+ * Returns the number of output points; X_out is column-major with leading dimension n (= return value),
+ * so the caller passes a buffer of 3 * (#masked pixels) doubles.  Returns -1 on allocation failure.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { unsigned idx; int order; } vox_entry;
+static int vox_cmp(const void *a, const void *b) {
+    const vox_entry *p = (const vox_entry *)a, *q = (const vox_entry *)b;
+    if (p->idx != q->idx) return p->idx < q->idx ? -1 : 1;
+    return p->order < q->order ? -1 : (p->order > q->order);
+}
+
+int ref_depth_to_cloud(const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                       double fx, double fy, double cx, double cy, double leaf_size, double *X_out, int *n_raw_out) {
+    const size_t P = (size_t)rows * cols;
+    float *px = (float *)malloc(sizeof(float) * 3 * (P ? P : 1));
+    vox_entry *ent = (vox_entry *)malloc(sizeof(vox_entry) * (P ? P : 1));
+    if (!px || !ent) { free(px); free(ent); return -1; }
+    float *py = px + P, *pz = py + P;
+    int n = 0;
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < cols; j++)
+            if (mask[(size_t)i * cols + j] != 0) {                                    /* trackdlo_node.cpp:212 */
+                const double pixel_x = (double)j, pixel_y = (double)i;
+                const double pc_z = depth[(size_t)i * cols + j] / 1000.0;             /* :220 */
+                px[n] = (float)((pixel_x - cx) * pc_z / fx);                          /* :222 */
+                py[n] = (float)((pixel_y - cy) * pc_z / fy);                          /* :223 */
+                pz[n] = (float)pc_z;                                                  /* :224 */
+                n++;
+            }
+    if (n_raw_out) *n_raw_out = n;
+    if (n == 0) { free(px); free(ent); return 0; }
+    const float leaf = (float)leaf_size, inv = 1.0f / leaf;                           /* setLeafSize: inverse_leaf_size_ = 1 / leaf (float) */
+    float mn[3] = {px[0], py[0], pz[0]}, mx[3] = {px[0], py[0], pz[0]};
+    for (int k = 1; k < n; k++) {
+        const float v[3] = {px[k], py[k], pz[k]};
+        for (int d = 0; d < 3; d++) { if (v[d] < mn[d]) mn[d] = v[d]; if (v[d] > mx[d]) mx[d] = v[d]; }
+    }
+    long long dd[3];
+    int min_b[3], div_b[3];
+    for (int d = 0; d < 3; d++) {
+        dd[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
+        min_b[d] = (int)floorf(mn[d] * inv);
+        div_b[d] = (int)floorf(mx[d] * inv) - min_b[d] + 1;
+    }
+    int n_out;
+    if (dd[0] * dd[1] * dd[2] > 2147483647LL) {           /* "Leaf size is too small": output = input */
+        for (int k = 0; k < n; k++) { X_out[k] = px[k]; X_out[n + k] = py[k]; X_out[2 * (size_t)n + k] = pz[k]; }
+        n_out = n;
+    } else {
+        const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+        for (int k = 0; k < n; k++) {
+            const int i0 = (int)(floorf(px[k] * inv) - (float)min_b[0]);
+            const int i1 = (int)(floorf(py[k] * inv) - (float)min_b[1]);
+            const int i2 = (int)(floorf(pz[k] * inv) - (float)min_b[2]);
+            ent[k].idx = (unsigned)(i0 + i1 * mul1 + i2 * mul2);
+            ent[k].order = k;
+        }
+        qsort(ent, (size_t)n, sizeof(vox_entry), vox_cmp);
+        n_out = 0;
+        for (int k = 0; k < n; k++) if (k == 0 || ent[k].idx != ent[k - 1].idx) n_out++;
+        int o = 0;
+        for (int k = 0; k < n;) {
+            int e = k;
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            while (e < n && ent[e].idx == ent[k].idx) { const int q = ent[e].order; sx += px[q]; sy += py[q]; sz += pz[q]; e++; }
+            const float cnt = (float)(e - k);
+            X_out[o] = (double)(sx / cnt); X_out[n_out + o] = (double)(sy / cnt); X_out[2 * (size_t)n_out + o] = (double)(sz / cnt);
+            o++; k = e;
+        }
+    }
+    free(px); free(ent);
+    return n_out;
+}

@@ -135,6 +135,13 @@ int ref_visibility_prepass(const double *X, int N, const double *Y, int M, doubl
 double ref_piecewise_error(const double *Y_track, int n1, const double *Y_true, int n2);
 double ref_compute_error(const double *Y_track, int n1, const double *Y_true, int n2);
 
+/* Depth image -> cloud (trackdlo/src/trackdlo_node.cpp:195-232) -> voxel-grid down-sample (:235-241, algorithm of
+ * PCL 1.10 pcl::VoxelGrid, restated; parity unpinned against PCL).  depth: rows x cols uint16 millimetres, mask:
+ * rows x cols uint8 (non-zero = rope pixel), both row-major.  X_out: column-major n x 3 with leading dimension n
+ * (= return value); give it room for 3 * (#non-zero mask pixels) doubles.  *n_raw_out = #points before down-sampling. */
+int ref_depth_to_cloud(const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                       double fx, double fy, double cx, double cy, double leaf_size, double *X_out, int *n_raw_out);
+
 /* dense helper exposed for tests: solve A x = B (A n x n col-major, B n x nrhs col-major)
  * by Householder QR with column pivoting (what completeOrthogonalDecomposition reduces to for
  * full-rank A, trackdlo.cpp:415). A and B are overwritten; solution returned in X (n x nrhs). */

@@ -156,6 +156,21 @@ def compute_error(Y_track, Y_true):
     return lib().ref_compute_error(_dp(a), C.c_int(a.shape[0]), _dp(b), C.c_int(b.shape[0]))
 
 
+def depth_to_cloud(depth, mask, fx, fy, cx, cy, leaf_size):
+    """trackdlo_node.cpp:195-241: masked back-projection + pcl::VoxelGrid.  Returns (X [n x 3], n_raw)."""
+    depth = np.ascontiguousarray(depth, dtype=np.uint16); mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    rows, cols = depth.shape
+    nmask = int(np.count_nonzero(mask))
+    buf = np.zeros(3 * max(nmask, 1))
+    nraw = C.c_int(0)
+    n = lib().ref_depth_to_cloud(depth.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p), C.c_int(rows), C.c_int(cols),
+                                 C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy), C.c_double(leaf_size),
+                                 _dp(buf), C.byref(nraw))
+    if n < 0:
+        raise MemoryError("ref_depth_to_cloud")
+    return buf[:3 * n].reshape(3, n).T.copy(), nraw.value
+
+
 def solve_qrcp(A, B):
     A = _f(A).copy(order="F"); B = _f(B).copy(order="F")
     n = A.shape[0]; nrhs = B.shape[1]

@@ -361,3 +361,71 @@ def test_tracking_sequence_in_evaluation_units(hip_ctx, oracle):
         assert B.compute_error(Yg, Yr) <= 1e-5                      # HIP vs oracle, in evaluation units
         assert abs(B.compute_error(Yg, truth) - oracle.compute_error(Yr, truth)) <= 1e-5
         assert B.compute_error(Yg, truth) < 0.004                   # and it actually tracks the moving rope
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,leaf,zero,shape", [(50, 0.008, 0, None), (30, 0.02, 7, None), (45, 0.004, 0, None), (50, 0.008, 0, (120, 161)),
+                                                (50, 0.0015, 0, None)])
+def test_depth_to_cloud_bit_exact(hip_ctx, oracle, M, leaf, zero, shape):
+    """SURVEY 8(f) row 2 (trackdlo_node.cpp:195-241): masked back-projection + voxel-grid centroids on the device are
+    BIT-EXACT against the oracle (float work in the same order): same count, same order, same doubles.  Cases: the launch
+    file's 8 mm leaf, a coarse leaf with invalid-depth pixels (back-projected to the origin, as the reference does), a fine
+    leaf, an odd image size (ragged last blocks), a leaf that needs three radix passes."""
+    from trackdlo_amd import synth
+    kw = dict(rows=shape[0], cols=shape[1]) if shape else {}
+    depth, mask, cam, _ = synth.depth_scene(M, config=9, frame=M, zero_depth_pixels=zero, **kw)
+    Xo, nraw_o = oracle.depth_to_cloud(depth, mask, cam["fx"], cam["fy"], cam["cx"], cam["cy"], leaf)
+    Xg, n, nraw = hip_ctx.depth_to_cloud(0, depth, mask, cam["fx"], cam["fy"], cam["cx"], cam["cy"], leaf)
+    assert nraw == nraw_o and n == Xo.shape[0]
+    assert np.array_equal(Xg, Xo)
+    # idempotent on repeat (workspace reuse), and the resident cloud is what came back
+    Xg2, n2, _ = hip_ctx.depth_to_cloud(0, depth, mask, cam["fx"], cam["fy"], cam["cx"], cam["cy"], leaf)
+    assert n2 == n and np.array_equal(Xg2, Xg)
+
+
+@pytest.mark.gpu
+def test_depth_to_cloud_edge_cases(hip_ctx, oracle):
+    from trackdlo_amd import synth, binding as B
+    depth, mask, cam, _ = synth.depth_scene(30, config=9)
+    args = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    X, n, nraw = hip_ctx.depth_to_cloud(0, depth, np.zeros_like(mask), *args, 0.008)          # nothing segmented
+    assert n == 0 and nraw == 0 and X.shape == (0, 3)
+    Xo, _ = oracle.depth_to_cloud(depth, mask, *args, 1e-5)                               # cell count overflows int32: pass-through
+    X, n, nraw = hip_ctx.depth_to_cloud(0, depth, mask, *args, 1e-5)
+    assert n == nraw == Xo.shape[0] and np.array_equal(X, Xo)
+    one = np.zeros_like(mask); one[100, 200] = 255                                        # a single pixel
+    Xo, _ = oracle.depth_to_cloud(depth, one, *args, 0.008)
+    X, n, _ = hip_ctx.depth_to_cloud(0, depth, one, *args, 0.008)
+    assert n == 1 and np.array_equal(X, Xo)
+    full = np.full_like(mask, 255)                                                        # every pixel (background wall included)
+    Xo, _ = oracle.depth_to_cloud(depth, full, *args, 0.02)
+    X, n, nraw = hip_ctx.depth_to_cloud(0, depth, full, *args, 0.02)
+    assert nraw == depth.size and np.array_equal(X, Xo)
+    with pytest.raises(B.TdloError):
+        hip_ctx.depth_to_cloud(0, depth, mask, *args, 0.0)
+
+
+@pytest.mark.gpu
+def test_frame_born_on_device_matches_host_path(hip_ctx, oracle):
+    """depth image -> cloud (device) -> visibility pre-pass -> tracking_step with X = NULL gives exactly the nodes of the
+    host path (oracle cloud uploaded through tracking_step(X))."""
+    from trackdlo_amd import synth, binding as B
+    M = 30            # 0.58 m of rope: fits the 640-pixel image at 0.6 m
+    P = synth.LAUNCH_PARAMS
+    depth, mask, cam, Y0 = synth.depth_scene(M, config=9, frame=3)
+    args = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    coord = synth.geodesic_coord(Y0)
+    def mk():
+        t = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 50, P["tol"],
+                       P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], ctx=hip_ctx)
+        t.initialize_nodes(Y0); t.initialize_geodesic_coord(coord)
+        return t
+    Xo, _ = oracle.depth_to_cloud(depth, mask, *args, 0.008)
+    vis = np.arange(M, dtype=np.int32)
+    a = mk(); a.tracking_step(Xo, vis, vis)
+    b = mk()
+    _, n, _ = hip_ctx.depth_to_cloud(0, depth, mask, *args, 0.008, fetch=False)
+    assert n == Xo.shape[0]
+    b.tracking_step(None, vis, vis)
+    assert np.array_equal(a.get_tracking_result(), b.get_tracking_result())
+    assert np.abs(a.get_tracking_result() - Y0).max() < 0.02

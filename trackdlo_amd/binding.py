@@ -53,6 +53,7 @@ SYMBOLS = [
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
     "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_depth_to_cloud",
 ]
 
 _lib = None
@@ -115,6 +116,7 @@ def load_library(path: str | None = None):
     lib.tdlo_compute_error.restype = cd
     lib.tdlo_compute_error.argtypes = [vp, ci, vp, ci]
     lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
+    lib.tdlo_depth_to_cloud.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     if path is None:
         _lib = lib
     return lib
@@ -220,6 +222,22 @@ class Context:
                                                    _ptr(dist), _ptr(vis), C.byref(nv), _ptr(ext), C.byref(ne)))
         return dist, vis[:nv.value].copy(), ext[:ne.value].copy()
 
+    def depth_to_cloud(self, slot, depth, mask, fx, fy, cx, cy, leaf_size, *, fetch=True):
+        """trackdlo_node.cpp:195-241: masked back-projection + pcl::VoxelGrid; the result becomes the slot's resident cloud.
+        Returns (X [n x 3] or None, n, n_raw)."""
+        depth = np.ascontiguousarray(depth, dtype=np.uint16); mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        if depth.ndim != 2 or depth.shape != mask.shape:
+            raise ValueError("depth and mask must be rows x cols images of the same shape")
+        rows, cols = depth.shape
+        cap = int(np.count_nonzero(mask)) if fetch else 0
+        buf = np.zeros(3 * max(cap, 1)) if fetch else None
+        n = C.c_int(0); nraw = C.c_int(0)
+        self._chk(self.lib.tdlo_depth_to_cloud(self.h, slot, depth.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p), rows, cols,
+                                               float(fx), float(fy), float(cx), float(cy), float(leaf_size),
+                                               _ptr(buf), cap, C.byref(n), C.byref(nraw)))
+        X = buf[:3 * n.value].reshape(3, n.value).T.copy() if fetch else None
+        return X, n.value, nraw.value
+
     def debug_read_cloud(self, max_points, slot=0):
         out = np.zeros((3, max_points)); ctr = np.zeros(3)
         n = self.lib.tdlo_debug_read_cloud(self.h, slot, _ptr(out), max_points, _ptr(ctr))
@@ -300,12 +318,12 @@ class trackdlo:
                       H_pre=None):
         """trackdlo::tracking_step (trackdlo.cpp:900-999). proj_matrix/img_rows/img_cols are accepted and ignored, as in
         the reference body."""
-        X = _f64(X_orig)
+        X = _f64(X_orig) if X_orig is not None else None      # None: the cloud resident in the tracker's slot (depth_to_cloud)
         v = np.ascontiguousarray(visible_nodes, dtype=np.int32)
         ve = np.ascontiguousarray(visible_nodes_extended, dtype=np.int32)
         Hm = _f64(H_pre) if H_pre is not None else None
         st = (Stats * 2)()
-        rc = self.ctx.lib.tdlo_tracker_tracking_step(self.h, _ptr(X), X.shape[0], _ptr(v), len(v), _ptr(ve), len(ve), _ptr(Hm),
+        rc = self.ctx.lib.tdlo_tracker_tracking_step(self.h, _ptr(X), X.shape[0] if X is not None else 0, _ptr(v), len(v), _ptr(ve), len(ve), _ptr(Hm),
                                                      C.cast(st, C.c_void_p))
         self.last_stats = [s.as_dict() for s in st]
         self.ctx._chk(rc)

@@ -69,6 +69,8 @@ struct tdlo_ctx {
     std::vector<FrameDev> fh;        // host copies of the frame descriptors of the last call
     FrameDev *fd = nullptr;          // device array [max_frames]
     double *pin = nullptr;           // pinned staging
+    void *cloud_ws = nullptr;        // depth -> cloud workspace (images, sort buffers)
+    size_t cloud_ws_cap = 0;
     size_t pin_doubles = 0;
     std::string err;
     int last_F = 0;
@@ -361,6 +363,7 @@ void tdlo_destroy(tdlo_ctx *c) {
         if (s.nodeblk) hipFree(s.nodeblk);
     }
     if (c->fd) hipFree(c->fd);
+    if (c->cloud_ws) hipFree(c->cloud_ws);
     if (c->pin) hipHostFree(c->pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -525,6 +528,83 @@ int tdlo_split_end(tdlo_ctx *c, double *Y, double *sigma2, tdlo_stats *stats) {
 }
 
 // ---- caller-side visibility pre-pass ------------------------------------------------------------
+int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                        double fx, double fy, double cx, double cy, double leaf_size,
+                        double *X_out, int x_capacity, int *n_out, int *n_raw_out) {
+    if (!c) return TDLO_E_INVALID;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
+    if (!depth || !mask || rows <= 0 || cols <= 0 || (long long)rows * cols > (1ll << 26)) return fail(c, TDLO_E_INVALID, "bad image");
+    if (!(leaf_size > 0) || fx == 0 || fy == 0) return fail(c, TDLO_E_INVALID, "bad leaf size / intrinsics");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot &s = c->slots[slot];
+    hipStream_t st = c->stream;
+    const int P = rows * cols;
+    const size_t img = (((size_t)P * 2 + 255) & ~(size_t)255) + (((size_t)P + 255) & ~(size_t)255);
+    const size_t need = img + cloud_ws_bytes(P);
+    if (need > c->cloud_ws_cap) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (c->cloud_ws) hipFree(c->cloud_ws);
+        c->cloud_ws = nullptr; c->cloud_ws_cap = 0;
+        HIPCHK(c, hipMalloc(&c->cloud_ws, need));
+        c->cloud_ws_cap = need;
+    }
+    int rc = ensure_pin(c, 16);
+    if (rc) return rc;
+    char *base = (char *)c->cloud_ws;
+    unsigned short *d_depth = (unsigned short *)base;
+    unsigned char *d_mask = (unsigned char *)(base + (((size_t)P * 2 + 255) & ~(size_t)255));
+    char *ws = base + img;
+    // the last 64 ints of the workspace: bounding box (6 ordered floats), masked-pixel count, output count
+    unsigned *d_bbox = (unsigned *)(ws + cloud_ws_bytes(P) - 256);
+    int *d_total = (int *)(d_bbox + 8);
+    unsigned *hb = (unsigned *)c->pin;
+    hb[0] = hb[1] = hb[2] = ~0u; hb[3] = hb[4] = hb[5] = 0u; hb[6] = 0u; hb[7] = 0u; hb[8] = 0u;
+    const double cam[4] = {fx, fy, cx, cy};
+    HIPCHK(c, hipMemcpyAsync(d_depth, depth, (size_t)P * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_mask, mask, (size_t)P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_bbox, hb, 9 * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    HIPCHK(c, launch_cloud_bbox(d_depth, d_mask, P, cols, cam, d_bbox, st));
+    HIPCHK(c, hipMemcpyAsync(hb, d_bbox, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int nraw = (int)hb[6];
+    if (n_raw_out) *n_raw_out = nraw;
+    if (n_out) *n_out = 0;
+    s.N0 = 0;
+    if (nraw == 0) return TDLO_OK;
+    auto decode = [](unsigned o) { const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; std::memcpy(&f, &u, 4); return f; };
+    float mn[3], mx[3];
+    for (int d = 0; d < 3; ++d) { mn[d] = decode(hb[d]); mx[d] = decode(hb[3 + d]); }
+    // pcl/filters/impl/voxel_grid.hpp applyFilter: leaf-size check, min_b / div_b / divb_mul (float arithmetic)
+    const float leaf = (float)leaf_size, inv = 1.0f / leaf;
+    long long dd[3]; int min_b[3], div_b[3];
+    for (int d = 0; d < 3; ++d) {
+        dd[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
+        min_b[d] = (int)std::floor(mn[d] * inv);
+        div_b[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+    }
+    const int nodown = (dd[0] * dd[1] * dd[2] > 2147483647ll) ? 1 : 0;
+    const long long cells = nodown ? 1 : (long long)div_b[0] * div_b[1] * div_b[2];
+    if (cells >= 0xffffffffll) return fail(c, TDLO_E_INVALID, "voxel grid has too many cells");
+    int passes = 1;
+    while (passes < 4 && (1ll << (8 * passes)) <= cells) ++passes;      // every valid key must stay below the all-ones sentinel
+    rc = ensure_points(c, s, nraw);
+    if (rc) return rc;
+    HIPCHK(c, launch_cloud_voxels(d_depth, d_mask, P, cols, cam, min_b, div_b[0], div_b[0] * div_b[1], inv, nodown, passes,
+                                  ws, d_total, s.cap_points, s.Xraw, st));
+    HIPCHK(c, hipMemcpyAsync(hb, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int n = (int)hb[0];
+    if (n < 0 || n > s.cap_points) return fail(c, TDLO_E_HIP, "voxel grid produced an impossible point count");
+    s.N0 = n;
+    if (n_out) *n_out = n;
+    if (X_out) {
+        if (n > x_capacity) return fail(c, TDLO_E_INVALID, "X_out too small for the down-sampled cloud");
+        HIPCHK(c, hipMemcpyAsync(X_out, s.Xraw, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    return TDLO_OK;
+}
+
 int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, double visibility_threshold, double d_vis,
                             const double *geodesic_coord, double *node_dist, int *visible_nodes, int *n_vis,
                             int *visible_nodes_extended, int *n_vis_ext) {
@@ -767,14 +847,16 @@ int tdlo_tracker_get_correspondence_pairs(const tdlo_tracker *t, double *out, in
 
 int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const int *vis, int n_vis,
                                const int *vis_ext, int n_ext, const double *H_pre, tdlo_stats *stats) {
-    if (!t || !X || !vis_ext) return TDLO_E_INVALID;
+    if (!t || !vis_ext) return TDLO_E_INVALID;
     tdlo_ctx *c = t->ctx;
     const int M = t->M;
     if (n_ext <= 0 || n_ext > M) return fail(c, TDLO_E_INVALID, "visible_nodes_extended must hold 1..M indices (empty is undefined in the reference, trackdlo_node.cpp:351)");
     for (int i = 0; i < n_ext; ++i) if (vis_ext[i] < 0 || vis_ext[i] >= M) return fail(c, TDLO_E_INVALID, "visible_nodes_extended index out of range");
     for (int i = 0; i < n_vis; ++i) if (vis[i] < 0 || vis[i] >= M) return fail(c, TDLO_E_INVALID, "visible_nodes index out of range");
     t->priors.clear();                                                   // :908
-    int rc = tdlo_set_cloud(c, t->slot, X, N);                           // X_orig by value: one upload for both registrations
+    int rc = TDLO_OK;
+    if (X) rc = tdlo_set_cloud(c, t->slot, X, N);                        // X_orig by value: one upload for both registrations
+    else if (c->slots[t->slot].N0 <= 0) rc = fail(c, TDLO_E_INVALID, "X is NULL and no cloud is resident in the tracker's slot");
     if (rc) return rc;
 
     // guide nodes = visible sub-chain (:913-921)

@@ -72,6 +72,12 @@ hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
 hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s);
 size_t mstep_lds_bytes(int M);
+// tdlo_cloud.hip: depth image -> cloud -> voxel grid
+size_t cloud_ws_bytes(int P);
+hipError_t launch_cloud_bbox(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], unsigned *bbox, hipStream_t s);
+hipError_t launch_cloud_voxels(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4],
+                               const int min_b[3], int mul1, int mul2, float inv_leaf, int nodown, int passes,
+                               void *ws, int *total_dev, int cap, double *Xraw, hipStream_t s);
 int check_device_image();
 
 }  // namespace tdlo

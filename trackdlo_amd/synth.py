@@ -76,3 +76,40 @@ def extend_visible(vis: np.ndarray, M: int, coord: np.ndarray, d_vis: float = 0.
             out.extend(range(vis[i] + 1, vis[i + 1]))
     out.append(vis[-1])
     return np.asarray(out, dtype=np.int32)
+
+
+# RealSense D435 colour stream at 640 x 480 (the resolution the reference's launch files use); these intrinsics play
+# the role of camera_info's P matrix (trackdlo_node.cpp:215-218).
+CAMERA = dict(rows=480, cols=640, fx=615.0, fy=615.0, cx=320.0, cy=240.0)
+
+
+def depth_scene(M: int, config: int = 0, frame: int = 0, *, radius: float = 0.006, samples: int = 400000,
+                shift=(0.0, 0.005, 0.0), rows: int = None, cols: int = None, zero_depth_pixels: int = 0):
+    """Synthetic aligned depth image + segmentation mask of the rope of `scene` (what the RGB-D driver and the HSV
+    threshold deliver to trackdlo_node.cpp:195): surface points of a tube of `radius` around the centreline are
+    projected with CAMERA, z-buffered, depth in uint16 millimetres.  zero_depth_pixels: that many mask pixels get
+    depth 0 (invalid depth; the reference back-projects them to the origin without a check).
+    Returns (depth [rows x cols uint16], mask [rows x cols uint8], camera dict, Y0)."""
+    cam = dict(CAMERA)
+    if rows is not None:
+        cam.update(rows=rows, cols=cols, cx=cols / 2.0, cy=rows / 2.0, fx=CAMERA["fx"] * cols / 640.0, fy=CAMERA["fy"] * cols / 640.0)
+    rng = np.random.default_rng(BASE_SEED + 1000 * config + frame + 77)
+    Y0 = nodes(M)
+    s = rng.random(samples)
+    c = centreline(s, M) + np.asarray(shift)[None, :]
+    ang = rng.random(samples) * 2 * np.pi
+    rad = radius * np.sqrt(rng.random(samples))
+    p = c + np.stack([np.zeros(samples), rad * np.cos(ang), rad * np.sin(ang)], axis=1)
+    u = np.rint(p[:, 0] * cam["fx"] / p[:, 2] + cam["cx"]).astype(np.int64)
+    v = np.rint(p[:, 1] * cam["fy"] / p[:, 2] + cam["cy"]).astype(np.int64)
+    ok = (u >= 0) & (u < cam["cols"]) & (v >= 0) & (v < cam["rows"])
+    u, v, z = u[ok], v[ok], p[ok, 2]
+    zmm = np.clip(np.rint(z * 1000.0), 1, 65535).astype(np.int64)
+    depth = np.full(cam["rows"] * cam["cols"], 65535, dtype=np.int64)
+    np.minimum.at(depth, v * cam["cols"] + u, zmm)
+    mask = (depth != 65535).astype(np.uint8) * 255
+    depth[depth == 65535] = 1500                      # background wall at 1.5 m
+    if zero_depth_pixels:
+        on = np.nonzero(mask)[0]
+        depth[on[rng.choice(len(on), size=min(zero_depth_pixels, len(on)), replace=False)]] = 0
+    return depth.astype(np.uint16).reshape(cam["rows"], cam["cols"]), mask.reshape(cam["rows"], cam["cols"]), cam, Y0
