@@ -182,6 +182,13 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N,
                                const int *visible_nodes_extended, int n_vis_ext,
                                const double *H_pre, tdlo_stats *stats);
 
+/* ---- plain GMM-EM initial registration ------------------------------------ */
+/* reg(pts, Y, sigma2, M, mu, max_iter), trackdlo/src/utils.cpp:21-82 (declared trackdlo/include/utils.h): M centroids
+ * fitted to the cloud with the Euclidean membership only; Y (M x 3 column-major) and sigma2 are pure outputs (the
+ * reference overwrites both, :24-29, :45).  Exactly max_iter iterations, no stopping rule, fp64.  pts == NULL: use the
+ * cloud resident in `slot`.  A centroid that attracts no probability mass comes back NaN, as in the reference. */
+int tdlo_reg(tdlo_ctx *ctx, int slot, const double *pts, int N, double *Y, double *sigma2, int M, double mu, int max_iter);
+
 /* ---- depth image -> cloud -> voxel-grid down-sample ------------------------ */
 /* The step right upstream of tracking_step in the ROS node (trackdlo/src/trackdlo_node.cpp:195-241): every pixel
  * with mask != 0 is back-projected ((u - cx) z / fx, (v - cy) z / fy, z = depth / 1000; float storage like

@@ -953,3 +953,61 @@ int ref_depth_to_cloud(const unsigned short *depth, const unsigned char *mask, i
     free(px); free(ent);
     return n_out;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * reg, trackdlo/src/utils.cpp:21-82: plain GMM-EM (Euclidean membership only).  pts N x 3 column-major.
+ * proto = 0: the C++ function.  proto = 1: the numpy prototype `register` (utils/tracking_test.py:118-172), which
+ * pins the shared maths: centroids start on the x axis (:122), sigma2 starts at 1 (:125), a zero column sum becomes
+ * eps (:142), and max_iter + 1 estimates are made (:165-170).
+ * ------------------------------------------------------------------------------------------------ */
+void ref_reg(const double *pts, int N, double *Y, double *sigma2, int M, double mu, int max_iter, int proto) {
+    const int D = 3;
+    for (int i = 0; i < M; i++) {
+        Y[i] = Y[M + i] = Y[2 * M + i] = 0.0;
+        if (proto) Y[i] = (double)i * (0.1 / M);                                     /* np.arange(0, 0.1, 0.1 / M) */
+        else Y[M + i] = 0.1 / (double)M * (double)i;                                 /* utils.cpp:26 */
+    }
+    double *d2 = (double *)malloc(sizeof(double) * (size_t)M * N);
+    double *P = (double *)malloc(sizeof(double) * (size_t)M * N);
+    double *P1 = (double *)malloc(sizeof(double) * M), *PX = (double *)malloc(sizeof(double) * 3 * M);
+    if (proto) *sigma2 = 1.0;
+    else {
+        double s = 0.0;
+        for (int n = 0; n < N; n++) for (int m = 0; m < M; m++) {                    /* :36-45 (column-major sum order) */
+            const double dx = Y[m] - pts[n], dy = Y[M + m] - pts[N + n], dz = Y[2 * M + m] - pts[2 * (size_t)N + n];
+            s += dx * dx + dy * dy + dz * dz;
+        }
+        *sigma2 = s / (double)(D * M * N);
+    }
+    const int iters = proto ? max_iter + 1 : max_iter;
+    for (int it = 0; it < iters; it++) {
+        const double s2 = *sigma2;
+        const double c = pow(2 * M_PI * s2, (double)D / 2) * mu / (1 - mu) * (double)M / N;     /* :57 */
+        for (int m = 0; m < M; m++) { P1[m] = 0; PX[m] = PX[M + m] = PX[2 * M + m] = 0; }
+        double num = 0.0, den_s = 0.0;
+        for (int n = 0; n < N; n++) {
+            double den = 0.0;
+            for (int m = 0; m < M; m++) {
+                const double dx = Y[m] - pts[n], dy = Y[M + m] - pts[N + n], dz = Y[2 * M + m] - pts[2 * (size_t)N + n];
+                const double q = dx * dx + dy * dy + dz * dz;
+                d2[(size_t)n * M + m] = q;
+                P[(size_t)n * M + m] = exp(-0.5 * q / s2);                           /* :55 */
+                den += P[(size_t)n * M + m];
+            }
+            if (proto && den == 0) den = 2.220446049250313e-16;
+            den += c;                                                                /* :58 */
+            for (int m = 0; m < M; m++) P[(size_t)n * M + m] /= den;
+        }
+        for (int n = 0; n < N; n++) for (int m = 0; m < M; m++) {
+            const double p = P[(size_t)n * M + m];
+            P1[m] += p; PX[m] += p * pts[n]; PX[M + m] += p * pts[N + n]; PX[2 * M + m] += p * pts[2 * (size_t)N + n];
+        }
+        for (int m = 0; m < M; m++) for (int n = 0; n < N; n++) {                    /* :73-78 */
+            num += P[(size_t)n * M + m] * d2[(size_t)n * M + m];
+            den_s += P[(size_t)n * M + m] * D;
+        }
+        for (int m = 0; m < M; m++) { Y[m] = PX[m] / P1[m]; Y[M + m] = PX[M + m] / P1[m]; Y[2 * M + m] = PX[2 * M + m] / P1[m]; }   /* :68 */
+        *sigma2 = num / den_s;                                                       /* :80 */
+    }
+    free(d2); free(P); free(P1); free(PX);
+}

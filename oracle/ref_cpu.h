@@ -135,6 +135,11 @@ int ref_visibility_prepass(const double *X, int N, const double *Y, int M, doubl
 double ref_piecewise_error(const double *Y_track, int n1, const double *Y_true, int n2);
 double ref_compute_error(const double *Y_track, int n1, const double *Y_true, int n2);
 
+/* reg, trackdlo/src/utils.cpp:21-82 (plain GMM-EM).  pts N x 3 column-major, Y M x 3 column-major (output), sigma2 output.
+ * proto = 1 reproduces the numpy prototype `register` (utils/tracking_test.py:118-172) instead; that mode pins the maths
+ * against tests/golden/proto_register.npz. */
+void ref_reg(const double *pts, int N, double *Y, double *sigma2, int M, double mu, int max_iter, int proto);
+
 /* Depth image -> cloud (trackdlo/src/trackdlo_node.cpp:195-232) -> voxel-grid down-sample (:235-241, algorithm of
  * PCL 1.10 pcl::VoxelGrid, restated; parity unpinned against PCL).  depth: rows x cols uint16 millimetres, mask:
  * rows x cols uint8 (non-zero = rope pixel), both row-major.  X_out: column-major n x 3 with leading dimension n

@@ -156,6 +156,14 @@ def compute_error(Y_track, Y_true):
     return lib().ref_compute_error(_dp(a), C.c_int(a.shape[0]), _dp(b), C.c_int(b.shape[0]))
 
 
+def reg(pts, M, mu=0.05, max_iter=50, proto=False):
+    """reg (utils.cpp:21-82); proto=True: the numpy prototype's `register` (tracking_test.py:118-172)."""
+    X = _f(pts)
+    Y = np.zeros((M, 3), order="F"); s2 = C.c_double(0.0)
+    lib().ref_reg(_dp(X), C.c_int(X.shape[0]), _dp(Y), C.byref(s2), C.c_int(M), C.c_double(mu), C.c_int(max_iter), C.c_int(int(proto)))
+    return Y, s2.value
+
+
 def depth_to_cloud(depth, mask, fx, fy, cx, cy, leaf_size):
     """trackdlo_node.cpp:195-241: masked back-projection + pcl::VoxelGrid.  Returns (X [n x 3], n_raw)."""
     depth = np.ascontiguousarray(depth, dtype=np.uint16); mask = np.ascontiguousarray(mask, dtype=np.uint8)

@@ -105,6 +105,19 @@ def main():
     np.savez_compressed(os.path.join(HERE, "proto_lle_weights.npz"), Y0=Y0, W_k2=Wk2,
                         nbr6_mask=np.array([[1.0 if j in set(ix.tolist()) else 0.0 for j in range(M)] for ix in idx6]),
                         W6_rowsum=W6.sum(axis=1))
+
+    # ---- G6: `register` (tracking_test.py:118-172), the prototype of utils.cpp's `reg`: plain GMM-EM.  Outputs after
+    # max_iter = 0, 1, 2, 5, 20 (i.e. 1, 2, 3, 6, 21 estimates) pin the E-step / Y = PX ./ P1 / sigma2 update trajectory.
+    Xr, _, _ = synth.scene(400, 12, config=91, frame=0)
+    Xr = np.ascontiguousarray(Xr) - np.array([0.0, 0.0, 0.6])      # near the prototype's start segment
+    reg_out = {}
+    for mu in (0.05, 0.0):
+        Ys, s2s = [], []
+        for it in (0, 1, 2, 5, 20):
+            Yn, sn = proto.register(Xr, 8, mu=mu, max_iter=it)
+            Ys.append(np.asarray(Yn)); s2s.append(float(sn))
+        reg_out[f"mu{mu}__Y"] = np.array(Ys); reg_out[f"mu{mu}__sigma2"] = np.array(s2s)
+    np.savez_compressed(os.path.join(HERE, "proto_register.npz"), X=Xr, M=8, iters=np.array([0, 1, 2, 5, 20]), **reg_out)
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

@@ -175,3 +175,19 @@ def test_visibility_prepass_oracle(oracle):
     np.testing.assert_array_equal(vis, np.nonzero(dn <= 0.008)[0])
     np.testing.assert_array_equal(ext, synth.extend_visible(vis, M, coord, 0.06))
     assert set(vis.tolist()) <= set(ext.tolist())
+
+
+def test_reg_matches_prototype_register(oracle):
+    """G6: `reg` (utils.cpp:21-82) restated; its prototype-mode switch reproduces the reference's numpy `register`
+    (tracking_test.py:118-172) on golden vectors generated by importing that prototype (make_golden.py)."""
+    z = np.load(f"{GOLDEN}/proto_register.npz")
+    for mu in (0.05, 0.0):
+        for k, it in enumerate(z["iters"]):
+            Y, s2 = oracle.reg(z["X"], int(z["M"]), mu=mu, max_iter=int(it), proto=True)
+            np.testing.assert_allclose(Y, z[f"mu{mu}__Y"][k], rtol=0, atol=1e-12)
+            assert abs(s2 - z[f"mu{mu}__sigma2"][k]) <= 1e-12 * s2
+    # the C++ variant differs only in the start (y axis, data-driven sigma2) and the iteration count
+    Y, s2 = oracle.reg(z["X"], 8, mu=0.05, max_iter=0)
+    assert np.array_equal(Y[:, 1], 0.1 / 8 * np.arange(8)) and np.all(Y[:, [0, 2]] == 0)
+    d2 = ((Y[:, None, :] - z["X"][None, :, :]) ** 2).sum()
+    assert abs(s2 - d2 / (3 * 8 * len(z["X"]))) <= 1e-13 * s2

@@ -429,3 +429,21 @@ def test_frame_born_on_device_matches_host_path(hip_ctx, oracle):
     b.tracking_step(None, vis, vis)
     assert np.array_equal(a.get_tracking_result(), b.get_tracking_result())
     assert np.abs(a.get_tracking_result() - Y0).max() < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,mu,iters", [(400, 8, 0.05, 20), (5000, 30, 0.05, 10), (50000, 50, 0.1, 5), (777, 5, 0.0, 50), (300, 8, 0.05, 0)])
+def test_reg_matches_oracle(hip_ctx, oracle, N, M, mu, iters):
+    """reg (utils.cpp:21-82) on the device against the oracle, fp64: centroids within 1e-9 m,
+    sigma2 within 1e-9 relative (summation order is the only difference)."""
+    from trackdlo_amd import synth
+    X, _, _ = synth.scene(N, max(M, 4), config=11, frame=N)
+    X = X - np.array([0.0, 0.0, 0.6])
+    Yo, so = oracle.reg(X, M, mu=mu, max_iter=iters)
+    Yg, sg = hip_ctx.reg(X, M, mu=mu, max_iter=iters)
+    assert np.all(np.isfinite(Yo))
+    np.testing.assert_allclose(Yg, Yo, rtol=0, atol=1e-9)
+    assert abs(sg - so) <= 1e-9 * so
+    # resident-cloud form gives the same bits
+    Yr, sr = hip_ctx.reg(None, M, mu=mu, max_iter=iters)
+    assert np.array_equal(Yr, Yg) and sr == sg

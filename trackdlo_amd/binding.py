@@ -53,7 +53,7 @@ SYMBOLS = [
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
     "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
-    "tdlo_depth_to_cloud",
+    "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def load_library(path: str | None = None):
     lib.tdlo_compute_error.restype = cd
     lib.tdlo_compute_error.argtypes = [vp, ci, vp, ci]
     lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
+    lib.tdlo_reg.argtypes = [vp, ci, vp, ci, vp, C.POINTER(cd), ci, cd, ci]
     lib.tdlo_depth_to_cloud.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     if path is None:
         _lib = lib
@@ -221,6 +222,13 @@ class Context:
         self._chk(self.lib.tdlo_visibility_prepass(self.h, slot, _ptr(Y), M, float(visibility_threshold), float(d_vis), _ptr(coord),
                                                    _ptr(dist), _ptr(vis), C.byref(nv), _ptr(ext), C.byref(ne)))
         return dist, vis[:nv.value].copy(), ext[:ne.value].copy()
+
+    def reg(self, pts, M, mu=0.05, max_iter=50, slot=0):
+        """reg (utils.cpp:21-82): plain GMM-EM.  pts=None: the slot's resident cloud.  Returns (Y [M x 3], sigma2)."""
+        X = _f64(pts) if pts is not None else None
+        Y = np.zeros((M, 3), order="F"); s2 = C.c_double(0.0)
+        self._chk(self.lib.tdlo_reg(self.h, slot, _ptr(X), X.shape[0] if X is not None else 0, _ptr(Y), C.byref(s2), int(M), float(mu), int(max_iter)))
+        return Y, s2.value
 
     def depth_to_cloud(self, slot, depth, mask, fx, fy, cx, cy, leaf_size, *, fetch=True):
         """trackdlo_node.cpp:195-241: masked back-projection + pcl::VoxelGrid; the result becomes the slot's resident cloud.

@@ -69,6 +69,8 @@ struct tdlo_ctx {
     std::vector<FrameDev> fh;        // host copies of the frame descriptors of the last call
     FrameDev *fd = nullptr;          // device array [max_frames]
     double *pin = nullptr;           // pinned staging
+    double *reg_ws = nullptr;        // `reg` workspace
+    size_t reg_ws_cap = 0;
     void *cloud_ws = nullptr;        // depth -> cloud workspace (images, sort buffers)
     size_t cloud_ws_cap = 0;
     size_t pin_doubles = 0;
@@ -364,6 +366,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     }
     if (c->fd) hipFree(c->fd);
     if (c->cloud_ws) hipFree(c->cloud_ws);
+    if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -528,6 +531,44 @@ int tdlo_split_end(tdlo_ctx *c, double *Y, double *sigma2, tdlo_stats *stats) {
 }
 
 // ---- caller-side visibility pre-pass ------------------------------------------------------------
+int tdlo_reg(tdlo_ctx *c, int slot, const double *pts, int N, double *Y, double *sigma2, int M, double mu, int max_iter) {
+    if (!c) return TDLO_E_INVALID;
+    if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
+    if (!Y || !sigma2 || M < 1 || M > 4096 || max_iter < 0 || !(mu >= 0 && mu < 1)) return fail(c, TDLO_E_INVALID, "bad reg arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = TDLO_OK;
+    if (pts) rc = tdlo_set_cloud(c, slot, pts, N);
+    else if (c->slots[slot].N0 <= 0) rc = fail(c, TDLO_E_INVALID, "pts is NULL and no cloud is resident in the slot");
+    if (rc) return rc;
+    Slot &s = c->slots[slot];
+    const int n = s.N0;
+    const int nblk = std::max(1, std::min((n + 255) / 256, 256));
+    const size_t need = reg_ws_doubles(M, nblk);
+    if (need > c->reg_ws_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->reg_ws) hipFree(c->reg_ws);
+        c->reg_ws = nullptr; c->reg_ws_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->reg_ws, need * sizeof(double)));
+        c->reg_ws_cap = need;
+    }
+    rc = ensure_pin(c, 8 + 3 * (size_t)M);
+    if (rc) return rc;
+    double *h = c->pin;
+    for (int i = 0; i < 8; ++i) h[i] = 0.0;
+    for (int i = 0; i < M; ++i) {                                         // utils.cpp:24-29
+        h[8 + i] = 0.0;
+        h[8 + M + i] = 0.1 / static_cast<double>(M) * static_cast<double>(i);
+        h[8 + 2 * M + i] = 0.0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->reg_ws, h, sizeof(double) * (8 + 3 * (size_t)M), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_reg(s.Xraw, n, M, mu, max_iter, nblk, c->reg_ws, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h, c->reg_ws, sizeof(double) * (8 + 3 * (size_t)M), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *sigma2 = h[0];
+    std::memcpy(Y, h + 8, sizeof(double) * 3 * (size_t)M);
+    return TDLO_OK;
+}
+
 int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
                         double fx, double fy, double cx, double cy, double leaf_size,
                         double *X_out, int x_capacity, int *n_out, int *n_raw_out) {
