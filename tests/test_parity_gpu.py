@@ -72,6 +72,11 @@ def test_per_iteration_trajectory(hip_ctx, prec):
     (5000, 65, 6, {}),                                     # first size needing a second node tile
     (4000, 100, 8, dict(vis=True)),
     (3000, 130, 4, {}),                                    # M-step leaves LDS (M > 128)
+    (3000, 61, 5, {}),                                     # first M outside the 64-column MFMA tableau (M + 3 > 64)
+    (3000, 200, 3, dict(priors=True)),                     # blocked M-step in global memory, with the alpha J G term
+    (2500, 80, 4, dict(lle=True)),                         # M > 64 with the LLE term: pivoted generic solve
+    (6000, 300, 3, {}),                                    # BASELINE.json configs[4] node count (C5)
+    (4000, 512, 2, {}),                                    # largest supported chain
 ], ids=lambda v: str(v).replace(" ", ""))
 def test_live_oracle_small(hip_ctx, oracle, N, M, iters, opts, prec):
     from trackdlo_amd import synth

@@ -52,7 +52,7 @@ struct NodeCarve {
         Yout = take(3 * m); st = take((sizeof(IterState) + 7) / 8); readback = o - Yout;
         ctr = take(4); Y = take(3 * m); Y0 = take(3 * m); nodes = take(4 * m); coord = take(m);
         G = take(mm); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2); dbg = take(64);
-        Ascr = take((size_t)(M | 1) * (m + 3));
+        Ascr = take(std::max((size_t)(M | 1) * (m + 3), mstep_big_scratch_doubles(M)));
         part = take((size_t)kMaxEstepBlocks * (4 * m + 2));
         total = o;
     }

@@ -19,80 +19,12 @@
 //   sum_mn P_mn |x_n - T_m|^2 = Q - 2 sum_m d_m.R_m + sum_m P1_m |d_m|^2,
 //   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m (accumulated directly by the E-step),  d_m = T_m - y_m
 // instead of :418-422's difference of three large traces, which would cancel catastrophically in fp32.
-#include "tdlo_internal.h"
+#include "tdlo_devcommon.h"
 #include <type_traits>
-#include "../../include/trackdlo_hip.h"
 #include <cstdio>
 #include <cstdlib>
 
 namespace tdlo {
-
-template <typename T> struct alignas(16) V4 { T x, y, z, w; };
-
-__device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
-__device__ __forceinline__ double tmin(double a, double b) { return ::fmin(a, b); }
-
-// Address-space casts.  Pointers reach the kernels through the FrameDev descriptor, so the compiler
-// only sees generic (flat) pointers and would emit flat_load + full waits.  Node data and parameters
-// are never written by the kernel that reads them, so they are read through the constant address
-// space (wave-uniform index => s_load into SGPRs, no VALU/LDS/VMEM cost); the cloud through global.
-#define TDLO_AS_CONST(TYPE, p) ((const __attribute__((address_space(4))) TYPE *)(uintptr_t)(p))
-#define TDLO_AS_GLOBAL(TYPE, p) ((const __attribute__((address_space(1))) TYPE *)(uintptr_t)(p))
-
-template <typename T> struct Num;
-template <> struct Num<float> {
-    static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
-    static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
-    static __device__ __forceinline__ unsigned long long bits(float x) { return (unsigned long long)__float_as_uint(x); }
-    static __device__ __forceinline__ double from_bits(unsigned long long b) { return (double)__uint_as_float((unsigned)b); }
-};
-template <> struct Num<double> {
-    static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
-    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
-    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-    static __device__ __forceinline__ unsigned long long bits(double x) { return (unsigned long long)__double_as_longlong(x); }
-    static __device__ __forceinline__ double from_bits(unsigned long long b) { return __longlong_as_double((long long)b); }
-};
-
-// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the
-// compiler has to be kept from reordering across the point.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// block-wide sum for kBlock threads; scratch holds >= 4 doubles; result valid in every thread
-__device__ __forceinline__ double block_sum(double v, double *scratch) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
-}
-
-// partial rows written by the E-step have an even stride so that the M-step can fetch them 16 bytes at a time
-// (fp32 mode: fp32 partials, stride a multiple of 4 floats; fp64 mode: fp64 partials, even stride)
-// block partial element type for compute precision T
-template <typename T> struct PartOf { typedef T type; };     // fp32 mode: fp32 partials (half the M-step's load); fp64 mode: fp64
-template <typename PT> __host__ __device__ inline int part_stride(int M) { return sizeof(PT) == 4 ? ((4 * M + 1 + 3) & ~3) : (4 * M + 2); }
-
-__device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
-    // c of trackdlo.cpp:300 (or c' of :378 when visibility weighting is active)
-    double c = pow(2.0 * M_PI * sigma2, 1.5) * f.mu / (1.0 - f.mu);
-    c = f.vis_branch ? c / Nc : c * (double)f.M / Nc;
-    st->sigma2 = sigma2;
-    st->Nc = Nc;
-    st->k2 = -1.4426950408889634 / (2.0 * sigma2);
-    st->c_norm = c;
-}
 
 // ------------------------------------------------------------------------------------------------
 // prune, trackdlo.cpp:177-195, fused with the sigma2 initialisation sum of :263-273
@@ -800,14 +732,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {     // 
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double fast_rcp(double v) {
-    double r = __builtin_amdgcn_rcp(v);
-    r = fma(fma(-v, r, 1.0), r, r);
-    r = fma(fma(-v, r, 1.0), r, r);
-    return r;
-}
 
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 // value of lane group g = lane >> 4 out of four wave-uniform-per-group candidates.  v_cndmask with the
 // four constant lane masks; written as inline asm because a ?: chain over array elements is turned into
@@ -1410,31 +1335,18 @@ static int mstep_mfma_enabled() {
     return v;
 }
 
-static int mstep_waves() {
-    static int v = 0;
-    if (!v) { const char *e = getenv("TDLO_MSTEP_WAVES"); v = e ? atoi(e) : 4; if (v != 4 && v != 8) v = 4; }
-    return v;
-}
-
 template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
     const int M = fh[0].M;
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
     if (M <= 60 && !any_lle && mstep_mfma_enabled()) return launch_mstep_fast<T, 4, 1, true>(fd, fh, F, from_sums, s);
+    if (M > 64 && !any_lle && mstep_mfma_enabled()) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     if (M <= 64) {
-        if (mstep_waves() == 8) {
-            const int mc = (M + 4 + 7) / 8;           // columns per wave: M matrix + 3 right-hand sides + 1 tracer
-            if (mc <= 3) return launch_mstep_fast<T, 8, 3>(fd, fh, F, from_sums, s);
-            if (mc <= 5) return launch_mstep_fast<T, 8, 5>(fd, fh, F, from_sums, s);
-            if (mc <= 7) return launch_mstep_fast<T, 8, 7>(fd, fh, F, from_sums, s);
-            return launch_mstep_fast<T, 8, 9>(fd, fh, F, from_sums, s);
-        } else {
-            const int mc = (M + 4 + 3) / 4;
-            if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
-            if (mc <= 10) return launch_mstep_fast<T, 4, 10>(fd, fh, F, from_sums, s);
-            if (mc <= 14) return launch_mstep_fast<T, 4, 14>(fd, fh, F, from_sums, s);
-            return launch_mstep_fast<T, 4, 17>(fd, fh, F, from_sums, s);
-        }
+        const int mc = (M + 4 + 3) / 4;               // columns per wave: M matrix + 3 right-hand sides + 1 tracer
+        if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
+        if (mc <= 10) return launch_mstep_fast<T, 4, 10>(fd, fh, F, from_sums, s);
+        if (mc <= 14) return launch_mstep_fast<T, 4, 14>(fd, fh, F, from_sums, s);
+        return launch_mstep_fast<T, 4, 17>(fd, fh, F, from_sums, s);
     } else if (M <= kLdsSolveMaxM) {
         const size_t lds = mstep_lds_bytes(M);
         TDLO_TRY(set_lds(k_mstep<T, true>, lds));

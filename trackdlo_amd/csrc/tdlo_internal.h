@@ -72,6 +72,9 @@ hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
 hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s);
 size_t mstep_lds_bytes(int M);
+// tdlo_mstep_big.hip: M-step for 60 < M <= kMaxNodes without LLE (blocked Gauss-Jordan, tableau in global memory)
+hipError_t launch_mstep_big(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
+size_t mstep_big_scratch_doubles(int M);
 // tdlo_reg.hip: plain GMM-EM `reg` (utils.cpp:21-82); ws layout: state (8) | Y (3 M) | block partials
 size_t reg_ws_doubles(int M, int nblk);
 hipError_t launch_reg(const double *X, int N, int M, double mu, int max_iter, int nblk, double *ws, hipStream_t s);

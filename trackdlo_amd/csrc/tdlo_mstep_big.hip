@@ -1,0 +1,274 @@
+// tdlo_mstep_big.hip -- M-step (trackdlo.cpp:392-437) for 60 < M <= 512 chain nodes without the LLE term
+// (BASELINE.json configs[4]: M = 300).
+//
+// Same mathematics as k_mstep_fast's MFMA variant in tdlo_device.hip -- Gauss-Jordan elimination without pivoting of
+// [A | B], A = c I + (diag(P1) + alpha J) G, which is the elimination of the SPD matrix G + c D^-1 -- but the
+// tableau (up to 512 x 528 doubles, 2 MB) cannot live in one CU's registers or LDS, so it sits in global memory
+// (L2-resident) and is processed by ONE workgroup of 16 waves in panels of 16 pivot columns:
+//   a. the 16 pivot rows (16 x live columns) are loaded one column per thread and reduced among themselves by 16
+//      sequential row operations held in registers; the only traffic per step is the pivot column, handed over through
+//      LDS (one barrier per step).  Result U (16 x Cp) -> LDS (MFMA B operand) and back to the tableau;
+//   b. every other row block, every column block right of the panel:  C -= L U  with four v_mfma_f64_16x16x4 per
+//      16 x 16 tile; L = the panel's columns, which are never written again (column blocks up to the panel are dead),
+//      so they are read straight from the tableau as the A operand.  Tiles are dealt round-robin to the 16 waves.
+// fp64 vector and matrix rates are equal on gfx950, so the MFMA buys data flow (no per-element index arithmetic),
+// not flops.  Measured at M = 300: 0.88 ms per M-step (15x the scalar column-at-a-time kernel it replaces), of which
+// 0.61 ms is the trailing update -- bound by what ONE CU can pull from L2 (about 17 B/clk observed: every panel re-reads
+// and re-writes the live part of the 760 KB tableau), 0.16 ms the 16-step pivot-row reductions, 0.07 ms partial sums
+// and tableau assembly.  Spreading the row blocks over several CUs (grid barrier per panel) is the next step.  Layout: row-major, Mp = M rounded up to 16 rows (identity padded),
+// Cp = Mp + 16 columns, right-hand sides in columns Mp .. Mp + 2.
+#include "tdlo_devcommon.h"
+#include <cstdlib>
+
+namespace tdlo {
+namespace {
+
+constexpr int kBig = 1024;
+
+__device__ __forceinline__ double block_sum16(double v, double *scratch) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double a = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += scratch[i];
+    return a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__ frames, int from_sums_in) {
+    // (U rows are padded to Us = Cp + 16 doubles: lane groups 0/1 and 2/3 then sit 32 banks apart)
+    const int from_sums = from_sums_in;
+    const FrameDev &f = frames[blockIdx.x];
+    IterState *st = f.st;
+    if (st->done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = f.M, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nS = 4 * M + 1;
+    const int Mp = (M + 15) & ~15, Cp = Mp + 16, nrb = Mp >> 4, ncb = Cp >> 4, Us = Cp + 16;
+    double *S = (double *)smem;               // nS (+pad)
+    double *W = S + ((nS + 1) & ~1);          // 3M (+pad)
+    double *Tn = W + ((3 * M + 1) & ~1);      // 3M (+pad)
+    double *scratch = Tn + ((3 * M + 1) & ~1);// 16
+    double *pcol = scratch + 16;              // 2 x 16: pivot column of the current step (double-buffered: one barrier per step)
+    double *U = pcol + 32;                    // 16 x Cp reduced pivot rows
+    const auto Tb = TDLO_AS_GLOBAL_RW(double, f.Ascr);     // Mp x Cp tableau, row-major (global address space: no flat ops)
+    const auto Gg = TDLO_AS_GLOBAL(double, f.G);
+
+#define BSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    BSTAMP(0);
+    // ---- 1. reduce the E-step block partials in a fixed order
+    if (from_sums != 1) {
+        typedef typename PartOf<T>::type PT;
+        const int nb = f.nblkE, nSp = part_stride<PT>(M);
+        const auto partT = TDLO_AS_GLOBAL(PT, f.part);
+        for (int e = t; e < nS; e += kBig) {
+            double a0 = 0;
+            for (int b = 0; b < nb; b += 16) {            // 16 loads in flight, block order kept
+                PT v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int bb = b + u < nb ? b + u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (b + u < nb) a0 += (double)v[u];
+            }
+            S[e] = a0;
+        }
+    } else {
+        for (int e = t; e < nS; e += kBig) S[e] = f.sums[e];
+    }
+    __syncthreads();
+    if (from_sums == 2) {       // split mode, export only
+        for (int e = t; e < nS; e += kBig) f.sums[e] = S[e];
+        if (t == 0) f.sums[nS] = (double)st->N;
+        return;
+    }
+
+    BSTAMP(1);
+    // ---- 2. tableau [A | B] (:392-413), identity padded; B = R + P1 (y - Y0) (+ alpha (Y_ext - Y0)), R from the E-step
+    const double sigma2 = st->sigma2;
+    const double c2 = f.lambda * sigma2;
+    const int pri = f.has_priors;
+    const V4<T> *ndq = (const V4<T> *)f.nodes;
+#pragma unroll 4
+    for (int e = t; e < Mp * Cp; e += kBig) {
+        const int i = e / Cp, j = e - i * Cp;
+        double v = 0.0;
+        if (i < M) {
+            if (j < M) v = (S[i] + (pri ? f.aJ[i] : 0.0)) * Gg[(size_t)i * M + j] + (i == j ? c2 : 0.0);      // G symmetric
+            else if (j >= Mp && j < Mp + 3) {
+                const int d = j - Mp, q = d * M + i;
+                const double yd = d == 0 ? (double)ndq[i].x : (d == 1 ? (double)ndq[i].y : (double)ndq[i].z);
+                v = S[M + q] + S[i] * (yd - f.Y0[q]);
+                if (pri) v += f.aYd[q];
+            }
+        } else if (i == j) v = 1.0;
+        Tb[e] = v;
+    }
+    __syncthreads();
+
+    BSTAMP(2);
+    // ---- 3. blocked Gauss-Jordan, 16 pivot columns per panel
+    int singular = 0;
+    const int cL = lane & 15, gL = lane >> 4;
+    for (int pb = 0; pb < nrb; ++pb) {
+        const int k0 = pb << 4;
+        // a. pivot rows: thread = column (k0 <= col < Cp), 16 entries in registers
+        const int col = k0 + t;
+        const bool act = col < Cp;
+        double u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = act ? Tb[(size_t)(k0 + r) * Cp + col] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double *pc = pcol + (j & 1) * 16;
+            if (t == j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pc[r] = u[r];
+            }
+            __syncthreads();
+            const double pv = pc[j];
+            {
+                const int e = (__double2hiint(pv) >> 20) & 0x7ff;
+                if (e == 0 || e == 0x7ff) singular = 1;          // zero / denormal / non-finite pivot
+            }
+            const double v = u[j] * fast_rcp(pv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = (r == j) ? v : fma(-pc[r], v, u[r]);
+        }
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { U[r * Us + col] = u[r]; if (t >= 16) Tb[(size_t)(k0 + r) * Cp + col] = u[r]; }
+        }
+        __syncthreads();
+        // b. trailing update: tiles (rb != pb, cb > pb)
+        const int nlive = ncb - pb - 1, ntile = (nrb - 1) * nlive;
+        // Every wave takes a CONTIGUOUS range of tiles in row-major order, TB at a time (all loads first, then the
+        // MFMAs, then the stores): consecutive tiles share the row block, so the strided L operand (16 rows x 32 B) is
+        // served by the L1 after its first use, and no tile needs an integer division.
+        constexpr int TB = 4;
+        const int chunk = (ntile + 15) >> 4;
+        const int tbeg = w * chunk, tend = (tbeg + chunk) < ntile ? (tbeg + chunk) : ntile;
+        int ri = tbeg / (nlive > 0 ? nlive : 1), ci = tbeg - ri * nlive;
+        for (int tile0 = tbeg; tile0 < tend; tile0 += TB) {
+            double a[TB][4], b[TB][4];
+            mfma_d4 C[TB];
+            __attribute__((address_space(1))) double *Ct[TB];
+#pragma unroll
+            for (int q = 0; q < TB; ++q) {
+                const bool on = tile0 + q < tend;
+                const int rq = on ? ri : 0, cq = on ? ci : 0;      // clamp: loads stay in bounds, result discarded
+                const int rb = rq < pb ? rq : rq + 1, cb = pb + 1 + cq;
+                const auto Lrow = Tb + (size_t)(16 * rb + cL) * Cp + k0 + gL;
+                Ct[q] = Tb + (size_t)(16 * rb + gL) * Cp + 16 * cb + cL;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { a[q][s4] = -Lrow[4 * s4]; b[q][s4] = U[(4 * s4 + gL) * Us + 16 * cb + cL]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[q][r] = Ct[q][(size_t)(4 * r) * Cp];
+                if (++ci == nlive) { ci = 0; ++ri; }
+            }
+#pragma unroll
+            for (int q = 0; q < TB; ++q) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) C[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][s4], b[q][s4], C[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < TB; ++q) {
+                if (tile0 + q < tend) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ct[q][(size_t)(4 * r) * Cp] = C[q][r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    BSTAMP(3);
+    for (int e = t; e < 3 * M; e += kBig) { const int i = e % M, d = e / M; W[e] = Tb[(size_t)i * Cp + Mp + d]; }
+    singular = __syncthreads_or(singular);
+
+    // ---- 4. T = Y0 + G W (:417): thread = (node, half of the k range)
+    {
+        const int i = t & 511, h = t >> 9;
+        double v0 = 0, v1 = 0, v2 = 0;
+        if (i < M) {
+            const int kh = (M + 1) >> 1, kb = h * kh, ke = (kb + kh) < M ? (kb + kh) : M;
+            for (int k = kb; k < ke; ++k) { const double gk = Gg[(size_t)k * M + i]; v0 += gk * W[k]; v1 += gk * W[M + k]; v2 += gk * W[2 * M + k]; }
+        }
+        double *tmp = U;                      // free now: 6 x 512 doubles <= 16 x Cp
+        if (i < M) { tmp[(h * 3 + 0) * 512 + i] = v0; tmp[(h * 3 + 1) * 512 + i] = v1; tmp[(h * 3 + 2) * 512 + i] = v2; }
+        __syncthreads();
+        for (int e = t; e < 3 * M; e += kBig) { const int m = e % M, d = e / M; Tn[e] = f.Y0[e] + (tmp[d * 512 + m] + tmp[(3 + d) * 512 + m]); }
+    }
+    __syncthreads();
+
+    BSTAMP(4);
+    // ---- 5. sigma2 (residual form of :418-422) and the convergence criterion (:424)
+    double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
+    for (int m = t; m < M; m += kBig) {
+        const double yx = (double)ndq[m].x, yy = (double)ndq[m].y, yz = (double)ndq[m].z;    // nodes as the E-step saw them
+        const double p1 = S[m];
+        const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
+        s_np += p1;
+        s_dr += dx * S[M + m] + dy * S[2 * M + m] + dz * S[3 * M + m];
+        s_pd += p1 * (dx * dx + dy * dy + dz * dz);
+        const double ex = f.Y[m] - Tn[m], ey = f.Y[M + m] - Tn[M + m], ez = f.Y[2 * M + m] - Tn[2 * M + m];
+        s_cr += ::sqrt(ex * ex + ey * ey + ez * ez);
+    }
+    s_np = block_sum16(s_np, scratch);
+    s_dr = block_sum16(s_dr, scratch);
+    s_pd = block_sum16(s_pd, scratch);
+    s_cr = block_sum16(s_cr, scratch);
+    const double new_sigma2 = (S[4 * M] - 2.0 * s_dr + s_pd) / (s_np * 3.0);
+    const double crit = s_cr / (double)M;
+
+    // ---- 6. publish Y, nodes, iteration state
+    V4<T> *nodes_w = (V4<T> *)f.nodes;
+    for (int m = t; m < M; m += kBig) {
+        V4<T> q; q.x = (T)Tn[m]; q.y = (T)Tn[M + m]; q.z = (T)Tn[2 * M + m]; q.w = (T)f.coord[m];
+        nodes_w[m] = q;
+        f.dminbits[m] = ~0ull;
+    }
+    for (int e = t; e < 3 * M; e += kBig) {
+        f.Y[e] = Tn[e];
+        f.Yout[e] = Tn[e] + f.ctr[e / M];
+    }
+    BSTAMP(5);
+    if (t == 0) {
+        const int it = st->it + 1;
+        st->it = it; st->crit = crit; st->Np = s_np;
+        const double Nc = st->Nc;
+        const bool finite_ok = (new_sigma2 == new_sigma2) && (fabs(new_sigma2) < 1e300) && (new_sigma2 > 0) && !singular;
+        if (finite_ok) set_iter_consts(f, st, new_sigma2, Nc);
+        else { st->sigma2 = new_sigma2; st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
+        if (crit < f.tol) st->done = 1;                                   // :424-428
+        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+    }
+}
+
+size_t big_lds_bytes(int M) {
+    const int nS = 4 * M + 1, Mp = (M + 15) & ~15, Cp = Mp + 16;
+    size_t d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 16 + 32 + (size_t)16 * (Cp + 16);
+    if (d < (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 48 + 6 * 512) d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 48 + 6 * 512;
+    return d * sizeof(double);
+}
+
+}  // namespace
+
+size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16); }
+
+hipError_t launch_mstep_big(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, bool f64, hipStream_t s) {
+    const size_t lds = big_lds_bytes(fh[0].M);
+    hipError_t e;
+    if (f64) {
+        e = hipFuncSetAttribute((const void *)k_mstep_big<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_mstep_big<double>), dim3(F), dim3(kBig), lds, s, fd, from_sums);
+    } else {
+        e = hipFuncSetAttribute((const void *)k_mstep_big<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_mstep_big<float>), dim3(F), dim3(kBig), lds, s, fd, from_sums);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tdlo
