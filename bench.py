@@ -113,8 +113,10 @@ def main():
         alg_bytes = 3 * 4 * N_POINTS * F
         achieved = alg_bytes / (est_us * 1e-6) / 1e9
         traffic = None
-        try:        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE calibrated, + WRITE_SIZE), see profiles/r01_pmc_hbm.json
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
+        try:        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE calibrated, + WRITE_SIZE): the newest
+            # profiles/*_pmc_hbm.json (made by scripts/gpu_profile.sh + scripts/pmc_summary.py from this same command)
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[-1]) as fh:
                 traffic = round(json.load(fh)["estep"]["traffic_bytes_per_launch"] * F)
         except Exception:
             traffic = None
