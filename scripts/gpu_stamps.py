@@ -10,7 +10,8 @@ g = ctx.cpd_lle(X, Y0, 0.0, pr)
 g = ctx.cpd_lle_resident(0, Y0, 0.0, pr)
 print('loop_ms', g['loop_ms'], 'total', g['total_ms'], 'host', g['host_ms'])
 st = ctx.debug_stamps(64).astype(np.int64)
-print('estep stamps', st[32:40] - st[32])
+print('timeline (10 ns ticks rel. to previous M-step end): E first-block start %d, E last-block end %d, M start %d, M end %d' % (st[34]-st[36], st[35]-st[36], st[37]-st[36], st[38]-st[36]))
+print('estep block 0 wave 0 stamps (cycles): start, loads+barrier, pass1, second node+window, pass2, column sums, block barrier, end', (st[40:48] - st[40]).tolist())
 print('stamps', st[:8] - st[0])
 print('wave load-done stamps', (st[8:12] - st[0]).tolist())
 print('estep', ctx.profile_kernel(0, 300), 'mstep', ctx.profile_kernel(2, 300))

@@ -180,9 +180,8 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.N0 = s.N0; f.M = M; f.ldx = s.cap_points;
     const int nbatch = (s.N0 + 63) / 64;
     // fp32: 8 waves per workgroup (half as many block partials for the M-step to add up); fp64 tiles are
-    // twice as large, so 4 waves.  TDLO_ESTEP_THREADS=256 forces the small variant (experiments).
+    // twice as large, so 4 waves.
     f.eb = (p->precision == TDLO_PREC_F32 && M <= 64) ? 512 : 256;
-    { const char *e = getenv("TDLO_ESTEP_THREADS"); if (e && atoi(e) == 256) f.eb = 256; }
     const int wpb = f.eb / 64;
     int nblk = (nbatch + wpb - 1) / wpb;
     int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : 256;
@@ -193,7 +192,6 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0) ? 1 : 0;
     (void)vis;
     f.precision = p->precision;
-    { const char *e = getenv("TDLO_NOSORT"); f.pad1 = e ? atoi(e) : 0; }
     f.nprune_blocks = (s.N0 + kBlock - 1) / kBlock;
     f.tol = p->tol; f.beta = p->beta; f.lambda = p->lambda; f.lle_weight = p->lle_weight; f.mu = p->mu;
     f.alpha = p->alpha; f.k_vis = p->k_vis; f.vis_thr = p->visibility_threshold; f.sigma2_in = sigma2;

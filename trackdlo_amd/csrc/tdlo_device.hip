@@ -54,7 +54,6 @@ __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restri
     const bool keep = valid && (::sqrt(best) < 0.1);
     // the kept points are stored sorted by their nearest node (stable), which makes the points of a
     // wave spatially coherent: the E-step then only touches the few nodes with non-zero membership
-    if (f.pad1 == 1) a0 = 0;                            // TDLO_NOSORT=1 (experiments): keep the original point order
     if (valid) f.bucket[n] = keep ? (unsigned short)a0 : (unsigned short)0xffff;
     if (keep) atomicAdd(&lh[a0], 1);
     const double s = block_sum(keep ? sum : 0.0, scratch);
@@ -316,6 +315,15 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     constexpr int NWE = EB / 64;
     const FrameDev &f = SINGLE ? f0 : frames[blockIdx.y];
     if ((int)blockIdx.x >= f.nblkE) return;
+#ifdef TDLO_ESTEP_STAMPS
+    if (threadIdx.x == 0) atomicMin(&f.dbg[32], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+#ifdef TDLO_ESTEP_STAMPS
+#define ESTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) f.dbg[40 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ESTAMP(i) do { } while (0)
+#endif
+    ESTAMP(0);
     const auto stg = TDLO_AS_GLOBAL(IterState, f.st);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = f.M;
@@ -364,6 +372,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         }
     }
     __syncthreads();
+    ESTAMP(1);
 
     double accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
 #pragma unroll
@@ -396,6 +405,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const T d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < best) { best = d2; a = m; }
         }
+        ESTAMP(2);
         // ---- second node by distance (:313-329)
         const int c1 = (a == 0) ? 2 : a - 1;
         const int c2 = (a == M - 1) ? M - 3 : a + 1;
@@ -421,10 +431,11 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             for (int o = 32; o > 0; o >>= 1) { amin = tmin(amin, __shfl_xor(amin, o)); amax = -tmin(-amax, -__shfl_xor(amax, o)); }
             const T cm = (lane < M) ? nodesL[lane].w : Num<T>::inf();
             const unsigned long long inw = __ballot(lane < M && cm > amin - Rwin && cm < amax + Rwin);
-            if (inw && f.pad1 != 3) { wlo = (int)__builtin_ctzll(inw); whi = 63 - (int)__builtin_clzll(inw); }
+            if (inw) { wlo = (int)__builtin_ctzll(inw); whi = 63 - (int)__builtin_clzll(inw); }
             wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
         }
 
+        ESTAMP(3);
         // ---- unnormalised membership, column sum, Q (:354-383)
         T sum = 0, qs = 0;
 #pragma unroll 4
@@ -439,12 +450,13 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             qs += p * d2;
             if (NCH == 1) pb[(m - wlo) * kPStride + lane] = p;
         }
+        ESTAMP(4);
         const T inv = valid ? T(1) / (sum + cn) : T(0);
         accQ += (double)(inv * qs);
         // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
         // wave's points within centimetres) and leave as the residual R_m = sum_n P_mn (x_n - y_m):
         // small numbers, so fp32 tile sums and fp32 block partials lose nothing that matters
-        const T ox = f.pad1 == 2 ? T(0) : __shfl(x, 0), oy = f.pad1 == 2 ? T(0) : __shfl(y, 0), oz = f.pad1 == 2 ? T(0) : __shfl(z, 0);
+        const T ox = __shfl(x, 0), oy = __shfl(y, 0), oz = __shfl(z, 0);
         V4<T> pw; pw.x = inv * (x - ox); pw.y = inv * (y - oy); pw.z = inv * (z - oz); pw.w = inv;
         pts[wave * 64 + lane] = pw;
 
@@ -512,8 +524,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         }
     }
 
+    ESTAMP(5);
     // ---- block partial: sum the waves in a fixed order, write [P1 | PXx | PXy | PXz | Q]
     __syncthreads();
+    ESTAMP(6);
     typedef typename PartOf<T>::type PT;
     PT *part = (PT *)f.part + (size_t)blockIdx.x * part_stride<PT>(M);
     if (NCH == 1) {
@@ -549,6 +563,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     const double q = block_sum_n<NWE>(accQ, scratch);
     if (tid == 0) part[4 * M] = (PT)q;
+    ESTAMP(7);
+#ifdef TDLO_ESTEP_STAMPS
+    if (tid == 0) atomicMax(&f.dbg[33], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -776,6 +794,9 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
 
 #define TDLO_STAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     TDLO_STAMP(0);
+#ifdef TDLO_ESTEP_STAMPS
+    if (t == 0) { f.dbg[34] = f.dbg[32]; f.dbg[35] = f.dbg[33]; f.dbg[36] = f.dbg[38]; f.dbg[37] = __builtin_amdgcn_s_memrealtime(); f.dbg[32] = ~0ull; f.dbg[33] = 0ull; }
+#endif
     const auto stg = TDLO_AS_GLOBAL(IterState, st);
     const int done = stg->done;
     const double sigma2 = stg->sigma2;
@@ -1192,6 +1213,9 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         f.Yout[i] = Tn[i] + (slot == 0 ? ctr0 : (slot == 1 ? ctr1 : ctr2));
     }
     TDLO_STAMP(7);
+#ifdef TDLO_ESTEP_STAMPS
+    if (t == 0) f.dbg[38] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (t == 0) {
         const int it = stg->it + 1;
         st->it = it; st->crit = crit; st->Np = s_np;
@@ -1329,18 +1353,13 @@ template <typename T, int NW, int MC, bool MFMA = false> static hipError_t launc
     return hipGetLastError();
 }
 
-static int mstep_mfma_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("TDLO_MSTEP_MFMA"); v = e ? atoi(e) : 1; }
-    return v;
-}
 
 template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
     const int M = fh[0].M;
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
-    if (M <= 60 && !any_lle && mstep_mfma_enabled()) return launch_mstep_fast<T, 4, 1, true>(fd, fh, F, from_sums, s);
-    if (M > 64 && !any_lle && mstep_mfma_enabled()) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
+    if (M <= 60 && !any_lle) return launch_mstep_fast<T, 4, 1, true>(fd, fh, F, from_sums, s);
+    if (M > 64 && !any_lle) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     if (M <= 64) {
         const int mc = (M + 4 + 3) / 4;               // columns per wave: M matrix + 3 right-hand sides + 1 tracer
         if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
