@@ -81,10 +81,19 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     {
         const int ml = t & 63, ch = t >> 6;
         const int cb0 = (int)((long long)nb * ch / 4), cb1 = (int)((long long)nb * (ch + 1) / 4);
-        for (int mg = 0; mg < M; mg += 64) {
+        const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);       // (global address space and 16 independent loads per trip:
+        for (int mg = 0; mg < M; mg += 64) {                  //  a load-add chain over ~50 blocks costs a memory latency each)
             const int m = mg + ml;
+            const int mc = m < M ? m : M - 1;
             int run = 0;
-            if (m < M) for (int b = cb0; b < cb1; ++b) run += f.hist[(size_t)b * M + m];
+            for (int b = cb0; b < cb1; b += 16) {
+                int v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + mc];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (b + u < cb1) run += v[u];
+            }
+            if (cb1 <= cb0 || m >= M) run = 0;
             csum[ch][ml] = run;
             __syncthreads();
             int start = 0;
@@ -92,7 +101,13 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
             if (ch == 3 && m < M) stot[m] = start + run;
             if (m < M) {
                 int r2 = start;
-                for (int b = cb0; b < cb1; ++b) { const int v = f.hist[(size_t)b * M + m]; f.hist[(size_t)b * M + m] = r2; r2 += v; }
+                for (int b = cb0; b < cb1; b += 16) {
+                    int v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + m];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) if (b + u < cb1) { hg[(size_t)(b + u) * M + m] = r2; r2 += v[u]; }
+                }
             }
             __syncthreads();
         }
@@ -112,7 +127,11 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         sN = run; sS = tot;
     }
     __syncthreads();
-    for (int i = t; i < nb * M; i += kBlock) f.hist[i] += stot[i % M];
+    {
+        const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);
+#pragma unroll 8
+        for (int i = t; i < nb * M; i += kBlock) hg[i] += stot[i % M];
+    }
     // centring offset
     if (t < 3) {
         double a = 0;
@@ -934,7 +953,8 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                     const double p1 = S[rwc];
                     const double gv = Gs[rwc * M + colc];                              // G symmetric: row-major read, conflict-free
                     const double va = (p1 + aux[384 + rwc]) * gv + (rw == col ? c2 : 0.0);
-                    const double vb = S[M + dcol * M + rwc] + p1 * aux[dcol * 64 + rwc] + aux[192 + dcol * 64 + rwc];
+                    double vb = 0.0;                  // right-hand sides live in wave 3 only (wave-uniform branch: the other
+                    if (w == 3) vb = S[M + dcol * M + rwc] + p1 * aux[dcol * 64 + rwc] + aux[192 + dcol * 64 + rwc];   // waves skip half of the LDS reads)
                     const double vin = isA ? va : (isB ? vb : 0.0);
                     C[rb][r] = rw < M ? vin : (rw == col ? 1.0 : 0.0);
                 }
@@ -952,11 +972,11 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         }
         auto panel = [&](auto PC) __attribute__((always_inline)) {
             constexpr int p = decltype(PC)::value;
-            // (waves left of the panel hold finished columns only; they run the same code -- a branch around it
-            //  would cost a copy of all accumulators at the join and they are not on the critical path)
             const int k0 = 4 * p, rb0 = k0 >> 4, r0 = (k0 & 15) >> 2, rr = k0 & 15;
             const double *buf = pan + (p & 1) * 256;
             __syncthreads();
+            if (w < (k0 >> 4)) return;                // wave-uniform: this wave holds finished columns only; staying out of
+                                                      // the LDS pipe shortens the panel for the waves that still work
             double ak[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
