@@ -132,35 +132,46 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
 #pragma unroll 8
         for (int i = t; i < nb * M; i += kBlock) hg[i] += stot[i % M];
     }
-    // centring offset
-    if (t < 3) {
-        double a = 0;
-        for (int m = 0; m < M; ++m) a += f.Yin[t * M + m];
-        sctr[t] = a / M; f.ctr[t] = a / M;
+    // centring offset, chain coordinate: the node block is staged in LDS first -- the serial sums below (same
+    // left-to-right order as the reference) would otherwise pay a global-memory round trip per term
+    __shared__ double sY[3 * kMaxNodes];
+    __shared__ double sc[kMaxNodes];
+    {
+        const auto Yg = TDLO_AS_GLOBAL(double, f.Yin);
+        for (int i = t; i < 3 * M; i += kBlock) sY[i] = Yg[i];
     }
     __syncthreads();
-    for (int i = t; i < 3 * M; i += kBlock) { const double v = f.Yin[i] - sctr[i / M]; f.Y[i] = v; f.Y0[i] = v; f.Yout[i] = f.Yin[i]; }
+    if (t < 3) {
+        double a = 0;
+        for (int m = 0; m < M; ++m) a += sY[t * M + m];
+        sctr[t] = a / M; f.ctr[t] = a / M;
+    }
     for (int i = t; i < M - 1; i += kBlock) {
-        const double dx = f.Yin[i + 1] - f.Yin[i], dy = f.Yin[M + i + 1] - f.Yin[M + i], dz = f.Yin[2 * M + i + 1] - f.Yin[2 * M + i];
-        f.coord[i + 1] = ::sqrt(dx * dx + dy * dy + dz * dz);
+        const double dx = sY[i + 1] - sY[i], dy = sY[M + i + 1] - sY[M + i], dz = sY[2 * M + i + 1] - sY[2 * M + i];
+        sc[i + 1] = ::sqrt(dx * dx + dy * dy + dz * dz);
     }
     __syncthreads();
     if (t == 0) {   // same left-to-right running sum as :219-223
-        double cur = 0; f.coord[0] = 0;
-        for (int i = 0; i < M - 1; ++i) { cur += f.coord[i + 1]; f.coord[i + 1] = cur; }
+        double cur = 0; sc[0] = 0;
+        for (int i = 0; i < M - 1; ++i) { cur += sc[i + 1]; sc[i + 1] = cur; }
     }
+    for (int i = t; i < 3 * M; i += kBlock) { const double v = sY[i] - sctr[i / M]; f.Y[i] = v; f.Y0[i] = v; f.Yout[i] = sY[i]; }
     __syncthreads();
     V4<T> *nodes = (V4<T> *)f.nodes;
     for (int m = t; m < M; m += kBlock) {
-        V4<T> q; q.x = (T)f.Y[m]; q.y = (T)f.Y[M + m]; q.z = (T)f.Y[2 * M + m]; q.w = (T)f.coord[m];
+        V4<T> q; q.x = (T)(sY[m] - sctr[0]); q.y = (T)(sY[M + m] - sctr[1]); q.z = (T)(sY[2 * M + m] - sctr[2]); q.w = (T)sc[m];
         nodes[m] = q;
+        f.coord[m] = sc[m];
         f.dminbits[m] = ~0ull;
     }
     const double beta = f.beta;
-    for (int e = t; e < M * M; e += kBlock) {
-        const int i = e % M, j = e / M;
-        const double dd = fabs(f.coord[i] - f.coord[j]);
-        f.G[e] = 1.0 / (2 * beta * 2 * beta) * ::exp(-::sqrt(2.0) * dd / beta) * (2 * dd + ::sqrt(2.0) * beta);
+    {
+        const auto Gw = TDLO_AS_GLOBAL_RW(double, f.G);
+        for (int e = t; e < M * M; e += kBlock) {
+            const int i = e % M, j = e / M;
+            const double dd = fabs(sc[i] - sc[j]);
+            Gw[e] = 1.0 / (2 * beta * 2 * beta) * ::exp(-::sqrt(2.0) * dd / beta) * (2 * dd + ::sqrt(2.0) * beta);
+        }
     }
     __syncthreads();
     if (f.include_lle) {
