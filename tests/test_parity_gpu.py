@@ -452,3 +452,39 @@ def test_reg_matches_oracle(hip_ctx, oracle, N, M, mu, iters):
     # resident-cloud form gives the same bits
     Yr, sr = hip_ctx.reg(None, M, mu=mu, max_iter=iters)
     assert np.array_equal(Yr, Yg) and sr == sg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_randomised_configurations(hip_ctx, oracle, seed):
+    """Seeded sweep over sizes, parameters and branches (visibility weighting, priors, LLE, carried-over sigma2, noise,
+    clutter, both precisions): every draw must meet the stated tolerances against the oracle after a fixed number of
+    iterations.  Draws stay in the regime the path is specified for (smooth chain, cloud on the chain)."""
+    from trackdlo_amd import synth
+    rng = np.random.default_rng(9000 + seed)
+    M = int(rng.integers(4, 65)) if seed % 6 else int(rng.integers(65, 140))
+    N = int(rng.integers(64, 12000))
+    iters = int(rng.integers(1, 9))
+    prec = int(rng.integers(0, 2))
+    vis = bool(rng.integers(0, 2)) and M >= 12
+    use_pri = bool(rng.integers(0, 2))
+    use_lle = bool(rng.integers(0, 3) == 0)
+    noise = float(rng.choice([0.0005, 0.002, 0.004]))
+    X, Y0, v = synth.scene(N, M, config=60 + seed, frame=seed, noise=noise, occlude=(0.35, 0.55) if vis else None,
+                           outliers=int(rng.integers(0, 20)), shift=(0.0, float(rng.uniform(0, 0.008)), float(rng.uniform(-0.003, 0.003))))
+    vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0)) if vis else None
+    kw = dict(beta=float(rng.choice([0.35, 0.6, 3.0])), lambda_=float(rng.choice([1.0, 500.0, 50000.0])), lle_weight=10.0,
+              mu=float(rng.choice([0.05, 0.1, 0.3])), max_iter=iters, tol=0.0, include_lle=False, alpha=0.0,
+              k_vis=50.0 if vis else 0.0, visibility_threshold=0.008)
+    pri = None; H = None
+    if use_pri:
+        idx = np.sort(rng.choice(M, size=max(1, M // 4), replace=False))
+        pri = np.concatenate([idx[:, None].astype(float), Y0[idx] + rng.normal(0, 0.003, size=(len(idx), 3))], axis=1)
+        kw["alpha"] = float(rng.choice([1.0, 3.0]))
+    if use_lle:
+        L = oracle.calc_lle_weights(Y0, 6); H = (np.eye(M) - L).T @ (np.eye(M) - L)
+        kw.update(include_lle=True, beta=3.0, lambda_=1.0)
+    s2 = float(rng.choice([0.0, 1e-4, 2e-5]))
+    o = oracle.cpd_lle(X, Y0, s2, priors=pri, visible_nodes=vext, H=H, **kw)
+    g = hip_ctx.cpd_lle(X, Y0, s2, _params(kw, prec), priors=pri, visible_nodes=vext, H=H)
+    _check(g, o, prec)

@@ -1409,7 +1409,10 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
     if (M <= 60 && !any_lle) return launch_mstep_fast<T, 4, 1, true>(fd, fh, F, from_sums, s);
-    if (M > 64 && !any_lle) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
+    // (M = 61..64 without LLE: the 64-column register tableau has no room for the right-hand sides; the tracer-column
+    //  variant of the register path is an order of magnitude less accurate at weak regularisation, so these sizes take
+    //  the blocked global-memory path as well)
+    if (M > 60 && !any_lle) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     if (M <= 64) {
         const int mc = (M + 4 + 3) / 4;               // columns per wave: M matrix + 3 right-hand sides + 1 tracer
         if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
