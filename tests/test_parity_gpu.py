@@ -455,7 +455,7 @@ def test_reg_matches_oracle(hip_ctx, oracle, N, M, mu, iters):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(64))
 def test_randomised_configurations(hip_ctx, oracle, seed):
     """Seeded sweep over sizes, parameters and branches (visibility weighting, priors, LLE, carried-over sigma2, noise,
     clutter, both precisions): every draw must meet the stated tolerances against the oracle after a fixed number of
