@@ -237,7 +237,10 @@ double tdlo_compute_error(const double *Y_track, int n_track, const double *Y_tr
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Launches the E-step kernel `reps` times back to back on the context's stream for the state left
  * by the last cpd_lle call on `slot` and returns the HIP-event average per launch (microseconds).
- * kind: 0 = membership/E-step kernel, 1 = per-node min-distance kernel, 2 = M-step kernel. */
+ * kind: 0 = membership/E-step kernel, 1 = per-node min-distance kernel, 2 = M-step kernel;
+ * kind 10 = the E-step IN SITU: `reps` (<= 256) real iterations (E-step and M-step alternating as in the loop), each
+ * E-step dispatch carrying its own start/stop events (hipExtLaunchKernelGGL) -- the per-dispatch duration a kernel
+ * trace reports, measured live on the context's stream. */
 int tdlo_profile_kernel(tdlo_ctx *ctx, int slot, int kind, int reps, float *avg_us);
 /* Development aid: copies the first n (<= 64) shader-clock stamps that the M-step kernel of the last
  * launch wrote at its phase boundaries (reduce / assemble / eliminate / update / publish). */

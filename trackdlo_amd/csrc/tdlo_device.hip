@@ -20,6 +20,7 @@
 //   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m (accumulated directly by the E-step),  d_m = T_m - y_m
 // instead of :418-422's difference of three large traces, which would cancel catastrophically in fp32.
 #include "tdlo_devcommon.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
@@ -1345,6 +1346,10 @@ template <typename T, int EB> static size_t estep_lds_bytes(int M) {
     return b;
 }
 
+// measurement aid (tdlo_profile_kernel kind 10): when set, the E-step is launched with start/stop events bound to the
+// dispatch itself (hipExtLaunchKernelGGL), i.e. the same begin/end timestamps a kernel trace reports
+static hipEvent_t g_estep_ev[2] = {nullptr, nullptr};
+
 template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
     const int M = fh[0].M, nch = nch_for(M);
     const bool vis = fh[0].vis_branch != 0;
@@ -1352,7 +1357,9 @@ template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *
     for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
     const dim3 grid(gx, F), block(EB);
     const size_t lds = estep_lds_bytes<T, EB>(M);
-#define TDLO_E2(NCH, VIS, SINGLE) do { TDLO_TRY(set_lds(k_estep<T, NCH, VIS, EB, SINGLE>, lds)); hipLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, fd, fh[0]); } while (0)
+#define TDLO_E2(NCH, VIS, SINGLE) do { TDLO_TRY(set_lds(k_estep<T, NCH, VIS, EB, SINGLE>, lds)); \
+        if (g_estep_ev[0]) hipExtLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, g_estep_ev[0], g_estep_ev[1], 0, fd, fh[0]); \
+        else hipLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, fd, fh[0]); } while (0)
 #define TDLO_E(NCH, VIS) do { if (F == 1) TDLO_E2(NCH, VIS, true); else TDLO_E2(NCH, VIS, false); } while (0)
     if (vis) { switch (nch) { case 1: TDLO_E(1, true); break; case 2: TDLO_E(2, true); break; case 4: TDLO_E(4, true); break; default: TDLO_E(8, true); } }
     else     { switch (nch) { case 1: TDLO_E(1, false); break; case 2: TDLO_E(2, false); break; case 4: TDLO_E(4, false); break; default: TDLO_E(8, false); } }
@@ -1448,6 +1455,13 @@ hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipSt
     TDLO_TRY(f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s));
     return hipSuccess;
+}
+
+hipError_t launch_iteration_timed(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop) {
+    g_estep_ev[0] = e_start; g_estep_ev[1] = e_stop;
+    const hipError_t e = launch_iteration(fd, fh, F, s);
+    g_estep_ev[0] = g_estep_ev[1] = nullptr;
+    return e;
 }
 
 // kind: 0 E-step, 1 dmin, 2 M-step (from block partials), 3 M-step export-only (split), 4 M-step from global sums (split)
