@@ -1081,48 +1081,27 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             a[c] = v;
         }
     }
-    {   // tracer column j = M + 3: t = A 1 (row sums).  Its solution is the all-ones vector, so after the
-        // elimination it holds each row's pivot entry times the row's accumulated scale: x = b / t with no
-        // per-column bookkeeping at all.
-        double rs = 0.0;
-#pragma unroll
-        for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j < M) rs += a[c]; }
-        colb[slot * 64 + row] = rs;                   // (the panel buffers are free until the elimination starts)
-        __syncthreads();
-        const int jt = M + 3;
-        if (slot == (jt & (NSLOT - 1))) {
-            const int ct = jt / NSLOT;
-            double tsum = 0.0;
-#pragma unroll
-            for (int s2 = 0; s2 < NSLOT; ++s2) tsum += colb[s2 * 64 + row];      // fixed order: deterministic
-#pragma unroll
-            for (int c = 0; c < MC; ++c) if (c == ct) a[c] = rowok ? tsum : 0.0;
-        }
-        __syncthreads();
-    }
-    // ---- 3. Gauss-Jordan elimination on [A | B]: straight-line code, ONE barrier per 8 columns.
-    // wave = column slot, lane = row; a lane keeps its row's entries of the columns j = slot + 8 c in
-    // registers.  Columns are eliminated in panels of 8 (one column from every wave):
-    //   * at the start of a panel the 8 columns are exchanged through LDS (4 KB, one barrier) and EVERY
+    // ---- 3. (register variant: the LLE system) Gauss-Jordan elimination on [A | B] with partial pivoting: straight-line
+    // code, ONE barrier per NB columns.  wave = column slot, lane = row; a lane keeps its row's entries of the columns
+    // j = slot + NB c in registers.  Columns are eliminated in panels of NB (one column from every wave):
+    //   * at the start of a panel the NB columns are exchanged through LDS (one barrier) and EVERY
     //     wave keeps a private copy `pc[]` which it updates redundantly while the panel is eliminated --
     //     the pivot column is therefore always local: no per-column hand-off, no spin, no chain of LDS
     //     round trips (the VALU has room: two waves per SIMD run this at full speed each);
     //   * the pivot ROW entries a wave needs are the ones its own lane `pw` holds -> v_readlane.
     // Row operation, division-free: row_i <- (p s) row_i - (a_ik s) row_k with s = 2^-exponent(p), so
     // p s is in [1, 2): rows grow by < 2x per column, no reciprocal on the dependency chain.  A row's
-    // pivot entry times its accumulated scale is read off the tracer column at the end: x = b / t.
-    //   include_lle == 0: A = c I + D G, D >= 0 diagonal, G SPD.  Row scaling does not change Gaussian
-    //     elimination, so this is the elimination of the SPD matrix G + c D^-1 (rows with D_i = 0 are
-    //     c e_i): stable without pivoting.
-    //   include_lle == 1: A = c I + (D + s H) G has no such structure -> partial pivoting, the row
-    //     permutation stays implicit (`mine`); every wave takes the same decision on its own copy.
+    // pivot entry times its accumulated scale is tracked exactly (`dgv`): x = b / dgv.
+    // A = c I + (D + s H) G has no SPD structure and H is ill-conditioned -> partial pivoting, the row
+    // permutation stays implicit (`mine`); every wave takes the same decision on its own copy.
+    // (Systems without the LLE term never come here: they take the MFMA tableau above or k_mstep_big.)
     TDLO_STAMP(3);
     constexpr int NB = NSLOT;                         // panel width
     static_assert(NB == 8 || NB == 4, "panel width");
     double *pan = colb;                               // 2 x NB x 64 doubles
-    int mine = lle ? -1 : row;                        // unknown this row ends up solving (row itself without pivoting)
+    int mine = -1;                                    // unknown this row ends up solving
     unsigned long long usedmask = 0;
-    double dgv = 1.0;                                 // pivoting path only: pivot entry times later row scalings
+    double dgv = 1.0;                                 // pivot entry times later row scalings
     // Panels are unrolled so that inside panel p the update loop is the static register range (p, MC):
     // finished columns are skipped without a single data-dependent branch.  (A rolled panel loop that
     // updates every register was measured slower: the extra column updates cost more than the
@@ -1141,8 +1120,8 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                 const int k = p * NB + sI;
                 if (k < M) {                          // wave-uniform
                     const double aik = pc[sI];
-                    int pw = k;
-                    if (lle) {
+                    int pw;
+                    {
                         double bv = (rowok && !((usedmask >> row) & 1ull)) ? fabs(aik) : -1.0;
                         double mx = bv;
 #pragma unroll
@@ -1158,10 +1137,8 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                     const bool self = (row == pw);
                     const double ps = self ? 1.0 : pv * sc;
                     const double ls = self ? 0.0 : aik * sc;
-                    if (lle) {                        // ill-conditioned system: exact bookkeeping instead of the tracer
-                        dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
-                        mine = self ? k : mine;
-                    }
+                    dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
+                    mine = self ? k : mine;
 #pragma unroll
                     for (int s2 = sI + 1; s2 < NB; ++s2) pc[s2] = fma(ps, pc[s2], -(ls * readlane_f64(pc[s2], pw)));
 #pragma unroll
@@ -1179,19 +1156,9 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         }
     }
     __syncthreads();
-    {   // x = b / t: the tracer column now holds (pivot entry x accumulated row scale)
-        const int jt = M + 3;
-        if (slot == (jt & (NSLOT - 1))) {
-            const int ct = jt / NSLOT;
+    if (rowok && mine >= 0) {
 #pragma unroll
-            for (int c = 0; c < MC; ++c) if (c == ct) colb[row] = a[c];
-        }
-        __syncthreads();
-        const double dg = lle ? dgv : colb[row];
-        if (rowok && mine >= 0) {
-#pragma unroll
-            for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dg; }
-        }
+        for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dgv; }
     }
     singular = __syncthreads_or(singular);
     }   // !MFMA
@@ -1421,7 +1388,7 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
     //  the blocked global-memory path as well)
     if (M > 60 && !any_lle) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     if (M <= 64) {
-        const int mc = (M + 4 + 3) / 4;               // columns per wave: M matrix + 3 right-hand sides + 1 tracer
+        const int mc = (M + 3 + 3) / 4;               // columns per wave: M matrix + 3 right-hand sides
         if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
         if (mc <= 10) return launch_mstep_fast<T, 4, 10>(fd, fh, F, from_sums, s);
         if (mc <= 14) return launch_mstep_fast<T, 4, 14>(fd, fh, F, from_sums, s);
