@@ -576,6 +576,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 
     ESTAMP(5);
     // ---- block partial: sum the waves in a fixed order, write [P1 | PXx | PXy | PXz | Q]
+    {
+        const double qw = wave_sum(accQ);             // Q rides on the same barrier as the node sums
+        if (lane == 0) scratch[wave] = qw;
+    }
     __syncthreads();
     ESTAMP(6);
     typedef typename PartOf<T>::type PT;
@@ -611,8 +615,12 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         __syncthreads();
     }
     }
-    const double q = block_sum_n<NWE>(accQ, scratch);
-    if (tid == 0) part[4 * M] = (PT)q;
+    if (tid == 0) {
+        double q = 0;
+#pragma unroll
+        for (int w = 0; w < NWE; ++w) q += scratch[w];
+        part[4 * M] = (PT)q;
+    }
     ESTAMP(7);
 #ifdef TDLO_ESTEP_STAMPS
     if (tid == 0) atomicMax(&f.dbg[33], (unsigned long long)__builtin_amdgcn_s_memrealtime());
