@@ -176,16 +176,22 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     }
     __syncthreads();
     if (f.include_lle) {
+        // H G and H Y0 (:396-401).  Global address space + unrolled k loop: independent loads in flight instead of one
+        // flat load per multiply-add (this block was 50 us of a 65 us kernel).
+        const auto Hg = TDLO_AS_GLOBAL(double, f.H);
+        const auto Gr = TDLO_AS_GLOBAL(double, f.G);
         for (int e = t; e < M * M; e += kBlock) {
             const int i = e % M, j = e / M;
             double a = 0;
-            for (int k = 0; k < M; ++k) a += f.H[(size_t)k * M + i] * f.G[(size_t)j * M + k];
+#pragma unroll 8
+            for (int k = 0; k < M; ++k) a += Hg[(size_t)k * M + i] * Gr[(size_t)j * M + k];
             f.HG[e] = a;
         }
         for (int e = t; e < 3 * M; e += kBlock) {
             const int i = e % M, d = e / M;
             double a = 0;
-            for (int k = 0; k < M; ++k) a += f.H[(size_t)k * M + i] * f.Yin[d * M + k];
+#pragma unroll 8
+            for (int k = 0; k < M; ++k) a += Hg[(size_t)k * M + i] * sY[d * M + k];
             f.HY0[e] = a;
         }
     }
