@@ -19,8 +19,8 @@ using namespace tdlo;
 namespace {
 
 constexpr int kMaxEstepBlocks = 1024;
-constexpr int kChunkIters = 4;          // EM iterations per early-exit polling chunk (the first two chunks are half as long:
-                                        // a tracker in steady state converges in one or two iterations)
+constexpr int kChunkIters = 4;          // EM iterations per early-exit polling chunk; the first chunks are shorter (1, 1, 2):
+                                        // a tracker in steady state converges in one or two iterations
 
 struct Slot {
     // cloud-sized
@@ -256,7 +256,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         int launched = 0, chunk = 0;
         bool stop = false;
         while (launched < p->max_iter && !stop) {
-            const int n = std::min(chunk < 2 ? kChunkIters / 2 : kChunkIters, p->max_iter - launched);
+            const int n = std::min(chunk < 2 ? 1 : (chunk == 2 ? 2 : kChunkIters), p->max_iter - launched);      // 1, 1, 2, 4, 4, ...
             for (int it = 0; it < n; ++it) HIPCHK(c, launch_iteration(c->fd, c->fh.data(), F, s));
             launched += n;
             const int slotp = chunk & 1;
