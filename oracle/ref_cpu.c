@@ -155,18 +155,22 @@ static double lu_inverse_small(const double *Ain, int n, double *inv) {
 static int nearest_indices(int k, int M, int idx, int extended, int *out) {
     int n = 0;
     if (!extended) {
-        /* trackdlo.cpp:92-117: truncated at the ends */
-        if (idx - k < 0) { for (int i = 0; i <= idx + k; i++) if (i != idx) out[n++] = i; }
-        else if (idx + k >= M) { for (int i = idx - k; i <= M - 1; i++) if (i != idx) out[n++] = i; }
-        else { for (int i = idx - k; i <= idx + k; i++) if (i != idx) out[n++] = i; }
+        /* trackdlo.cpp:92-117: truncated at the ends.  For chains shorter than 2k + 1 nodes the reference clips one
+         * side only and then reads Y out of bounds (undefined behaviour); the restatement clips both sides. */
+        int first = idx - k, last = idx + k;
+        if (idx - k < 0) first = 0;
+        else if (idx + k >= M) last = M - 1;
+        if (last > M - 1) last = M - 1;
+        if (first < 0) first = 0;
+        for (int i = first; i <= last; i++) if (i != idx) out[n++] = i;
     } else {
         /* tracking_test.py:233-247: extended on the other side */
         if (idx - k < 0) {
             for (int i = 0; i < idx; i++) out[n++] = i;
-            for (int i = idx + 1; i < idx + k + 1 + abs(idx - k); i++) out[n++] = i;
+            for (int i = idx + 1; i < idx + k + 1 + abs(idx - k); i++) if (i < M) out[n++] = i;      /* (i < M: short chains) */
         } else if (idx + k >= M) {
             int last = M - 1;
-            for (int i = idx - k - (idx + k - last); i < idx; i++) out[n++] = i;
+            for (int i = idx - k - (idx + k - last); i < idx; i++) if (i >= 0) out[n++] = i;
             for (int i = idx + 1; i < last + 1; i++) out[n++] = i;
         } else {
             for (int i = idx - k; i < idx; i++) out[n++] = i;

@@ -170,3 +170,22 @@ def test_depth_to_cloud_oracle_properties(oracle):
     assert X.shape == (0, 3) and nraw == 0
     X, nraw = oracle.depth_to_cloud(depth, mask, cam["fx"], cam["fy"], cam["cx"], cam["cy"], 1e-5)
     assert X.shape[0] == nraw
+
+
+def test_lle_weights_short_chains(oracle):
+    """Chains shorter than 7 nodes: the reference's neighbour selection (trackdlo.cpp:92-117) clips one side only and then
+    indexes out of bounds (undefined behaviour).  Product and oracle clip both sides: indices stay inside the chain, rows
+    of L sum to one, and the sparsity patterns agree."""
+    from trackdlo_amd import binding as B
+    rng = np.random.default_rng(5)
+    for M in range(4, 10):
+        Y = np.stack([0.02 * np.arange(M), 0.01 * np.sin(0.7 * np.arange(M)), 0.6 + 0.002 * rng.normal(size=M)], axis=1)
+        Lp = B.calc_LLE_weights(6, Y)
+        Lo = oracle.calc_lle_weights(Y, 6)
+        assert Lp.shape == (M, M) and np.all(np.isfinite(Lp)) and np.all(np.isfinite(Lo))
+        np.testing.assert_allclose(Lp.sum(axis=1), 1.0, atol=1e-9)
+        np.testing.assert_allclose(Lo.sum(axis=1), 1.0, atol=1e-9)
+        assert np.array_equal(Lp != 0, Lo != 0)
+        for i in range(M):
+            nz = np.nonzero(Lp[i])[0]
+            assert i not in nz and nz.min() >= max(0, i - 3) and nz.max() <= min(M - 1, i + 3)

@@ -488,3 +488,34 @@ def test_randomised_configurations(hip_ctx, oracle, seed):
     o = oracle.cpd_lle(X, Y0, s2, priors=pri, visible_nodes=vext, H=H, **kw)
     g = hip_ctx.cpd_lle(X, Y0, s2, _params(kw, prec), priors=pri, visible_nodes=vext, H=H)
     _check(g, o, prec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_visible", [4, 5, 6, 7])
+def test_tracking_step_with_few_visible_nodes(hip_ctx, oracle, n_visible):
+    """Only a handful of nodes visible: the pre-processing registration runs on a 4..7-node chain, where the reference's
+    LLE neighbour selection indexes out of bounds (trackdlo.cpp:92-117).  Product and oracle clip the neighbourhood; the
+    step must run and agree (same H is injected so that the ill-conditioned weights do not enter the comparison)."""
+    from trackdlo_amd import synth, binding as B
+    M = 30
+    P = synth.LAUNCH_PARAMS
+    X, Y0, _ = synth.scene(3000, M, config=31, occlude=(n_visible / (M - 1) + 0.01, 1.0))
+    coord = synth.geodesic_coord(Y0)
+    vis = np.arange(n_visible, dtype=np.int32)
+    Yg = Y0[vis]
+    L = oracle.calc_lle_weights(Yg, 6); H = (np.eye(n_visible) - L).T @ (np.eye(n_visible) - L)
+    t = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 50, P["tol"],
+                   P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], ctx=hip_ctx, precision=B.PREC_F64)
+    t.initialize_nodes(Y0); t.initialize_geodesic_coord(coord)
+    o = oracle.Tracker(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 50, P["tol"],
+                       P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"])
+    o.initialize_nodes(Y0); o.initialize_geodesic_coord(coord)
+    t.tracking_step(X, vis, vis, H_pre=H)
+    o.tracking_step(X, vis, vis, H_pre=H)
+    np.testing.assert_allclose(t.get_tracking_result(), o.get_tracking_result(), rtol=0, atol=1e-6)
+    # and without an injected H (weights computed inside the product): must simply run and stay finite
+    t2 = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 50, P["tol"],
+                    P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], ctx=hip_ctx)
+    t2.initialize_nodes(Y0); t2.initialize_geodesic_coord(coord)
+    t2.tracking_step(X, vis, vis)
+    assert np.all(np.isfinite(t2.get_tracking_result()))

@@ -366,7 +366,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const int M = f.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rows = M < kChunk ? M : kChunk;
+    // tile rows: one frame (SINGLE) cannot fill the GPU anyway, so it keeps the whole window in the tile; batches use the
+    // small tile (two workgroups per CU) and recompute the memberships of the later chunks of a wide window
+    constexpr int RT = (NCH == 1 && !SINGLE) ? kTileRows : kChunk;
+    const int rows = M < RT ? M : RT;
     // LDS carve (every offset a multiple of 16 bytes)
     V4<T> *nodesL = (V4<T> *)smem;                                    // M
     V4<T> *pts = nodesL + M;                                          // NWE x 64
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const T d2 = ddx * ddx + ddy * ddy + ddz * ddz;
             sum += p;
             qs += p * d2;
-            if (NCH == 1) pb[(m - wlo) * kPStride + lane] = p;
+            if (NCH == 1 && m - wlo < RT) pb[(m - wlo) * kPStride + lane] = p;     // first chunk of the window
         }
         ESTAMP(4);
         const T inv = valid ? T(1) / (sum + cn) : T(0);
@@ -517,15 +520,31 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         pts[wave * 64 + lane] = pw;
 
         if (NCH == 1) {
-            // ---- column sums (:386-389): lane = (node of the window, slice of the 64 points)
+            // ---- column sums (:386-389): lane = (node of the window, slice of the 64 points).  The window is summed in
+            // chunks of kTileRows nodes (identical order in both tile variants, so a batch gives the bits of a single
+            // frame): once sigma is millimetres the whole window is one chunk; the wide windows of the first iterations
+            // take several.  With the small batch tile the memberships of the later chunks are recomputed (same
+            // expression, same bits) instead of being kept in a 64-row tile.
+            const int Wtot = whi - wlo + 1;
+            for (int c0 = 0; c0 < Wtot; c0 += kTileRows) {
+            const int Wn = (Wtot - c0) < kTileRows ? (Wtot - c0) : kTileRows;
+            const int wlo_c = wlo + c0;
+            const int rbase = RT >= kChunk ? c0 : 0;                     // first tile row of this chunk
+            if (RT < kChunk && c0 > 0) {
+#pragma unroll 4
+                for (int m = wlo_c; m < wlo_c + Wn; ++m) {
+                    T e = geo_arg<T>(m, lo, hi, nodes[m].w, c_lo, d_lo, c_hi, d_hi) * k2;
+                    if (VIS) e += lvL[m];
+                    pb[(m - wlo_c) * kPStride + lane] = Num<T>::exp2(e);
+                }
+            }
             wave_lds_sync();
-            const int Wn = whi - wlo + 1;
-            const int shift = Wn <= 16 ? 4 : (Wn <= 32 ? 5 : 6);         // wave-uniform
+            const int shift = Wn <= 16 ? 4 : 5;                          // wave-uniform
             const int wl = lane & ((1 << shift) - 1), sl = lane >> shift;
-            const int nj = 1 << shift;                                   // points per slice: 16 / 32 / 64
+            const int nj = 1 << shift;                                   // points per slice: 16 / 32
             T s0 = 0, sx = 0, sy = 0, sz = 0;
             if (wl < Wn) {
-                const T *prow = pb + wl * kPStride + sl * nj;
+                const T *prow = pb + (rbase + wl) * kPStride + sl * nj;
                 const V4<T> *pw_ = pts + wave * 64 + sl * nj;
 #pragma unroll 8
                 for (int j = 0; j < nj; ++j) {
@@ -534,11 +553,11 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                     s0 += p * w.w; sx += p * w.x; sy += p * w.y; sz += p * w.z;
                 }
             }
-            if (shift <= 5) { s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32); }
+            s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
             if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
             if (lane < Wn) {
-                double *ac = accL + (size_t)(wlo + lane) * 4;
-                const V4<T> ym = nodesL[wlo + lane];
+                double *ac = accL + (size_t)(wlo_c + lane) * 4;
+                const V4<T> ym = nodesL[wlo_c + lane];
                 const double w0 = (double)s0;
                 ac[0] += w0;
                 ac[1] += (double)sx + ((double)ox - (double)ym.x) * w0;
@@ -546,6 +565,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 ac[3] += (double)sz + ((double)oz - (double)ym.z) * w0;
             }
             wave_lds_sync();
+            }
         } else {
         // ---- column sums with lane = node (:386-389)
 #pragma unroll
@@ -1316,8 +1336,9 @@ template <typename K> static hipError_t set_lds(K kernel, size_t bytes) {
 
 #define TDLO_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-template <typename T, int EB> static size_t estep_lds_bytes(int M) {
-    const int rows = M < kChunk ? M : kChunk;
+template <typename T, int EB> static size_t estep_lds_bytes(int M, bool single) {
+    const int rt = (M <= kChunk && !single) ? kTileRows : kChunk;
+    const int rows = M < rt ? M : rt;
     constexpr int NWE = EB / 64;
     const size_t tile = sizeof(T) * (((size_t)NWE * rows * kPStride + 7) & ~(size_t)3);
     const size_t red = (size_t)NWE * 64 * 4 * sizeof(double);
@@ -1337,7 +1358,7 @@ template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *
     int gx = 0;
     for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
     const dim3 grid(gx, F), block(EB);
-    const size_t lds = estep_lds_bytes<T, EB>(M);
+    const size_t lds = estep_lds_bytes<T, EB>(M, F == 1);
 #define TDLO_E2(NCH, VIS, SINGLE) do { TDLO_TRY(set_lds(k_estep<T, NCH, VIS, EB, SINGLE>, lds)); \
         if (g_estep_ev[0]) hipExtLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, g_estep_ev[0], g_estep_ev[1], 0, fd, fh[0]); \
         else hipLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, fd, fh[0]); } while (0)

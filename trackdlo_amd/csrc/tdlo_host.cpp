@@ -73,6 +73,10 @@ std::vector<int> chain_neighbours(int half, int M, int idx) {   // trackdlo.cpp:
     int first = idx - half, last = idx + half;
     if (idx - half < 0) first = 0;
     else if (idx + half >= M) last = M - 1;
+    // Chains shorter than 2 * half + 1 nodes: the reference's if / else-if clips one side only and then indexes Y out of
+    // bounds (undefined behaviour, trackdlo.cpp:96-104).  Here the range is clipped on both sides.
+    if (last > M - 1) last = M - 1;
+    if (first < 0) first = 0;
     std::vector<int> out;
     for (int i = first; i <= last; ++i) if (i != idx) out.push_back(i);
     return out;

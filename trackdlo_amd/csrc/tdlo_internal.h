@@ -9,6 +9,8 @@ constexpr int kBlock = 256;          // workgroup size of the point-parallel ker
 constexpr int kWave = 64;
 constexpr int kChunk = 64;           // nodes handled per lane-transposed tile
 constexpr int kPStride = 65;         // LDS row stride of the 64 x 64 transposition tile (conflict-free)
+constexpr int kTileRows = 24;        // rows of the E-step's transposition tile when M <= 64: the node window is processed
+                                     // in chunks of this many nodes (6 KB of LDS per wave -> two workgroups per CU)
 constexpr int kMaxNodes = 512;       // E-step template covers ceil(M/64) in {1,2,4,8}
 constexpr int kLdsSolveMaxM = 128;   // M-step keeps [A|B] in LDS up to this M
 
