@@ -519,3 +519,54 @@ def test_tracking_step_with_few_visible_nodes(hip_ctx, oracle, n_visible):
     t2.initialize_nodes(Y0); t2.initialize_geodesic_coord(coord)
     t2.tracking_step(X, vis, vis)
     assert np.all(np.isfinite(t2.get_tracking_result()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_tracking_sequences(hip_ctx, oracle, seed):
+    """Seeded sweep over tracking_step (trackdlo.cpp:900-999): random chain length, cloud size, a random occluded interval
+    per frame (head, tail, middle, none, or only a few nodes left visible), small inter-frame motion, four frames with the
+    tracker state carried over.  The visible sets come from the product's own visibility pre-pass; the LLE regulariser of
+    the pre-processing registration is injected in both (its weights are ill-conditioned by construction).  Per frame: the
+    same occlusion branch (number of priors), guide nodes, priors, nodes and sigma2 within the fp32-mode tolerances."""
+    from trackdlo_amd import synth, binding as B
+    rng = np.random.default_rng(31000 + seed)
+    P = synth.LAUNCH_PARAMS
+    M = int(rng.integers(12, 56))
+    N = int(rng.integers(800, 6000))
+    Y0 = synth.nodes(M); coord = synth.geodesic_coord(Y0)
+    args = (M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+            P["lambda_pre_proc"], P["lle_weight"])
+    ref = oracle.Tracker(*args); ref.initialize_nodes(Y0); ref.initialize_geodesic_coord(coord)
+    trk = B.trackdlo(*args, ctx=hip_ctx); trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+    for frame in range(4):
+        kind = int(rng.integers(0, 5))
+        occl = None
+        if kind == 1: occl = (0.0, float(rng.uniform(0.1, 0.4)))
+        elif kind == 2: occl = (float(rng.uniform(0.6, 0.9)), 1.0)
+        elif kind == 3:
+            a = float(rng.uniform(0.2, 0.6)); occl = (a, a + float(rng.uniform(0.05, 0.3)))
+        elif kind == 4: occl = (float(rng.uniform(0.15, 0.3)), 1.0)                       # only the head stays visible
+        X, _, _ = synth.scene(N, M, config=70 + seed, frame=frame, occlude=occl, noise=0.0015,
+                              shift=(0.0, 0.002 * (frame + 1), 0.0))
+        Ycur = ref.get_tracking_result()
+        hip_ctx.set_cloud(0, X)
+        _, vis, vext = hip_ctx.visibility_prepass(0, Ycur, P["visibility_threshold"], 0.06, coord)
+        if len(vis) < 4:
+            continue                                                                       # the reference needs a chain to register
+        Lg = oracle.calc_lle_weights(Ycur[vext], 6)
+        Hpre = (np.eye(len(vext)) - Lg).T @ (np.eye(len(vext)) - Lg)
+        try:
+            ref.tracking_step(X, vis, vext, H_pre=Hpre)
+        except Exception:
+            with pytest.raises(B.TdloError):                                                # traverse_euclidean would read out of bounds:
+                trk.tracking_step(X, vis, vext, None, 0, 0, H_pre=Hpre)                     # the product reports it as an error too
+            break
+        trk.tracking_step(X, vis, vext, None, 0, 0, H_pre=Hpre)
+        assert trk.last_stats[0]["iters"] == ref.stats_pre.iters and trk.last_stats[1]["iters"] == ref.stats_main.iters
+        kp, kr = trk.get_correspondence_pairs(), ref.get_correspondence_pairs()
+        assert kp.shape == kr.shape
+        np.testing.assert_allclose(kp, kr, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(trk.get_guide_nodes(), ref.get_guide_nodes(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(trk.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=1e-5)
+        assert abs(trk.get_sigma2() - ref.get_sigma2()) <= 1e-3 * ref.get_sigma2()
