@@ -570,3 +570,55 @@ def test_randomised_tracking_sequences(hip_ctx, oracle, seed):
         np.testing.assert_allclose(trk.get_guide_nodes(), ref.get_guide_nodes(), rtol=0, atol=1e-5)
         np.testing.assert_allclose(trk.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=1e-5)
         assert abs(trk.get_sigma2() - ref.get_sigma2()) <= 1e-3 * ref.get_sigma2()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_depth_images(hip_ctx, oracle, seed):
+    """Random image sizes, masks (rope, scattered salt pixels, blobs), depth noise, invalid depths and leaf sizes: the
+    device voxel grid must reproduce the oracle bit for bit (count, order, values)."""
+    from trackdlo_amd import synth
+    rng = np.random.default_rng(52000 + seed)
+    rows = int(rng.integers(17, 300)); cols = int(rng.integers(33, 400))
+    depth, mask, cam, _ = synth.depth_scene(int(rng.integers(10, 40)), config=80 + seed, frame=seed, rows=rows, cols=cols,
+                                            samples=60000, zero_depth_pixels=int(rng.integers(0, 4)))
+    depth = depth.astype(np.int64) + rng.integers(-3, 4, size=depth.shape)                 # sensor noise in millimetres
+    depth = np.clip(depth, 0, 65535).astype(np.uint16)
+    salt = rng.random(mask.shape) < float(rng.choice([0.0, 0.001, 0.02]))                   # isolated false positives
+    mask = np.where(salt, 255, mask).astype(np.uint8)
+    if rng.integers(0, 2):
+        r0, c0 = int(rng.integers(0, rows - 8)), int(rng.integers(0, cols - 8)); mask[r0:r0 + 8, c0:c0 + 8] = 255   # a blob
+    leaf = float(rng.choice([0.003, 0.008, 0.02, 0.05, 0.3]))
+    args = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    Xo, nraw_o = oracle.depth_to_cloud(depth, mask, *args, leaf)
+    Xg, n, nraw = hip_ctx.depth_to_cloud(0, depth, mask, *args, leaf)
+    assert nraw == nraw_o == np.count_nonzero(mask) and n == Xo.shape[0]
+    assert np.array_equal(Xg, Xo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_batches(hip_ctx, oracle, seed):
+    """Random batches: 2..8 frames of different sizes registered concurrently must equal, bit for bit, the same frames
+    registered one at a time (both precisions, with and without priors / visibility weighting)."""
+    from trackdlo_amd import synth
+    rng = np.random.default_rng(77000 + seed)
+    P = synth.LAUNCH_PARAMS
+    F = int(rng.integers(2, 9)); M = int(rng.integers(8, 61)); prec = int(rng.integers(0, 2)); iters = int(rng.integers(2, 9))
+    vis_on = bool(rng.integers(0, 2)) and M >= 12
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=iters, tol=0.0, include_lle=False,
+              alpha=0.0, k_vis=P["k_vis"] if vis_on else 0.0, visibility_threshold=P["visibility_threshold"])
+    params = _params(kw, prec)
+    Ys, s2s, single = [], [], []
+    vext = None
+    for f in range(F):
+        X, Y0, v = synth.scene(int(rng.integers(200, 9000)), M, config=90 + seed, frame=f, occlude=(0.4, 0.6) if vis_on else None)
+        if vis_on: vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0))
+        hip_ctx.set_cloud(f, X)
+        Ys.append(Y0); s2s.append(float(rng.choice([0.0, 1e-4])))
+    for f in range(F):
+        single.append(hip_ctx.cpd_lle_resident(f, Ys[f], s2s[f], params, visible_nodes=vext))
+    out = hip_ctx.cpd_lle_batch(Ys, s2s, params, visible_nodes=vext)
+    for f in range(F):
+        assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"]
+        assert out["stats"][f]["iters"] == single[f]["iters"]
