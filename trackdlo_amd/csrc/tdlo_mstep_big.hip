@@ -9,14 +9,19 @@
 //      sequential row operations held in registers; the only traffic per step is the pivot column, handed over through
 //      LDS (one barrier per step).  Result U (16 x Cp) -> LDS (MFMA B operand) and back to the tableau;
 //   b. every other row block, every column block right of the panel:  C -= L U  with four v_mfma_f64_16x16x4 per
-//      16 x 16 tile; L = the panel's columns, which are never written again (column blocks up to the panel are dead),
-//      so they are read straight from the tableau as the A operand.  Tiles are dealt round-robin to the 16 waves.
+//      16 x 16 tile; L = the panel's columns, which are never written again (column blocks up to the panel are dead).
+//      Every wave takes a contiguous row-major range of tiles.
 // fp64 vector and matrix rates are equal on gfx950, so the MFMA buys data flow (no per-element index arithmetic),
-// not flops.  Measured at M = 300: 0.88 ms per M-step (15x the scalar column-at-a-time kernel it replaces), of which
-// 0.61 ms is the trailing update -- bound by what ONE CU can pull from L2 (about 17 B/clk observed: every panel re-reads
-// and re-writes the live part of the 760 KB tableau), 0.16 ms the 16-step pivot-row reductions, 0.07 ms partial sums
-// and tableau assembly.  Spreading the row blocks over several CUs (grid barrier per panel) is the next step.  Layout: row-major, Mp = M rounded up to 16 rows (identity padded),
-// Cp = Mp + 16 columns, right-hand sides in columns Mp .. Mp + 2.
+// not flops.  What bounds the kernel is ONE CU's memory path: every panel re-reads and re-writes the live part of the
+// tableau.  Three layout decisions follow from measurements (M = 300: 0.88 -> 0.51 ms; the scalar column-at-a-time
+// kernel it replaces took 12.9 ms):
+//   * the tableau is tile-major in accumulator order (tix()): a tile is 2 KB of contiguous memory, 32 bytes per lane;
+//   * the panel's columns are re-ordered once per panel into A-operand order (Lb): scattered 8-byte reads cost a
+//     128-byte line each in the address pipeline and had been half of the run time;
+//   * U lives in LDS in B-operand order; consecutive tiles of a wave share the row block, so the A operand is reused.
+// Remaining: 0.16 ms of 16-step pivot-row reductions (one barrier per step), 0.07 ms partial sums and tableau assembly,
+// 0.28 ms trailing update at about 32 B/clk.  Spreading the row blocks over several CUs is the next step.
+// Mp = M rounded up to 16 rows (identity padded), Cp = Mp + 16 columns, right-hand sides in columns Mp .. Mp + 2.
 #include "tdlo_devcommon.h"
 #include <cstdlib>
 
@@ -24,6 +29,14 @@ namespace tdlo {
 namespace {
 
 constexpr int kBig = 1024;
+
+// Tableau storage: tile-major, every 16 x 16 tile in the register order of the MFMA accumulator (lane = col + 16 (row & 3),
+// register = row >> 2), so a wave reads or writes a tile as 2 KB of contiguous memory, 32 bytes per lane -- with a
+// row-major tableau the same tile is 16 strided 128-byte pieces fetched 8 bytes per lane, and one CU's memory path
+// sustains a third of the bandwidth.
+__device__ __forceinline__ size_t tix(int i, int j, int ncb) {
+    return ((size_t)((i >> 4) * ncb + (j >> 4)) << 8) + (size_t)((((j & 15) + 16 * (i & 3)) << 2) + ((i & 15) >> 2));
+}
 
 __device__ __forceinline__ double block_sum16(double v, double *scratch) {
     v = wave_sum(v);
@@ -38,7 +51,6 @@ __device__ __forceinline__ double block_sum16(double v, double *scratch) {
 
 template <typename T>
 __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__ frames, int from_sums_in) {
-    // (U rows are padded to Us = Cp + 16 doubles: lane groups 0/1 and 2/3 then sit 32 banks apart)
     const int from_sums = from_sums_in;
     const FrameDev &f = frames[blockIdx.x];
     IterState *st = f.st;
@@ -46,15 +58,16 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = f.M, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nS = 4 * M + 1;
-    const int Mp = (M + 15) & ~15, Cp = Mp + 16, nrb = Mp >> 4, ncb = Cp >> 4, Us = Cp + 16;
+    const int Mp = (M + 15) & ~15, Cp = Mp + 16, nrb = Mp >> 4, ncb = Cp >> 4;
     double *S = (double *)smem;               // nS (+pad)
     double *W = S + ((nS + 1) & ~1);          // 3M (+pad)
     double *Tn = W + ((3 * M + 1) & ~1);      // 3M (+pad)
     double *scratch = Tn + ((3 * M + 1) & ~1);// 16
-    double *pcol = scratch + 16;              // 2 x 16: pivot column of the current step (double-buffered: one barrier per step)
-    double *U = pcol + 32;                    // 16 x Cp reduced pivot rows
+    double *pcol = scratch + 16;              // pivot column of the current step, double-buffered (one barrier per step)
+    double *U = pcol + 272;                   // 16 x Cp reduced pivot rows (B-operand order)
     const auto Tb = TDLO_AS_GLOBAL_RW(double, f.Ascr);     // Mp x Cp tableau, row-major (global address space: no flat ops)
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
+    const auto Lb = Tb + (size_t)Mp * Cp;                   // panel columns in MFMA A-operand order: [rb][k-step][lane], negated
 
 #define BSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     BSTAMP(0);
@@ -91,8 +104,9 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
     const int pri = f.has_priors;
     const V4<T> *ndq = (const V4<T> *)f.nodes;
 #pragma unroll 4
-    for (int e = t; e < Mp * Cp; e += kBig) {
-        const int i = e / Cp, j = e - i * Cp;
+    for (int e = t; e < Mp * Cp; e += kBig) {            // e runs in storage order: coalesced stores
+        const int tile = e >> 8, rbt = tile / ncb, cbt = tile - rbt * ncb, ln = (e >> 2) & 63;
+        const int i = 16 * rbt + 4 * (e & 3) + (ln >> 4), j = 16 * cbt + (ln & 15);
         double v = 0.0;
         if (i < M) {
             if (j < M) v = (S[i] + (pri ? f.aJ[i] : 0.0)) * Gg[(size_t)i * M + j] + (i == j ? c2 : 0.0);      // G symmetric
@@ -118,7 +132,14 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
         const bool act = col < Cp;
         double u[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = act ? Tb[(size_t)(k0 + r) * Cp + col] : 0.0;
+        for (int r = 0; r < 16; ++r) u[r] = 0.0;
+        const auto ucol = Tb + (((size_t)(pb * ncb + ((act ? col : k0) >> 4))) << 8) + (size_t)((col & 15) << 2);   // + 64 g + r
+        if (act) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[4 * r + g4] = ucol[64 * g4 + r];
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             double *pc = pcol + (j & 1) * 16;
@@ -138,7 +159,25 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
         }
         if (act) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { U[r * Us + col] = u[r]; if (t >= 16) Tb[(size_t)(k0 + r) * Cp + col] = u[r]; }
+            for (int r = 0; r < 16; ++r) U[((col >> 4) << 8) + ((r >> 2) << 6) + (col & 15) + 16 * (r & 3)] = u[r];     // B-operand order: [cb][k-step][lane]
+            if (t >= 16) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ucol[64 * g4 + r] = u[4 * r + g4];
+            }
+        }
+        // a'. the panel's columns, re-ordered once per panel into the A-operand layout (lane = row + 16 (col & 3) of k-step
+        //     col >> 2): the trailing update then fetches them with one coalesced load per k-step instead of 64 scattered
+        //     8-byte reads per tile, which is what bounded this kernel (the address pipeline pays per 128-byte line)
+        for (int rbx = w; rbx < nrb; rbx += 16) {
+            if (rbx == pb) continue;
+            const auto src = Tb + (((size_t)(rbx * ncb + pb)) << 8) + (size_t)(lane << 2);
+            double v4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = src[r];          // elements (row 4 r + gL, column cL) of tile (rbx, pb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Lb[(size_t)rbx * 256 + (cL >> 2) * 64 + (4 * r + gL) + 16 * (cL & 3)] = -v4[r];
         }
         __syncthreads();
         // b. trailing update: tiles (rb != pb, cb > pb)
@@ -154,17 +193,26 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
             double a[TB][4], b[TB][4];
             mfma_d4 C[TB];
             __attribute__((address_space(1))) double *Ct[TB];
+            int rb_prev = -1;
 #pragma unroll
             for (int q = 0; q < TB; ++q) {
                 const bool on = tile0 + q < tend;
                 const int rq = on ? ri : 0, cq = on ? ci : 0;      // clamp: loads stay in bounds, result discarded
                 const int rb = rq < pb ? rq : rq + 1, cb = pb + 1 + cq;
-                const auto Lrow = Tb + (size_t)(16 * rb + cL) * Cp + k0 + gL;
-                Ct[q] = Tb + (size_t)(16 * rb + gL) * Cp + 16 * cb + cL;
+                const auto Lt = Lb + (size_t)rb * 256 + lane;
+                Ct[q] = Tb + (((size_t)(rb * ncb + cb)) << 8) + (size_t)(lane << 2);
+                if (q == 0 || rb != rb_prev) {                     // wave-uniform: consecutive tiles mostly share the row block
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) { a[q][s4] = -Lrow[4 * s4]; b[q][s4] = U[(4 * s4 + gL) * Us + 16 * cb + cL]; }
+                    for (int s4 = 0; s4 < 4; ++s4) a[q][s4] = Lt[64 * s4];
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) C[q][r] = Ct[q][(size_t)(4 * r) * Cp];
+                    for (int s4 = 0; s4 < 4; ++s4) a[q][s4] = a[q > 0 ? q - 1 : 0][s4];
+                }
+                rb_prev = rb;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) b[q][s4] = U[(cb << 8) + (s4 << 6) + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[q][r] = Ct[q][r];
                 if (++ci == nlive) { ci = 0; ++ri; }
             }
 #pragma unroll
@@ -176,14 +224,14 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
             for (int q = 0; q < TB; ++q) {
                 if (tile0 + q < tend) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Ct[q][(size_t)(4 * r) * Cp] = C[q][r];
+                    for (int r = 0; r < 4; ++r) Ct[q][r] = C[q][r];
                 }
             }
         }
         __syncthreads();
     }
     BSTAMP(3);
-    for (int e = t; e < 3 * M; e += kBig) { const int i = e % M, d = e / M; W[e] = Tb[(size_t)i * Cp + Mp + d]; }
+    for (int e = t; e < 3 * M; e += kBig) { const int i = e % M, d = e / M; W[e] = Tb[tix(i, Mp + d, ncb)]; }
     singular = __syncthreads_or(singular);
 
     // ---- 4. T = Y0 + G W (:417): thread = (node, half of the k range)
@@ -247,14 +295,14 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
 
 size_t big_lds_bytes(int M) {
     const int nS = 4 * M + 1, Mp = (M + 15) & ~15, Cp = Mp + 16;
-    size_t d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 16 + 32 + (size_t)16 * (Cp + 16);
-    if (d < (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 48 + 6 * 512) d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 48 + 6 * 512;
+    size_t d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 16 + 272 + (size_t)16 * (Cp + 16);
+    if (d < (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 288 + 6 * 512) d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 288 + 6 * 512;
     return d * sizeof(double);
 }
 
 }  // namespace
 
-size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16); }
+size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16) + Mp * 16; }
 
 hipError_t launch_mstep_big(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, bool f64, hipStream_t s) {
     const size_t lds = big_lds_bytes(fh[0].M);
