@@ -78,12 +78,12 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
         const auto partT = TDLO_AS_GLOBAL(PT, f.part);
         for (int e = t; e < nS; e += kBig) {
             double a0 = 0;
-            for (int b = 0; b < nb; b += 16) {            // 16 loads in flight, block order kept
-                PT v[16];
+            for (int b = 0; b < nb; b += 32) {            // 32 loads in flight, block order kept
+                PT v[32];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const int bb = b + u < nb ? b + u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
+                for (int u = 0; u < 32; ++u) { const int bb = b + u < nb ? b + u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) if (b + u < nb) a0 += (double)v[u];
+                for (int u = 0; u < 32; ++u) if (b + u < nb) a0 += (double)v[u];
             }
             S[e] = a0;
         }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
     const double c2 = f.lambda * sigma2;
     const int pri = f.has_priors;
     const V4<T> *ndq = (const V4<T> *)f.nodes;
-#pragma unroll 4
+#pragma unroll 8
     for (int e = t; e < Mp * Cp; e += kBig) {            // e runs in storage order: coalesced stores
         const int tile = e >> 8, rbt = tile / ncb, cbt = tile - rbt * ncb, ln = (e >> 2) & 63;
         const int i = 16 * rbt + 4 * (e & 3) + (ln >> 4), j = 16 * cbt + (ln & 15);
