@@ -442,17 +442,31 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         // runs over the index range of those candidates (a relative margin of 1e-4 dwarfs the rounding of the fp32
         // distances): the same argmin, first index on ties, from typically 5 instead of M candidates.
         int plo = 0, phi = M - 1;
-        if (NCH == 1) {
+        {
             const T cx = __shfl(x, 0), cy = __shfl(y, 0), cz = __shfl(z, 0);
             T r2 = valid ? (x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz) : T(0);
-            T Dm = Num<T>::inf();
-            if (lane < M) { const V4<T> qn = nodesL[lane]; Dm = Num<T>::sqrt((qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz)); }
-            T dmin_w = Dm;
+            T Dm[NCH];
+            T dmin_w = Num<T>::inf();
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {                  // lane = node 64 c + lane
+                const int m = c * kChunk + lane;
+                Dm[c] = Num<T>::inf();
+                if (m < M) { const V4<T> qn = nodesL[m]; Dm[c] = Num<T>::sqrt((qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz)); }
+                dmin_w = tmin(dmin_w, Dm[c]);
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { r2 = -tmin(-r2, -__shfl_xor(r2, o)); dmin_w = tmin(dmin_w, __shfl_xor(dmin_w, o)); }
             const T lim = (dmin_w + T(2) * Num<T>::sqrt(r2)) * T(1.0001) + T(1e-30);
-            const unsigned long long cand = __ballot(lane < M && Dm <= lim);
-            if (cand) { plo = (int)__builtin_ctzll(cand); phi = 63 - (int)__builtin_clzll(cand); }
+            int first = M, last = -1;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const unsigned long long cand = __ballot(c * kChunk + lane < M && Dm[c] <= lim);
+                if (cand) {
+                    const int lo_c = c * kChunk + (int)__builtin_ctzll(cand), hi_c = c * kChunk + 63 - (int)__builtin_clzll(cand);
+                    first = lo_c < first ? lo_c : first; last = hi_c > last ? hi_c : last;
+                }
+            }
+            if (last >= 0) { plo = first; phi = last; }
             plo = __builtin_amdgcn_readfirstlane(plo); phi = __builtin_amdgcn_readfirstlane(phi);
         }
         T best = Num<T>::inf();
@@ -482,17 +496,30 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         const T d_lo = a_lo ? ea : eb, d_hi = a_lo ? eb : ea;
         const T c_lo = a_lo ? qa.w : cb, c_hi = a_lo ? cb : qa.w;
 
-        // ---- node window of this wave (NCH == 1)
+        // ---- node window of this wave
         int wlo = 0, whi = M - 1;
-        if (NCH == 1) {
+        {
             T amin = valid ? c_lo : Num<T>::inf(), amax = valid ? c_hi : -Num<T>::inf();
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { amin = tmin(amin, __shfl_xor(amin, o)); amax = -tmin(-amax, -__shfl_xor(amax, o)); }
-            const T cm = (lane < M) ? nodesL[lane].w : Num<T>::inf();
-            const unsigned long long inw = __ballot(lane < M && cm > amin - Rwin && cm < amax + Rwin);
-            if (inw) { wlo = (int)__builtin_ctzll(inw); whi = 63 - (int)__builtin_clzll(inw); }
+            int first = M, last = -1;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int m = c * kChunk + lane;
+                const T cm = (m < M) ? nodesL[m].w : Num<T>::inf();
+                const unsigned long long inw = __ballot(m < M && cm > amin - Rwin && cm < amax + Rwin);
+                if (inw) {
+                    const int lo_c = c * kChunk + (int)__builtin_ctzll(inw), hi_c = c * kChunk + 63 - (int)__builtin_clzll(inw);
+                    first = lo_c < first ? lo_c : first; last = hi_c > last ? hi_c : last;
+                }
+            }
+            if (last >= 0) { wlo = first; whi = last; }
             wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
         }
+        // M > 64: the windowed column sums need the window inside one 64-row tile; wider windows (first iterations) take
+        // the chunked path over all nodes below
+        const bool windowed = (NCH == 1) || (whi - wlo + 1 <= kChunk);
+        if (NCH > 1 && !windowed) { wlo = 0; whi = M - 1; }
 
         ESTAMP(3);
         // ---- unnormalised membership, column sum, Q (:354-383)
@@ -507,7 +534,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const T d2 = ddx * ddx + ddy * ddy + ddz * ddz;
             sum += p;
             qs += p * d2;
-            if (NCH == 1 && m - wlo < RT) pb[(m - wlo) * kPStride + lane] = p;     // first chunk of the window
+            if (windowed && m - wlo < RT) pb[(m - wlo) * kPStride + lane] = p;       // first chunk of the window
         }
         ESTAMP(4);
         const T inv = valid ? T(1) / (sum + cn) : T(0);
@@ -519,7 +546,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         V4<T> pw; pw.x = inv * (x - ox); pw.y = inv * (y - oy); pw.z = inv * (z - oz); pw.w = inv;
         pts[wave * 64 + lane] = pw;
 
-        if (NCH == 1) {
+        if (windowed) {
             // ---- column sums (:386-389): lane = (node of the window, slice of the 64 points).  The window is summed in
             // chunks of kTileRows nodes (identical order in both tile variants, so a batch gives the bits of a single
             // frame): once sigma is millimetres the whole window is one chunk; the wide windows of the first iterations
@@ -555,16 +582,40 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             }
             s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
             if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
-            if (lane < Wn) {
-                double *ac = accL + (size_t)(wlo_c + lane) * 4;
-                const V4<T> ym = nodesL[wlo_c + lane];
-                const double w0 = (double)s0;
-                ac[0] += w0;
-                ac[1] += (double)sx + ((double)ox - (double)ym.x) * w0;
-                ac[2] += (double)sy + ((double)oy - (double)ym.y) * w0;
-                ac[3] += (double)sz + ((double)oz - (double)ym.z) * w0;
+            if (NCH == 1) {
+                if (lane < Wn) {
+                    double *ac = accL + (size_t)(wlo_c + lane) * 4;
+                    const V4<T> ym = nodesL[wlo_c + lane];
+                    const double w0 = (double)s0;
+                    ac[0] += w0;
+                    ac[1] += (double)sx + ((double)ox - (double)ym.x) * w0;
+                    ac[2] += (double)sy + ((double)oy - (double)ym.y) * w0;
+                    ac[3] += (double)sz + ((double)oz - (double)ym.z) * w0;
+                }
+                wave_lds_sync();
+            } else {
+                // M > 64: the sums of node wlo_c + lane go to the lane that owns that node in the register accumulators
+                // (lane = node - 64 c) by cross-lane reads; a window touches at most two node chunks
+                double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                if (lane < Wn) {
+                    const V4<T> ym = nodesL[wlo_c + lane];
+                    v0 = (double)s0;
+                    v1 = (double)sx + ((double)ox - (double)ym.x) * v0;
+                    v2 = (double)sy + ((double)oy - (double)ym.y) * v0;
+                    v3 = (double)sz + ((double)oz - (double)ym.z) * v0;
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c * kChunk + 63 >= wlo_c && c * kChunk < wlo_c + Wn) {       // wave-uniform
+                        const int idx = c * kChunk + lane - wlo_c;
+                        const bool ok = idx >= 0 && idx < Wn;
+                        const int src = ok ? idx : 0;
+                        const double g0 = __shfl(v0, src), g1 = __shfl(v1, src), g2 = __shfl(v2, src), g3 = __shfl(v3, src);
+                        if (ok) { accP[c] += g0; accX[c] += g1; accY[c] += g2; accZ[c] += g3; }
+                    }
+                }
+                wave_lds_sync();
             }
-            wave_lds_sync();
             }
         } else {
         // ---- column sums with lane = node (:386-389)
