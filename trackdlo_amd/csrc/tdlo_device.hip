@@ -369,6 +369,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     // tile rows: one frame (SINGLE) cannot fill the GPU anyway, so it keeps the whole window in the tile; batches use the
     // small tile (two workgroups per CU) and recompute the memberships of the later chunks of a wide window
     constexpr int RT = (NCH == 1 && !SINGLE) ? kTileRows : kChunk;
+    constexpr int RS = (RT / kTileRows) * kTileRows;       // stored rows: whole chunks only (48 of 64, 24 of 24)
     const int rows = M < RT ? M : RT;
     // LDS carve (every offset a multiple of 16 bytes)
     V4<T> *nodesL = (V4<T> *)smem;                                    // M
@@ -516,10 +517,6 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             if (last >= 0) { wlo = first; whi = last; }
             wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
         }
-        // M > 64: the windowed column sums need the window inside one 64-row tile; wider windows (first iterations) take
-        // the chunked path over all nodes below
-        const bool windowed = (NCH == 1) || (whi - wlo + 1 <= kChunk);
-        if (NCH > 1 && !windowed) { wlo = 0; whi = M - 1; }
 
         ESTAMP(3);
         // ---- unnormalised membership, column sum, Q (:354-383)
@@ -534,7 +531,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const T d2 = ddx * ddx + ddy * ddy + ddz * ddz;
             sum += p;
             qs += p * d2;
-            if (windowed && m - wlo < RT) pb[(m - wlo) * kPStride + lane] = p;       // first chunk of the window
+            if (m - wlo < RS) pb[(m - wlo) * kPStride + lane] = p;                   // the chunks of the window that fit the tile
         }
         ESTAMP(4);
         const T inv = valid ? T(1) / (sum + cn) : T(0);
@@ -546,7 +543,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         V4<T> pw; pw.x = inv * (x - ox); pw.y = inv * (y - oy); pw.z = inv * (z - oz); pw.w = inv;
         pts[wave * 64 + lane] = pw;
 
-        if (windowed) {
+        {
             // ---- column sums (:386-389): lane = (node of the window, slice of the 64 points).  The window is summed in
             // chunks of kTileRows nodes (identical order in both tile variants, so a batch gives the bits of a single
             // frame): once sigma is millimetres the whole window is one chunk; the wide windows of the first iterations
@@ -556,8 +553,9 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             for (int c0 = 0; c0 < Wtot; c0 += kTileRows) {
             const int Wn = (Wtot - c0) < kTileRows ? (Wtot - c0) : kTileRows;
             const int wlo_c = wlo + c0;
-            const int rbase = RT >= kChunk ? c0 : 0;                     // first tile row of this chunk
-            if (RT < kChunk && c0 > 0) {
+            const bool rec = c0 >= RS;                                   // chunk beyond the stored part of the window
+            const int rbase = rec ? 0 : c0;                              // first tile row of this chunk
+            if (rec) {
 #pragma unroll 4
                 for (int m = wlo_c; m < wlo_c + Wn; ++m) {
                     T e = geo_arg<T>(m, lo, hi, nodes[m].w, c_lo, d_lo, c_hi, d_hi) * k2;
@@ -617,37 +615,6 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 wave_lds_sync();
             }
             }
-        } else {
-        // ---- column sums with lane = node (:386-389)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int m0 = c * kChunk, m1 = min(M, m0 + kChunk);
-            for (int m = m0; m < m1; ++m) {
-                V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
-                T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
-                if (VIS) e += lvL[m];
-                pb[(m - m0) * kPStride + lane] = Num<T>::exp2(e);
-            }
-            wave_lds_sync();
-            if (m0 + lane < m1) {
-                T s0 = 0, sx = 0, sy = 0, sz = 0;
-                const T *prow = pb + lane * kPStride;
-                const V4<T> *pw_ = pts + wave * 64;
-#pragma unroll 8
-                for (int j = 0; j < 64; ++j) {
-                    const T p = prow[j];
-                    const V4<T> w = pw_[j];
-                    s0 += p * w.w; sx += p * w.x; sy += p * w.y; sz += p * w.z;
-                }
-                const V4<T> ym = nodesL[m0 + lane];
-                const double w0 = (double)s0;
-                accP[c] += w0;
-                accX[c] += (double)sx + ((double)ox - (double)ym.x) * w0;
-                accY[c] += (double)sy + ((double)oy - (double)ym.y) * w0;
-                accZ[c] += (double)sz + ((double)oz - (double)ym.z) * w0;
-            }
-            wave_lds_sync();
-        }
         }
     }
 
