@@ -603,7 +603,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     HIPCHK(c, hipMemcpyAsync(d_depth, depth, (size_t)P * 2, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_mask, mask, (size_t)P, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_bbox, hb, 9 * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    HIPCHK(c, launch_cloud_bbox(d_depth, d_mask, P, cols, cam, d_bbox, st));
+    HIPCHK(c, launch_cloud_bbox(d_depth, d_mask, P, cols, cam, d_bbox, ws, st));
     HIPCHK(c, hipMemcpyAsync(hb, d_bbox, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     const int nraw = (int)hb[6];
@@ -629,7 +629,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     while (passes < 4 && (1ll << (8 * passes)) <= cells) ++passes;      // every valid key must stay below the all-ones sentinel
     rc = ensure_points(c, s, nraw);
     if (rc) return rc;
-    HIPCHK(c, launch_cloud_voxels(d_depth, d_mask, P, cols, cam, min_b, div_b[0], div_b[0] * div_b[1], inv, nodown, passes,
+    HIPCHK(c, launch_cloud_voxels(d_depth, d_mask, P, cols, cam, min_b, div_b[0], div_b[0] * div_b[1], inv, nodown, passes, nraw,
                                   ws, d_total, s.cap_points, s.Xraw, st));
     HIPCHK(c, hipMemcpyAsync(hb, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

@@ -11,9 +11,9 @@
 // one centroid per occupied cell, ascending cell index, float sums in input order.
 //
 // Integer/byte work, HBM-bound and tiny (0.3 M pixels): no MFMA, no LDS tiling to speak of.  Design:
-//   * no compaction pass: every pixel gets a 32-bit key (cell index, or 0xffffffff when the mask is off) and the
-//     payload is its pixel number; a stable LSD radix sort (8-bit digits, only as many passes as the cell count
-//     needs) groups the cells and leaves the masked-out pixels at the end;
+//   * the bounding-box pass also counts the masked pixels per 1024-pixel tile; the key pass compacts them in pixel
+//     order (32-bit key = cell index, payload = pixel number); a stable LSD radix sort (8-bit digits, only as many
+//     passes as the cell count needs) over the masked pixels only groups the cells;
 //   * the sort is three small kernels per pass: per-block digit histogram, one-block exclusive scan, stable
 //     scatter (wave-level match by ballots, wave/round offsets through LDS) -- element order is the pixel order;
 //   * centroids: the thread of a cell's first element walks the cell's run (runs are short: a handful of pixels
@@ -49,7 +49,8 @@ __device__ __forceinline__ unsigned ordered_bits(float v) {
 
 // bbox[0..2] = min (ordered bits), bbox[3..5] = max, bbox[6] = number of masked pixels
 __global__ __launch_bounds__(kCB) void k_cloud_bbox(const unsigned short *__restrict__ depth, const unsigned char *__restrict__ mask, int P, int cols,
-                                                    const Cam cam, unsigned *__restrict__ bbox) {
+                                                    const Cam cam, unsigned *__restrict__ bbox, int *__restrict__ blkcnt) {
+    __shared__ int wc[4];
     unsigned mn[3] = {~0u, ~0u, ~0u}, mx[3] = {0u, 0u, 0u};
     int cnt = 0;
 #pragma unroll
@@ -77,27 +78,49 @@ __global__ __launch_bounds__(kCB) void k_cloud_bbox(const unsigned short *__rest
         for (int d = 0; d < 3; ++d) { atomicMin(&bbox[d], mn[d]); atomicMax(&bbox[3 + d], mx[d]); }
         atomicAdd(&bbox[6], (unsigned)cnt);
     }
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blkcnt[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];     // masked pixels of this 1024-pixel tile
 }
 
 struct Grid { int min_b[3]; int mul1, mul2; float inv; int nodown; };
 
+// Compaction + keys: the masked pixels of tile b go to positions blkoff[b] .. in pixel order (the order of the reference's
+// row-major scan, trackdlo_node.cpp:197-198); key = cell index, payload = pixel number.
 __global__ __launch_bounds__(kCB) void k_cloud_keys(const unsigned short *__restrict__ depth, const unsigned char *__restrict__ mask, int P, int cols,
-                                                    const Cam cam, const Grid g, unsigned *__restrict__ key, unsigned *__restrict__ val) {
-    const int p = blockIdx.x * kCB + threadIdx.x;
-    if (p >= P) return;
-    unsigned k = kSent;
-    if (mask[p] != 0) {
-        if (g.nodown) k = 0;                                        // "leaf size too small": output = input, pixel order
-        else {
-            float x, y, z;
-            back_project(depth, p, cols, cam, x, y, z);
-            const int i0 = (int)(floorf(x * g.inv) - (float)g.min_b[0]);     // voxel_grid.hpp: ijk = floor(p * inv_leaf) - min_b
-            const int i1 = (int)(floorf(y * g.inv) - (float)g.min_b[1]);
-            const int i2 = (int)(floorf(z * g.inv) - (float)g.min_b[2]);
-            k = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
+                                                    const Cam cam, const Grid g, const int *__restrict__ blkoff,
+                                                    unsigned *__restrict__ key, unsigned *__restrict__ val) {
+    __shared__ int wc[4];
+    __shared__ int run;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) run = blkoff[blockIdx.x];
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < kItems; ++u) {
+        const int p = blockIdx.x * kTile + u * kCB + t;
+        const bool on = p < P && mask[p] != 0;
+        const unsigned long long bl = __ballot(on);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (lane == 0) wc[w] = __popcll(bl);
+        __syncthreads();
+        if (on) {
+            int dst = run + __popcll(bl & below);
+            for (int ww = 0; ww < w; ++ww) dst += wc[ww];
+            unsigned k = 0;                                         // "leaf size too small": output = input, pixel order
+            if (!g.nodown) {
+                float x, y, z;
+                back_project(depth, p, cols, cam, x, y, z);
+                const int i0 = (int)(floorf(x * g.inv) - (float)g.min_b[0]);     // voxel_grid.hpp: ijk = floor(p * inv_leaf) - min_b
+                const int i1 = (int)(floorf(y * g.inv) - (float)g.min_b[1]);
+                const int i2 = (int)(floorf(z * g.inv) - (float)g.min_b[2]);
+                k = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
+            }
+            key[dst] = k; val[dst] = (unsigned)p;
         }
+        __syncthreads();
+        if (t == 0) run += wc[0] + wc[1] + wc[2] + wc[3];
+        __syncthreads();
     }
-    key[p] = k; val[p] = (unsigned)p;
 }
 
 // hist[d * nblk + b] = number of elements of block b whose digit is d
@@ -114,25 +137,39 @@ __global__ __launch_bounds__(kCB) void k_radix_hist(const unsigned *__restrict__
     hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-// in-place exclusive scan of data[0..n) by ONE block of 1024 threads; *total = sum
+// in-place exclusive scan of data[0..n) by ONE block of 1024 threads; *total = sum.  The array is walked in tiles of
+// 4096 elements, four consecutive ints per thread (coalesced 16-byte accesses), with a running carry.
 __global__ __launch_bounds__(1024) void k_scan_single(int *__restrict__ data, int n, int *__restrict__ total) {
     __shared__ int wsum[16];
-    __shared__ int carry;
+    __shared__ int carry_s;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int per = (n + 1023) / 1024;
-    const int b = t * per, e = (b + per) < n ? (b + per) : n;
-    int s = 0;
-    for (int i = b; i < e; ++i) s += data[i];
-    int incl = s;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + 4 * t;
+        int v[4];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    if (t == 0) { int a = 0; for (int i = 0; i < 16; ++i) { const int v = wsum[i]; wsum[i] = a; a += v; } carry = a; }
-    __syncthreads();
-    int run = wsum[w] + incl - s;
-    for (int i = b; i < e; ++i) { const int v = data[i]; data[i] = run; run += v; }
-    if (t == 0 && total) *total = carry;
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? data[i0 + k] : 0;
+        const int s = v[0] + v[1] + v[2] + v[3];
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int woff = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) woff += (i < w) ? wsum[i] : 0;
+        int tilesum = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tilesum += wsum[i];
+        int run = carry_s + woff + incl - s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < n) data[i0 + k] = run; run += v[k]; }
+        __syncthreads();
+        if (t == 0) carry_s += tilesum;
+        __syncthreads();
+    }
+    if (t == 0 && total) *total = carry_s;
 }
 
 // stable scatter of one radix pass; `hist` holds the scanned offsets
@@ -243,32 +280,40 @@ size_t cloud_ws_bytes(int P) {
     return sizeof(unsigned) * 4 * (size_t)P + sizeof(int) * (256 * nblk + nblk + 64) + 256;
 }
 
-hipError_t launch_cloud_bbox(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], unsigned *bbox, hipStream_t s) {
+static int *blkcnt_of(void *ws, int P) {          // per-tile masked-pixel counts live where the head counts go later
+    const int nblk = (P + kTile - 1) / kTile;
+    return (int *)((unsigned *)ws + 4 * (size_t)P) + 256 * (size_t)nblk;
+}
+
+hipError_t launch_cloud_bbox(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], unsigned *bbox, void *ws, hipStream_t s) {
     const Cam c{cam[0], cam[1], cam[2], cam[3]};
     const int nblk = (P + kTile - 1) / kTile;
-    hipLaunchKernelGGL(k_cloud_bbox, dim3(nblk), dim3(kCB), 0, s, depth, mask, P, cols, c, bbox);
+    hipLaunchKernelGGL(k_cloud_bbox, dim3(nblk), dim3(kCB), 0, s, depth, mask, P, cols, c, bbox, blkcnt_of(ws, P));
     return hipGetLastError();
 }
 
 hipError_t launch_cloud_voxels(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4],
-                               const int min_b[3], int mul1, int mul2, float inv_leaf, int nodown, int passes,
+                               const int min_b[3], int mul1, int mul2, float inv_leaf, int nodown, int passes, int n,
                                void *ws, int *total_dev, int cap, double *Xraw, hipStream_t s) {
     const Cam c{cam[0], cam[1], cam[2], cam[3]};
     Grid g; g.min_b[0] = min_b[0]; g.min_b[1] = min_b[1]; g.min_b[2] = min_b[2]; g.mul1 = mul1; g.mul2 = mul2; g.inv = inv_leaf; g.nodown = nodown;
-    const int nblk = (P + kTile - 1) / kTile;
+    // n = number of masked pixels (known to the host from the bounding-box pass): everything after the compaction
+    // works on n elements, typically a few per cent of the image
+    const int nblkP = (P + kTile - 1) / kTile, nblk = (n + kTile - 1) / kTile;
     unsigned *keyA = (unsigned *)ws, *valA = keyA + P, *keyB = valA + P, *valB = keyB + P;
-    int *hist = (int *)(valB + P), *cnt = hist + 256 * (size_t)nblk;
-    hipLaunchKernelGGL(k_cloud_keys, dim3((P + kCB - 1) / kCB), dim3(kCB), 0, s, depth, mask, P, cols, c, g, keyA, valA);
+    int *hist = (int *)(valB + P), *cnt = blkcnt_of(ws, P);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, cnt, nblkP, (int *)nullptr);
+    hipLaunchKernelGGL(k_cloud_keys, dim3(nblkP), dim3(kCB), 0, s, depth, mask, P, cols, c, g, cnt, keyA, valA);
     for (int pass = 0; pass < passes; ++pass) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(kCB), 0, s, keyA, P, 8 * pass, nblk, hist);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(kCB), 0, s, keyA, n, 8 * pass, nblk, hist);
         hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, hist, 256 * nblk, (int *)nullptr);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kCB), 0, s, keyA, valA, P, 8 * pass, nblk, hist, keyB, valB);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kCB), 0, s, keyA, valA, n, 8 * pass, nblk, hist, keyB, valB);
         unsigned *tk = keyA; keyA = keyB; keyB = tk;
         unsigned *tv = valA; valA = valB; valB = tv;
     }
-    hipLaunchKernelGGL(k_cloud_heads, dim3(nblk), dim3(kCB), 0, s, keyA, P, nodown, cnt);
+    hipLaunchKernelGGL(k_cloud_heads, dim3(nblk), dim3(kCB), 0, s, keyA, n, nodown, cnt);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, cnt, nblk, total_dev);
-    hipLaunchKernelGGL(k_cloud_centroid, dim3(nblk), dim3(kCB), 0, s, depth, P, cols, c, nodown, keyA, valA, cnt, total_dev, cap, Xraw);
+    hipLaunchKernelGGL(k_cloud_centroid, dim3(nblk), dim3(kCB), 0, s, depth, n, cols, c, nodown, keyA, valA, cnt, total_dev, cap, Xraw);
     return hipGetLastError();
 }
 

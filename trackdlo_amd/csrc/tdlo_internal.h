@@ -83,9 +83,9 @@ size_t reg_ws_doubles(int M, int nblk);
 hipError_t launch_reg(const double *X, int N, int M, double mu, int max_iter, int nblk, double *ws, hipStream_t s);
 // tdlo_cloud.hip: depth image -> cloud -> voxel grid
 size_t cloud_ws_bytes(int P);
-hipError_t launch_cloud_bbox(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], unsigned *bbox, hipStream_t s);
+hipError_t launch_cloud_bbox(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], unsigned *bbox, void *ws, hipStream_t s);
 hipError_t launch_cloud_voxels(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4],
-                               const int min_b[3], int mul1, int mul2, float inv_leaf, int nodown, int passes,
+                               const int min_b[3], int mul1, int mul2, float inv_leaf, int nodown, int passes, int n,
                                void *ws, int *total_dev, int cap, double *Xraw, hipStream_t s);
 int check_device_image();
 
