@@ -1,0 +1,45 @@
+"""Bug hunting: the randomised configuration sweep of tests/test_parity_gpu.py over many seeds, printing the draws that miss
+the tolerance."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import ref_cpu as R
+from trackdlo_amd import binding as B, synth
+ctx = B.Context(max_frames=2, max_points=1 << 16, max_nodes=160)
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+for seed in range(lo, hi):
+    rng = np.random.default_rng(9000 + seed)
+    M = int(rng.integers(4, 65)) if seed % 6 else int(rng.integers(65, 140))
+    N = int(rng.integers(64, 12000)); iters = int(rng.integers(1, 9)); prec = int(rng.integers(0, 2))
+    vis = bool(rng.integers(0, 2)) and M >= 12; use_pri = bool(rng.integers(0, 2)); use_lle = bool(rng.integers(0, 3) == 0)
+    noise = float(rng.choice([0.0005, 0.002, 0.004]))
+    X, Y0, v = synth.scene(N, M, config=60 + seed, frame=seed, noise=noise, occlude=(0.35, 0.55) if vis else None,
+                           outliers=int(rng.integers(0, 20)), shift=(0.0, float(rng.uniform(0, 0.008)), float(rng.uniform(-0.003, 0.003))))
+    vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0)) if vis else None
+    kw = dict(beta=float(rng.choice([0.35, 0.6, 3.0])), lambda_=float(rng.choice([1.0, 500.0, 50000.0])), lle_weight=10.0,
+              mu=float(rng.choice([0.05, 0.1, 0.3])), max_iter=iters, tol=0.0, include_lle=False, alpha=0.0,
+              k_vis=50.0 if vis else 0.0, visibility_threshold=0.008)
+    pri = None; H = None
+    if use_pri:
+        idx = np.sort(rng.choice(M, size=max(1, M // 4), replace=False))
+        pri = np.concatenate([idx[:, None].astype(float), Y0[idx] + rng.normal(0, 0.003, size=(len(idx), 3))], axis=1)
+        kw["alpha"] = float(rng.choice([1.0, 3.0]))
+    if use_lle:
+        L = R.calc_lle_weights(Y0, 6); H = (np.eye(M) - L).T @ (np.eye(M) - L)
+        kw.update(include_lle=True, beta=3.0, lambda_=1.0)
+    s2 = float(rng.choice([0.0, 1e-4, 2e-5]))
+    o = R.cpd_lle(X, Y0, s2, priors=pri, visible_nodes=vext, H=H, **kw)
+    g = ctx.cpd_lle(X, Y0, s2, B.make_params(precision=prec, **kw), priors=pri, visible_nodes=vext, H=H, check=False)
+    dy = np.abs(g["Y"] - o["Y"]).max()
+    gate = 1e-9 if prec else 1e-5
+    if dy > gate or g["rc"] != 0 or g["iters"] != o["iters"] or g["n_kept"] != o["n_kept"]:
+        # per-iteration divergence
+        tr = []
+        for it in range(1, iters + 1):
+            kw2 = dict(kw, max_iter=it)
+            oo = R.cpd_lle(X, Y0, s2, priors=pri, visible_nodes=vext, H=H, **kw2)
+            gg = ctx.cpd_lle(X, Y0, s2, B.make_params(precision=prec, **kw2), priors=pri, visible_nodes=vext, H=H, check=False)
+            tr.append('%.1e' % np.abs(gg["Y"] - oo["Y"]).max())
+        print(seed, 'M', M, 'N', N, 'it', iters, 'f64' if prec else 'f32', 'vis' if vis else '-', 'pri%g' % kw['alpha'] if use_pri else '-', 'lle' if use_lle else '-',
+              'beta', kw['beta'], 'lam', kw['lambda_'], 'mu', kw['mu'], 's2in', s2, 'noise', noise, 'rc', g['rc'], 'dY %.2e' % dy, 'sigma2 %.2e/%.2e' % (g['sigma2'], o['sigma2']), 'trace', tr, flush=True)
+print('done')
