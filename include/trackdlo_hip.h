@@ -52,7 +52,8 @@ typedef struct {
     int max_frames;          /* number of frame slots (>= 1); slots are independent clouds/trackers */
     int max_points;          /* initial per-slot capacity in points (grown on demand) */
     int max_nodes;           /* initial capacity in nodes (grown on demand) */
-    int use_graph;           /* 1: replay the EM loop from a captured hipGraph (default 1) */
+    int use_graph;           /* reserved, ignored: the loop is enqueued as plain launches on one stream -- kernel durations
+                              * add up to the loop time to within 0.4 us per iteration (bench.py), a graph has nothing to recover */
     int estep_blocks;        /* 0 = auto; otherwise workgroups per frame for the E-step */
 } tdlo_config;
 
@@ -144,6 +145,21 @@ int tdlo_split_dmin(tdlo_ctx *ctx, double *dmin_sq /* out M, local */);
 int tdlo_split_estep(tdlo_ctx *ctx, const double *dmin_sq_global /* in M or NULL */, double *sums /* out 4M+2 */);
 int tdlo_split_mstep(tdlo_ctx *ctx, const double *sums_global /* in 4M+2 */, int *done /* out */);
 int tdlo_split_end(tdlo_ctx *ctx, double *Y, double *sigma2, tdlo_stats *stats);
+
+/* Device-resident exchange (the form the 8-GPU run uses): the two buffers the ranks all-reduce live in DEVICE memory
+ * owned by the caller -- e.g. a tensor handed to RCCL -- and the calls below only enqueue work on the context's stream
+ * (tdlo_stream), so one EM iteration is   dmin_enqueue, all-reduce MIN d_dmin, estep_enqueue, all-reduce SUM d_sums,
+ * mstep_enqueue   with every collective issued on (or ordered after) that stream and NO host synchronisation; the
+ * stopping rule is evaluated on the device and read with tdlo_split_poll every few iterations (kernels of a finished
+ * registration are no-ops, all ranks see the same flag because they solve the same system).
+ *   d_dmin: M doubles, per-node minimum SQUARED distance (1e300 where a shard holds no point); only touched when
+ *           visibility weighting is active.   d_sums: 4M+2 doubles, layout as above.
+ * Bind before tdlo_split_begin; bind (NULL, NULL) to return to the host-buffer calls. */
+int tdlo_split_bind_exchange(tdlo_ctx *ctx, double *d_dmin /* device, M */, double *d_sums /* device, 4M+2 */);
+int tdlo_split_dmin_enqueue(tdlo_ctx *ctx);    /* local dmin -> d_dmin */
+int tdlo_split_estep_enqueue(tdlo_ctx *ctx);   /* d_dmin (global) -> E-step on the shard -> local sums -> d_sums */
+int tdlo_split_mstep_enqueue(tdlo_ctx *ctx);   /* d_sums (global) -> M-step (:392-437), identical on every rank */
+int tdlo_split_poll(tdlo_ctx *ctx, int *done, int *iters);   /* synchronises the stream */
 
 /* ---- tracker object: class trackdlo (trackdlo/include/trackdlo.h:53-130) ---------------------- */
 typedef struct tdlo_tracker tdlo_tracker;

@@ -98,3 +98,28 @@ class NumpyShard:
 
     def end(self):
         return dict(Y=self.Y, sigma2=self.sigma2, iters=self.it, converged=self.converged, n_kept=len(self.X))
+
+
+class NumpyDeviceShard(NumpyShard):
+    """The same arithmetic behind the enqueue-style interface of trackdlo_amd.nsplit.HipDeviceShard: the exchange buffers are
+    the torch tensors of a TorchDeviceExchange (CPU tensors under gloo), filled / consumed in place."""
+
+    def __init__(self, X_shard, xch):
+        super().__init__(X_shard)
+        self.xch = xch
+
+    def dmin_enqueue(self):
+        if not self.done:
+            self.xch.dmin.numpy()[:] = self.dmin()
+
+    def estep_enqueue(self):
+        if not self.done:                                   # kernels of a finished registration are no-ops
+            d = self.xch.dmin.numpy().copy() if self.vis_branch else None
+            self.xch.sums.numpy()[:] = self.estep(d)
+
+    def mstep_enqueue(self):
+        if not self.done:
+            self.mstep(self.xch.sums.numpy().copy())
+
+    def poll(self):
+        return self.done, self.it

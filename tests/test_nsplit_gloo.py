@@ -31,14 +31,22 @@ def _worker(rank, world, port, case, q):
                                include_lle=False, alpha=0.0, k_vis=P["k_vis"] if case["vis"] else 0.0,
                                visibility_threshold=P["visibility_threshold"])
         n = X.shape[0]; lo = rank * n // world; hi = (rank + 1) * n // world      # contiguous shard per rank
-        out = nsplit.cpd_lle_nsplit(NumpyShard(X[lo:hi]), nsplit.TorchComm(), Y0, 0.0, params, visible_nodes=vext)
+        if case.get("device"):                  # enqueue-style driver, exchange buffers = one torch tensor reduced in place
+            from numpy_shard import NumpyDeviceShard
+            xch = nsplit.TorchDeviceExchange(24, "cpu")
+            out = nsplit.cpd_lle_nsplit_device(NumpyDeviceShard(X[lo:hi], xch), xch, nsplit.TorchComm(), Y0, 0.0, params, visible_nodes=vext)
+        else:
+            out = nsplit.cpd_lle_nsplit(NumpyShard(X[lo:hi]), nsplit.TorchComm(), Y0, 0.0, params, visible_nodes=vext)
         q.put((rank, out["Y"], out["sigma2"], out["iters"], out["converged"], out["n_kept"], out["n_kept_global"]))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("case", [dict(vis=False, max_iter=8, tol=0.0), dict(vis=True, max_iter=8, tol=0.0),
-                                  dict(vis=False, max_iter=50, tol=2e-4)], ids=["plain", "vis", "tol"])
+                                  dict(vis=False, max_iter=50, tol=2e-4),
+                                  dict(vis=False, max_iter=8, tol=0.0, device=True), dict(vis=True, max_iter=8, tol=0.0, device=True),
+                                  dict(vis=True, max_iter=50, tol=2e-4, device=True)],
+                         ids=["plain", "vis", "tol", "device-plain", "device-vis", "device-vis-tol"])
 def test_nsplit_two_ranks_equal_whole_cloud(oracle, case):
     import torch.multiprocessing as mp
     from trackdlo_amd import synth

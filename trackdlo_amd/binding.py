@@ -48,6 +48,7 @@ SYMBOLS = [
     "tdlo_abi_version", "tdlo_device_count", "tdlo_default_config", "tdlo_create", "tdlo_destroy", "tdlo_last_error",
     "tdlo_stream", "tdlo_synchronize", "tdlo_set_cloud", "tdlo_cpd_lle_resident", "tdlo_cpd_lle", "tdlo_cpd_lle_batch",
     "tdlo_split_begin", "tdlo_split_set_global", "tdlo_split_dmin", "tdlo_split_estep", "tdlo_split_mstep", "tdlo_split_end",
+    "tdlo_split_bind_exchange", "tdlo_split_dmin_enqueue", "tdlo_split_estep_enqueue", "tdlo_split_mstep_enqueue", "tdlo_split_poll",
     "tdlo_tracker_create", "tdlo_tracker_create_default", "tdlo_tracker_destroy", "tdlo_tracker_set_precision",
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
@@ -57,6 +58,33 @@ SYMBOLS = [
 ]
 
 _lib = None
+_hip_runtime = None
+
+
+def _pin_hip_runtime():
+    """One process can hold only ONE HIP/HSA runtime.  The PyTorch wheel ships its own libamdhip64.so (soname
+    libamdhip64.so.7, found through an $ORIGIN rpath under the unversioned file name), so `import torch` AFTER this library
+    has pulled in /opt/rocm's copy maps a second runtime, whose initialisation then fails ("No HIP GPUs are available").
+    The N-split driver needs both in one process (RCCL through torch.distributed reduces buffers on this library's stream),
+    so when a torch installation is present its runtime is mapped first -- without importing torch -- and the DT_NEEDED
+    entry of libtrackdlo_hip.so binds to it by soname, whichever of the two is imported first.
+    TDLO_HIP_RUNTIME=system keeps /opt/rocm's runtime (processes that never import torch); =torch insists on torch's."""
+    global _hip_runtime
+    if _hip_runtime is not None:
+        return _hip_runtime
+    mode = os.environ.get("TDLO_HIP_RUNTIME", "auto")
+    _hip_runtime = "system"
+    if mode != "system":
+        import importlib.util
+        import sys
+        spec = sys.modules["torch"].__spec__ if "torch" in sys.modules else importlib.util.find_spec("torch")
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+        if cand and os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            _hip_runtime = cand
+        elif mode == "torch":
+            raise FileNotFoundError("TDLO_HIP_RUNTIME=torch, but no torch/lib/libamdhip64.so was found")
+    return _hip_runtime
 
 
 def load_library(path: str | None = None):
@@ -67,6 +95,7 @@ def load_library(path: str | None = None):
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise FileNotFoundError(f"{p} not built: run `make -C trackdlo_amd/csrc` (needs hipcc); there is no CPU fallback")
+    _pin_hip_runtime()
     lib = C.CDLL(p)
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double
     lib.tdlo_abi_version.restype = ci
@@ -90,6 +119,11 @@ def load_library(path: str | None = None):
     lib.tdlo_split_estep.argtypes = [vp, vp, vp]
     lib.tdlo_split_mstep.argtypes = [vp, vp, C.POINTER(ci)]
     lib.tdlo_split_end.argtypes = [vp, vp, C.POINTER(cd), C.POINTER(Stats)]
+    lib.tdlo_split_bind_exchange.argtypes = [vp, vp, vp]
+    lib.tdlo_split_dmin_enqueue.argtypes = [vp]
+    lib.tdlo_split_estep_enqueue.argtypes = [vp]
+    lib.tdlo_split_mstep_enqueue.argtypes = [vp]
+    lib.tdlo_split_poll.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.tdlo_tracker_create.restype = vp
     lib.tdlo_tracker_create.argtypes = [vp, ci, ci, cd, cd, cd, cd, cd, cd, ci, cd, cd, cd, cd]
     lib.tdlo_tracker_create_default.restype = vp
@@ -166,6 +200,10 @@ class Context:
 
     def synchronize(self):
         self._chk(self.lib.tdlo_synchronize(self.h))
+
+    def stream_ptr(self):
+        """Raw hipStream_t of the context (an integer), for callers that order their own work on it."""
+        return int(self.lib.tdlo_stream(self.h) or 0)
 
     def set_cloud(self, slot, X):
         X = _f64(X)

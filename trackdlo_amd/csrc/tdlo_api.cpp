@@ -79,7 +79,8 @@ struct tdlo_ctx {
     int last_F = 0;
     // split-mode scratch
     int split_active = 0;
-    std::vector<double> split_Y;
+    double *xch_dmin = nullptr;      // caller-owned device memory of the device-resident N-split exchange (tdlo_split_bind_exchange)
+    double *xch_sums = nullptr;
 };
 
 namespace {
@@ -437,6 +438,7 @@ int tdlo_split_begin(tdlo_ctx *c, const double *Y, int M, double sigma2, const t
     c->fh.assign(1, FrameDev{});
     rc = prepare_frame(c, 0, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, c->pin, c->fh[0]);
     if (rc) return rc;
+    if (c->xch_sums) c->fh[0].sums = c->xch_sums;       // the reduced sums are exported to / consumed from the caller's buffer
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p) * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev), hipMemcpyHostToDevice, s));
@@ -509,6 +511,53 @@ int tdlo_split_mstep(tdlo_ctx *c, const double *sums_global, int *done) {
     IterState is;
     std::memcpy(&is, c->pin + 4 * M + 4, sizeof is);
     if (done) *done = is.done;
+    return TDLO_OK;
+}
+
+// Device-resident exchange: nothing below synchronises with the host except tdlo_split_poll.
+int tdlo_split_bind_exchange(tdlo_ctx *c, double *d_dmin, double *d_sums) {
+    if (!c) return TDLO_E_INVALID;
+    if (c->split_active) return fail(c, TDLO_E_INVALID, "tdlo_split_bind_exchange inside a split registration");
+    if ((d_dmin == nullptr) != (d_sums == nullptr)) return fail(c, TDLO_E_INVALID, "bind both exchange buffers or neither");
+    c->xch_dmin = d_dmin; c->xch_sums = d_sums;
+    return TDLO_OK;
+}
+
+int tdlo_split_dmin_enqueue(tdlo_ctx *c) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    if (!c->xch_dmin) return fail(c, TDLO_E_INVALID, "no exchange buffers bound");
+    if (!c->fh[0].vis_branch) return TDLO_OK;
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 1, c->stream));
+    HIPCHK(c, launch_split_dmin_xch(c->fd, c->fh.data(), c->xch_dmin, 0, c->stream));
+    return TDLO_OK;
+}
+
+int tdlo_split_estep_enqueue(tdlo_ctx *c) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    if (!c->xch_sums) return fail(c, TDLO_E_INVALID, "no exchange buffers bound");
+    hipStream_t s = c->stream;
+    if (c->fh[0].vis_branch) HIPCHK(c, launch_split_dmin_xch(c->fd, c->fh.data(), c->xch_dmin, 1, s));
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));        // block partials -> the bound sums buffer
+    return TDLO_OK;
+}
+
+int tdlo_split_mstep_enqueue(tdlo_ctx *c) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    if (!c->xch_sums) return fail(c, TDLO_E_INVALID, "no exchange buffers bound");
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 4, c->stream));
+    return TDLO_OK;
+}
+
+int tdlo_split_poll(tdlo_ctx *c, int *done, int *iters) {
+    if (!c || !c->split_active) return TDLO_E_INVALID;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->pin, c->fh[0].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    IterState is;
+    std::memcpy(&is, c->pin, sizeof is);
+    if (done) *done = is.done;
+    if (iters) *iters = is.it;
     return TDLO_OK;
 }
 
@@ -696,7 +745,7 @@ int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, doubl
 // ---- measurement ---------------------------------------------------------------------------------
 int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us) {
     if (!c || c->last_F < 1 || c->fh.empty()) return TDLO_E_INVALID;
-    if (!((kind >= 0 && kind <= 2) || kind == 10) || reps < 1 || (kind == 10 && reps > 256)) return fail(c, TDLO_E_INVALID, "bad kind / reps");
+    if (!((kind >= 0 && kind <= 4) || kind == 10) || reps < 1 || (kind == 10 && reps > 256)) return fail(c, TDLO_E_INVALID, "bad kind / reps");
     (void)slot;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;

@@ -1507,6 +1507,24 @@ hipError_t launch_split_setup(const FrameDev *fd, const FrameDev *fh, hipStream_
     return hipGetLastError();
 }
 
+// N-split with a device-resident exchange: the per-node minimum goes to / comes from caller-owned device memory as plain
+// doubles (what an RCCL all-reduce MIN understands); inside the path it stays in ordered-bits form for atomicMin.
+template <typename T>
+__global__ void k_split_dmin_xch(const FrameDev *__restrict__ frames, double *__restrict__ xch, int import) {
+    const FrameDev &f = frames[0];
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= f.M) return;
+    if (import) f.dminbits[m] = Num<T>::bits((T)xch[m]);
+    else { const unsigned long long b = f.dminbits[m]; xch[m] = b == ~0ull ? 1e300 : Num<T>::from_bits(b); }   // ~0: no point on this shard
+}
+
+hipError_t launch_split_dmin_xch(const FrameDev *fd, const FrameDev *fh, double *xch, int import, hipStream_t s) {
+    const dim3 grid((fh[0].M + 63) / 64), block(64);
+    if (fh[0].precision == TDLO_PREC_F64) hipLaunchKernelGGL((k_split_dmin_xch<double>), grid, block, 0, s, fd, xch, import);
+    else hipLaunchKernelGGL((k_split_dmin_xch<float>), grid, block, 0, s, fd, xch, import);
+    return hipGetLastError();
+}
+
 hipError_t launch_split_set_global(const FrameDev *fd, double Nglob, double Sglob, hipStream_t s) {
     hipLaunchKernelGGL(k_split_set_global, dim3(1), dim3(64), 0, s, fd, Nglob, Sglob);
     return hipGetLastError();
