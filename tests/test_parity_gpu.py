@@ -291,6 +291,7 @@ def test_nsplit_device_exchange_single_rank_rccl(hip_ctx):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one-rank group on a box without network: bootstrap over loopback
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:

@@ -186,7 +186,12 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.eb = (p->precision == TDLO_PREC_F32 && M <= 64) ? 512 : 256;
     const int wpb = f.eb / 64;
     int nblk = (nbatch + wpb - 1) / wpb;
-    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : 256;
+    // One frame of moderate size keeps its whole node window in a 64-row tile (133 KB of LDS: one workgroup per CU, which
+    // such a frame cannot fill anyway).  A cloud that needs 512 workgroups or more is VALU-bound instead: it takes the 24-row
+    // tile of the batch path (three workgroups per CU hide the LDS / scalar-load latencies: 47 -> 36 us at N = 2 000 000) and
+    // twice the block partials.  Batches (run_frames, F > 1) always use the small tile.
+    f.wide_tile = (M > kChunk || nblk < 512) ? 1 : 0;
+    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : (f.wide_tile ? 256 : 512);
     cap = std::min(cap, kMaxEstepBlocks);
     f.nblkE = std::max(1, std::min(nblk, cap));
     f.max_iter = p->max_iter; f.include_lle = p->include_lle ? 1 : 0; f.has_priors = K > 0 ? 1 : 0;
@@ -238,6 +243,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
                            c->pin + (size_t)i * nc.upload, c->fh[i]);
         if (rc) return rc;
+        if (F > 1) c->fh[i].wide_tile = 0;
     }
     hipStream_t s = c->stream;
     HIPCHK(c, hipEventRecord(c->ev[0], s));

@@ -9,6 +9,8 @@ template <typename T> struct alignas(16) V4 { T x, y, z, w; };
 
 __device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double tmin(double a, double b) { return ::fmin(a, b); }
+__device__ __forceinline__ float tabs(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ double tabs(double a) { return __builtin_fabs(a); }
 
 // Address-space casts.  Pointers reach the kernels through the FrameDev descriptor, so the compiler
 // only sees generic (flat) pointers and would emit flat_load + full waits.  Node data and parameters
@@ -23,6 +25,10 @@ template <> struct Num<float> {
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
     static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
     static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    // one instruction each (v_sqrt_f32, 1 ulp; v_rcp_f32 + one Newton step): the correctly rounded forms cost ~12 VALU
+    // instructions apiece, and a point's distances / normalisation carry a 1e-7 relative error either way
+    static __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float rcp_fast(float x) { const float r = __builtin_amdgcn_rcpf(x); return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r); }
     static __device__ __forceinline__ unsigned long long bits(float x) { return (unsigned long long)__float_as_uint(x); }
     static __device__ __forceinline__ double from_bits(unsigned long long b) { return (double)__uint_as_float((unsigned)b); }
 };
@@ -30,6 +36,8 @@ template <> struct Num<double> {
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
     static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double sqrt_fast(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
     static __device__ __forceinline__ unsigned long long bits(double x) { return (unsigned long long)__double_as_longlong(x); }
     static __device__ __forceinline__ double from_bits(unsigned long long b) { return __longlong_as_double((long long)b); }
 };
@@ -40,6 +48,45 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// value of the first active lane, as a wave-uniform (SGPR) operand
+__device__ __forceinline__ float bcast_first(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+__device__ __forceinline__ double bcast_first(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Wave-wide min / max of NON-NEGATIVE values (+inf allowed), wave-uniform result.  fp32: the IEEE bit patterns of
+// non-negative floats order like unsigned integers, so the reduction runs on v_min_u32 / v_max_u32 with DPP operands
+// (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast 15 / 31 across rows; total in lane 63): 6 VALU
+// instructions and no LDS traffic, against 6 dependent ds_bpermute round trips for the __shfl_xor butterfly.
+template <bool MAX> __device__ __forceinline__ unsigned wave_minmax_u32(unsigned u) {
+    constexpr int idn = MAX ? 0 : -1;                      // identity: lanes without a source keep it
+#define TDLO_DPP_STEP(CTRL, ROWMASK) do { \
+        const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(idn, (int)u, CTRL, ROWMASK, 0xf, false); \
+        u = MAX ? (u > o_ ? u : o_) : (u < o_ ? u : o_); } while (0)
+    TDLO_DPP_STEP(0x111, 0xf);      // row_shr:1
+    TDLO_DPP_STEP(0x112, 0xf);      // row_shr:2
+    TDLO_DPP_STEP(0x114, 0xf);      // row_shr:4
+    TDLO_DPP_STEP(0x118, 0xf);      // row_shr:8   -> lane 15 of every row holds the row's result
+    TDLO_DPP_STEP(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    TDLO_DPP_STEP(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+#undef TDLO_DPP_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)u, 63);
+}
+__device__ __forceinline__ float wave_min_nonneg(float v) { return __uint_as_float(wave_minmax_u32<false>(__float_as_uint(v))); }
+__device__ __forceinline__ float wave_max_nonneg(float v) { return __uint_as_float(wave_minmax_u32<true>(__float_as_uint(v))); }
+__device__ __forceinline__ double wave_min_nonneg(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = tmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = -tmin(-v, -__shfl_xor(v, o));
+    return v;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -334,6 +334,17 @@ __device__ __forceinline__ T geo_arg(int m, int lo, int hi, T cm, T c_lo, T d_lo
     return t * t;
 }
 
+// The same value when hi == lo + 1 (every point but the rare end-node case of :313-321, where the node between lo and
+// hi keeps the zero of :305): coord is non-decreasing, so c_lo - cm = |cm - c_lo| for m <= lo and cm - c_hi = |cm - c_hi|
+// for m > lo -- one compare, two selects, |a - b| + d instead of both branches and two compare/select pairs.
+template <typename T>
+__device__ __forceinline__ T geo_arg_adj(int m, int lo, T cm, T c_lo, T d_lo, T c_hi, T d_hi) {
+    const bool s = m <= lo;
+    const T c = s ? c_lo : c_hi, d = s ? d_lo : d_hi;
+    const T t = tabs(cm - c) + d;
+    return t * t;
+}
+
 template <int NW> __device__ __forceinline__ double block_sum_n(double v, double *scratch) {
     v = wave_sum(v);
     __syncthreads();
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         // distances): the same argmin, first index on ties, from typically 5 instead of M candidates.
         int plo = 0, phi = M - 1;
         {
-            const T cx = __shfl(x, 0), cy = __shfl(y, 0), cz = __shfl(z, 0);
+            const T cx = bcast_first(x), cy = bcast_first(y), cz = bcast_first(z);      // all 64 lanes are active here
             T r2 = valid ? (x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz) : T(0);
             T Dm[NCH];
             T dmin_w = Num<T>::inf();
@@ -452,12 +463,11 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             for (int c = 0; c < NCH; ++c) {                  // lane = node 64 c + lane
                 const int m = c * kChunk + lane;
                 Dm[c] = Num<T>::inf();
-                if (m < M) { const V4<T> qn = nodesL[m]; Dm[c] = Num<T>::sqrt((qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz)); }
+                if (m < M) { const V4<T> qn = nodesL[m]; Dm[c] = Num<T>::sqrt_fast((qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz)); }
                 dmin_w = tmin(dmin_w, Dm[c]);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { r2 = -tmin(-r2, -__shfl_xor(r2, o)); dmin_w = tmin(dmin_w, __shfl_xor(dmin_w, o)); }
-            const T lim = (dmin_w + T(2) * Num<T>::sqrt(r2)) * T(1.0001) + T(1e-30);
+            r2 = wave_max_nonneg(r2); dmin_w = wave_min_nonneg(dmin_w);
+            const T lim = (dmin_w + T(2) * Num<T>::sqrt_fast(r2)) * T(1.0001) + T(1e-30);
             int first = M, last = -1;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -472,12 +482,20 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         }
         T best = Num<T>::inf();
         int a = plo;
-#pragma unroll 4
-        for (int m = plo; m <= phi; ++m) {
-            V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
-            const T dx = x - q.x, dy = y - q.y, dz = z - q.z;
-            const T d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < best) { best = d2; a = m; }
+        // candidates in groups of 4: the group's scalar loads are issued together (index clamped to phi), the evaluations
+        // beyond phi are skipped by wave-uniform branches -- one scalar-memory latency per group instead of one per node
+        for (int m0 = plo; m0 <= phi; m0 += 4) {
+            V4<T> q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int mk = (m0 + k) < phi ? (m0 + k) : phi; q[k].x = nodes[mk].x; q[k].y = nodes[mk].y; q[k].z = nodes[mk].z; q[k].w = nodes[mk].w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (m0 + k <= phi) {
+                    const T dx = x - q[k].x, dy = y - q[k].y, dz = z - q[k].z;
+                    const T d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < best) { best = d2; a = m0 + k; }
+                }
+            }
         }
         ESTAMP(2);
         // ---- second node by distance (:313-329)
@@ -485,13 +503,15 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         const int c2 = (a == M - 1) ? M - 3 : a + 1;
         const V4<T> q1 = nodesL[c1], q2 = nodesL[c2], qa = nodesL[a];
         T dx = x - q1.x, dy = y - q1.y, dz = z - q1.z;
-        const T e1 = Num<T>::sqrt(dx * dx + dy * dy + dz * dz);
+        const T s1 = dx * dx + dy * dy + dz * dz;
         dx = x - q2.x; dy = y - q2.y; dz = z - q2.z;
-        const T e2 = Num<T>::sqrt(dx * dx + dy * dy + dz * dz);
-        const bool first = e1 < e2;
+        const T s2 = dx * dx + dy * dy + dz * dz;
+        bool first; T eb;
+        if constexpr (sizeof(T) == 4) { first = s1 < s2; eb = Num<T>::sqrt_fast(first ? s1 : s2); }      // the decision of :324 on the squares: one square root
+        else { const T e1 = Num<T>::sqrt_fast(s1), e2 = Num<T>::sqrt_fast(s2); first = e1 < e2; eb = first ? e1 : e2; }   // fp64: the reference's comparison of norms
         const int b = first ? c1 : c2;
-        const T eb = first ? e1 : e2, cb = first ? q1.w : q2.w;
-        const T ea = Num<T>::sqrt(best);
+        const T cb = first ? q1.w : q2.w;
+        const T ea = Num<T>::sqrt_fast(best);
         const bool a_lo = a < b;
         const int lo = a_lo ? a : b, hi = a_lo ? b : a;
         const T d_lo = a_lo ? ea : eb, d_hi = a_lo ? eb : ea;
@@ -500,9 +520,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         // ---- node window of this wave
         int wlo = 0, whi = M - 1;
         {
-            T amin = valid ? c_lo : Num<T>::inf(), amax = valid ? c_hi : -Num<T>::inf();
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { amin = tmin(amin, __shfl_xor(amin, o)); amax = -tmin(-amax, -__shfl_xor(amax, o)); }
+            const T amin = wave_min_nonneg(valid ? c_lo : Num<T>::inf()), amax = wave_max_nonneg(valid ? c_hi : T(0));   // coord >= 0
             int first = M, last = -1;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -520,27 +538,42 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 
         ESTAMP(3);
         // ---- unnormalised membership, column sum, Q (:354-383)
+        // adj: no point of this wave has the end-node gap (hi == lo + 2), the cheaper form of the exponent applies
+        const bool adj = __ballot(valid && hi - lo != 1) == 0;
         T sum = 0, qs = 0;
-#pragma unroll 4
-        for (int m = wlo; m <= whi; ++m) {
-            V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
-            T e = geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi) * k2;
+        auto member = [&](const V4<T> &q, int m, auto ADJ, auto STORE) {
+            T e = (decltype(ADJ)::value ? geo_arg_adj<T>(m, lo, q.w, c_lo, d_lo, c_hi, d_hi) : geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi)) * k2;
             if (VIS) e += lvL[m];
             const T p = Num<T>::exp2(e);
             const T ddx = x - q.x, ddy = y - q.y, ddz = z - q.z;
             const T d2 = ddx * ddx + ddy * ddy + ddz * ddz;
             sum += p;
             qs += p * d2;
-            if (m - wlo < RS) pb[(m - wlo) * kPStride + lane] = p;                   // the chunks of the window that fit the tile
+            if (decltype(STORE)::value) pb[(m - wlo) * kPStride + lane] = p;          // the chunks of the window that fit the tile
+        };
+        // [from, to] in groups of 4 nodes: scalar loads first (clamped index), evaluations beyond `to` skipped wave-uniformly
+        auto span = [&](int from, int to, auto ADJ, auto STORE) {
+            for (int m0 = from; m0 <= to; m0 += 4) {
+                V4<T> q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int mk = (m0 + k) < to ? (m0 + k) : to; q[k].x = nodes[mk].x; q[k].y = nodes[mk].y; q[k].z = nodes[mk].z; q[k].w = nodes[mk].w; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (m0 + k <= to) member(q[k], m0 + k, ADJ, STORE);
+            }
+        };
+        {
+            const int wst = (wlo + RS - 1) < whi ? (wlo + RS - 1) : whi;              // last node whose membership is stored
+            if (adj) { span(wlo, wst, std::true_type(), std::true_type()); span(wst + 1, whi, std::true_type(), std::false_type()); }
+            else { span(wlo, wst, std::false_type(), std::true_type()); span(wst + 1, whi, std::false_type(), std::false_type()); }
         }
         ESTAMP(4);
-        const T inv = valid ? T(1) / (sum + cn) : T(0);
+        const T inv = valid ? Num<T>::rcp_fast(sum + cn) : T(0);
         accQ += (double)(inv * qs);
         // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
         // wave's points within centimetres) and leave as the residual R_m = sum_n P_mn (x_n - y_m):
         // small numbers, so fp32 tile sums and fp32 block partials lose nothing that matters
-        const T ox = __shfl(x, 0), oy = __shfl(y, 0), oz = __shfl(z, 0);
-        V4<T> pw; pw.x = inv * (x - ox); pw.y = inv * (y - oy); pw.z = inv * (z - oz); pw.w = inv;
+        const T ox = bcast_first(x), oy = bcast_first(y), oz = bcast_first(z);
+        V4<T> pw; pw.x = inv; pw.y = inv * (x - ox); pw.z = inv * (y - oy); pw.w = inv * (z - oz);     // (s0, sx) and (sy, sz) pair up for v_pk_fma
         pts[wave * 64 + lane] = pw;
 
         {
@@ -558,7 +591,8 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             if (rec) {
 #pragma unroll 4
                 for (int m = wlo_c; m < wlo_c + Wn; ++m) {
-                    T e = geo_arg<T>(m, lo, hi, nodes[m].w, c_lo, d_lo, c_hi, d_hi) * k2;
+                    const T cm = nodes[m].w;
+                    T e = (adj ? geo_arg_adj<T>(m, lo, cm, c_lo, d_lo, c_hi, d_hi) : geo_arg<T>(m, lo, hi, cm, c_lo, d_lo, c_hi, d_hi)) * k2;
                     if (VIS) e += lvL[m];
                     pb[(m - wlo_c) * kPStride + lane] = Num<T>::exp2(e);
                 }
@@ -575,7 +609,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 for (int j = 0; j < nj; ++j) {
                     const T p = prow[j];
                     const V4<T> w = pw_[j];
-                    s0 += p * w.w; sx += p * w.x; sy += p * w.y; sz += p * w.z;
+                    s0 += p * w.x; sx += p * w.y; sy += p * w.z; sz += p * w.w;
                 }
             }
             s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
@@ -1376,11 +1410,12 @@ template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *
     int gx = 0;
     for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
     const dim3 grid(gx, F), block(EB);
-    const size_t lds = estep_lds_bytes<T, EB>(M, F == 1);
+    const bool single = F == 1 && fh[0].wide_tile;
+    const size_t lds = estep_lds_bytes<T, EB>(M, single);
 #define TDLO_E2(NCH, VIS, SINGLE) do { TDLO_TRY(set_lds(k_estep<T, NCH, VIS, EB, SINGLE>, lds)); \
         if (g_estep_ev[0]) hipExtLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, g_estep_ev[0], g_estep_ev[1], 0, fd, fh[0]); \
         else hipLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, fd, fh[0]); } while (0)
-#define TDLO_E(NCH, VIS) do { if (F == 1) TDLO_E2(NCH, VIS, true); else TDLO_E2(NCH, VIS, false); } while (0)
+#define TDLO_E(NCH, VIS) do { if (single) TDLO_E2(NCH, VIS, true); else TDLO_E2(NCH, VIS, false); } while (0)
     if (vis) { switch (nch) { case 1: TDLO_E(1, true); break; case 2: TDLO_E(2, true); break; case 4: TDLO_E(4, true); break; default: TDLO_E(8, true); } }
     else     { switch (nch) { case 1: TDLO_E(1, false); break; case 2: TDLO_E(2, false); break; case 4: TDLO_E(4, false); break; default: TDLO_E(8, false); } }
 #undef TDLO_E

@@ -36,7 +36,7 @@ struct FrameDev {
     // sizes / parameters (trackdlo.h:80-94)
     int N0, M, ldx, nblkE;
     int max_iter, include_lle, has_priors, vis_branch;
-    int precision, nprune_blocks, eb, pad1;    // eb: E-step workgroup size (256 or 512)
+    int precision, nprune_blocks, eb, wide_tile;    // eb: E-step workgroup size (256 or 512); wide_tile: 64-row transposition tile (one frame of moderate size)
     double tol, beta, lambda, lle_weight, mu, alpha, k_vis, vis_thr, sigma2_in;
     // cloud
     const double *Xraw;     // N0 x 3 column-major as uploaded
