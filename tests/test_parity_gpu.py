@@ -123,6 +123,40 @@ def test_c2_full_size_against_oracle(hip_ctx, oracle):
     assert g["converged"]
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_large_cloud_grouped_partials(hip_ctx, oracle, prec):
+    """A cloud that needs 512+ E-step workgroups (N >= 262 144): 24-row tile at several workgroups per CU, grid-stride batches,
+    block partials summed in 32 groups (k_part_reduce) before the M-step; with and without visibility weighting, and as a
+    batch of two frames (bit-identical to the single calls)."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 300000, 50
+    ctx = B.Context(device=0, max_frames=2, max_points=N, max_nodes=M)
+    try:
+        outs = []
+        for f, occl in enumerate((None, (0.4, 0.6))):
+            X, Y0, v = synth.scene(N, M, config=41, frame=f, occlude=occl, outliers=50)
+            vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0)) if occl else None
+            kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=4, tol=0.0, include_lle=False,
+                      alpha=0.0, k_vis=P["k_vis"] if occl else 0.0, visibility_threshold=P["visibility_threshold"])
+            o = oracle.cpd_lle(X, Y0, 0.0, visible_nodes=vext, **kw)
+            g = ctx.cpd_lle(X, Y0, 0.0, _params(kw, prec), visible_nodes=vext)
+            _check(g, o, prec)
+            if occl is None:
+                outs.append((X, Y0, g))
+        # two frames through the batch entry point: same bits as the single calls
+        X, Y0, g0 = outs[0]
+        X1, Y1, _ = synth.scene(N, M, config=41, frame=7, outliers=50)
+        kw["k_vis"] = 0.0
+        g1 = ctx.cpd_lle(X1, Y1, 0.0, _params(kw, prec))
+        ctx.set_cloud(0, X); ctx.set_cloud(1, X1)
+        b = ctx.cpd_lle_batch([Y0, Y1], [0.0, 0.0], _params(kw, prec))
+        np.testing.assert_array_equal(b["Y"][0], g0["Y"]); np.testing.assert_array_equal(b["Y"][1], g1["Y"])
+        assert b["sigma2"][0] == g0["sigma2"] and b["sigma2"][1] == g1["sigma2"]
+    finally:
+        ctx.close()
+
+
 def test_early_exit_and_max_iter_flags(hip_ctx, oracle):
     from trackdlo_amd import synth
     P = synth.LAUNCH_PARAMS

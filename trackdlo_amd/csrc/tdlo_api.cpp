@@ -54,7 +54,7 @@ struct NodeCarve {
         ctr = take(4); Y = take(3 * m); Y0 = take(3 * m); nodes = take(4 * m); coord = take(m);
         G = take(mm); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2); dbg = take(64);
         Ascr = take(std::max((size_t)(M | 1) * (m + 3), mstep_big_scratch_doubles(M)));
-        part = take((size_t)kMaxEstepBlocks * (4 * m + 2));
+        part = take((size_t)(kMaxEstepBlocks + kPartGroups) * (4 * m + 2));     // block partials + their group sums
         total = o;
     }
 };
@@ -216,6 +216,9 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
     f.coord = blk + nc.coord; f.G = blk + nc.G; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
     f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
+    // M-step input: the block partials themselves, or (large clouds) kPartGroups group sums stored behind the last block row
+    f.partM = blk + nc.part; f.nblkM = f.nblkE;
+    if (f.nblkE > kPartDirect) { f.partM = blk + nc.part + (size_t)kMaxEstepBlocks * (4 * (size_t)M + 2); f.nblkM = kPartGroups; }
     f.part = blk + nc.part; f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
     f.st = (IterState *)(blk + nc.st);
     return 0;

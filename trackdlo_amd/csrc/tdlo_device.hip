@@ -729,8 +729,8 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     // ---- 1. reduce the E-step block partials in a fixed order
     if (from_sums != 1) {
         typedef typename PartOf<T>::type PT;
-        const int nb = f.nblkE, nSp = part_stride<PT>(M);
-        const PT *partT = (const PT *)f.part;
+        const int nb = f.nblkM, nSp = part_stride<PT>(M);
+        const PT *partT = (const PT *)f.partM;
         for (int e = t; e < nS; e += kBlock) {
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int b = 0;
@@ -968,8 +968,8 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
 #pragma unroll
     for (int u = 0; u < GQ; ++u) { const int i = t + u * MB; gq[u] = i < M * M ? Gg[i] : 0.0; }
     if (from_sums != 1 && g < NG) {
-        const auto part = TDLO_AS_GLOBAL(pvec, f.part);
-        const int nb = f.nblkE;
+        const auto part = TDLO_AS_GLOBAL(pvec, f.partM);
+        const int nb = f.nblkM;
         constexpr int UL = 20;                        // loads in flight per thread; no scalar remainder loop (a
         for (int b = g; b < nb; b += UL * NG) {       // dependent load per trip costs a full memory latency each)
             pvec v[UL];
@@ -1504,10 +1504,46 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     return hipGetLastError();
 }
 
+// Large clouds (more than kPartDirect E-step workgroups): the block partials are first summed in kPartGroups groups of
+// consecutive blocks, spread over kPartGroups CUs, so that the single-workgroup M-step fetches 32 rows instead of 512
+// (400 KB through one CU took 25 us).  Fixed order inside a group, fp64 accumulation, one rounding to the partial type.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_part_reduce(const FrameDev *__restrict__ frames) {
+    const FrameDev &f = frames[blockIdx.y];
+    if (f.nblkE <= kPartDirect || f.st->done) return;
+    typedef typename PartOf<T>::type PT;
+    const int M = f.M, nS = 4 * M + 1, nSp = part_stride<PT>(M), nb = f.nblkE;
+    const int per = (nb + kPartGroups - 1) / kPartGroups;
+    const int b0 = blockIdx.x * per, b1 = (b0 + per) < nb ? (b0 + per) : nb;
+    const auto src = TDLO_AS_GLOBAL(PT, f.part);
+    PT *dst = (PT *)f.partM + (size_t)blockIdx.x * nSp;
+    for (int e = threadIdx.x; e < nS; e += kBlock) {
+        double a = 0;
+        for (int b = b0; b < b1; b += 16) {
+            PT v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int bb = (b + u) < b1 ? (b + u) : (b1 - 1); v[u] = src[(size_t)bb * nSp + e]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (b + u < b1) a += (double)v[u];
+        }
+        dst[e] = (PT)a;                  // an empty group (b0 >= nb) writes zeros
+    }
+}
+
+static hipError_t launch_part_reduce(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+    bool any = false;
+    for (int i = 0; i < F; ++i) any = any || fh[i].nblkE > kPartDirect;
+    if (!any) return hipSuccess;
+    if (fh[0].precision == TDLO_PREC_F64) hipLaunchKernelGGL((k_part_reduce<double>), dim3(kPartGroups, F), dim3(kBlock), 0, s, fd);
+    else hipLaunchKernelGGL((k_part_reduce<float>), dim3(kPartGroups, F), dim3(kBlock), 0, s, fd);
+    return hipGetLastError();
+}
+
 hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     if (fh[0].vis_branch) TDLO_TRY(f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s));
+    TDLO_TRY(launch_part_reduce(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s));
     return hipSuccess;
 }
@@ -1525,8 +1561,8 @@ hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int 
     switch (kind) {
         case 0: return f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s);
         case 1: return f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s);
-        case 2: return f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s);
-        case 3: return f64 ? launch_mstep_T<double>(fd, fh, F, 2, s) : launch_mstep_T<float>(fd, fh, F, 2, s);
+        case 2: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s);
+        case 3: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 2, s) : launch_mstep_T<float>(fd, fh, F, 2, s);
         case 4: return f64 ? launch_mstep_T<double>(fd, fh, F, 1, s) : launch_mstep_T<float>(fd, fh, F, 1, s);
         default: return hipErrorInvalidValue;
     }

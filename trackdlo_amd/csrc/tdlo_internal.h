@@ -9,6 +9,8 @@ constexpr int kBlock = 256;          // workgroup size of the point-parallel ker
 constexpr int kWave = 64;
 constexpr int kChunk = 64;           // nodes handled per lane-transposed tile
 constexpr int kPStride = 65;         // LDS row stride of the 64 x 64 transposition tile (conflict-free)
+constexpr int kPartDirect = 256;    // up to this many block partials go straight to the M-step (80 KB of fp32 at M = 50) ...
+constexpr int kPartGroups = 32;     // ... more are first summed in this many groups of consecutive blocks by k_part_reduce
 constexpr int kTileRows = 24;        // rows of the E-step's transposition tile when M <= 64: the node window is processed
                                      // in chunks of this many nodes (6 KB of LDS per wave -> two workgroups per CU)
 constexpr int kMaxNodes = 512;       // E-step template covers ceil(M/64) in {1,2,4,8}
@@ -59,6 +61,8 @@ struct FrameDev {
     const double *aYd;      // M x 3: alpha * (Y_extended - Y0) (:407)
     unsigned long long *dminbits;  // M: per-node min squared distance, as ordered bits
     double *part;           // nblkE x (4M+1) block partials [P1 | PXx | PXy | PXz | Q]
+    double *partM;          // the rows the M-step adds up: part itself, or the kPartGroups group sums behind it (nblkE > kPartDirect)
+    int nblkM, pad2;        // number of those rows
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result

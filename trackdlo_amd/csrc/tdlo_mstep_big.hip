@@ -74,8 +74,8 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
     // ---- 1. reduce the E-step block partials in a fixed order
     if (from_sums != 1) {
         typedef typename PartOf<T>::type PT;
-        const int nb = f.nblkE, nSp = part_stride<PT>(M);
-        const auto partT = TDLO_AS_GLOBAL(PT, f.part);
+        const int nb = f.nblkM, nSp = part_stride<PT>(M);
+        const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
         for (int e = t; e < nS; e += kBig) {
             double a0 = 0;
             for (int b = 0; b < nb; b += 32) {            // 32 loads in flight, block order kept
