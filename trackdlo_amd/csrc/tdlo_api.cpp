@@ -18,7 +18,10 @@ using namespace tdlo;
 
 namespace {
 
+#define TDLO_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
 constexpr int kMaxEstepBlocks = 1024;
+constexpr int kBatchStreams = 4;       // streams a batch of frames is spread over (run_frames); more than 4 lose (measured: 6 or 8 fall below one stream)
 constexpr int kChunkIters = 4;          // EM iterations per early-exit polling chunk; the first chunks are shorter (1, 1, 2):
                                         // a tracker in steady state converges in one or two iterations
 
@@ -64,6 +67,8 @@ struct NodeCarve {
 struct tdlo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2[kBatchStreams - 1] = {};   // further groups of a batch: their E-steps overlap another group's one-workgroup-per-frame M-step
+    hipEvent_t evx[kBatchStreams] = {}, evj[kBatchStreams] = {};   // fork / join of the batch groups
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0..3 timing, 4..5 early-exit polling
     tdlo_config cfg{};
     std::vector<Slot> slots;
@@ -255,9 +260,52 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
     HIPCHK(c, launch_prune_and_setup(c->fd, c->fh.data(), F, s));
     HIPCHK(c, hipEventRecord(c->ev[1], s));
+    // A batch runs as up to kBatchStreams groups of frames on as many streams, each group one E-step behind the previous
+    // one: a batch's M-step is one workgroup per frame (F of the 256 CUs busy for 17 us), and meanwhile the other groups'
+    // E-steps have the rest of the GPU.  The groups are independent registrations: the results do not depend on the split
+    // (TDLO_BATCH_STREAMS=1 disables it).
+    static const int ns_env = getenv("TDLO_BATCH_STREAMS") ? atoi(getenv("TDLO_BATCH_STREAMS")) : 0;
+    int NS = ns_env > 0 ? ns_env : (F >= 16 ? 4 : (F >= 8 ? 2 : 1));
+    NS = std::max(1, std::min(std::min(NS, kBatchStreams), F));
+    int goff[kBatchStreams + 1];
+    for (int g = 0; g <= NS; ++g) goff[g] = (int)(((long long)F * g) / NS);
+    hipStream_t gs[kBatchStreams];
+    gs[0] = s;
+    for (int g = 1; g < NS; ++g) gs[g] = c->stream2[g - 1];
+    bool forked = false;
+    auto iterate = [&](int n) -> hipError_t {
+        for (int it = 0; it < n; ++it) {
+            for (int g = 0; g < NS; ++g) {
+                const FrameDev *fdg = c->fd + goff[g], *fhg = c->fh.data() + goff[g];
+                const int Fg = goff[g + 1] - goff[g];
+                if (NS > 1 && !forked && g + 1 < NS) {
+                    // first iteration, kernel by kernel (same kernels, same order as launch_iteration), so that the next group
+                    // can be released when this group's first E-step has drained
+                    if (fhg[0].vis_branch) TDLO_RET(launch_estep_only(fdg, fhg, Fg, 1, gs[g]));
+                    TDLO_RET(launch_estep_only(fdg, fhg, Fg, 0, gs[g]));
+                    TDLO_RET(hipEventRecord(c->evx[g], gs[g]));
+                    TDLO_RET(hipStreamWaitEvent(gs[g + 1], c->evx[g], 0));
+                    TDLO_RET(launch_estep_only(fdg, fhg, Fg, 2, gs[g]));
+                } else {
+                    TDLO_RET(launch_iteration(fdg, fhg, Fg, gs[g]));
+                }
+            }
+            forked = true;
+        }
+        return hipSuccess;
+    };
+    auto join = [&]() -> hipError_t {          // everything enqueued on the other streams so far precedes what follows on the first
+        if (NS < 2 || !forked) return hipSuccess;
+        for (int g = 1; g < NS; ++g) {
+            TDLO_RET(hipEventRecord(c->evj[g - 1], gs[g]));
+            TDLO_RET(hipStreamWaitEvent(s, c->evj[g - 1], 0));
+        }
+        return hipSuccess;
+    };
+    auto stream_of = [&](int i) { int g = 0; while (g + 1 < NS && i >= goff[g + 1]) ++g; return gs[g]; };
     if (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) {
         // fixed iteration count: enqueue everything, no host involvement
-        for (int it = 0; it < p->max_iter; ++it) HIPCHK(c, launch_iteration(c->fd, c->fh.data(), F, s));
+        HIPCHK(c, iterate(p->max_iter));
     } else {
         // early exit (trackdlo.cpp:424-428) is decided on the device; kernels of finished frames are
         // no-ops.  To avoid enqueueing up to max_iter of them, iterations go out in chunks and the
@@ -267,11 +315,12 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         bool stop = false;
         while (launched < p->max_iter && !stop) {
             const int n = std::min(chunk < 2 ? 1 : (chunk == 2 ? 2 : kChunkIters), p->max_iter - launched);      // 1, 1, 2, 4, 4, ...
-            for (int it = 0; it < n; ++it) HIPCHK(c, launch_iteration(c->fd, c->fh.data(), F, s));
+            HIPCHK(c, iterate(n));
             launched += n;
             const int slotp = chunk & 1;
             for (int i = 0; i < F; ++i)
-                HIPCHK(c, hipMemcpyAsync(&flags[slotp * F + i], c->fh[i].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipMemcpyAsync(&flags[slotp * F + i], c->fh[i].st, sizeof(IterState), hipMemcpyDeviceToHost, stream_of(i)));
+            HIPCHK(c, join());
             HIPCHK(c, hipEventRecord(c->ev[4 + slotp], s));
             if (chunk > 0) {
                 const int prev = (chunk - 1) & 1;
@@ -283,6 +332,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             ++chunk;
         }
     }
+    HIPCHK(c, join());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
     for (int i = 0; i < F; ++i)
@@ -351,6 +401,9 @@ tdlo_ctx *tdlo_create(const tdlo_config *cfg_in, int *err) {
     c->device = cfg.device; c->cfg = cfg;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
+    for (auto &q : c->stream2) if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
+    for (auto &e : c->evx) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
+    for (auto &e : c->evj) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
     c->slots.resize(cfg.max_frames);
     if (hipMalloc((void **)&c->fd, sizeof(FrameDev) * cfg.max_frames) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
     for (auto &s : c->slots) {
@@ -378,6 +431,9 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
+    for (auto &e : c->evx) if (e) hipEventDestroy(e);
+    for (auto &e : c->evj) if (e) hipEventDestroy(e);
+    for (auto &q : c->stream2) if (q) hipStreamDestroy(q);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
