@@ -9,6 +9,8 @@ setup, 50 iterations, read-back of Y / sigma2) on a cloud that is already reside
 With --gpus N (torch.distributed.run, one rank per GPU, RCCL only for the barrier and the max-over-ranks
 of the time) every rank registers its own frame(s): frames are independent, so scaling is "weak" and
 there is no data-path collective (BASELINE.json configs[2]).
+--mode nsplit is BASELINE.json configs[3] instead: ONE frame of 2 000 000 points split over the ranks, per EM
+iteration an RCCL all-reduce of the 4M+2 sums on the context's stream ("scaling": "strong"; its own metric line).
 
 Extra objects on the JSON line:
   roofline     dominant kernel (the fused E-step): algorithmic bytes per launch (3 * 4 B * N, one read of
@@ -38,6 +40,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1, help="independent frames registered concurrently per rank (C2: 1)")
+    ap.add_argument("--mode", choices=["frames", "nsplit"], default="frames",
+                    help="frames (default, the BASELINE.json metric): every rank registers its own frame(s); nsplit (BASELINE.json "
+                         "configs[3]): ONE frame of 2 000 000 points split over the ranks, RCCL all-reduce of the 4M+2 sums per iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=5)
     args = ap.parse_args()
@@ -66,6 +71,8 @@ def main():
 
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
+    if args.mode == "nsplit":
+        return bench_nsplit(args, rank, world, dev_index, dist, torch, backend)
     F = args.frames
     ctx = B.Context(device=dev_index, max_frames=F, max_points=N_POINTS, max_nodes=M_NODES)   # raises without a GPU
     params = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
@@ -157,6 +164,66 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_nsplit(args, rank, world, dev_index, dist, torch, backend):
+    """BASELINE.json configs[3]: one frame, N = 2 000 000 points, M = 50, contiguous shard per rank; per EM iteration an
+    all-reduce SUM of [P1 | PX | Q | N] (4M+2 doubles) on the context's stream, identical M-step on every rank
+    (trackdlo_amd/nsplit.py, device-resident exchange).  Total work is fixed: "scaling": "strong".  A step is one whole
+    cpd_lle call on shards that are already resident in HBM."""
+    from trackdlo_amd import binding as B, nsplit, synth
+    P = synth.LAUNCH_PARAMS
+    NT, M = 2000000, M_NODES
+    if dist is None:                      # one rank: a one-rank RCCL group, so that the collectives are real launches
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+    dev = f"cuda:{dev_index}"
+    X, Y0, _ = synth.scene(NT, M, config=4)
+    lo, hi = rank * NT // world, (rank + 1) * NT // world
+    ctx = B.Context(device=dev_index, max_points=hi - lo, max_nodes=M)
+    params = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
+                           alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
+    xch = nsplit.TorchDeviceExchange(M, dev, stream_ptr=ctx.stream_ptr())
+    shard = nsplit.HipDeviceShard(ctx, X[lo:hi], xch)          # uploads the shard once; every step re-binds and re-registers
+    comm = nsplit.TorchComm(dev if backend == "nccl" else None)
+
+    def step():
+        shard.bind()
+        return nsplit.cpd_lle_nsplit_device(shard, xch, comm, Y0, 0.0, params)
+
+    def barrier():
+        dist.barrier(); torch.cuda.synchronize(); ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        est_us = ctx.profile_kernel(0, 50)
+        alg = 3 * 4 * (hi - lo)
+        line = dict(metric="EM iterations/sec at N=2M cloud pts, M=50 nodes, cloud split over the ranks", value=round(args.steps * EM_ITERS / dt, 2),
+                    unit="EM iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt * 1e3 / args.steps, 4),
+                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload=f"C4: one frame, N={NT} points split over {world} rank(s) ({hi - lo} per rank), M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, fp32 E-step + fp64 M-step",
+                                parallelism=f"points sharded over {world} rank(s); per iteration all-reduce SUM of 4M+2 doubles ({backend}), identical M-step on every rank"),
+                    us_per_iteration=round(dt * 1e6 / (args.steps * EM_ITERS), 2), iters=out["iters"], n_kept_global=out["n_kept_global"],
+                    roofline=dict(bound="hbm", kernel="k_estep<float,1,false>", achieved=round(alg / (est_us * 1e-6) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=round(alg / (est_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), traffic=None, avg_launch_us_back_to_back=round(est_us, 3),
+                                  algorithmic_bytes_per_launch=alg), cpu_baseline=None)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -149,7 +149,11 @@ class HipDeviceShard(HipShard):
     def __init__(self, ctx: B.Context, X_shard, xch):
         super().__init__(ctx, X_shard)
         self.xch = xch
-        ctx._chk(ctx.lib.tdlo_split_bind_exchange(ctx.h, C.c_void_p(xch.dmin.data_ptr()), C.c_void_p(xch.sums.data_ptr())))
+        self.bind()
+
+    def bind(self):
+        """(Re-)binds the exchange buffers; end() unbinds them, so a shard that registers again calls this first."""
+        self.ctx._chk(self.ctx.lib.tdlo_split_bind_exchange(self.ctx.h, C.c_void_p(self.xch.dmin.data_ptr()), C.c_void_p(self.xch.sums.data_ptr())))
 
     def dmin_enqueue(self):
         self.ctx._chk(self.ctx.lib.tdlo_split_dmin_enqueue(self.ctx.h))
