@@ -177,9 +177,11 @@ def bench_nsplit(args, rank, world, dev_index, dist, torch, backend):
     if dist is None:                      # one rank: a one-rank RCCL group, so that the collectives are real launches
         import torch
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        import tempfile
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         torch.cuda.set_device(dev_index)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+        dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="tdlo_pg_"), "store"), rank=0, world_size=1,
+                                device_id=torch.device("cuda", dev_index))
     dev = f"cuda:{dev_index}"
     X, Y0, _ = synth.scene(NT, M, config=4)
     lo, hi = rank * NT // world, (rank + 1) * NT // world

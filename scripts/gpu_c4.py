@@ -25,9 +25,11 @@ for N in (2000000, 250000):
     # rank they move no data, so this is the per-iteration cost of the protocol without the xGMI hop)
     import torch, torch.distributed as dist
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
+        import tempfile
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="tdlo_pg_"), "store"), rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
     for vis in (False, True):
         Xv, Yv, v = synth.scene(N, M, config=4, occlude=(0.4, 0.6) if vis else None)
         vext = synth.extend_visible(v, M, synth.geodesic_coord(Yv)) if vis else None

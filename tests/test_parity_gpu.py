@@ -317,17 +317,15 @@ def test_nsplit_device_exchange_single_rank_rccl(hip_ctx):
     """The device-resident N-split exchange (tdlo_split_*_enqueue + RCCL all-reduce of the bound device buffers, ordered on
     the context's stream, no host synchronisation inside an iteration) with a one-rank RCCL group reproduces the plain call,
     with fixed iteration counts and with the production stopping rule (device-side flag polled every few iterations)."""
-    import socket
+    import tempfile
     import torch
     import torch.distributed as dist
     from trackdlo_amd import binding as B, nsplit, synth
     P = synth.LAUNCH_PARAMS
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one-rank group on a box without network: bootstrap over loopback
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    store = os.path.join(tempfile.mkdtemp(prefix="tdlo_pg_"), "store")      # file rendezvous: no TCP store, no host-name lookups
+    dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         for vis, tol, prec in ((False, 0.0, B.PREC_F32), (True, 0.0, B.PREC_F32), (True, 2e-4, B.PREC_F32), (True, 0.0, B.PREC_F64)):
             X, Y0, v = synth.scene(6000, 40, config=6, occlude=(0.4, 0.6) if vis else None, outliers=11)
