@@ -245,6 +245,38 @@ def test_batch_equals_single(hip_ctx):
         assert out["stats"][f]["iters"] == 12 and out["stats"][f]["n_kept"] == single[f]["n_kept"]
 
 
+@pytest.mark.parametrize("F,tol,vis_on", [(8, 0.0, False), (13, 0.0, True), (16, 2e-4, False), (20, 2e-4, True), (9, 2e-4, False)])
+def test_batch_stream_groups_equal_single_calls(F, tol, vis_on):
+    """Batches of 8+ frames run as 2 or 4 groups of frames on as many streams (run_frames): fixed iteration counts and the
+    early-exit polling path (frames stop after different numbers of iterations), with and without visibility weighting --
+    every frame must equal, bit for bit, the same frame registered on its own."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M = 32
+    rng = np.random.default_rng(4200 + F)
+    ctx = B.Context(device=0, max_frames=F, max_points=1 << 14, max_nodes=64)
+    try:
+        kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=40 if tol else 7, tol=tol, include_lle=False,
+                  alpha=0.0, k_vis=P["k_vis"] if vis_on else 0.0, visibility_threshold=P["visibility_threshold"])
+        params = _params(kw, 0)
+        Ys, s2s, single, vext = [], [], [], None
+        for f in range(F):
+            X, Y0, v = synth.scene(int(rng.integers(300, 12000)), M, config=130 + F, frame=f, occlude=(0.4, 0.6) if vis_on else None)
+            if vis_on: vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0))
+            ctx.set_cloud(f, X)
+            Ys.append(Y0); s2s.append(float(rng.choice([0.0, 1e-4, 1e-5])))
+        for f in range(F):
+            single.append(ctx.cpd_lle_resident(f, Ys[f], s2s[f], params, visible_nodes=vext))
+        out = ctx.cpd_lle_batch(Ys, s2s, params, visible_nodes=vext)
+        for f in range(F):
+            assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"]
+            assert out["stats"][f]["iters"] == single[f]["iters"] and out["stats"][f]["converged"] == single[f]["converged"]
+        if tol:
+            assert len({out["stats"][f]["iters"] for f in range(F)}) > 1          # the frames did stop at different iterations
+    finally:
+        ctx.close()
+
+
 def test_nsplit_single_rank_equals_plain(hip_ctx):
     """The N-split entry points with one rank (identity collectives) reproduce the plain call."""
     from trackdlo_amd import binding as B, nsplit, synth
