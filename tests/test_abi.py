@@ -31,6 +31,22 @@ def test_abi_version(lib):
     assert lib.tdlo_abi_version() == 1
 
 
+def test_one_hip_runtime_per_process():
+    """Loading the library and then importing torch (the order the N-split driver meets in a test process) must leave ONE
+    libamdhip64 mapped: a second copy cannot initialise ("No HIP GPUs are available").  Run in a fresh interpreter."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from trackdlo_amd import binding\n"
+            "binding.load_library()\n"
+            "import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(len(libs), libs)\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().startswith("1 "), out.stdout
+
+
 def test_no_silent_cpu_fallback(lib):
     """Without a usable GPU the product must refuse to run rather than compute on the host."""
     from trackdlo_amd import binding
