@@ -37,17 +37,19 @@ __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lh = (int *)smem;                            // M: kept points of this block per nearest node
     const int N0 = f.N0, M = f.M;
-    for (int m = threadIdx.x; m < M; m += kBlock) lh[m] = 0;
-    __syncthreads();
+    double *Yl = (double *)(lh + ((M + 3) & ~3));     // 3M: the nodes, staged once per block (a scalar load per node and
+    for (int m = threadIdx.x; m < M; m += kBlock) lh[m] = 0;                           // coordinate stalled every trip of the loop)
+    for (int i = threadIdx.x; i < 3 * M; i += kBlock) Yl[i] = f.Yin[i];
     const int n = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = n < N0;
     double x = 0, y = 0, z = 0;
     if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
-    const double *__restrict__ Yi = f.Yin;
+    __syncthreads();
     double best = 1e300, sum = 0;
     int a0 = 0;
+#pragma unroll 4
     for (int m = 0; m < M; ++m) {
-        const double dx = Yi[m] - x, dy = Yi[M + m] - y, dz = Yi[2 * M + m] - z;
+        const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
         const double d2 = dx * dx + dy * dy + dz * dz;
         if (d2 < best) { best = d2; a0 = m; }
         sum += d2;
@@ -1496,7 +1498,7 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     int gx = 0;
     for (int i = 0; i < F; ++i) gx = fh[i].nprune_blocks > gx ? fh[i].nprune_blocks : gx;
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
-    hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * fh[0].M, s, fd);
+    hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(F), dim3(kBlock), 0, s, fd, 0);
     else hipLaunchKernelGGL((k_setup<float>), dim3(F), dim3(kBlock), 0, s, fd, 0);
     if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
@@ -1570,7 +1572,7 @@ hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int 
 
 hipError_t launch_split_setup(const FrameDev *fd, const FrameDev *fh, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
-    hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * fh[0].M, s, fd);
+    hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(1), dim3(kBlock), 0, s, fd, 1);
     else hipLaunchKernelGGL((k_setup<float>), dim3(1), dim3(kBlock), 0, s, fd, 1);
     if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
