@@ -204,7 +204,11 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0) ? 1 : 0;
     (void)vis;
     f.precision = p->precision;
-    f.nprune_blocks = (s.N0 + kBlock - 1) / kBlock;
+    // prune / counting-sort workgroups: 256 points each up to 1024 workgroups; larger clouds give every workgroup 2, 4, 8 ...
+    // consecutive tiles, so that the one-workgroup scan of the (workgroup, node) histogram in k_setup stays ~1000 rows
+    f.prune_tiles = 1;
+    while ((s.N0 + kBlock * f.prune_tiles - 1) / (kBlock * f.prune_tiles) > 1024) f.prune_tiles *= 2;
+    f.nprune_blocks = (s.N0 + kBlock * f.prune_tiles - 1) / (kBlock * f.prune_tiles);
     f.tol = p->tol; f.beta = p->beta; f.lambda = p->lambda; f.lle_weight = p->lle_weight; f.mu = p->mu;
     f.alpha = p->alpha; f.k_vis = p->k_vis; f.vis_thr = p->visibility_threshold; f.sigma2_in = sigma2;
     {   // per (prune block, node) histogram of the counting sort

@@ -40,29 +40,32 @@ __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restri
     double *Yl = (double *)(lh + ((M + 3) & ~3));     // 3M: the nodes, staged once per block (a scalar load per node and
     for (int m = threadIdx.x; m < M; m += kBlock) lh[m] = 0;                           // coordinate stalled every trip of the loop)
     for (int i = threadIdx.x; i < 3 * M; i += kBlock) Yl[i] = f.Yin[i];
-    const int n = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = n < N0;
-    double x = 0, y = 0, z = 0;
-    if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
     __syncthreads();
-    double best = 1e300, sum = 0;
-    int a0 = 0;
+    double ssum = 0;
+    for (int tt = 0; tt < f.prune_tiles; ++tt) {          // consecutive 256-point tiles of this workgroup
+        const int n = (blockIdx.x * f.prune_tiles + tt) * kBlock + threadIdx.x;
+        const bool valid = n < N0;
+        double x = 0, y = 0, z = 0;
+        if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
+        double best = 1e300, sum = 0;
+        int a0 = 0;
 #pragma unroll 4
-    for (int m = 0; m < M; ++m) {
-        const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        if (d2 < best) { best = d2; a0 = m; }
-        sum += d2;
+        for (int m = 0; m < M; ++m) {
+            const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) { best = d2; a0 = m; }
+            sum += d2;
+        }
+        const bool keep = valid && (::sqrt(best) < 0.1);
+        // the kept points are stored sorted by their nearest node (stable), which makes the points of a
+        // wave spatially coherent: the E-step then only touches the few nodes with non-zero membership
+        if (valid) f.bucket[n] = keep ? (unsigned short)a0 : (unsigned short)0xffff;
+        if (keep) atomicAdd(&lh[a0], 1);
+        ssum += block_sum(keep ? sum : 0.0, scratch);     // per tile, tiles in order: one tile per workgroup gives the former sums
     }
-    const bool keep = valid && (::sqrt(best) < 0.1);
-    // the kept points are stored sorted by their nearest node (stable), which makes the points of a
-    // wave spatially coherent: the E-step then only touches the few nodes with non-zero membership
-    if (valid) f.bucket[n] = keep ? (unsigned short)a0 : (unsigned short)0xffff;
-    if (keep) atomicAdd(&lh[a0], 1);
-    const double s = block_sum(keep ? sum : 0.0, scratch);
     __syncthreads();
     for (int m = threadIdx.x; m < M; m += kBlock) f.hist[(size_t)blockIdx.x * M + m] = lh[m];
-    if (threadIdx.x == 0) f.blksum[blockIdx.x] = s;
+    if (threadIdx.x == 0) f.blksum[blockIdx.x] = ssum;
 }
 
 // One workgroup per frame: scan of the prune counts, centring, chain coordinate + kernel G
@@ -218,34 +221,43 @@ __global__ __launch_bounds__(kBlock) void k_prune_scatter(const FrameDev *__rest
     const FrameDev &f = frames[blockIdx.y];
     if ((int)blockIdx.x >= f.nprune_blocks) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *wcnt = (int *)smem;                          // 4 x M: kept points per (wave, nearest node)
+    int *wcnt = (int *)smem;                          // 4 x M: kept points per (wave, nearest node) of the current tile
     const int M = f.M;
-    const int n = blockIdx.x * kBlock + threadIdx.x;
+    int *base = wcnt + 4 * M;                         // M: where this workgroup's next point of a node goes
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * M; i += kBlock) wcnt[i] = 0;
-    __syncthreads();
-    const int b = (n < f.N0) ? (int)f.bucket[n] : 0xffff;
-    const bool keep = b != 0xffff;
-    // rank of this point among the earlier points of the wave with the same nearest node (stable order)
-    int rank = 0;
-    unsigned long long remaining = __ballot(keep);
-    while (remaining) {
-        const int leader = (int)__builtin_ctzll(remaining);
-        const int b0 = __builtin_amdgcn_readlane(b, leader);
-        const unsigned long long mask = __ballot(keep && b == b0);
-        if (keep && b == b0) rank = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == leader) wcnt[w * M + b0] = __popcll(mask);
-        remaining &= ~mask;
-    }
-    __syncthreads();
-    if (keep) {
-        int dst = f.hist[(size_t)blockIdx.x * M + b] + rank;
-        for (int i = 0; i < w; ++i) dst += wcnt[i * M + b];
-        T *xs = (T *)f.Xs;
-        const size_t N0 = f.N0, ld = f.ldx;
-        xs[dst] = (T)(f.Xraw[n] - f.ctr[0]);
-        xs[ld + dst] = (T)(f.Xraw[N0 + n] - f.ctr[1]);
-        xs[2 * ld + dst] = (T)(f.Xraw[2 * N0 + n] - f.ctr[2]);
+    for (int m = threadIdx.x; m < M; m += kBlock) base[m] = f.hist[(size_t)blockIdx.x * M + m];
+    for (int tt = 0; tt < f.prune_tiles; ++tt) {          // the workgroup's tiles in order: the sort stays stable
+        const int n = (blockIdx.x * f.prune_tiles + tt) * kBlock + threadIdx.x;
+        for (int i = threadIdx.x; i < 4 * M; i += kBlock) wcnt[i] = 0;
+        __syncthreads();
+        const int b = (n < f.N0) ? (int)f.bucket[n] : 0xffff;
+        const bool keep = b != 0xffff;
+        // rank of this point among the earlier points of the wave with the same nearest node (stable order)
+        int rank = 0;
+        unsigned long long remaining = __ballot(keep);
+        while (remaining) {
+            const int leader = (int)__builtin_ctzll(remaining);
+            const int b0 = __builtin_amdgcn_readlane(b, leader);
+            const unsigned long long mask = __ballot(keep && b == b0);
+            if (keep && b == b0) rank = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == leader) wcnt[w * M + b0] = __popcll(mask);
+            remaining &= ~mask;
+        }
+        __syncthreads();
+        if (keep) {
+            int dst = base[b] + rank;
+            for (int i = 0; i < w; ++i) dst += wcnt[i * M + b];
+            T *xs = (T *)f.Xs;
+            const size_t N0 = f.N0, ld = f.ldx;
+            xs[dst] = (T)(f.Xraw[n] - f.ctr[0]);
+            xs[ld + dst] = (T)(f.Xraw[N0 + n] - f.ctr[1]);
+            xs[2 * ld + dst] = (T)(f.Xraw[2 * N0 + n] - f.ctr[2]);
+        }
+        if (tt + 1 < f.prune_tiles) {
+            __syncthreads();
+            for (int m = threadIdx.x; m < M; m += kBlock) base[m] += wcnt[m] + wcnt[M + m] + wcnt[2 * M + m] + wcnt[3 * M + m];
+            __syncthreads();
+        }
     }
 }
 
@@ -1501,8 +1513,8 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(F), dim3(kBlock), 0, s, fd, 0);
     else hipLaunchKernelGGL((k_setup<float>), dim3(F), dim3(kBlock), 0, s, fd, 0);
-    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
-    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
+    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
+    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
     return hipGetLastError();
 }
 
@@ -1575,8 +1587,8 @@ hipError_t launch_split_setup(const FrameDev *fd, const FrameDev *fh, hipStream_
     hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(1), dim3(kBlock), 0, s, fd, 1);
     else hipLaunchKernelGGL((k_setup<float>), dim3(1), dim3(kBlock), 0, s, fd, 1);
-    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
-    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 4 * fh[0].M, s, fd);
+    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
+    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
     return hipGetLastError();
 }
 

@@ -62,7 +62,7 @@ struct FrameDev {
     unsigned long long *dminbits;  // M: per-node min squared distance, as ordered bits
     double *part;           // nblkE x (4M+1) block partials [P1 | PXx | PXy | PXz | Q]
     double *partM;          // the rows the M-step adds up: part itself, or the kPartGroups group sums behind it (nblkE > kPartDirect)
-    int nblkM, pad2;        // number of those rows
+    int nblkM, prune_tiles; // number of those rows; 256-point tiles one prune workgroup handles (1 up to 262 144 points)
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
