@@ -124,7 +124,11 @@ int tdlo_cpd_lle(tdlo_ctx *ctx, const double *X, int N, double *Y, int M, double
 /* Batched form: F independent registrations (slots 0..F-1, clouds already resident), executed
  * concurrently on the GPU.  Arrays are indexed by frame; Y is F consecutive M x 3 blocks; priors/
  * visible_nodes are shared by all frames (pass K = 0 / n_vis = 0 for none).  No reference
- * counterpart: the reference processes one frame per call (BASELINE.json configs[2]). */
+ * counterpart: the reference processes one frame per call (BASELINE.json configs[2]).
+ * Batches of 8 or more frames are spread over 2 (16 or more: 4) streams owned by the context, staggered by one E-step,
+ * so that one group's M-step (one workgroup per frame) overlaps another group's E-step; every frame's result is the
+ * same, bit for bit, as from tdlo_cpd_lle_resident (environment TDLO_BATCH_STREAMS=1: one stream).  The call returns
+ * after all streams have drained. */
 int tdlo_cpd_lle_batch(tdlo_ctx *ctx, int F, double *Y, int M, double *sigma2,
                        const tdlo_params *params, const double *priors, int K,
                        const int *visible_nodes, int n_vis, const double *H_override,
