@@ -80,8 +80,14 @@ def _pin_hip_runtime():
         spec = sys.modules["torch"].__spec__ if "torch" in sys.modules else importlib.util.find_spec("torch")
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
         if cand and os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-            _hip_runtime = cand
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                _hip_runtime = cand
+            except OSError as e:           # a torch installation whose runtime cannot be mapped: keep /opt/rocm's
+                if mode == "torch":
+                    raise
+                import sys
+                print(f"trackdlo_amd: could not map {cand} ({e}); using the system HIP runtime", file=sys.stderr)
         elif mode == "torch":
             raise FileNotFoundError("TDLO_HIP_RUNTIME=torch, but no torch/lib/libamdhip64.so was found")
     return _hip_runtime
