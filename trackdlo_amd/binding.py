@@ -245,17 +245,16 @@ class Context:
         return self.cpd_lle_resident(0, Y, sigma2, params, priors, visible_nodes, H, check)
 
     def cpd_lle_batch(self, Ys, sigma2s, params: Params, priors=None, visible_nodes=None, H=None):
-        Ys = [np.asarray(y, dtype=np.float64) for y in Ys]
-        F = len(Ys); M = Ys[0].shape[0]
-        Yb = np.empty((F, 3, M), dtype=np.float64)
-        for i, y in enumerate(Ys):
-            Yb[i] = y.T
-        s2 = np.ascontiguousarray(np.asarray(sigma2s, dtype=np.float64)).copy()
+        Ya = np.asarray(Ys, dtype=np.float64)                     # F x M x 3
+        F, M = Ya.shape[0], Ya.shape[1]
+        Yb = np.ascontiguousarray(Ya.transpose(0, 2, 1))           # F consecutive column-major M x 3 blocks
+        s2 = np.array(sigma2s, dtype=np.float64)
         st = (Stats * F)()
         pri, K, vis, nv, Hm = self._opt(priors, visible_nodes, H)
         self._chk(self.lib.tdlo_cpd_lle_batch(self.h, F, _ptr(Yb), M, _ptr(s2), C.byref(params), _ptr(pri), K, _ptr(vis), nv,
                                               _ptr(Hm), C.cast(st, C.c_void_p)))
-        return dict(Y=[Yb[i].T.copy() for i in range(F)], sigma2=s2, stats=[s.as_dict() for s in st])
+        Yo = np.ascontiguousarray(Yb.transpose(0, 2, 1))
+        return dict(Y=[Yo[i] for i in range(F)], sigma2=s2, stats=[s.as_dict() for s in st])
 
     def visibility_prepass(self, slot, Y, visibility_threshold, d_vis, geodesic_coord):
         """trackdlo_node.cpp:257-277 + :345-360 (distance test and gap fill; no painter test)."""

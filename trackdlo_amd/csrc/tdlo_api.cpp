@@ -67,6 +67,8 @@ struct NodeCarve {
 struct tdlo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    double *xfer = nullptr;          // batches: device mirror of [F upload blocks | F read-back blocks], moved with one copy each way
+    size_t xfer_doubles = 0;
     hipStream_t stream2[kBatchStreams - 1] = {};   // further groups of a batch: their E-steps overlap another group's one-workgroup-per-frame M-step
     hipEvent_t evx[kBatchStreams] = {}, evj[kBatchStreams] = {};   // fork / join of the batch groups
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0..3 timing, 4..5 early-exit polling
@@ -108,6 +110,17 @@ int ensure_pin(tdlo_ctx *c, size_t doubles) {
     c->pin = nullptr; c->pin_doubles = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->pin, doubles * sizeof(double), hipHostMallocDefault));
     c->pin_doubles = doubles;
+    return 0;
+}
+
+int ensure_xfer(tdlo_ctx *c, size_t doubles) {
+    if (doubles <= c->xfer_doubles) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->xfer) hipFree(c->xfer);
+    c->xfer = nullptr; c->xfer_doubles = 0;
+    HIPCHK(c, hipMalloc((void **)&c->xfer, doubles * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(c->xfer, 0, doubles * sizeof(double), c->stream));
+    c->xfer_doubles = doubles;
     return 0;
 }
 
@@ -248,19 +261,33 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (F < 1 || F > c->cfg.max_frames) return fail(c, TDLO_E_INVALID, "bad frame count");
     NodeCarve nc(M);
     const size_t up = upload_doubles(nc, p);
-    rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2) + 2 * (size_t)F * ((sizeof(IterState) + 7) / 8) + 4);
+    // Batches move their host-supplied blocks and their results with ONE copy each way: every small copy is a 4-5 us blit
+    // kernel on the stream, and 32 frames x (upload + read-back [+ flags per polling chunk]) had grown to 0.3 ms of a 2.3 ms
+    // call.  The frames' [Yin | aJ | aYd | H] and [Yout | IterState] then live in one device buffer instead of the slots'
+    // node blocks (the kernels only see pointers).
+    const bool merged = F > 1;
+    const size_t ustride = merged ? up : nc.upload;
+    rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2) + 2 * (size_t)F * std::max(nc.readback, (sizeof(IterState) + 7) / 8) + 4);
     if (rc) return rc;
+    if (merged) { rc = ensure_xfer(c, (size_t)F * (up + nc.readback)); if (rc) return rc; }
     c->fh.assign(F, FrameDev{});
     for (int i = 0; i < F; ++i) {
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
-                           c->pin + (size_t)i * nc.upload, c->fh[i]);
+                           c->pin + (size_t)i * ustride, c->fh[i]);
         if (rc) return rc;
-        if (F > 1) c->fh[i].wide_tile = 0;
+        if (merged) {
+            FrameDev &f = c->fh[i];
+            f.wide_tile = 0;
+            double *bu = c->xfer + (size_t)i * up, *br = c->xfer + (size_t)F * up + (size_t)i * nc.readback;
+            f.Yin = bu + nc.Yin; f.aJ = bu + nc.aJ; f.aYd = bu + nc.aYd;
+            if (p->include_lle) f.H = bu + nc.H;
+            f.Yout = br; f.st = (IterState *)(br + (nc.st - nc.Yout));
+        }
     }
     hipStream_t s = c->stream;
     HIPCHK(c, hipEventRecord(c->ev[0], s));
-    for (int i = 0; i < F; ++i)
-        HIPCHK(c, hipMemcpyAsync(c->slots[slots[i]].nodeblk, c->pin + (size_t)i * nc.upload, up * sizeof(double), hipMemcpyHostToDevice, s));
+    if (merged) HIPCHK(c, hipMemcpyAsync(c->xfer, c->pin, (size_t)F * up * sizeof(double), hipMemcpyHostToDevice, s));
+    else HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
     HIPCHK(c, launch_prune_and_setup(c->fd, c->fh.data(), F, s));
     HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -306,7 +333,6 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         }
         return hipSuccess;
     };
-    auto stream_of = [&](int i) { int g = 0; while (g + 1 < NS && i >= goff[g + 1]) ++g; return gs[g]; };
     if (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) {
         // fixed iteration count: enqueue everything, no host involvement
         HIPCHK(c, iterate(p->max_iter));
@@ -314,7 +340,8 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         // early exit (trackdlo.cpp:424-428) is decided on the device; kernels of finished frames are
         // no-ops.  To avoid enqueueing up to max_iter of them, iterations go out in chunks and the
         // `done` flags of chunk i are inspected while chunk i+1 is already running (the GPU never idles).
-        IterState *flags = (IterState *)(c->pin + (size_t)F * nc.upload);     // pinned, 2 x F entries
+        IterState *flags = (IterState *)(c->pin + (size_t)F * nc.upload);     // pinned, 2 x F entries (one frame) ...
+        double *fl_rb = c->pin + (size_t)F * nc.upload;                        // ... or 2 x F read-back blocks (batches)
         int launched = 0, chunk = 0;
         bool stop = false;
         while (launched < p->max_iter && !stop) {
@@ -322,15 +349,24 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             HIPCHK(c, iterate(n));
             launched += n;
             const int slotp = chunk & 1;
-            for (int i = 0; i < F; ++i)
-                HIPCHK(c, hipMemcpyAsync(&flags[slotp * F + i], c->fh[i].st, sizeof(IterState), hipMemcpyDeviceToHost, stream_of(i)));
-            HIPCHK(c, join());
+            if (merged) {           // the whole read-back area (Yout + IterState per frame) in one copy, after the groups have joined
+                HIPCHK(c, join());
+                HIPCHK(c, hipMemcpyAsync(fl_rb + (size_t)slotp * F * nc.readback, c->xfer + (size_t)F * up, (size_t)F * nc.readback * sizeof(double),
+                                         hipMemcpyDeviceToHost, s));
+            } else {
+                HIPCHK(c, hipMemcpyAsync(&flags[slotp * F], c->fh[0].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+            }
             HIPCHK(c, hipEventRecord(c->ev[4 + slotp], s));
             if (chunk > 0) {
                 const int prev = (chunk - 1) & 1;
                 HIPCHK(c, hipEventSynchronize(c->ev[4 + prev]));
                 bool all = true;
-                for (int i = 0; i < F; ++i) all = all && flags[prev * F + i].done != 0;
+                for (int i = 0; i < F; ++i) {
+                    IterState is;
+                    if (merged) std::memcpy(&is, fl_rb + ((size_t)prev * F + i) * nc.readback + (nc.st - nc.Yout), sizeof is);
+                    else is = flags[prev * F + i];
+                    all = all && is.done != 0;
+                }
                 stop = all;
             }
             ++chunk;
@@ -339,8 +375,9 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     HIPCHK(c, join());
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
-    for (int i = 0; i < F; ++i)
-        HIPCHK(c, hipMemcpyAsync(c->pin + (size_t)i * nc.upload, c->slots[slots[i]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+    const size_t rstride = merged ? nc.readback : nc.upload;
+    if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+    else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     HIPCHK(c, hipStreamSynchronize(s));
     c->last_F = F;
@@ -350,7 +387,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     int worst = 0;
     for (int i = 0; i < F; ++i) {
-        const double *rb = c->pin + (size_t)i * nc.upload;
+        const double *rb = c->pin + (size_t)i * rstride;
         IterState is;
         std::memcpy(&is, rb + (nc.st - nc.Yout), sizeof is);
         if (is.status == 0 || is.status == TDLO_E_NUMERIC) {
@@ -435,6 +472,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
+    if (c->xfer) hipFree(c->xfer);
     for (auto &e : c->evx) if (e) hipEventDestroy(e);
     for (auto &e : c->evj) if (e) hipEventDestroy(e);
     for (auto &q : c->stream2) if (q) hipStreamDestroy(q);
