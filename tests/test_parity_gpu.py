@@ -191,6 +191,41 @@ def test_error_paths(hip_ctx):
     assert g["rc"] == 0 and g["iters"] == 5
 
 
+def test_batch_with_an_empty_frame():
+    """A batch (stream groups, merged copies) in which one frame loses every point to the prune: the call reports
+    TDLO_E_EMPTY, the other frames are registered as if alone, and the context stays usable."""
+    import ctypes as C
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    F, M = 9, 20
+    ctx = B.Context(device=0, max_frames=F, max_points=1 << 13, max_nodes=32)
+    try:
+        pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 6, 0.0, False)
+        Ys, single = [], []
+        for f in range(F):
+            X, Y0, _ = synth.scene(1500 + 100 * f, M, config=55, frame=f)
+            if f == 6: X = X + np.array([0, 0, 5.0])
+            ctx.set_cloud(f, X); Ys.append(Y0)
+        for f in range(F):
+            single.append(ctx.cpd_lle_resident(f, Ys[f], 0.0, pr, check=False))
+        assert single[6]["rc"] == B.TDLO_E_EMPTY
+        Yb = np.ascontiguousarray(np.asarray(Ys).transpose(0, 2, 1)); s2 = np.zeros(F); st = (B.Stats * F)()
+        rc = ctx.lib.tdlo_cpd_lle_batch(ctx.h, F, B._ptr(Yb), M, B._ptr(s2), C.byref(pr), None, 0, None, 0, None, C.cast(st, C.c_void_p))
+        assert rc == B.TDLO_E_EMPTY
+        for f in range(F):
+            if f == 6:
+                assert st[f].status == B.TDLO_E_EMPTY
+                np.testing.assert_array_equal(Yb[f].T, Ys[f])                                # untouched
+            else:
+                assert st[f].status == 0 and st[f].iters == 6
+                np.testing.assert_array_equal(Yb[f].T, single[f]["Y"])
+        ctx.set_cloud(6, synth.scene(2100, M, config=55, frame=6)[0])
+        out = ctx.cpd_lle_batch(Ys, [0.0] * F, pr)
+        assert all(s["status"] == 0 and s["iters"] == 6 for s in out["stats"])
+    finally:
+        ctx.close()
+
+
 def test_bitwise_repeatable(hip_ctx):
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
