@@ -39,6 +39,7 @@ struct Slot {
     int cap_nodes = 0;
     double *nodeblk = nullptr;
     size_t nodeblk_doubles = 0;
+    unsigned *sync = nullptr;        // 64 words, zeroed once: cross-workgroup hand-off state of the multi-CU M-step
 };
 
 struct NodeCarve {
@@ -148,6 +149,10 @@ int ensure_nodes(tdlo_ctx *c, Slot &s, int M) {
     NodeCarve nc(cap);
     HIPCHK(c, hipMalloc((void **)&s.nodeblk, nc.total * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(s.nodeblk, 0, nc.total * sizeof(double), c->stream));
+    if (!s.sync) {
+        HIPCHK(c, hipMalloc((void **)&s.sync, 64 * sizeof(unsigned)));
+        HIPCHK(c, hipMemsetAsync(s.sync, 0, 64 * sizeof(unsigned), c->stream));
+    }
     s.nodeblk_doubles = nc.total;
     s.cap_nodes = cap;
     return 0;
@@ -242,6 +247,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.partM = blk + nc.part; f.nblkM = f.nblkE;
     if (f.nblkE > kPartDirect) { f.partM = blk + nc.part + (size_t)kMaxEstepBlocks * (4 * (size_t)M + 2); f.nblkM = kPartGroups; }
     f.part = blk + nc.part; f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
+    f.sync = s.sync;
     f.st = (IterState *)(blk + nc.st);
     return 0;
 }
@@ -466,6 +472,7 @@ void tdlo_destroy(tdlo_ctx *c) {
         if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.bucket); hipFree(s.blksum); }
         if (s.hist) hipFree(s.hist);
         if (s.nodeblk) hipFree(s.nodeblk);
+        if (s.sync) hipFree(s.sync);
     }
     if (c->fd) hipFree(c->fd);
     if (c->cloud_ws) hipFree(c->cloud_ws);

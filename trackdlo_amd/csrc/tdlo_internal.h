@@ -67,6 +67,7 @@ struct FrameDev {
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
     unsigned long long *dbg; // 64 shader-clock stamps written by the M-step (tdlo_debug_stamps)
+    unsigned *sync;         // 64 words, zeroed when the slot is created: generation / arrivals / flags of k_mstep_mcu's hand-offs
     IterState *st;
 };
 

@@ -293,6 +293,306 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_mstep_mcu: the same elimination spread over the row blocks' own CUs (one workgroup per 16 rows of the tableau).
+//
+// Gauss-Jordan updates EVERY row block in every panel, so the row blocks never exchange anything but the panel's 16
+// reduced pivot rows U.  Workgroup rb keeps its 16 x Cp row block in MFMA accumulators from assembly to the end (the
+// tableau never touches memory); per panel pb
+//   * the owner (rb == pb) turns its tiles over through LDS (accumulator order -> thread = column), reduces the 16
+//     pivot rows exactly as k_mstep_big does (same operations in the same order: both kernels give the same bits),
+//     takes the result back into its accumulators and publishes U (<= 40 KB at M = 300) write-through (16-byte sc1
+//     buffer stores), drains, and one lane stores the panel's flag (agent scope, relaxed);
+//   * everybody else negates its tile (rb, pb) into A-operand order in LDS, one lane polls the flag (relaxed, s_sleep,
+//     bounded by the real-time clock), ONE agent-scope acquire, barrier, then C -= L U with four MFMAs per live tile
+//     and U read straight from memory in B-operand order (coalesced 512-byte rows).
+// Critical path per panel = reduce + publish + flag hop + one row block's update; the trailing update of the whole
+// tableau (0.28 of k_mstep_big's 0.51 ms at M = 300) runs beside it on the other CUs.  The last workgroup to arrive
+// (agent-scope ticket) gathers W and finishes the iteration (T = Y0 + G W, sigma2, stopping rule, publish).
+// Hand-off protocol and its costs: /opt/skills guide "Inter-workgroup communication" (sc1 payload + drained flag,
+// relaxed poll + one acquire).  Flags carry (generation, panel): the generation counter lives in the slot's sync words
+// and is advanced by the finishing workgroup, so no memset is needed between the iterations of a call.
+// sync words (unsigned, zeroed once when the slot is created): [0] generation, [1] arrivals, [2] singular, [16 + pb] flags.
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define TDLO_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr int kTS = 272;            // LDS stride of one 16 x 16 tile of the row block (256 + 16: thread = column reads spread over the banks)
+constexpr unsigned long long kSpinTicks = 5000000ull;     // 50 ms of the 100 MHz real-time clock: a hand-off takes microseconds
+
+template <typename T>
+__global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__ frames, int from_sums_in) {
+    const int from_sums = from_sums_in;
+    const FrameDev &f = frames[blockIdx.y];
+    IterState *st = f.st;
+    if (st->done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = f.M, t = threadIdx.x, lane = t & 63, w = t >> 6, rb = blockIdx.x;
+    const int nS = 4 * M + 1;
+    const int Mp = (M + 15) & ~15, Cp = Mp + 16, nrb = Mp >> 4, ncb = Cp >> 4;
+    double *S = (double *)smem;               // nS (+pad)
+    double *W = S + ((nS + 1) & ~1);          // 3M (+pad)
+    double *Tn = W + ((3 * M + 1) & ~1);      // 3M (+pad)
+    double *scratch = Tn + ((3 * M + 1) & ~1);// 16
+    double *pcol = scratch + 16;              // 2 x 16: pivot column of the current step, double-buffered
+    double *Abuf = pcol + 32;                 // 2 x 256: -tile (rb, pb) in A-operand order, double-buffered over panels
+    double *Ul = Abuf + 512;                  // ncb x kTS: the row block in B-operand order (= accumulator registers, lane-minor)
+    int *flg = (int *)(Ul + (ncb * kTS > 6 * 512 ? ncb * kTS : 6 * 512));   // [0] last arriver, [1] a spin ran into its time limit
+    const auto Gg = TDLO_AS_GLOBAL(double, f.G);
+    const auto Ub = TDLO_AS_GLOBAL_RW(double, f.Ascr);              // [pb][cb][s4][lane]: published pivot rows
+    const auto Wg = Ub + (size_t)Mp * Cp;                            // [d][Mp]: solution rows as the row blocks finish
+    gu32 *sync = (gu32 *)(uintptr_t)f.sync;
+    const unsigned gen = sync[0];                                    // written by the previous launch's finishing workgroup
+    const int cL = lane & 15, gL = lane >> 4;
+    if (t < 2) flg[t] = 0;
+
+    // ---- 1. block partials -> S (every workgroup, same order: the sums agree bit for bit)
+    if (from_sums != 1) {
+        typedef typename PartOf<T>::type PT;
+        const int nb = f.nblkM, nSp = part_stride<PT>(M);
+        const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
+        for (int e = t; e < nS; e += kBig) {
+            double a0 = 0;
+            for (int b = 0; b < nb; b += 32) {
+                PT v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) { const int bb = b + u < nb ? b + u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) if (b + u < nb) a0 += (double)v[u];
+            }
+            S[e] = a0;
+        }
+    } else {
+        for (int e = t; e < nS; e += kBig) S[e] = f.sums[e];
+    }
+    __syncthreads();
+
+    // ---- 2. this workgroup's rows of [A | B] (:392-413), straight into the accumulators: wave w holds column blocks w, w + 16, w + 32
+    const double sigma2 = st->sigma2;
+    const double c2 = f.lambda * sigma2;
+    const int pri = f.has_priors;
+    const V4<T> *ndq = (const V4<T> *)f.nodes;
+    mfma_d4 C[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int cb = w + 16 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * rb + 4 * r + gL, j = 16 * cb + cL;
+            double v = 0.0;
+            if (cb < ncb) {
+                if (i < M) {
+                    if (j < M) v = (S[i] + (pri ? f.aJ[i] : 0.0)) * Gg[(size_t)i * M + j] + (i == j ? c2 : 0.0);      // G symmetric
+                    else if (j >= Mp && j < Mp + 3) {
+                        const int d = j - Mp, qq = d * M + i;
+                        const double yd = d == 0 ? (double)ndq[i].x : (d == 1 ? (double)ndq[i].y : (double)ndq[i].z);
+                        v = S[M + qq] + S[i] * (yd - f.Y0[qq]);
+                        if (pri) v += f.aYd[qq];
+                    }
+                } else if (i == j) v = 1.0;
+            }
+            C[q][r] = v;
+        }
+    }
+
+    // ---- 3. blocked Gauss-Jordan, 16 pivot columns per panel
+    int singular = 0, timed_out = 0;
+    const size_t utile = (size_t)ncb << 8;                            // doubles per published panel
+    // buffer descriptor of the publish area (wave-uniform by construction: readfirstlane of the two address halves)
+    const unsigned long long ub_addr = (unsigned long long)(uintptr_t)f.Ascr;
+    const unsigned ub_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ub_addr), ub_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ub_addr >> 32));
+    const __amdgpu_buffer_rsrc_t ub_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((unsigned long long)ub_hi << 32) | ub_lo), 0,
+                                                                             (int)((size_t)Mp * Cp * sizeof(double)), 0x00020000);
+    for (int pb = 0; pb < nrb; ++pb) {
+        const int k0 = pb << 4;
+        const unsigned epoch = gen * 64u + (unsigned)pb + 1u;
+        if (rb == pb) {
+            // a. owner: row block -> LDS -> thread = column
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int cb = w + 16 * q;
+                if (cb >= pb && cb < ncb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ul[cb * kTS + (r << 6) + lane] = C[q][r];
+                }
+            }
+            __syncthreads();
+            const int col = k0 + t;
+            const bool act = col < Cp;
+            double u[16];
+            double *ucol = Ul + ((act ? col : k0) >> 4) * kTS + (col & 15);        // + 64 (r >> 2) + 16 (r & 3)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = act ? ucol[((r >> 2) << 6) + 16 * (r & 3)] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double *pc = pcol + (j & 1) * 16;
+                if (t == j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pc[r] = u[r];
+                }
+                __syncthreads();
+                const double pv = pc[j];
+                {
+                    const int e = (__double2hiint(pv) >> 20) & 0x7ff;
+                    if (e == 0 || e == 0x7ff) singular = 1;          // zero / denormal / non-finite pivot
+                }
+                const double v = u[j] * fast_rcp(pv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = (r == j) ? v : fma(-pc[r], v, u[r]);
+            }
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ucol[((r >> 2) << 6) + 16 * (r & 3)] = u[r];
+            }
+            __syncthreads();
+            // b. back into the accumulators, and out to the other row blocks (write-through, 16 bytes per lane)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int cb = w + 16 * q;
+                if (cb > pb && cb < ncb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) C[q][r] = Ul[cb * kTS + (r << 6) + lane];
+                }
+            }
+            const int n2 = (ncb - pb - 1) << 7;                       // 16-byte pieces of the live tiles
+            for (int e = t; e < n2; e += kBig) {
+                const int cb = pb + 1 + (e >> 7), off = (e & 127) << 1;
+                const u32x4 v = *(const u32x4 *)(Ul + cb * kTS + off);
+                __builtin_amdgcn_raw_buffer_store_b128(v, ub_rsrc, (int)(((size_t)pb * utile + ((size_t)cb << 8) + off) * sizeof(double)), 0, /*sc1*/ 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(sync + 16 + pb, epoch, TDLO_RLX_AGENT);
+        } else {
+            // c. everybody else: -L in A-operand order, wait for U, C -= L U
+            double *Ab = Abuf + (pb & 1) * 256;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (w + 16 * q == pb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ab[(cL >> 2) * 64 + (4 * r + gL) + 16 * (cL & 3)] = -C[q][r];
+                }
+            }
+            if (t == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(sync + 16 + pb, TDLO_RLX_AGENT) != epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) { flg[1] = 1; break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            double a[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) a[s4] = Ab[64 * s4 + lane];
+            const auto Up = Ub + (size_t)pb * utile + lane;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int cb = w + 16 * q;
+                if (cb > pb && cb < ncb) {
+                    double b[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) b[s4] = Up[((size_t)cb << 8) + (s4 << 6)];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) C[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], C[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    timed_out = flg[1];
+
+    // ---- 4. solution rows out, arrival ticket; the last workgroup finishes the iteration
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (w + 16 * q == nrb && cL < 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __hip_atomic_store((__attribute__((address_space(1))) unsigned long long *)(Wg + (size_t)cL * Mp + 16 * rb + 4 * r + gL),
+                                   (unsigned long long)__double_as_longlong(C[q][r]), TDLO_RLX_AGENT);
+        }
+    }
+    singular = __syncthreads_or(singular | timed_out);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        if (singular) __hip_atomic_fetch_or(sync + 2, 1u, TDLO_RLX_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(sync + 1, 1u, TDLO_RLX_AGENT);
+        flg[0] = (old == (unsigned)nrb - 1u);
+        if (flg[0]) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!flg[0]) return;
+    singular = (int)__hip_atomic_load(sync + 2, TDLO_RLX_AGENT);
+    for (int e = t; e < 3 * M; e += kBig) { const int i = e % M, d = e / M; W[e] = Wg[(size_t)d * Mp + i]; }
+    __syncthreads();
+
+    // ---- 5. T = Y0 + G W (:417): thread = (node, half of the k range)
+    {
+        const int i = t & 511, h = t >> 9;
+        double v0 = 0, v1 = 0, v2 = 0;
+        if (i < M) {
+            const int kh = (M + 1) >> 1, kb = h * kh, ke = (kb + kh) < M ? (kb + kh) : M;
+            for (int k = kb; k < ke; ++k) { const double gk = Gg[(size_t)k * M + i]; v0 += gk * W[k]; v1 += gk * W[M + k]; v2 += gk * W[2 * M + k]; }
+        }
+        double *tmp = Ul;                     // free now: 6 x 512 doubles
+        if (i < M) { tmp[(h * 3 + 0) * 512 + i] = v0; tmp[(h * 3 + 1) * 512 + i] = v1; tmp[(h * 3 + 2) * 512 + i] = v2; }
+        __syncthreads();
+        for (int e = t; e < 3 * M; e += kBig) { const int m = e % M, d = e / M; Tn[e] = f.Y0[e] + (tmp[d * 512 + m] + tmp[(3 + d) * 512 + m]); }
+    }
+    __syncthreads();
+
+    // ---- 6. sigma2 (residual form of :418-422) and the convergence criterion (:424)
+    double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
+    for (int m = t; m < M; m += kBig) {
+        const double yx = (double)ndq[m].x, yy = (double)ndq[m].y, yz = (double)ndq[m].z;    // nodes as the E-step saw them
+        const double p1 = S[m];
+        const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
+        s_np += p1;
+        s_dr += dx * S[M + m] + dy * S[2 * M + m] + dz * S[3 * M + m];
+        s_pd += p1 * (dx * dx + dy * dy + dz * dz);
+        const double ex = f.Y[m] - Tn[m], ey = f.Y[M + m] - Tn[M + m], ez = f.Y[2 * M + m] - Tn[2 * M + m];
+        s_cr += ::sqrt(ex * ex + ey * ey + ez * ez);
+    }
+    s_np = block_sum16(s_np, scratch);
+    s_dr = block_sum16(s_dr, scratch);
+    s_pd = block_sum16(s_pd, scratch);
+    s_cr = block_sum16(s_cr, scratch);
+    const double new_sigma2 = (S[4 * M] - 2.0 * s_dr + s_pd) / (s_np * 3.0);
+    const double crit = s_cr / (double)M;
+
+    // ---- 7. publish Y, nodes, iteration state; re-arm the sync words for the next launch
+    V4<T> *nodes_w = (V4<T> *)f.nodes;
+    for (int m = t; m < M; m += kBig) {
+        V4<T> q; q.x = (T)Tn[m]; q.y = (T)Tn[M + m]; q.z = (T)Tn[2 * M + m]; q.w = (T)f.coord[m];
+        nodes_w[m] = q;
+        f.dminbits[m] = ~0ull;
+    }
+    for (int e = t; e < 3 * M; e += kBig) {
+        f.Y[e] = Tn[e];
+        f.Yout[e] = Tn[e] + f.ctr[e / M];
+    }
+    if (t == 0) {
+        __hip_atomic_store(sync + 1, 0u, TDLO_RLX_AGENT);
+        __hip_atomic_store(sync + 2, 0u, TDLO_RLX_AGENT);
+        __hip_atomic_store(sync + 0, gen + 1u, TDLO_RLX_AGENT);
+        const int it = st->it + 1;
+        st->it = it; st->crit = crit; st->Np = s_np;
+        const double Nc = st->Nc;
+        const bool finite_ok = (new_sigma2 == new_sigma2) && (fabs(new_sigma2) < 1e300) && (new_sigma2 > 0) && !singular;
+        if (finite_ok) set_iter_consts(f, st, new_sigma2, Nc);
+        else { st->sigma2 = new_sigma2; st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
+        if (crit < f.tol) st->done = 1;                                   // :424-428
+        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+    }
+}
+
+size_t mcu_lds_bytes(int M) {
+    const int nS = 4 * M + 1, Mp = (M + 15) & ~15, Cp = Mp + 16, ncb = Cp >> 4;
+    size_t ul = (size_t)ncb * kTS;
+    if (ul < 6 * 512) ul = 6 * 512;
+    const size_t d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 16 + 32 + 512 + ul + 2;
+    return d * sizeof(double);
+}
+
 size_t big_lds_bytes(int M) {
     const int nS = 4 * M + 1, Mp = (M + 15) & ~15, Cp = Mp + 16;
     size_t d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 16 + 272 + (size_t)16 * (Cp + 16);
@@ -304,9 +604,31 @@ size_t big_lds_bytes(int M) {
 
 size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16) + Mp * 16; }
 
+// TDLO_MSTEP_BIG=1wg keeps the whole elimination in one workgroup (k_mstep_big, the comparator of the tests and of
+// scripts/gpu_c5.py); the export-only form of the N-split interface (from_sums == 2) has no elimination and stays there.
+static bool mcu_enabled() {
+    static const int on = [] { const char *e = getenv("TDLO_MSTEP_BIG"); return (e && e[0] == '1') ? 0 : 1; }();
+    return on != 0;
+}
+
 hipError_t launch_mstep_big(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, bool f64, hipStream_t s) {
-    const size_t lds = big_lds_bytes(fh[0].M);
+    const int M = fh[0].M;
     hipError_t e;
+    if (from_sums != 2 && mcu_enabled()) {
+        const size_t lds = mcu_lds_bytes(M);
+        const dim3 grid((unsigned)((M + 15) >> 4), (unsigned)F);
+        if (f64) {
+            e = hipFuncSetAttribute((const void *)k_mstep_mcu<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_mstep_mcu<double>), grid, dim3(kBig), lds, s, fd, from_sums);
+        } else {
+            e = hipFuncSetAttribute((const void *)k_mstep_mcu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_mstep_mcu<float>), grid, dim3(kBig), lds, s, fd, from_sums);
+        }
+        return hipGetLastError();
+    }
+    const size_t lds = big_lds_bytes(M);
     if (f64) {
         e = hipFuncSetAttribute((const void *)k_mstep_big<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
