@@ -339,33 +339,59 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     int *flg = (int *)(Ul + (ncb * kTS > 6 * 512 ? ncb * kTS : 6 * 512));   // [0] last arriver, [1] a spin ran into its time limit
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
     const auto Ub = TDLO_AS_GLOBAL_RW(double, f.Ascr);              // [pb][cb][s4][lane]: published pivot rows
-    const auto Wg = Ub + (size_t)Mp * Cp;                            // [d][Mp]: solution rows as the row blocks finish
+    const auto Tp = Ub + (size_t)Mp * Cp + (size_t)Mp * 16;         // [rb][d][M]: the row blocks' contributions G[:, rows] W[rows] to G W
     gu32 *sync = (gu32 *)(uintptr_t)f.sync;
     const unsigned gen = sync[0];                                    // written by the previous launch's finishing workgroup
     const int cL = lane & 15, gL = lane >> 4;
     if (t < 2) flg[t] = 0;
+#ifdef TDLO_MCU_STAMPS
+#define MSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
+    if (rb == 0) MSTAMP(0);
 
-    // ---- 1. block partials -> S (every workgroup, same order: the sums agree bit for bit)
-    if (from_sums != 1) {
-        typedef typename PartOf<T>::type PT;
-        const int nb = f.nblkM, nSp = part_stride<PT>(M);
-        const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
-        for (int e = t; e < nS; e += kBig) {
+    // ---- 1. block partials -> the 4 x 16 sums this row block needs (P1, PX of its 16 nodes): wave = group of every 16th
+    //         partial row, lane = (quantity, node); the 16 groups are added in a fixed order.  The sums go to f.sums for the
+    //         workgroup that finishes the iteration (every workgroup reading all 256 rows cost 35 us at N >= 64 000).
+    double *Sown = W;                               // 64 doubles; W and Tn are only used by the finishing workgroup afterwards
+    {
+        const int ii = lane & 15, kk = lane >> 4, irow = 16 * rb + ii;
+        const bool valid = irow < M;
+        const int e = kk * M + (valid ? irow : 0);
+        auto sums_g = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.sums;
+        if (from_sums != 1) {
+            typedef typename PartOf<T>::type PT;
+            const int nb = f.nblkM, nSp = part_stride<PT>(M);
+            const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
             double a0 = 0;
-            for (int b = 0; b < nb; b += 32) {
-                PT v[32];
+            for (int b = w; b < nb; b += 256) {
+                PT v[16];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) { const int bb = b + u < nb ? b + u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
+                for (int u = 0; u < 16; ++u) { const int bb = b + 16 * u < nb ? b + 16 * u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
 #pragma unroll
-                for (int u = 0; u < 32; ++u) if (b + u < nb) a0 += (double)v[u];
+                for (int u = 0; u < 16; ++u) if (b + 16 * u < nb) a0 += (double)v[u];
             }
-            S[e] = a0;
-        }
-    } else {
-        for (int e = t; e < nS; e += kBig) S[e] = f.sums[e];
+            double *red = Ul;
+            red[w * 64 + lane] = a0;
+            __syncthreads();
+            if (w == 0) {
+                double a = 0;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) a += red[g * 64 + lane];
+                Sown[lane] = valid ? a : 0.0;
+                if (valid) __hip_atomic_store(sums_g + e, (unsigned long long)__double_as_longlong(a), TDLO_RLX_AGENT);
+            }
+            if (rb == 0) {                     // Q = sum P |x - y|^2, only needed for sigma2
+                double q = 0;
+                for (int b = t; b < nb; b += kBig) q += (double)partT[(size_t)b * nSp + 4 * M];
+                q = block_sum16(q, scratch);
+                if (t == 0) __hip_atomic_store(sums_g + 4 * M, (unsigned long long)__double_as_longlong(q), TDLO_RLX_AGENT);
+            }
+        } else if (w == 0) Sown[lane] = valid ? f.sums[e] : 0.0;
     }
     __syncthreads();
-
+    if (rb == 0) MSTAMP(1);
     // ---- 2. this workgroup's rows of [A | B] (:392-413), straight into the accumulators: wave w holds column blocks w, w + 16, w + 32
     const double sigma2 = st->sigma2;
     const double c2 = f.lambda * sigma2;
@@ -381,11 +407,11 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
             double v = 0.0;
             if (cb < ncb) {
                 if (i < M) {
-                    if (j < M) v = (S[i] + (pri ? f.aJ[i] : 0.0)) * Gg[(size_t)i * M + j] + (i == j ? c2 : 0.0);      // G symmetric
+                    if (j < M) v = (Sown[4 * r + gL] + (pri ? f.aJ[i] : 0.0)) * Gg[(size_t)i * M + j] + (i == j ? c2 : 0.0);      // G symmetric
                     else if (j >= Mp && j < Mp + 3) {
                         const int d = j - Mp, qq = d * M + i;
                         const double yd = d == 0 ? (double)ndq[i].x : (d == 1 ? (double)ndq[i].y : (double)ndq[i].z);
-                        v = S[M + qq] + S[i] * (yd - f.Y0[qq]);
+                        v = Sown[16 * (1 + d) + 4 * r + gL] + Sown[4 * r + gL] * (yd - f.Y0[qq]);
                         if (pri) v += f.aYd[qq];
                     }
                 } else if (i == j) v = 1.0;
@@ -394,6 +420,7 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
         }
     }
 
+    if (rb == 0) MSTAMP(2);
     // ---- 3. blocked Gauss-Jordan, 16 pivot columns per panel
     int singular = 0, timed_out = 0;
     const size_t utile = (size_t)ncb << 8;                            // doubles per published panel
@@ -407,39 +434,56 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
         const unsigned epoch = gen * 64u + (unsigned)pb + 1u;
         if (rb == pb) {
             // a. owner: row block -> LDS -> thread = column
+            MSTAMP(8 + pb);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int cb = w + 16 * q;
-                if (cb >= pb && cb < ncb) {
-#pragma unroll
+                if (cb < ncb) {                   // dead tiles (cb < pb) too: the accumulators are reloaded wholesale below, so
+#pragma unroll                            // that they do not occupy registers during the reduction
                     for (int r = 0; r < 4; ++r) Ul[cb * kTS + (r << 6) + lane] = C[q][r];
                 }
             }
             __syncthreads();
+            // Every wave with live columns runs the 16 steps on its own: besides its 64 columns it carries a copy of the
+            // 16 pivot columns (lanes 0..15 of pk), whose j-th column after j steps is the multiplier column of step j and
+            // reaches the FMAs as wave-uniform operands (v_readlane).  No barrier and no LDS traffic inside the 16 steps
+            // (one barrier + 16 broadcast LDS reads per step and wave had made this phase 8.2 us; the operations on every
+            // element are those of k_mstep_big, in the same order).
             const int col = k0 + t;
             const bool act = col < Cp;
+            const bool wlive = k0 + 64 * w < Cp;
             double u[16];
-            double *ucol = Ul + ((act ? col : k0) >> 4) * kTS + (col & 15);        // + 64 (r >> 2) + 16 (r & 3)
+            if (wlive) {
+                double pk[16];
+                const double *ucol = Ul + ((act ? col : k0) >> 4) * kTS + (col & 15);        // + 64 (r >> 2) + 16 (r & 3)
+                const double *pkcol = Ul + pb * kTS + cL;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u[r] = act ? ucol[((r >> 2) << 6) + 16 * (r & 3)] : 0.0;
+                for (int r = 0; r < 16; ++r) { u[r] = ucol[((r >> 2) << 6) + 16 * (r & 3)]; pk[r] = pkcol[((r >> 2) << 6) + 16 * (r & 3)]; }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double *pc = pcol + (j & 1) * 16;
-                if (t == j) {
+                for (int j = 0; j < 16; ++j) {
+                    double pc[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pc[r] = u[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const long long b = __double_as_longlong(pk[r]);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, j), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), j);
+                        pc[r] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                    }
+                    const double pv = pc[j];
+                    singular |= (int)((unsigned)(((__double2hiint(pv) >> 20) & 0x7ff) - 1) >= 0x7feu);     // zero / denormal / non-finite pivot
+                    const double ri = fast_rcp(pv);
+                    const double v = u[j] * ri, vk = pk[j] * ri;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { u[r] = (r == j) ? v : fma(-pc[r], v, u[r]); pk[r] = (r == j) ? vk : fma(-pc[r], vk, pk[r]); }
+                    // keep the two chains in step: left alone, the scheduler runs the 16 steps on pk first and parks all 256
+                    // multipliers in spill lanes (512 v_writelane + 512 v_readlane)
+                    asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]),
+                                      "+v"(u[8]), "+v"(u[9]), "+v"(u[10]), "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15]));
                 }
-                __syncthreads();
-                const double pv = pc[j];
-                {
-                    const int e = (__double2hiint(pv) >> 20) & 0x7ff;
-                    if (e == 0 || e == 0x7ff) singular = 1;          // zero / denormal / non-finite pivot
-                }
-                const double v = u[j] * fast_rcp(pv);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u[r] = (r == j) ? v : fma(-pc[r], v, u[r]);
             }
-            if (act) {
+            MSTAMP(28 + pb);
+            __syncthreads();                      // every wave has fetched its copy of the pivot columns
+            if (wlive && act) {
+                double *ucol = Ul + (col >> 4) * kTS + (col & 15);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ucol[((r >> 2) << 6) + 16 * (r & 3)] = u[r];
             }
@@ -448,10 +492,8 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int cb = w + 16 * q;
-                if (cb > pb && cb < ncb) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) C[q][r] = Ul[cb * kTS + (r << 6) + lane];
-                }
+                for (int r = 0; r < 4; ++r) C[q][r] = cb < ncb ? Ul[cb * kTS + (r << 6) + lane] : 0.0;
             }
             const int n2 = (ncb - pb - 1) << 7;                       // 16-byte pieces of the live tiles
             for (int e = t; e < n2; e += kBig) {
@@ -500,14 +542,34 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     }
     timed_out = flg[1];
 
-    // ---- 4. solution rows out, arrival ticket; the last workgroup finishes the iteration
+    // ---- 4. this row block's share of G W (:417): G[:, its rows] W[its rows], M x 3, handed to the finishing workgroup
+    {
+        double *Wown = Abuf;                  // [d][16]
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        if (w + 16 * q == nrb && cL < 3) {
+        for (int q = 0; q < 3; ++q) {
+            if (w + 16 * q == nrb && cL < 3) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                __hip_atomic_store((__attribute__((address_space(1))) unsigned long long *)(Wg + (size_t)cL * Mp + 16 * rb + 4 * r + gL),
-                                   (unsigned long long)__double_as_longlong(C[q][r]), TDLO_RLX_AGENT);
+                for (int r = 0; r < 4; ++r) Wown[cL * 16 + 4 * r + gL] = C[q][r];
+            }
+        }
+        __syncthreads();
+        const int i = t & 511, h = t >> 9;
+        double v0 = 0, v1 = 0, v2 = 0;
+        if (i < M) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = 8 * h + k, row = 16 * rb + kk;
+                if (row < M) { const double gk = Gg[(size_t)row * M + i]; v0 += gk * Wown[kk]; v1 += gk * Wown[16 + kk]; v2 += gk * Wown[32 + kk]; }
+            }
+        }
+        double *tmp = Ul;
+        if (h == 1 && i < M) { tmp[i] = v0; tmp[512 + i] = v1; tmp[1024 + i] = v2; }
+        __syncthreads();
+        if (h == 0 && i < M) {
+            auto tp = (__attribute__((address_space(1))) unsigned long long *)(Tp + (size_t)rb * 3 * M);
+            __hip_atomic_store(tp + i, (unsigned long long)__double_as_longlong(v0 + tmp[i]), TDLO_RLX_AGENT);
+            __hip_atomic_store(tp + M + i, (unsigned long long)__double_as_longlong(v1 + tmp[512 + i]), TDLO_RLX_AGENT);
+            __hip_atomic_store(tp + 2 * M + i, (unsigned long long)__double_as_longlong(v2 + tmp[1024 + i]), TDLO_RLX_AGENT);
         }
     }
     singular = __syncthreads_or(singular | timed_out);
@@ -521,22 +583,14 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     }
     __syncthreads();
     if (!flg[0]) return;
+    MSTAMP(3);
     singular = (int)__hip_atomic_load(sync + 2, TDLO_RLX_AGENT);
-    for (int e = t; e < 3 * M; e += kBig) { const int i = e % M, d = e / M; W[e] = Wg[(size_t)d * Mp + i]; }
-    __syncthreads();
-
-    // ---- 5. T = Y0 + G W (:417): thread = (node, half of the k range)
-    {
-        const int i = t & 511, h = t >> 9;
-        double v0 = 0, v1 = 0, v2 = 0;
-        if (i < M) {
-            const int kh = (M + 1) >> 1, kb = h * kh, ke = (kb + kh) < M ? (kb + kh) : M;
-            for (int k = kb; k < ke; ++k) { const double gk = Gg[(size_t)k * M + i]; v0 += gk * W[k]; v1 += gk * W[M + k]; v2 += gk * W[2 * M + k]; }
-        }
-        double *tmp = Ul;                     // free now: 6 x 512 doubles
-        if (i < M) { tmp[(h * 3 + 0) * 512 + i] = v0; tmp[(h * 3 + 1) * 512 + i] = v1; tmp[(h * 3 + 2) * 512 + i] = v2; }
-        __syncthreads();
-        for (int e = t; e < 3 * M; e += kBig) { const int m = e % M, d = e / M; Tn[e] = f.Y0[e] + (tmp[d * 512 + m] + tmp[(3 + d) * 512 + m]); }
+    // ---- 5. the finishing workgroup: all sums, T = Y0 + sum over the row blocks' shares (fixed order)
+    for (int e = t; e < nS; e += kBig) S[e] = f.sums[e];
+    for (int e = t; e < 3 * M; e += kBig) {
+        double a = 0;
+        for (int rbx = 0; rbx < nrb; ++rbx) a += Tp[(size_t)rbx * 3 * M + e];
+        Tn[e] = f.Y0[e] + a;
     }
     __syncthreads();
 
@@ -570,6 +624,7 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
         f.Y[e] = Tn[e];
         f.Yout[e] = Tn[e] + f.ctr[e / M];
     }
+    MSTAMP(4);
     if (t == 0) {
         __hip_atomic_store(sync + 1, 0u, TDLO_RLX_AGENT);
         __hip_atomic_store(sync + 2, 0u, TDLO_RLX_AGENT);
@@ -602,7 +657,8 @@ size_t big_lds_bytes(int M) {
 
 }  // namespace
 
-size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16) + Mp * 16; }
+// tableau (k_mstep_big) or published pivot rows (k_mstep_mcu) | panel columns | the row blocks' shares of G W
+size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16) + Mp * 16 + (Mp / 16) * 3 * Mp; }
 
 // TDLO_MSTEP_BIG=1wg keeps the whole elimination in one workgroup (k_mstep_big, the comparator of the tests and of
 // scripts/gpu_c5.py); the export-only form of the N-split interface (from_sums == 2) has no elimination and stays there.
