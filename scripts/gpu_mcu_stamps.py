@@ -18,3 +18,6 @@ print('owner starts :', us(st[8:8 + nrb]))
 print('owner reduced:', us(st[28:28 + nrb]))
 print('reduce us    :', np.round((st[28:28 + nrb] - st[8:8 + nrb]) / 100.0, 2).tolist())
 print('reduced -> next owner starts us:', np.round((st[9:8 + nrb] - st[28:27 + nrb]) / 100.0, 2).tolist())
+for pb, o in ((1, 48), (8, 56)):
+    print(f'panel {pb}: reduced -> write-back barrier -> flag stored -> next owner sees flag -> next owner starts (us rel. reduced):',
+          np.round((np.array([st[o], st[o + 1], st[o + 2], st[8 + pb + 1]]) - st[28 + pb]) / 100.0, 2).tolist())

@@ -860,3 +860,102 @@ def test_randomised_batches(hip_ctx, oracle, seed):
     for f in range(F):
         assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"]
         assert out["stats"][f]["iters"] == single[f]["iters"]
+
+
+# ---- multi-CU M-step (k_mstep_mcu, 60 < M <= 512 without the LLE term): one workgroup per 16 rows of the tableau,
+# ---- pivot rows handed over between workgroups inside the launch
+
+@pytest.mark.parametrize("M,F,tol", [(100, 5, 0.0), (200, 12, 2e-4), (300, 24, 0.0), (61, 9, 0.0), (512, 10, 0.0)])
+def test_multi_cu_mstep_batches_equal_single_calls(M, F, tol):
+    """Frames registered concurrently (grid.y = frame; 8+ frames on 2 / 4 stream groups; 24 frames x 19 row blocks are more
+    workgroups than the GPU has CUs, so row blocks wait for workgroups that are not resident yet) must equal, bit for bit,
+    the same frames registered one at a time, and repeated calls on a slot must repeat (generation counter of the flags)."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    rng = np.random.default_rng(9100 + M + F)
+    ctx = B.Context(device=0, max_frames=F, max_points=1 << 14, max_nodes=M)
+    try:
+        pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 30 if tol else 4, tol, False)
+        Ys, s2s, single = [], [], []
+        for f in range(F):
+            X, Y0, _ = synth.scene(int(rng.integers(1500, 9000)), M, config=140 + F, frame=f)
+            ctx.set_cloud(f, X)
+            Ys.append(Y0); s2s.append(float(rng.choice([0.0, 1e-4])))
+        for f in range(F):
+            single.append(ctx.cpd_lle_resident(f, Ys[f], s2s[f], pr))
+        for rep in range(2):
+            out = ctx.cpd_lle_batch(Ys, s2s, pr)
+            for f in range(F):
+                assert out["stats"][f]["status"] == 0
+                assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"]
+                assert out["stats"][f]["iters"] == single[f]["iters"] and out["stats"][f]["converged"] == single[f]["converged"]
+        again = ctx.cpd_lle_resident(0, Ys[0], s2s[0], pr)
+        assert np.array_equal(again["Y"], single[0]["Y"]) and again["sigma2"] == single[0]["sigma2"]
+    finally:
+        ctx.close()
+
+
+_ONE_WG_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from trackdlo_amd import binding as B, synth
+P = synth.LAUNCH_PARAMS
+res = {}
+for i, (N, M, prec, iters, pri) in enumerate(eval(sys.argv[3])):
+    ctx = B.Context(max_points=N, max_nodes=M)
+    X, Y0, _ = synth.scene(N, M, config=150 + i)
+    pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], iters, 0.0, False, P['alpha'] if pri else 0.0, precision=prec)
+    kw = {}
+    if pri:
+        idx = np.arange(0, M, 7)
+        kw['priors'] = np.column_stack([idx, Y0[idx] + 0.003])
+    g = ctx.cpd_lle(X, Y0, 0.0, pr, **kw)
+    res[f'Y{i}'] = g['Y']; res[f's{i}'] = np.array([g['sigma2'], g['iters'], g['status']])
+    ctx.close()
+np.savez(sys.argv[2], **res)
+"""
+
+
+def test_multi_cu_mstep_matches_one_workgroup_kernel(tmp_path):
+    """k_mstep_mcu against k_mstep_big (TDLO_MSTEP_BIG=1wg, the whole elimination in one workgroup): the eliminations perform
+    the same operations in the same order; the block partials and G W are summed in a different (fixed) order, so the
+    results agree to rounding (observed <= 7e-15 m after 30 iterations at M = 300)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(3000, 61, 0, 5, False), (3000, 130, 1, 4, False), (3000, 200, 0, 3, True), (6000, 300, 1, 8, False), (9000, 512, 0, 3, False), (70000, 90, 0, 6, False)]
+    outs = []
+    for mode in ("mcu", "1wg"):
+        env = dict(os.environ)
+        env.pop("TDLO_MSTEP_BIG", None)
+        if mode == "1wg": env["TDLO_MSTEP_BIG"] = "1wg"
+        out = tmp_path / f"{mode}.npz"
+        r = subprocess.run([sys.executable, "-c", _ONE_WG_SCRIPT, root, str(out), repr(cases)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    for i in range(len(cases)):
+        assert a[f"s{i}"][2] == 0 and b[f"s{i}"][2] == 0 and a[f"s{i}"][1] == b[f"s{i}"][1]
+        assert np.abs(a[f"Y{i}"] - b[f"Y{i}"]).max() <= 1e-12
+        assert abs(a[f"s{i}"][0] - b[f"s{i}"][0]) <= 1e-10 * b[f"s{i}"][0]
+
+
+def test_multi_cu_mstep_nsplit_and_oracle_at_c5_nodes(hip_ctx, oracle):
+    """M = 300 (BASELINE.json configs[4]): fp64 against the oracle, and the N-split interface (sums exported by the
+    one-workgroup kernel, solved by the multi-CU kernel from the reduced sums) against the plain call."""
+    from trackdlo_amd import binding as B, nsplit, synth
+    P = synth.LAUNCH_PARAMS
+
+    class Identity:
+        def all_reduce_sum(self, a): return np.array(a, dtype=np.float64)
+        def all_reduce_min(self, a): return np.array(a, dtype=np.float64)
+
+    X, Y0, _ = synth.scene(8000, 300, config=8)
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=6, tol=0.0, include_lle=False,
+              alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+    pr = _params(kw, 1)
+    a = hip_ctx.cpd_lle(X, Y0, 0.0, pr)
+    o = oracle.cpd_lle(X, Y0, 0.0, **kw)
+    _check(a, o, 1)
+    b = nsplit.cpd_lle_nsplit(nsplit.HipShard(hip_ctx, X), Identity(), Y0, 0.0, pr)
+    assert np.abs(a["Y"] - b["Y"]).max() <= 1e-12 and abs(a["sigma2"] - b["sigma2"]) <= 1e-10 * a["sigma2"]
+    assert b["iters"] == 6 and b["n_kept"] == a["n_kept"]

@@ -3,8 +3,13 @@
 //
 // Same mathematics as k_mstep_fast's MFMA variant in tdlo_device.hip -- Gauss-Jordan elimination without pivoting of
 // [A | B], A = c I + (diag(P1) + alpha J) G, which is the elimination of the SPD matrix G + c D^-1 -- but the
-// tableau (up to 512 x 528 doubles, 2 MB) cannot live in one CU's registers or LDS, so it sits in global memory
-// (L2-resident) and is processed by ONE workgroup of 16 waves in panels of 16 pivot columns:
+// tableau (up to 512 x 528 doubles, 2 MB) cannot live in one CU's registers or LDS.  Two kernels:
+//   * k_mstep_mcu (the product path, second half of this file): one workgroup per 16 rows, the row block stays in MFMA
+//     accumulators, the panel's reduced pivot rows travel between workgroups inside the launch.  M = 300: 131 us.
+//   * k_mstep_big (first half): the whole elimination in ONE workgroup of 16 waves with the tableau in global memory
+//     (L2-resident).  It is the comparator of the tests (TDLO_MSTEP_BIG=1wg: the two eliminations perform the same
+//     operations in the same order) and serves the export-only call of the N-split interface.  M = 300: 528 us.
+// k_mstep_big processes panels of 16 pivot columns:
 //   a. the 16 pivot rows (16 x live columns) are loaded one column per thread and reduced among themselves by 16
 //      sequential row operations held in registers; the only traffic per step is the pivot column, handed over through
 //      LDS (one barrier per step).  Result U (16 x Cp) -> LDS (MFMA B operand) and back to the tableau;
@@ -12,15 +17,13 @@
 //      16 x 16 tile; L = the panel's columns, which are never written again (column blocks up to the panel are dead).
 //      Every wave takes a contiguous row-major range of tiles.
 // fp64 vector and matrix rates are equal on gfx950, so the MFMA buys data flow (no per-element index arithmetic),
-// not flops.  What bounds the kernel is ONE CU's memory path: every panel re-reads and re-writes the live part of the
+// not flops.  What bounds k_mstep_big is ONE CU's memory path: every panel re-reads and re-writes the live part of the
 // tableau.  Three layout decisions follow from measurements (M = 300: 0.88 -> 0.51 ms; the scalar column-at-a-time
-// kernel it replaces took 12.9 ms):
+// kernel it replaced took 12.9 ms):
 //   * the tableau is tile-major in accumulator order (tix()): a tile is 2 KB of contiguous memory, 32 bytes per lane;
 //   * the panel's columns are re-ordered once per panel into A-operand order (Lb): scattered 8-byte reads cost a
 //     128-byte line each in the address pipeline and had been half of the run time;
 //   * U lives in LDS in B-operand order; consecutive tiles of a wave share the row block, so the A operand is reused.
-// Remaining: 0.16 ms of 16-step pivot-row reductions (one barrier per step), 0.07 ms partial sums and tableau assembly,
-// 0.28 ms trailing update at about 32 B/clk.  Spreading the row blocks over several CUs is the next step.
 // Mp = M rounded up to 16 rows (identity padded), Cp = Mp + 16 columns, right-hand sides in columns Mp .. Mp + 2.
 #include "tdlo_devcommon.h"
 #include <cstdlib>
@@ -300,15 +303,16 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
 // reduced pivot rows U.  Workgroup rb keeps its 16 x Cp row block in MFMA accumulators from assembly to the end (the
 // tableau never touches memory); per panel pb
 //   * the owner (rb == pb) turns its tiles over through LDS (accumulator order -> thread = column), reduces the 16
-//     pivot rows exactly as k_mstep_big does (same operations in the same order: both kernels give the same bits),
+//     pivot rows by the row operations of k_mstep_big in the same order (same bits), every live wave on its own,
 //     takes the result back into its accumulators and publishes U (<= 40 KB at M = 300) write-through (16-byte sc1
 //     buffer stores), drains, and one lane stores the panel's flag (agent scope, relaxed);
 //   * everybody else negates its tile (rb, pb) into A-operand order in LDS, one lane polls the flag (relaxed, s_sleep,
-//     bounded by the real-time clock), ONE agent-scope acquire, barrier, then C -= L U with four MFMAs per live tile
-//     and U read straight from memory in B-operand order (coalesced 512-byte rows).
-// Critical path per panel = reduce + publish + flag hop + one row block's update; the trailing update of the whole
-// tableau (0.28 of k_mstep_big's 0.51 ms at M = 300) runs beside it on the other CUs.  The last workgroup to arrive
-// (agent-scope ticket) gathers W and finishes the iteration (T = Y0 + G W, sigma2, stopping rule, publish).
+//     bounded by the real-time clock), barrier, then C -= L U with four MFMAs per live tile
+//     and U read straight from memory in B-operand order (coalesced 512-byte rows, sc1 loads).
+// Critical path per panel = reduce (2.8 us) + publish (1) + flag hop (0.6) + one row block's update (1); the trailing
+// update of the whole tableau (0.28 of k_mstep_big's 0.51 ms at M = 300) runs beside it on the other CUs.  Every row block contributes
+// G[:, its rows] W[its rows]; the last workgroup to arrive (agent-scope ticket, one acquire) adds the shares in a fixed
+// order and finishes the iteration (T = Y0 + G W, sigma2, stopping rule, publish).
 // Hand-off protocol and its costs: /opt/skills guide "Inter-workgroup communication" (sc1 payload + drained flag,
 // relaxed poll + one acquire).  Flags carry (generation, panel): the generation counter lives in the slot's sync words
 // and is advanced by the finishing workgroup, so no memset is needed between the iterations of a call.
@@ -488,13 +492,8 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
                 for (int r = 0; r < 16; ++r) ucol[((r >> 2) << 6) + 16 * (r & 3)] = u[r];
             }
             __syncthreads();
-            // b. back into the accumulators, and out to the other row blocks (write-through, 16 bytes per lane)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int cb = w + 16 * q;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) C[q][r] = cb < ncb ? Ul[cb * kTS + (r << 6) + lane] : 0.0;
-            }
+            // b. out to the other row blocks (write-through, 16 bytes per lane), then back into the accumulators
+            if (pb == 1) MSTAMP(48); if (pb == 8) MSTAMP(56);
             const int n2 = (ncb - pb - 1) << 7;                       // 16-byte pieces of the live tiles
             for (int e = t; e < n2; e += kBig) {
                 const int cb = pb + 1 + (e >> 7), off = (e & 127) << 1;
@@ -504,6 +503,13 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
             __syncthreads();
             if (t == 0) __hip_atomic_store(sync + 16 + pb, epoch, TDLO_RLX_AGENT);
+            if (pb == 1) MSTAMP(49); if (pb == 8) MSTAMP(57);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int cb = w + 16 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[q][r] = cb < ncb ? Ul[cb * kTS + (r << 6) + lane] : 0.0;
+            }
         } else {
             // c. everybody else: -L in A-operand order, wait for U, C -= L U
             double *Ab = Abuf + (pb & 1) * 256;
@@ -520,20 +526,21 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
                     __builtin_amdgcn_s_sleep(1);
                     if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) { flg[1] = 1; break; }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
+            if (rb == pb + 1) { if (pb == 1) MSTAMP(50); if (pb == 8) MSTAMP(58); }
             __syncthreads();
             double a[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) a[s4] = Ab[64 * s4 + lane];
-            const auto Up = Ub + (size_t)pb * utile + lane;
+            // U was stored write-through, so loads that bypass this CU's L1 (sc1) see it without an acquire (1.7 us per panel)
+            const auto Up = (__attribute__((address_space(1))) unsigned long long *)(Ub + (size_t)pb * utile + lane);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int cb = w + 16 * q;
                 if (cb > pb && cb < ncb) {
                     double b[4];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) b[s4] = Up[((size_t)cb << 8) + (s4 << 6)];
+                    for (int s4 = 0; s4 < 4; ++s4) b[s4] = __longlong_as_double((long long)__hip_atomic_load(Up + ((size_t)cb << 8) + (s4 << 6), TDLO_RLX_AGENT));
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) C[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], C[q], 0, 0, 0);
                 }
