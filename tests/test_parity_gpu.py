@@ -959,3 +959,62 @@ def test_multi_cu_mstep_nsplit_and_oracle_at_c5_nodes(hip_ctx, oracle):
     b = nsplit.cpd_lle_nsplit(nsplit.HipShard(hip_ctx, X), Identity(), Y0, 0.0, pr)
     assert np.abs(a["Y"] - b["Y"]).max() <= 1e-12 and abs(a["sigma2"] - b["sigma2"]) <= 1e-10 * a["sigma2"]
     assert b["iters"] == 6 and b["n_kept"] == a["n_kept"]
+
+
+def test_multi_cu_mstep_hand_offs_under_uneven_load():
+    """The in-launch hand-offs of k_mstep_mcu (write-through pivot rows + flag, L1-bypassing loads) must not depend on
+    timing or placement: batches of M = 130 / 300 frames are registered while a second context (its own stream, driven from
+    another thread) keeps the GPU busy with the E-steps of a 1 000 000-point cloud, and every frame of every repetition
+    must equal, bit for bit, the same frame registered alone on an idle GPU."""
+    import threading
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    stop, running = threading.Event(), threading.Event()
+    errors, calls = [], [0]
+
+    def background():
+        try:
+            ctx = B.Context(device=0, max_frames=1, max_points=1 << 20, max_nodes=64)
+            X, Y0, _ = synth.scene(1000000, 50, config=160)
+            pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 20, 0.0, False)
+            ctx.set_cloud(0, X)
+            while not stop.is_set():
+                ctx.cpd_lle_resident(0, Y0, 1e-4, pr)
+                calls[0] += 1
+                running.set()
+            ctx.close()
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+
+    for M, F in ((130, 16), (300, 20)):
+        rng = np.random.default_rng(9300 + M)
+        ctx = B.Context(device=0, max_frames=F, max_points=1 << 14, max_nodes=M)
+        try:
+            pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 5, 0.0, False, precision=1)
+            Ys, s2s, single = [], [], []
+            for f in range(F):
+                X, Y0, _ = synth.scene(int(rng.integers(2000, 12000)), M, config=170 + M, frame=f)
+                ctx.set_cloud(f, X)
+                Ys.append(Y0); s2s.append(0.0)
+            for f in range(F):
+                single.append(ctx.cpd_lle_resident(f, Ys[f], s2s[f], pr))
+            stop.clear(); running.clear()
+            th = threading.Thread(target=background)
+            th.start()
+            try:
+                assert running.wait(timeout=120) or errors
+                c0 = calls[0]
+                for rep in range(40):
+                    out = ctx.cpd_lle_batch(Ys, s2s, pr)
+                    for f in range(F):
+                        assert out["stats"][f]["status"] == 0
+                        assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"], (M, rep, f)
+                    g = ctx.cpd_lle_resident(rep % F, Ys[rep % F], 0.0, pr)
+                    assert np.array_equal(g["Y"], single[rep % F]["Y"])
+                assert calls[0] > c0 + 3        # the other context did run beside the batches
+            finally:
+                stop.set()
+                th.join(timeout=120)
+            assert not errors, errors
+        finally:
+            ctx.close()
