@@ -722,8 +722,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 // ------------------------------------------------------------------------------------------------
 // M-step, trackdlo.cpp:392-437.  One workgroup per frame.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool LDSA>
-__global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ frames, int from_sums) {
+// NT threads: 256 with the tableau in LDS; 1024 with the tableau in global memory (more element updates in flight: M = 300
+// 7.1 -> 5.4 ms; what is left is one CU's path to the L2, 1.45 MB per column)
+template <typename T, bool LDSA, int NT>
+__global__ __launch_bounds__(NT) void k_mstep(const FrameDev *__restrict__ frames, int from_sums) {
     const FrameDev &f = frames[blockIdx.x];
     IterState *st = f.st;
     if (st->done) return;
@@ -734,8 +736,8 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     double *S = (double *)smem;               // nS (+pad)
     double *W = S + ((nS + 1) & ~1);          // 3M
     double *Tn = W + 3 * M;                   // 3M
-    double *scratch = Tn + 3 * M;             // 8
-    int *piv = (int *)(scratch + 8);          // M (rounded to a multiple of 4 ints)
+    double *scratch = Tn + 3 * M;             // 16
+    int *piv = (int *)(scratch + 16);          // M (rounded to a multiple of 4 ints)
     int *used = piv + ((M + 3) & ~3);         // M (rounded)
     double *Alds = (double *)(used + ((M + 3) & ~3));
     double *A = LDSA ? Alds : f.Ascr;         // ld x (M+3)
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
         typedef typename PartOf<T>::type PT;
         const int nb = f.nblkM, nSp = part_stride<PT>(M);
         const PT *partT = (const PT *)f.partM;
-        for (int e = t; e < nS; e += kBlock) {
+        for (int e = t; e < nS; e += NT) {
             double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int b = 0;
             for (; b + 3 < nb; b += 4) {
@@ -756,11 +758,11 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
             S[e] = (a0 + a1) + (a2 + a3);
         }
     } else {
-        for (int e = t; e < nS; e += kBlock) S[e] = f.sums[e];
+        for (int e = t; e < nS; e += NT) S[e] = f.sums[e];
     }
     __syncthreads();
     if (from_sums == 2) {       // split mode, export only: publish local sums and stop
-        for (int e = t; e < nS; e += kBlock) f.sums[e] = S[e];
+        for (int e = t; e < nS; e += NT) f.sums[e] = S[e];
         if (t == 0) f.sums[nS] = (double)st->N;
         return;
     }
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     // ---- 2. assemble [A | B] (:392-413)
     const double sigma2 = st->sigma2;
     const double c2 = f.lambda * sigma2, sg = sigma2 * f.lle_weight;
-    for (int e = t; e < M * M; e += kBlock) {
+    for (int e = t; e < M * M; e += NT) {
         const int i = e % M, j = e / M;
         const double g = f.G[e];
         double a = S[i] * g + (i == j ? c2 : 0.0);
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
         if (f.has_priors) a += f.aJ[i] * g;
         A[(size_t)j * ld + i] = a;
     }
-    for (int e = t; e < 3 * M; e += kBlock) {
+    for (int e = t; e < 3 * M; e += NT) {
         const int i = e % M, d = e / M;
         const V4<T> *ndq = (const V4<T> *)f.nodes;
         const double yd = d == 0 ? (double)ndq[i].x : (d == 1 ? (double)ndq[i].y : (double)ndq[i].z);
@@ -785,11 +787,15 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
         if (f.has_priors) b += f.aYd[e];
         A[(size_t)(M + d) * ld + i] = b;
     }
-    for (int i = t; i < M; i += kBlock) used[i] = 0;
+    for (int i = t; i < M; i += NT) used[i] = 0;
     __syncthreads();
 
     // ---- 3. Gauss-Jordan elimination with partial pivoting, rows permuted implicitly (:415)
     int singular = 0;
+    const int Mr = (M + 63) & ~63;                                   // rows rounded up to whole waves
+    const int ncs = Mr <= NT ? NT / Mr : 1;                  // column slots: NT / rows
+    const int ri = Mr <= NT ? t % Mr : t, cs = Mr <= NT ? t / Mr : 0, rstep = Mr <= NT ? Mr : NT;
+    const int rend = cs < ncs ? M : 0;                               // threads beyond the last whole slot (e.g. 192 rows: 5 slots of 1024 threads) idle
     for (int k = 0; k < M; ++k) {
         // every wave finds the pivot row redundantly (no hand-off needed)
         double bv = -1.0; int bi = 0x7fffffff;
@@ -809,18 +815,26 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
         const double pv = A[(size_t)k * ld + p];
         if (!(bv > 0.0)) singular = 1;
         const double rp = (bv > 0.0) ? 1.0 / pv : 0.0;
-        const int ncol = M + 2 - k;          // columns k+1 .. M+2
-        for (int e = t; e < ncol * M; e += kBlock) {
-            const int i = e % M, j = k + 1 + e / M;
+        // thread = (row, column slot): the multiplier of a row is formed once, and no element pays an integer division
+        // (M is a run-time value: `e % M, e / M` per element had been most of this kernel's instructions)
+        for (int i = ri; i < rend; i += rstep) {
             if (i != p) {
                 const double l = A[(size_t)k * ld + i] * rp;
-                A[(size_t)j * ld + i] -= l * A[(size_t)j * ld + p];
+                int j = k + 1 + cs;
+                for (; j + 7 * ncs < M + 3; j += 8 * ncs) {        // 8 independent element updates in flight (the tableau may be in global memory)
+                    double a[8], b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a[u] = A[(size_t)(j + u * ncs) * ld + i]; b[u] = A[(size_t)(j + u * ncs) * ld + p]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) A[(size_t)(j + u * ncs) * ld + i] = a[u] - l * b[u];
+                }
+                for (; j < M + 3; j += ncs) A[(size_t)j * ld + i] -= l * A[(size_t)j * ld + p];
             }
         }
         if (t == 0) { piv[k] = p; used[p] = 1; }
         __syncthreads();
     }
-    for (int e = t; e < 3 * M; e += kBlock) {
+    for (int e = t; e < 3 * M; e += NT) {
         const int k = e % M, d = e / M;
         const int p = piv[k];
         W[e] = A[(size_t)(M + d) * ld + p] / A[(size_t)k * ld + p];
@@ -828,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     __syncthreads();
 
     // ---- 4. T = Y0 + G W (:417)
-    for (int e = t; e < 3 * M; e += kBlock) {
+    for (int e = t; e < 3 * M; e += NT) {
         const int i = e % M, d = e / M;
         double a = 0;
         for (int k = 0; k < M; ++k) a += f.G[(size_t)k * M + i] * W[d * M + k];
@@ -839,7 +853,7 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
     // ---- 5. sigma2 (residual form of :418-422) and the convergence criterion (:424)
     const V4<T> *nodes = (const V4<T> *)f.nodes;
     double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
-    for (int m = t; m < M; m += kBlock) {
+    for (int m = t; m < M; m += NT) {
         V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
         const double yx = (double)q.x, yy = (double)q.y, yz = (double)q.z;    // nodes as the E-step saw them
         const double p1 = S[m];
@@ -851,21 +865,21 @@ __global__ __launch_bounds__(kBlock) void k_mstep(const FrameDev *__restrict__ f
         const double ex = f.Y[m] - Tn[m], ey = f.Y[M + m] - Tn[M + m], ez = f.Y[2 * M + m] - Tn[2 * M + m];
         s_cr += ::sqrt(ex * ex + ey * ey + ez * ez);
     }
-    s_np = block_sum(s_np, scratch);
-    s_dr = block_sum(s_dr, scratch);
-    s_pd = block_sum(s_pd, scratch);
-    s_cr = block_sum(s_cr, scratch);
+    s_np = block_sum_n<NT / 64>(s_np, scratch);
+    s_dr = block_sum_n<NT / 64>(s_dr, scratch);
+    s_pd = block_sum_n<NT / 64>(s_pd, scratch);
+    s_cr = block_sum_n<NT / 64>(s_cr, scratch);
     const double new_sigma2 = (S[4 * M] - 2.0 * s_dr + s_pd) / (s_np * 3.0);
     const double crit = s_cr / (double)M;
 
     // ---- 6. publish Y, nodes, iteration state
     V4<T> *nodes_w = (V4<T> *)f.nodes;
-    for (int m = t; m < M; m += kBlock) {
+    for (int m = t; m < M; m += NT) {
         V4<T> q; q.x = (T)Tn[m]; q.y = (T)Tn[M + m]; q.z = (T)Tn[2 * M + m]; q.w = (T)f.coord[m];
         nodes_w[m] = q;
         f.dminbits[m] = ~0ull;
     }
-    for (int e = t; e < 3 * M; e += kBlock) {
+    for (int e = t; e < 3 * M; e += NT) {
         f.Y[e] = Tn[e];
         f.Yout[e] = Tn[e] + f.ctr[e / M];
     }
@@ -1390,7 +1404,7 @@ template <typename T> static size_t dmin_lds_bytes(int M) {
 }
 size_t mstep_lds_bytes(int M) {
     const int nS = 4 * M + 1, ld = M | 1;
-    size_t b = sizeof(double) * (size_t)(((nS + 1) & ~1) + 6 * M + 8) + sizeof(int) * 2 * (size_t)((M + 3) & ~3) + 16;
+    size_t b = sizeof(double) * (size_t)(((nS + 1) & ~1) + 6 * M + 16) + sizeof(int) * 2 * (size_t)((M + 3) & ~3) + 16;
     if (M <= kLdsSolveMaxM) b += sizeof(double) * (size_t)ld * (M + 3);
     return b;
 }
@@ -1497,11 +1511,11 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
         return launch_mstep_fast<T, 4, 17>(fd, fh, F, from_sums, s);
     } else if (M <= kLdsSolveMaxM) {
         const size_t lds = mstep_lds_bytes(M);
-        TDLO_TRY(set_lds(k_mstep<T, true>, lds));
-        hipLaunchKernelGGL((k_mstep<T, true>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
+        TDLO_TRY(set_lds((k_mstep<T, true, kBlock>), lds));
+        hipLaunchKernelGGL((k_mstep<T, true, kBlock>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
     } else {
         const size_t lds = mstep_lds_bytes(M);
-        hipLaunchKernelGGL((k_mstep<T, false>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
+        hipLaunchKernelGGL((k_mstep<T, false, 1024>), dim3(F), dim3(1024), lds, s, fd, from_sums);
     }
     return hipGetLastError();
 }
