@@ -596,7 +596,13 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     for (int e = t; e < nS; e += kBig) S[e] = f.sums[e];
     for (int e = t; e < 3 * M; e += kBig) {
         double a = 0;
-        for (int rbx = 0; rbx < nrb; ++rbx) a += Tp[(size_t)rbx * 3 * M + e];
+        for (int r0 = 0; r0 < nrb; r0 += 8) {             // 8 loads in flight, row-block order kept
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Tp[(size_t)(r0 + u < nrb ? r0 + u : nrb - 1) * 3 * M + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (r0 + u < nrb) a += v[u];
+        }
         Tn[e] = f.Y0[e] + a;
     }
     __syncthreads();
