@@ -43,6 +43,48 @@ def build(force: bool = False) -> str:
     return so
 
 
+_LIB_OMP = None
+
+
+def host_cores() -> int:
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a container may see 256 cores
+    in its mask and be allowed 8; 256 threads on such a box ran 6x slower than one)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):                       # cgroup v2
+            with open("/sys/fs/cgroup/cpu.max") as fh:
+                q, per = fh.read().split()[:2]
+        else:                                                              # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = fh.read().strip()
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                per = fh.read().strip()
+        if q not in ("max", "-1"):
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def set_threads(n: int) -> None:
+    lib_omp().ref_set_threads(C.c_int(int(n)))
+
+
+def lib_omp():
+    """The same restatement compiled with -fopenmp (points spread over the host cores): ONLY for bench.py's secondary
+    all-cores timing column; sums over points are per-thread partial sums there, so it is never the checker."""
+    global _LIB_OMP
+    if _LIB_OMP is None:
+        so = os.path.join(_HERE, "libref_cpu_omp.so")
+        src = os.path.join(_HERE, "ref_cpu.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libref_cpu_omp.so"])
+        _LIB_OMP = C.CDLL(so)
+        _LIB_OMP.ref_cpd_lle.restype = C.c_int
+        _LIB_OMP.ref_set_threads(C.c_int(host_cores()))
+    return _LIB_OMP
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -69,7 +111,7 @@ def _dp(a):
 
 def cpd_lle(X, Y, sigma2, *, beta, lambda_, lle_weight, mu, max_iter=30, tol=1e-4, include_lle=True,
             priors=None, alpha=0.0, visible_nodes=None, k_vis=0.0, visibility_threshold=0.01,
-            H=None, trace=False, **proto):
+            H=None, trace=False, all_cores=False, **proto):
     """trackdlo::cpd_lle (trackdlo.cpp:161-441). Returns dict(Y, sigma2, converged, iters, n_kept, ...)."""
     X = _f(X); Y = _f(Y).copy(order="F")
     N, M = X.shape[0], Y.shape[0]
@@ -91,7 +133,7 @@ def cpd_lle(X, Y, sigma2, *, beta, lambda_, lle_weight, mu, max_iter=30, tol=1e-
         bufs = dict(P1=np.zeros((max_iter, M)), PX=np.zeros((max_iter, 3, M)), Np=np.zeros(max_iter),
                     sigma2=np.zeros(max_iter), Y=np.zeros((max_iter, 3, M)))
         tr = RefTrace(*[_dp(bufs[k]) for k in ("P1", "PX", "Np", "sigma2", "Y")])
-    rc = lib().ref_cpd_lle(_dp(X), C.c_int(N), _dp(Y), C.c_int(M), C.byref(s2), C.byref(p), _dp(pri), C.c_int(K),
+    rc = (lib_omp() if all_cores else lib()).ref_cpd_lle(_dp(X), C.c_int(N), _dp(Y), C.c_int(M), C.byref(s2), C.byref(p), _dp(pri), C.c_int(K),
                            _dp(vis), C.c_int(nv), _dp(Hm), C.byref(st), C.byref(tr) if tr else None)
     if rc != 0:
         raise ValueError(f"ref_cpd_lle failed rc={rc}")

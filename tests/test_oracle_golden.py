@@ -191,3 +191,21 @@ def test_reg_matches_prototype_register(oracle):
     assert np.array_equal(Y[:, 1], 0.1 / 8 * np.arange(8)) and np.all(Y[:, [0, 2]] == 0)
     d2 = ((Y[:, None, :] - z["X"][None, :, :]) ** 2).sum()
     assert abs(s2 - d2 / (3 * 8 * len(z["X"]))) <= 1e-13 * s2
+
+
+def test_openmp_build_of_the_oracle_agrees_with_the_serial_one():
+    """libref_cpu_omp.so (bench.py's all-cores timing column only, never the checker) spreads the points over threads; its
+    sums over points are per-thread partial sums, so it agrees with the serial restatement to rounding, not bit for bit."""
+    import numpy as np
+    from oracle import ref_cpu
+    from trackdlo_amd import synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, v = synth.scene(4000, 30, config=1, occlude=(0.4, 0.6))
+    vext = synth.extend_visible(v, 30, synth.geodesic_coord(Y0))
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=8, tol=0.0, include_lle=False,
+              alpha=0.0, k_vis=P["k_vis"], visibility_threshold=P["visibility_threshold"], visible_nodes=vext)
+    a = ref_cpu.cpd_lle(X, Y0, 0.0, **kw)
+    ref_cpu.set_threads(3)
+    b = ref_cpu.cpd_lle(X, Y0, 0.0, all_cores=True, **kw)
+    assert a["iters"] == b["iters"] and a["n_kept"] == b["n_kept"] and a["gap_quirk"] == b["gap_quirk"]
+    assert np.abs(a["Y"] - b["Y"]).max() <= 1e-11 and abs(a["sigma2"] - b["sigma2"]) <= 1e-10 * a["sigma2"]
