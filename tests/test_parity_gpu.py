@@ -901,11 +901,14 @@ sys.path.insert(0, sys.argv[1])
 from trackdlo_amd import binding as B, synth
 P = synth.LAUNCH_PARAMS
 res = {}
-for i, (N, M, prec, iters, pri) in enumerate(eval(sys.argv[3])):
+for i, (N, M, prec, iters, pri, lle) in enumerate(eval(sys.argv[3])):
     ctx = B.Context(max_points=N, max_nodes=M)
     X, Y0, _ = synth.scene(N, M, config=150 + i)
     pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], iters, 0.0, False, P['alpha'] if pri else 0.0, precision=prec)
     kw = {}
+    if lle:     # the pre-processing registration of tracking_step (launch values), well-conditioned stand-in for H
+        pr = B.make_params(3.0, 1.0, 10.0, 0.1, iters, 0.0, True, P['alpha'] if pri else 0.0, precision=prec)
+        kw['H'] = np.eye(M) * 0.1 + 0.01 * np.diag(np.ones(M - 1), 1) + 0.01 * np.diag(np.ones(M - 1), -1)
     if pri:
         idx = np.arange(0, M, 7)
         kw['priors'] = np.column_stack([idx, Y0[idx] + 0.003])
@@ -922,12 +925,16 @@ def test_multi_cu_mstep_matches_one_workgroup_kernel(tmp_path):
     results agree to rounding (observed <= 7e-15 m after 30 iterations at M = 300)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cases = [(3000, 61, 0, 5, False), (3000, 130, 1, 4, False), (3000, 200, 0, 3, True), (6000, 300, 1, 8, False), (9000, 512, 0, 3, False), (70000, 90, 0, 6, False)]
+    cases = [(3000, 61, 0, 5, False, False), (3000, 130, 1, 4, False, False), (3000, 200, 0, 3, True, False), (6000, 300, 1, 8, False, False),
+             (9000, 512, 0, 3, False, False), (70000, 90, 0, 6, False, False),
+             # with the LLE term beyond 128 nodes: k_mstep_pivot_mcu against the one-workgroup k_mstep (TDLO_MSTEP_LLE=1wg)
+             (4000, 129, 1, 3, False, True), (4000, 200, 0, 2, True, True), (5000, 300, 1, 2, False, True)]
     outs = []
     for mode in ("mcu", "1wg"):
         env = dict(os.environ)
         env.pop("TDLO_MSTEP_BIG", None)
-        if mode == "1wg": env["TDLO_MSTEP_BIG"] = "1wg"
+        env.pop("TDLO_MSTEP_LLE", None)
+        if mode == "1wg": env["TDLO_MSTEP_BIG"] = "1wg"; env["TDLO_MSTEP_LLE"] = "1wg"
         out = tmp_path / f"{mode}.npz"
         r = subprocess.run([sys.executable, "-c", _ONE_WG_SCRIPT, root, str(out), repr(cases)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -935,8 +942,11 @@ def test_multi_cu_mstep_matches_one_workgroup_kernel(tmp_path):
     a, b = outs
     for i in range(len(cases)):
         assert a[f"s{i}"][2] == 0 and b[f"s{i}"][2] == 0 and a[f"s{i}"][1] == b[f"s{i}"][1]
-        assert np.abs(a[f"Y{i}"] - b[f"Y{i}"]).max() <= 1e-12
-        assert abs(a[f"s{i}"][0] - b[f"s{i}"][0]) <= 1e-10 * b[f"s{i}"][0]
+        # the pivoted eliminations of the (ill-conditioned: c = lambda sigma2 ~ 1e-5 against entries of order 100) LLE system
+        # differ in the order of their row operations: two valid solutions of such a system agree to ~1e-7 m
+        ty, ts = (1e-6, 1e-5) if cases[i][5] else (1e-12, 1e-10)
+        assert np.abs(a[f"Y{i}"] - b[f"Y{i}"]).max() <= ty
+        assert abs(a[f"s{i}"][0] - b[f"s{i}"][0]) <= ts * b[f"s{i}"][0]
 
 
 def test_multi_cu_mstep_nsplit_and_oracle_at_c5_nodes(hip_ctx, oracle):
@@ -1018,3 +1028,37 @@ def test_multi_cu_mstep_hand_offs_under_uneven_load():
             assert not errors, errors
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("M,F", [(129, 3), (200, 9), (300, 5)])
+def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F):
+    """k_mstep_pivot_mcu (LLE term, more than 128 nodes: 16 rows per workgroup, pivot search across the workgroups, one
+    hand-off per column): against the oracle -- stated tolerance 1e-6 m / 1e-5 relative in sigma2 for this regime: the
+    pre-processing system (lambda = 1, sigma2 ~ 1e-5) is ill-conditioned at these sizes and the oracle's own QR solution
+    carries the same ~1e-8..1e-7 m uncertainty (`scripts/gpu_lle_acc.py`: the one-workgroup kernel sits at the same distance)
+    -- and frames registered concurrently / repeatedly must reproduce the single call bit for bit."""
+    from trackdlo_amd import binding as B, synth
+    rng = np.random.default_rng(9500 + M)
+    ctx = B.Context(device=0, max_frames=F, max_points=1 << 14, max_nodes=M)
+    try:
+        kw = dict(beta=3.0, lambda_=1.0, lle_weight=10.0, mu=0.1, max_iter=3, tol=0.0, include_lle=True, alpha=0.0, k_vis=0.0, visibility_threshold=0.008)
+        pr = _params(kw, 1)
+        H = np.eye(M) * 0.1 + 0.01 * np.diag(np.ones(M - 1), 1) + 0.01 * np.diag(np.ones(M - 1), -1)
+        Ys, s2s, single = [], [], []
+        for f in range(F):
+            X, Y0, _ = synth.scene(int(rng.integers(2000, 7000)), M, config=180 + M, frame=f, noise=0.004)
+            ctx.set_cloud(f, X)
+            Ys.append(Y0); s2s.append(2e-5)
+            g = ctx.cpd_lle_resident(f, Y0, 2e-5, pr, H=H)
+            single.append(g)
+            if f == 0:
+                o = oracle.cpd_lle(X, Y0, 2e-5, H=H, **kw)
+                assert g["status"] == 0 and g["iters"] == o["iters"] and g["n_kept"] == o["n_kept"]
+                assert np.abs(g["Y"] - o["Y"]).max() <= 1e-6 and abs(g["sigma2"] - o["sigma2"]) <= 1e-5 * o["sigma2"]
+        for rep in range(3):
+            out = ctx.cpd_lle_batch(Ys, s2s, pr, H=H)
+            for f in range(F):
+                assert out["stats"][f]["status"] == 0
+                assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"]
+    finally:
+        ctx.close()

@@ -1513,6 +1513,8 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
         const size_t lds = mstep_lds_bytes(M);
         TDLO_TRY(set_lds((k_mstep<T, true, kBlock>), lds));
         hipLaunchKernelGGL((k_mstep<T, true, kBlock>), dim3(F), dim3(kBlock), lds, s, fd, from_sums);
+    } else if (from_sums != 2 && mstep_pivot_mcu_enabled()) {
+        return launch_mstep_pivot_mcu(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     } else {
         const size_t lds = mstep_lds_bytes(M);
         hipLaunchKernelGGL((k_mstep<T, false, 1024>), dim3(F), dim3(1024), lds, s, fd, from_sums);

@@ -67,7 +67,7 @@ struct FrameDev {
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
     unsigned long long *dbg; // 64 shader-clock stamps written by the M-step (tdlo_debug_stamps)
-    unsigned *sync;         // 64 words, zeroed when the slot is created: generation / arrivals / flags of k_mstep_mcu's hand-offs
+    unsigned *sync;         // 128 words, zeroed when the slot is created: generation / arrivals / flags of the multi-CU M-steps' hand-offs
     IterState *st;
 };
 
@@ -84,6 +84,9 @@ size_t mstep_lds_bytes(int M);
 // tdlo_mstep_big.hip: M-step for 60 < M <= kMaxNodes without LLE (blocked Gauss-Jordan, tableau in global memory)
 hipError_t launch_mstep_big(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
 size_t mstep_big_scratch_doubles(int M);
+// M-step with the LLE term for M > kLdsSolveMaxM: 16 rows per workgroup, partial pivoting across the workgroups
+hipError_t launch_mstep_pivot_mcu(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
+bool mstep_pivot_mcu_enabled();
 // tdlo_reg.hip: plain GMM-EM `reg` (utils.cpp:21-82); ws layout: state (8) | Y (3 M) | block partials
 size_t reg_ws_doubles(int M, int nblk);
 hipError_t launch_reg(const double *X, int N, int M, double mu, int max_iter, int nblk, double *ws, hipStream_t s);

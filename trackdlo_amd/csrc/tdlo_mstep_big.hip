@@ -653,6 +653,288 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_mstep_pivot_mcu: the M-step WITH the LLE term (A = c I + (D + sigma2 gamma H + alpha J) G, no SPD structure: partial
+// pivoting, trackdlo.cpp:396-415) for more than 128 nodes, where the one-workgroup kernel k_mstep keeps the tableau in
+// global memory and is bound by one CU's path to the L2 (M = 300: 5.5 ms).  One workgroup (256 threads) per 16 rows; the
+// rows stay in LDS for the whole elimination.  Gauss-Jordan with partial pivoting, one column at a time, ONE hand-off per
+// column: every workgroup publishes its best pivot candidate TOGETHER with that row's live entries (header {|a_pk|, p} +
+// <= M + 3 values, write-through), drains, raises its flag; one wave per workgroup waits for all flags, reads the headers,
+// takes the largest |a_pk| (ties: lowest row) -- every workgroup arrives at the same winner -- and the winner's row is
+// read (L1-bypassing loads), normalised and applied to the own 16 rows.  Candidate slots and flags are double-buffered by
+// column parity: nobody can publish column k + 2 before everybody has consumed column k + 1, hence finished reading k.
+// The pivot rows are not moved (used[] / kof[]: row -> column it pivots); at the end row piv(k) holds W_k, every workgroup
+// contributes G[:, its pivot columns] W[...] and the last one to arrive finishes the iteration as in k_mstep_mcu.
+// sync words: [0] generation, [1] arrivals, [2] singular, [64 + 32 (k & 1) + rb] flags.
+constexpr int kPT = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restrict__ frames, int from_sums_in) {
+    const int from_sums = from_sums_in;
+    const FrameDev &f = frames[blockIdx.y];
+    IterState *st = f.st;
+    if (st->done) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = f.M, t = threadIdx.x, lane = t & 63, w = t >> 6, rb = blockIdx.x;
+    const int nS = 4 * M + 1, Mp = (M + 15) & ~15, nrb = Mp >> 4, Cp = Mp + 16;
+    const int NC = M + 3, ld = NC | 1;                 // row stride in LDS (odd)
+    const int slotsz = (NC + 2 + 1) & ~1;              // published candidate: {|a|, row} + NC values
+    double *S = (double *)smem;                        // nS (+pad): all sums, finishing workgroup only
+    double *Tn = S + ((nS + 1) & ~1);                  // 3M (+pad)
+    double *scratch = Tn + ((3 * M + 1) & ~1);         // 16
+    double *Sown = scratch + 16;                       // 64: P1, PX of the own 16 nodes
+    double *prow = Sown + 64;                          // NC (+pad): normalised pivot row of the current column
+    double *R = prow + ((NC + 1) & ~1);                // 16 x ld: the own rows of [A | B]
+    int *ib = (int *)(R + (16 * ld > 1536 ? 16 * ld : 1536));
+    int *used = ib, *kof = ib + 16, *flg = ib + 32;    // flg: [0] last arriver, [1] a spin ran into its time limit, [2] local candidate row, [3] winner row
+    double *dflg = (double *)(ib + 40);                // [0] |a| of the local candidate, [1] |a| of the winner
+    const auto Gg = TDLO_AS_GLOBAL(double, f.G);
+    const auto Cb = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.Ascr;      // [parity][rb][slotsz]
+    const auto Tp = TDLO_AS_GLOBAL_RW(double, f.Ascr) + (size_t)Mp * Cp + (size_t)Mp * 16;          // [rb][d][M]
+    gu32 *sync = (gu32 *)(uintptr_t)f.sync;
+    const unsigned gen = sync[0];
+    if (t < 4) flg[t] = 0;
+    if (t < 16) { used[t] = (16 * rb + t < M) ? 0 : 1; kof[t] = -1; }      // padding rows never pivot
+
+    // ---- 1. block partials -> the own 4 x 16 sums (wave = every 4th partial row; groups added in a fixed order)
+    {
+        const int ii = lane & 15, kk = lane >> 4, irow = 16 * rb + ii;
+        const bool valid = irow < M;
+        const int e = kk * M + (valid ? irow : 0);
+        auto sums_g = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.sums;
+        if (from_sums != 1) {
+            typedef typename PartOf<T>::type PT;
+            const int nb = f.nblkM, nSp = part_stride<PT>(M);
+            const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
+            double a0 = 0;
+            for (int b = w; b < nb; b += 64) {
+                PT v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const int bb = b + 4 * u < nb ? b + 4 * u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (b + 4 * u < nb) a0 += (double)v[u];
+            }
+            double *red = R;
+            red[w * 64 + lane] = a0;
+            __syncthreads();
+            if (w == 0) {
+                const double a = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+                Sown[lane] = valid ? a : 0.0;
+                if (valid) __hip_atomic_store(sums_g + e, (unsigned long long)__double_as_longlong(a), TDLO_RLX_AGENT);
+            }
+            if (rb == 0) {
+                double q = 0;
+                for (int b = t; b < nb; b += kPT) q += (double)partT[(size_t)b * nSp + 4 * M];
+                q = block_sum(q, scratch);
+                if (t == 0) __hip_atomic_store(sums_g + 4 * M, (unsigned long long)__double_as_longlong(q), TDLO_RLX_AGENT);
+            }
+        } else if (w == 0) Sown[lane] = valid ? f.sums[e] : 0.0;
+    }
+    __syncthreads();
+
+    // ---- 2. own rows of [A | B] (:392-413)
+    {
+        const double sigma2 = st->sigma2;
+        const double c2 = f.lambda * sigma2, sg = sigma2 * f.lle_weight;
+        const int lle = f.include_lle, pri = f.has_priors;
+        const V4<T> *ndq = (const V4<T> *)f.nodes;
+        for (int e = t; e < 16 * NC; e += kPT) {
+            const int r = e & 15, j = e >> 4, i = 16 * rb + r;
+            double v = 0.0;
+            if (i < M) {
+                if (j < M) {
+                    const size_t ge = (size_t)j * M + i;              // G symmetric; H G as stored by k_setup
+                    v = (Sown[r] + (pri ? f.aJ[i] : 0.0)) * Gg[ge] + (i == j ? c2 : 0.0);
+                    if (lle) v += sg * f.HG[ge];
+                } else {
+                    const int d = j - M, q = d * M + i;
+                    const double yd = d == 0 ? (double)ndq[i].x : (d == 1 ? (double)ndq[i].y : (double)ndq[i].z);
+                    v = Sown[16 * (1 + d) + r] + Sown[r] * (yd - f.Y0[q]);
+                    if (lle) v -= sg * f.HY0[q];
+                    if (pri) v += f.aYd[q];
+                }
+            }
+            R[r * ld + j] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. Gauss-Jordan with partial pivoting across the workgroups, one hand-off per column
+    int singular = 0;
+    for (int k = 0; k < M; ++k) {
+        const unsigned epoch = gen * 1024u + (unsigned)k + 1u;
+        const int par = k & 1;
+        // a. local candidate
+        if (w == 0) {
+            double av = -1.0; int ri = 0x7fffffff;
+            if (lane < 16 && !used[lane]) { av = fabs(R[lane * ld + k]); ri = lane; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(av, o); const int oi = __shfl_xor(ri, o);
+                if (ov > av || (ov == av && oi < ri)) { av = ov; ri = oi; }
+            }
+            if (lane == 0) { flg[2] = av >= 0.0 ? ri : -1; dflg[0] = av; }
+        }
+        __syncthreads();
+        // b. publish {|a|, row, entries k .. NC-1 of that row}
+        {
+            const int lr = flg[2];
+            const auto slot = Cb + ((size_t)par * nrb + rb) * slotsz;
+            if (t == 0) {
+                __hip_atomic_store(slot, (unsigned long long)__double_as_longlong(dflg[0]), TDLO_RLX_AGENT);
+                __hip_atomic_store(slot + 1, (unsigned long long)__double_as_longlong((double)(16 * rb + (lr >= 0 ? lr : 0))), TDLO_RLX_AGENT);
+            }
+            if (lr >= 0)
+                for (int j = k + t; j < NC; j += kPT) __hip_atomic_store(slot + 2 + j, (unsigned long long)__double_as_longlong(R[lr * ld + j]), TDLO_RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(sync + 64 + 32 * par + rb, epoch, TDLO_RLX_AGENT);
+        }
+        // c. all candidates in: the winner
+        if (w == 0) {
+            if (!flg[1]) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    const bool ok = lane >= nrb || __hip_atomic_load(sync + 64 + 32 * par + (lane < nrb ? lane : 0), TDLO_RLX_AGENT) == epoch;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) { if (lane == 0) flg[1] = 1; break; }
+                }
+            }
+            double av = -1.0; int ri = 0x7fffffff;
+            if (lane < nrb) {
+                const auto sl = Cb + ((size_t)par * nrb + lane) * slotsz;
+                av = __longlong_as_double((long long)__hip_atomic_load(sl, TDLO_RLX_AGENT));
+                ri = (int)__longlong_as_double((long long)__hip_atomic_load(sl + 1, TDLO_RLX_AGENT));
+                if (!(av >= 0.0)) { av = -1.0; ri = 0x7fffffff; }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(av, o); const int oi = __shfl_xor(ri, o);
+                if (ov > av || (ov == av && oi < ri)) { av = ov; ri = oi; }
+            }
+            if (lane == 0) { flg[3] = ri; dflg[1] = av; }
+        }
+        __syncthreads();
+        const int p = flg[3];
+        const double wav = dflg[1];
+        const bool okp = wav > 0.0 && p < M;
+        if (!okp) singular = 1;
+        // d. the winner's row, normalised
+        {
+            const auto wsl = Cb + ((size_t)par * nrb + (okp ? (p >> 4) : 0)) * slotsz + 2;
+            const double pv = __longlong_as_double((long long)__hip_atomic_load(wsl + k, TDLO_RLX_AGENT));
+            const double rp = okp ? 1.0 / pv : 0.0;
+            for (int j = k + t; j < NC; j += kPT) prow[j] = __longlong_as_double((long long)__hip_atomic_load(wsl + j, TDLO_RLX_AGENT)) * rp;
+        }
+        __syncthreads();
+        // e. own rows
+        if (okp) {
+            const int r = t & 15, cs = t >> 4;
+            if (16 * rb + r == p) {
+                for (int j = k + cs; j < NC; j += 16) R[r * ld + j] = prow[j];
+                if (cs == 0) { used[r] = 1; kof[r] = k; }
+            } else {
+                const double l = R[r * ld + k];
+                for (int j = k + 1 + cs; j < NC; j += 16) R[r * ld + j] = fma(-l, prow[j], R[r * ld + j]);
+            }
+        }
+        __syncthreads();
+    }
+    const int timed_out = flg[1];
+
+    // ---- 4. share of G W: sum over the own pivot rows r (pivot of column kof[r]) of G[:, kof[r]] W[kof[r]]
+    {
+        auto tp = (__attribute__((address_space(1))) unsigned long long *)(Tp + (size_t)rb * 3 * M);
+        for (int i = t; i < M; i += kPT) {
+            double v0 = 0, v1 = 0, v2 = 0;
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) {
+                const int kc = kof[r];
+                if (kc >= 0) { const double gk = Gg[(size_t)kc * M + i]; v0 += gk * R[r * ld + M]; v1 += gk * R[r * ld + M + 1]; v2 += gk * R[r * ld + M + 2]; }
+            }
+            __hip_atomic_store(tp + i, (unsigned long long)__double_as_longlong(v0), TDLO_RLX_AGENT);
+            __hip_atomic_store(tp + M + i, (unsigned long long)__double_as_longlong(v1), TDLO_RLX_AGENT);
+            __hip_atomic_store(tp + 2 * M + i, (unsigned long long)__double_as_longlong(v2), TDLO_RLX_AGENT);
+        }
+    }
+    singular = __syncthreads_or(singular | timed_out);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        if (singular) __hip_atomic_fetch_or(sync + 2, 1u, TDLO_RLX_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(sync + 1, 1u, TDLO_RLX_AGENT);
+        flg[0] = (old == (unsigned)nrb - 1u);
+        if (flg[0]) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!flg[0]) return;
+    singular = (int)__hip_atomic_load(sync + 2, TDLO_RLX_AGENT);
+
+    // ---- 5. the finishing workgroup: all sums, T = Y0 + sum of the shares (fixed order), sigma2, stopping rule, publish
+    for (int e = t; e < nS; e += kPT) S[e] = f.sums[e];
+    for (int e = t; e < 3 * M; e += kPT) {
+        double a = 0;
+        for (int r0 = 0; r0 < nrb; r0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Tp[(size_t)(r0 + u < nrb ? r0 + u : nrb - 1) * 3 * M + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (r0 + u < nrb) a += v[u];
+        }
+        Tn[e] = f.Y0[e] + a;
+    }
+    __syncthreads();
+    const V4<T> *ndq = (const V4<T> *)f.nodes;
+    double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
+    for (int m = t; m < M; m += kPT) {
+        const double yx = (double)ndq[m].x, yy = (double)ndq[m].y, yz = (double)ndq[m].z;    // nodes as the E-step saw them
+        const double p1 = S[m];
+        const double dx = Tn[m] - yx, dy = Tn[M + m] - yy, dz = Tn[2 * M + m] - yz;
+        s_np += p1;
+        s_dr += dx * S[M + m] + dy * S[2 * M + m] + dz * S[3 * M + m];
+        s_pd += p1 * (dx * dx + dy * dy + dz * dz);
+        const double ex = f.Y[m] - Tn[m], ey = f.Y[M + m] - Tn[M + m], ez = f.Y[2 * M + m] - Tn[2 * M + m];
+        s_cr += ::sqrt(ex * ex + ey * ey + ez * ez);
+    }
+    s_np = block_sum(s_np, scratch);
+    s_dr = block_sum(s_dr, scratch);
+    s_pd = block_sum(s_pd, scratch);
+    s_cr = block_sum(s_cr, scratch);
+    const double new_sigma2 = (S[4 * M] - 2.0 * s_dr + s_pd) / (s_np * 3.0);
+    const double crit = s_cr / (double)M;
+    V4<T> *nodes_w = (V4<T> *)f.nodes;
+    for (int m = t; m < M; m += kPT) {
+        V4<T> q; q.x = (T)Tn[m]; q.y = (T)Tn[M + m]; q.z = (T)Tn[2 * M + m]; q.w = (T)f.coord[m];
+        nodes_w[m] = q;
+        f.dminbits[m] = ~0ull;
+    }
+    for (int e = t; e < 3 * M; e += kPT) {
+        f.Y[e] = Tn[e];
+        f.Yout[e] = Tn[e] + f.ctr[e / M];
+    }
+    if (t == 0) {
+        __hip_atomic_store(sync + 1, 0u, TDLO_RLX_AGENT);
+        __hip_atomic_store(sync + 2, 0u, TDLO_RLX_AGENT);
+        __hip_atomic_store(sync + 0, gen + 1u, TDLO_RLX_AGENT);
+        const int it = st->it + 1;
+        st->it = it; st->crit = crit; st->Np = s_np;
+        const double Nc = st->Nc;
+        const bool finite_ok = (new_sigma2 == new_sigma2) && (fabs(new_sigma2) < 1e300) && (new_sigma2 > 0) && !singular;
+        if (finite_ok) set_iter_consts(f, st, new_sigma2, Nc);
+        else { st->sigma2 = new_sigma2; st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
+        if (crit < f.tol) st->done = 1;                                   // :424-428
+        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+    }
+}
+
+size_t pivot_mcu_lds_bytes(int M) {
+    const int nS = 4 * M + 1, NC = M + 3, ld = NC | 1;
+    const size_t rr = (size_t)(16 * ld > 1536 ? 16 * ld : 1536);
+    const size_t d = (size_t)((nS + 1) & ~1) + (size_t)((3 * M + 1) & ~1) + 16 + 64 + (size_t)((NC + 1) & ~1) + rr;
+    return d * sizeof(double) + 40 * sizeof(int) + 2 * sizeof(double) + 16;
+}
+
 size_t mcu_lds_bytes(int M) {
     const int nS = 4 * M + 1, Mp = (M + 15) & ~15, Cp = Mp + 16, ncb = Cp >> 4;
     size_t ul = (size_t)ncb * kTS;
@@ -678,6 +960,30 @@ size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~
 static bool mcu_enabled() {
     static const int on = [] { const char *e = getenv("TDLO_MSTEP_BIG"); return (e && e[0] == '1') ? 0 : 1; }();
     return on != 0;
+}
+
+// M-step with the LLE term beyond kLdsSolveMaxM nodes: rows over the CUs, pivot search across the workgroups.
+// TDLO_MSTEP_LLE=1wg keeps the one-workgroup kernel k_mstep (comparator).
+bool mstep_pivot_mcu_enabled() {
+    static const int on = [] { const char *e = getenv("TDLO_MSTEP_LLE"); return (e && e[0] == '1') ? 0 : 1; }();
+    return on != 0;
+}
+
+hipError_t launch_mstep_pivot_mcu(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, bool f64, hipStream_t s) {
+    const int M = fh[0].M;
+    const size_t lds = pivot_mcu_lds_bytes(M);
+    const dim3 grid((unsigned)((M + 15) >> 4), (unsigned)F);
+    hipError_t e;
+    if (f64) {
+        e = hipFuncSetAttribute((const void *)k_mstep_pivot_mcu<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_mstep_pivot_mcu<double>), grid, dim3(kPT), lds, s, fd, from_sums);
+    } else {
+        e = hipFuncSetAttribute((const void *)k_mstep_pivot_mcu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_mstep_pivot_mcu<float>), grid, dim3(kPT), lds, s, fd, from_sums);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_mstep_big(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, bool f64, hipStream_t s) {
