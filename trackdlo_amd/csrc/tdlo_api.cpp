@@ -39,7 +39,7 @@ struct Slot {
     int cap_nodes = 0;
     double *nodeblk = nullptr;
     size_t nodeblk_doubles = 0;
-    unsigned *sync = nullptr;        // 128 words, zeroed once: cross-workgroup hand-off state of the multi-CU M-step
+    unsigned *sync = nullptr;        // 256 words, zeroed once: cross-workgroup hand-off state of the multi-CU M-step
 };
 
 struct NodeCarve {
@@ -150,8 +150,8 @@ int ensure_nodes(tdlo_ctx *c, Slot &s, int M) {
     HIPCHK(c, hipMalloc((void **)&s.nodeblk, nc.total * sizeof(double)));
     HIPCHK(c, hipMemsetAsync(s.nodeblk, 0, nc.total * sizeof(double), c->stream));
     if (!s.sync) {
-        HIPCHK(c, hipMalloc((void **)&s.sync, 128 * sizeof(unsigned)));
-        HIPCHK(c, hipMemsetAsync(s.sync, 0, 128 * sizeof(unsigned), c->stream));
+        HIPCHK(c, hipMalloc((void **)&s.sync, 256 * sizeof(unsigned)));
+        HIPCHK(c, hipMemsetAsync(s.sync, 0, 256 * sizeof(unsigned), c->stream));
     }
     s.nodeblk_doubles = nc.total;
     s.cap_nodes = cap;

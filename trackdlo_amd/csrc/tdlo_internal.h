@@ -67,7 +67,7 @@ struct FrameDev {
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
     unsigned long long *dbg; // 64 shader-clock stamps written by the M-step (tdlo_debug_stamps)
-    unsigned *sync;         // 128 words, zeroed when the slot is created: generation / arrivals / flags of the multi-CU M-steps' hand-offs
+    unsigned *sync;         // 256 words, zeroed when the slot is created: generation / arrivals / flags of the multi-CU M-steps' hand-offs
     IterState *st;
 };
 

@@ -658,14 +658,14 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
 // pivoting, trackdlo.cpp:396-415) for more than 128 nodes, where the one-workgroup kernel k_mstep keeps the tableau in
 // global memory and is bound by one CU's path to the L2 (M = 300: 5.5 ms).  One workgroup (256 threads) per 16 rows; the
 // rows stay in LDS for the whole elimination.  Gauss-Jordan with partial pivoting, one column at a time, ONE hand-off per
-// column: every workgroup publishes its best pivot candidate TOGETHER with that row's live entries (header {|a_pk|, p} +
-// <= M + 3 values, write-through), drains, raises its flag; one wave per workgroup waits for all flags, reads the headers,
-// takes the largest |a_pk| (ties: lowest row) -- every workgroup arrives at the same winner -- and the winner's row is
+// column: every workgroup publishes its best pivot candidate's live entries (<= M + 3 values, write-through), drains, and
+// raises its flag, which carries the candidate's row and a 32-bit key of |a_pk|; one wave per workgroup waits for all
+// flags and takes the largest key (ties: lowest row) -- every workgroup arrives at the same winner -- and the winner's row is
 // read (L1-bypassing loads), normalised and applied to the own 16 rows.  Candidate slots and flags are double-buffered by
 // column parity: nobody can publish column k + 2 before everybody has consumed column k + 1, hence finished reading k.
 // The pivot rows are not moved (used[] / kof[]: row -> column it pivots); at the end row piv(k) holds W_k, every workgroup
 // contributes G[:, its pivot columns] W[...] and the last one to arrive finishes the iteration as in k_mstep_mcu.
-// sync words: [0] generation, [1] arrivals, [2] singular, [64 + 32 (k & 1) + rb] flags.
+// sync words: [0] generation, [1] arrivals, [2] singular, 64-bit flags from word 128: [32 (k & 1) + rb].
 constexpr int kPT = 256;
 
 template <typename T>
@@ -692,6 +692,10 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
     const auto Cb = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.Ascr;      // [parity][rb][slotsz]
     const auto Tp = TDLO_AS_GLOBAL_RW(double, f.Ascr) + (size_t)Mp * Cp + (size_t)Mp * 16;          // [rb][d][M]
     gu32 *sync = (gu32 *)(uintptr_t)f.sync;
+    // flags: one 64-bit word per (column parity, workgroup) = {column + 1 : 16 | candidate row : 16 | key of |a| : 32}; the key is
+    // the upper half of the fp64 pattern (monotone for non-negative values).  The flag IS the candidate's header (no second
+    // dependent load); the finishing workgroup zeroes all flags, so a tag only has to be unique within a launch.
+    const auto flag64 = (__attribute__((address_space(1))) unsigned long long *)(sync + 128);
     const unsigned gen = sync[0];
     if (t < 4) flg[t] = 0;
     if (t < 16) { used[t] = (16 * rb + t < M) ? 0 : 1; kof[t] = -1; }      // padding rows never pivot
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
     // ---- 3. Gauss-Jordan with partial pivoting across the workgroups, one hand-off per column
     int singular = 0;
     for (int k = 0; k < M; ++k) {
-        const unsigned epoch = gen * 1024u + (unsigned)k + 1u;
+        const unsigned long long tag = (unsigned long long)(k + 1);
         const int par = k & 1;
         // a. local candidate
         if (w == 0) {
@@ -780,40 +784,35 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
         {
             const int lr = flg[2];
             const auto slot = Cb + ((size_t)par * nrb + rb) * slotsz;
-            if (t == 0) {
-                __hip_atomic_store(slot, (unsigned long long)__double_as_longlong(dflg[0]), TDLO_RLX_AGENT);
-                __hip_atomic_store(slot + 1, (unsigned long long)__double_as_longlong((double)(16 * rb + (lr >= 0 ? lr : 0))), TDLO_RLX_AGENT);
-            }
             if (lr >= 0)
                 for (int j = k + t; j < NC; j += kPT) __hip_atomic_store(slot + 2 + j, (unsigned long long)__double_as_longlong(R[lr * ld + j]), TDLO_RLX_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t == 0) __hip_atomic_store(sync + 64 + 32 * par + rb, epoch, TDLO_RLX_AGENT);
+            if (t == 0) {
+                const unsigned key = lr >= 0 ? (unsigned)__double2hiint(dflg[0]) : 0u;
+                __hip_atomic_store(flag64 + 32 * par + rb, (tag << 48) | ((unsigned long long)(16 * rb + (lr >= 0 ? lr : 0)) << 32) | key, TDLO_RLX_AGENT);
+            }
         }
         // c. all candidates in: the winner
         if (w == 0) {
+            unsigned long long word = 0;
             if (!flg[1]) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
-                    const bool ok = lane >= nrb || __hip_atomic_load(sync + 64 + 32 * par + (lane < nrb ? lane : 0), TDLO_RLX_AGENT) == epoch;
-                    if (__all(ok)) break;
+                    if (lane < nrb) word = __hip_atomic_load(flag64 + 32 * par + lane, TDLO_RLX_AGENT);
+                    if (__all(lane >= nrb || (word >> 48) == tag)) break;
                     __builtin_amdgcn_s_sleep(1);
                     if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) { if (lane == 0) flg[1] = 1; break; }
                 }
             }
-            double av = -1.0; int ri = 0x7fffffff;
-            if (lane < nrb) {
-                const auto sl = Cb + ((size_t)par * nrb + lane) * slotsz;
-                av = __longlong_as_double((long long)__hip_atomic_load(sl, TDLO_RLX_AGENT));
-                ri = (int)__longlong_as_double((long long)__hip_atomic_load(sl + 1, TDLO_RLX_AGENT));
-                if (!(av >= 0.0)) { av = -1.0; ri = 0x7fffffff; }
-            }
+            unsigned key = 0; int ri = 0x7fffffff;
+            if (lane < nrb && (word >> 48) == tag) { key = (unsigned)word; ri = (int)((word >> 32) & 0xffffu); }
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) {
-                const double ov = __shfl_xor(av, o); const int oi = __shfl_xor(ri, o);
-                if (ov > av || (ov == av && oi < ri)) { av = ov; ri = oi; }
+                const unsigned ok_ = (unsigned)__shfl_xor((int)key, o); const int oi = __shfl_xor(ri, o);
+                if (ok_ > key || (ok_ == key && oi < ri)) { key = ok_; ri = oi; }
             }
-            if (lane == 0) { flg[3] = ri; dflg[1] = av; }
+            if (lane == 0) { flg[3] = ri; dflg[1] = key ? 1.0 : 0.0; }
         }
         __syncthreads();
         const int p = flg[3];
@@ -913,6 +912,7 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
         f.Y[e] = Tn[e];
         f.Yout[e] = Tn[e] + f.ctr[e / M];
     }
+    if (t < 64) __hip_atomic_store(flag64 + t, 0ull, TDLO_RLX_AGENT);      // every workgroup has arrived: nobody polls any more
     if (t == 0) {
         __hip_atomic_store(sync + 1, 0u, TDLO_RLX_AGENT);
         __hip_atomic_store(sync + 2, 0u, TDLO_RLX_AGENT);
