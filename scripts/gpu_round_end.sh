@@ -13,6 +13,8 @@ bash scripts/gpu_profile_extra.sh $tag >> $R/gpurun_out/$tag/profile.log 2>&1
   echo "== mcu (multi-CU M-step, default)"; timeout 200 python scripts/gpu_mcu.py dump $R/gpurun_out/$tag/mcu.npz
   echo "== 1wg (TDLO_MSTEP_BIG=1wg comparator)"; TDLO_MSTEP_BIG=1wg timeout 200 python scripts/gpu_mcu.py dump $R/gpurun_out/$tag/onewg.npz
   python scripts/gpu_mcu.py compare $R/gpurun_out/$tag/mcu.npz $R/gpurun_out/$tag/onewg.npz
+  echo "== lle (M-step with the LLE term over M)"; timeout 200 python scripts/gpu_lle_time.py
+  echo "== lle accuracy against the oracle"; timeout 200 python scripts/gpu_lle_acc.py
   echo "== c4";   timeout 300 python scripts/gpu_c4.py
   echo "== prod"; timeout 200 python scripts/gpu_prod.py
   echo "== track"; timeout 200 python scripts/gpu_track.py

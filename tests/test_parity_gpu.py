@@ -996,18 +996,23 @@ def test_multi_cu_mstep_hand_offs_under_uneven_load():
         except Exception as e:      # pragma: no cover
             errors.append(e)
 
-    for M, F in ((130, 16), (300, 20)):
+    for M, F, lle in ((130, 16, False), (300, 20, False), (200, 8, True)):      # the last: k_mstep_pivot_mcu (a hand-off per column)
         rng = np.random.default_rng(9300 + M)
         ctx = B.Context(device=0, max_frames=F, max_points=1 << 14, max_nodes=M)
         try:
             pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 5, 0.0, False, precision=1)
+            Hk = {}
+            if lle:
+                pr = B.make_params(3.0, 1.0, 10.0, 0.1, 3, 0.0, True, precision=1)
+                Hk = dict(H=np.eye(M) * 0.1 + 0.01 * np.diag(np.ones(M - 1), 1) + 0.01 * np.diag(np.ones(M - 1), -1))
             Ys, s2s, single = [], [], []
             for f in range(F):
                 X, Y0, _ = synth.scene(int(rng.integers(2000, 12000)), M, config=170 + M, frame=f)
                 ctx.set_cloud(f, X)
                 Ys.append(Y0); s2s.append(0.0)
+            if lle: s2s = [2e-5] * F
             for f in range(F):
-                single.append(ctx.cpd_lle_resident(f, Ys[f], s2s[f], pr))
+                single.append(ctx.cpd_lle_resident(f, Ys[f], s2s[f], pr, **Hk))
             stop.clear(); running.clear()
             th = threading.Thread(target=background)
             th.start()
@@ -1015,11 +1020,11 @@ def test_multi_cu_mstep_hand_offs_under_uneven_load():
                 assert running.wait(timeout=120) or errors
                 c0 = calls[0]
                 for rep in range(40):
-                    out = ctx.cpd_lle_batch(Ys, s2s, pr)
+                    out = ctx.cpd_lle_batch(Ys, s2s, pr, **Hk)
                     for f in range(F):
                         assert out["stats"][f]["status"] == 0
                         assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"], (M, rep, f)
-                    g = ctx.cpd_lle_resident(rep % F, Ys[rep % F], 0.0, pr)
+                    g = ctx.cpd_lle_resident(rep % F, Ys[rep % F], s2s[rep % F], pr, **Hk)
                     assert np.array_equal(g["Y"], single[rep % F]["Y"])
                 assert calls[0] > c0 + 3        # the other context did run beside the batches
             finally:
