@@ -109,9 +109,9 @@ int tdlo_set_cloud(tdlo_ctx *ctx, int slot, const double *X, int N);
  *   H_override optional M x M column-major matrix used in place of the LLE regulariser
  *              H = (I-L)^T (I-L) of :236-237 (whose weights are numerically ill-defined).
  * Returns 0 or an error; stats->converged carries the reference's bool result.
- * Chains of more than 60 nodes (without the LLE term) solve the M x M system on one CU per 16 rows; environment
- * TDLO_MSTEP_BIG=1wg (read once per process) keeps that elimination in one workgroup -- same operations, the
- * comparator of the tests. */
+ * Chains of more than 60 nodes (without the LLE term) and of more than 128 nodes (with it) solve the M x M system on
+ * one CU per 16 rows; environment TDLO_MSTEP_BIG=1wg / TDLO_MSTEP_LLE=1wg (read once per process) keep those
+ * eliminations in one workgroup -- the comparators of the tests. */
 int tdlo_cpd_lle_resident(tdlo_ctx *ctx, int slot, double *Y, int M, double *sigma2,
                           const tdlo_params *params, const double *priors, int K,
                           const int *visible_nodes, int n_vis, const double *H_override,
