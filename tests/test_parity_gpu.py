@@ -483,16 +483,26 @@ def test_nsplit_device_exchange_two_shards_on_one_gpu(hip_ctx, oracle):
 def test_tracking_step_against_oracle(hip_ctx, oracle, occl):
     """trackdlo::tracking_step (trackdlo.cpp:900-999) through the tracker object, all five occlusion states.
     The pre-processing registration's LLE matrix is injected on both sides (its weights are ill-conditioned)."""
+    _tracking_step_case(hip_ctx, oracle, occl, 30, 3000)
+
+
+@pytest.mark.parametrize("occl", [None, (0.45, 0.55), (0.0, 0.2)], ids=["all", "mid", "head"])
+def test_tracking_step_long_chain(hip_ctx, oracle, occl):
+    """The same on a chain of 160 nodes: the pre-processing registration (LLE term) runs on k_mstep_pivot_mcu when more than
+    128 nodes are visible (k_mstep below), the main registration on k_mstep_mcu."""
+    _tracking_step_case(hip_ctx, oracle, occl, 160, 9000)
+
+
+def _tracking_step_case(hip_ctx, oracle, occl, M, N):
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
-    M = 30
     Y0 = synth.nodes(M); coord = synth.geodesic_coord(Y0)
     if occl is None:
-        X, _, _ = synth.scene(3000, M, config=20); vis = np.arange(M)
+        X, _, _ = synth.scene(N, M, config=20); vis = np.arange(M)
     elif len(occl) == 2:
-        X, _, vis = synth.scene(3000, M, config=20, occlude=occl)
+        X, _, vis = synth.scene(N, M, config=20, occlude=occl)
     else:
-        X, _, _ = synth.scene(3000, M, config=20)
+        X, _, _ = synth.scene(N, M, config=20)
         s = np.linspace(0, 1, M)
         vis = np.nonzero((s > occl[1]) & (s < occl[2]))[0].astype(np.int32)
         d = np.linalg.norm(X[:, None, :] - Y0[None, vis, :], axis=2).min(axis=1)
