@@ -334,11 +334,10 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     const int nS = 4 * M + 1;
     const int Mp = (M + 15) & ~15, Cp = Mp + 16, nrb = Mp >> 4, ncb = Cp >> 4;
     double *S = (double *)smem;               // nS (+pad)
-    double *W = S + ((nS + 1) & ~1);          // 3M (+pad)
-    double *Tn = W + ((3 * M + 1) & ~1);      // 3M (+pad)
+    double *Sown = S + ((nS + 1) & ~1);       // 64 (3M reserved): P1, PX of the own 16 nodes
+    double *Tn = Sown + ((3 * M + 1) & ~1);   // 3M (+pad)
     double *scratch = Tn + ((3 * M + 1) & ~1);// 16
-    double *pcol = scratch + 16;              // 2 x 16: pivot column of the current step, double-buffered
-    double *Abuf = pcol + 32;                 // 2 x 256: -tile (rb, pb) in A-operand order, double-buffered over panels
+    double *Abuf = scratch + 16;                // 2 x 256: -tile (rb, pb) in A-operand order, double-buffered over panels
     double *Ul = Abuf + 512;                  // ncb x kTS: the row block in B-operand order (= accumulator registers, lane-minor)
     int *flg = (int *)(Ul + (ncb * kTS > 6 * 512 ? ncb * kTS : 6 * 512));   // [0] last arriver, [1] a spin ran into its time limit
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
@@ -358,7 +357,6 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     // ---- 1. block partials -> the 4 x 16 sums this row block needs (P1, PX of its 16 nodes): wave = group of every 16th
     //         partial row, lane = (quantity, node); the 16 groups are added in a fixed order.  The sums go to f.sums for the
     //         workgroup that finishes the iteration (every workgroup reading all 256 rows cost 35 us at N >= 64 000).
-    double *Sown = W;                               // 64 doubles; W and Tn are only used by the finishing workgroup afterwards
     {
         const int ii = lane & 15, kk = lane >> 4, irow = 16 * rb + ii;
         const bool valid = irow < M;
@@ -939,7 +937,7 @@ size_t mcu_lds_bytes(int M) {
     const int nS = 4 * M + 1, Mp = (M + 15) & ~15, Cp = Mp + 16, ncb = Cp >> 4;
     size_t ul = (size_t)ncb * kTS;
     if (ul < 6 * 512) ul = 6 * 512;
-    const size_t d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 16 + 32 + 512 + ul + 2;
+    const size_t d = (size_t)((nS + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 16 + 512 + ul + 2;
     return d * sizeof(double);
 }
 
