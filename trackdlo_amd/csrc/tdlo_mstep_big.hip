@@ -684,8 +684,7 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
     double *prow = Sown + 64;                          // NC (+pad): normalised pivot row of the current column
     double *R = prow + ((NC + 1) & ~1);                // 16 x ld: the own rows of [A | B]
     int *ib = (int *)(R + (16 * ld > 1536 ? 16 * ld : 1536));
-    int *used = ib, *kof = ib + 16, *flg = ib + 32;    // flg: [0] last arriver, [1] a spin ran into its time limit, [2] local candidate row, [3] winner row
-    double *dflg = (double *)(ib + 40);                // [0] |a| of the local candidate, [1] |a| of the winner
+    int *used = ib, *kof = ib + 16, *flg = ib + 32;    // flg: [0] last arriver, [1] a spin ran into its time limit
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
     const auto Cb = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.Ascr;      // [parity][rb][slotsz]
     const auto Tp = TDLO_AS_GLOBAL_RW(double, f.Ascr) + (size_t)Mp * Cp + (size_t)Mp * 16;          // [rb][d][M]
@@ -766,33 +765,33 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
     for (int k = 0; k < M; ++k) {
         const unsigned long long tag = (unsigned long long)(k + 1);
         const int par = k & 1;
-        // a. local candidate
-        if (w == 0) {
+        // a. local candidate: every wave on its own (wave-uniform result, no LDS hand-off, no barrier)
+        int lr; double lav;
+        {
             double av = -1.0; int ri = 0x7fffffff;
             if (lane < 16 && !used[lane]) { av = fabs(R[lane * ld + k]); ri = lane; }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
+            for (int o = 32; o > 0; o >>= 1) {
                 const double ov = __shfl_xor(av, o); const int oi = __shfl_xor(ri, o);
                 if (ov > av || (ov == av && oi < ri)) { av = ov; ri = oi; }
             }
-            if (lane == 0) { flg[2] = av >= 0.0 ? ri : -1; dflg[0] = av; }
+            lr = av >= 0.0 ? ri : -1; lav = av;
         }
-        __syncthreads();
-        // b. publish {|a|, row, entries k .. NC-1 of that row}
+        // b. publish the entries k .. NC-1 of that row, then the flag {column, row, key of |a|}
         {
-            const int lr = flg[2];
             const auto slot = Cb + ((size_t)par * nrb + rb) * slotsz;
             if (lr >= 0)
                 for (int j = k + t; j < NC; j += kPT) __hip_atomic_store(slot + 2 + j, (unsigned long long)__double_as_longlong(R[lr * ld + j]), TDLO_RLX_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0) {
-                const unsigned key = lr >= 0 ? (unsigned)__double2hiint(dflg[0]) : 0u;
+                const unsigned key = lr >= 0 ? (unsigned)__double2hiint(lav) : 0u;
                 __hip_atomic_store(flag64 + 32 * par + rb, (tag << 48) | ((unsigned long long)(16 * rb + (lr >= 0 ? lr : 0)) << 32) | key, TDLO_RLX_AGENT);
             }
         }
-        // c. all candidates in: the winner
-        if (w == 0) {
+        // c. all candidates in: the winner (every wave polls and decides on its own; the words are final once all tags match)
+        int p; bool okp;
+        {
             unsigned long long word = 0;
             if (!flg[1]) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -806,16 +805,12 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
             unsigned key = 0; int ri = 0x7fffffff;
             if (lane < nrb && (word >> 48) == tag) { key = (unsigned)word; ri = (int)((word >> 32) & 0xffffu); }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
+            for (int o = 32; o > 0; o >>= 1) {
                 const unsigned ok_ = (unsigned)__shfl_xor((int)key, o); const int oi = __shfl_xor(ri, o);
                 if (ok_ > key || (ok_ == key && oi < ri)) { key = ok_; ri = oi; }
             }
-            if (lane == 0) { flg[3] = ri; dflg[1] = key ? 1.0 : 0.0; }
+            p = ri; okp = key != 0u && p < M;
         }
-        __syncthreads();
-        const int p = flg[3];
-        const double wav = dflg[1];
-        const bool okp = wav > 0.0 && p < M;
         if (!okp) singular = 1;
         // d. the winner's row, normalised
         {
