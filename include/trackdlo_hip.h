@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDLO_ABI_VERSION 1
+#define TDLO_ABI_VERSION 2
 
 enum {
     TDLO_OK = 0,
@@ -52,8 +52,6 @@ typedef struct {
     int max_frames;          /* number of frame slots (>= 1); slots are independent clouds/trackers */
     int max_points;          /* initial per-slot capacity in points (grown on demand) */
     int max_nodes;           /* initial capacity in nodes (grown on demand) */
-    int use_graph;           /* reserved, ignored: the loop is enqueued as plain launches on one stream -- kernel durations
-                              * add up to the loop time to within 0.4 us per iteration (bench.py), a graph has nothing to recover */
     int estep_blocks;        /* 0 = auto; otherwise workgroups per frame for the E-step */
 } tdlo_config;
 
@@ -81,6 +79,8 @@ typedef struct {
     float loop_ms;        /* HIP-event time of the EM loop body on the context's stream (trackdlo.cpp:275-438) */
     float total_ms;       /* HIP-event time of the whole device-side call (prune + setup + loop + readback) */
     double host_ms;       /* host wall time of the call including uploads and the final synchronise */
+    int mstep_retries;    /* iterations whose multi-CU elimination (more than 60 nodes) ran into the time limit of an
+                           * inter-workgroup hand-off and were redone by the one-workgroup elimination (normally 0) */
 } tdlo_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -152,6 +152,9 @@ int tdlo_split_dmin(tdlo_ctx *ctx, double *dmin_sq /* out M, local */);
 int tdlo_split_estep(tdlo_ctx *ctx, const double *dmin_sq_global /* in M or NULL */, double *sums /* out 4M+2 */);
 int tdlo_split_mstep(tdlo_ctx *ctx, const double *sums_global /* in 4M+2 */, int *done /* out */);
 int tdlo_split_end(tdlo_ctx *ctx, double *Y, double *sigma2, tdlo_stats *stats);
+/* Leaves a split registration without results (e.g. after the global kept-point count came back 0): drains the stream,
+ * unbinds the exchange buffers, so that the context can begin the next registration. */
+int tdlo_split_abort(tdlo_ctx *ctx);
 
 /* Device-resident exchange (the form the 8-GPU run uses): the two buffers the ranks all-reduce live in DEVICE memory
  * owned by the caller -- e.g. a tensor handed to RCCL -- and the calls below only enqueue work on the context's stream
@@ -186,6 +189,11 @@ int tdlo_tracker_set_precision(tdlo_tracker *t, int precision);
 int tdlo_tracker_initialize_nodes(tdlo_tracker *t, const double *Y_init /* M x 3 */);
 /* trackdlo::initialize_geodesic_coord (trackdlo.cpp:77-81; appends, like the reference) */
 int tdlo_tracker_initialize_geodesic_coord(tdlo_tracker *t, const double *coord, int n);
+/* The implicit copy assignment of class trackdlo (trackdlo/include/trackdlo.h:104-121 has no user-defined one: every member is
+ * copied -- Y_, guide_nodes_, sigma2_, the eleven parameters, geodesic_coord_, correspondence_priors_).  The ROS node relies on
+ * it once (trackdlo_node.cpp:131 assigns a configured object to the file-scope default-constructed one, :54).  Both trackers
+ * must have the same number of nodes; dst keeps its own context and slot. */
+int tdlo_tracker_copy_state(tdlo_tracker *dst, const tdlo_tracker *src);
 /* trackdlo::get_sigma2 / set_sigma2 (trackdlo.cpp:61-63, :88-90) */
 double tdlo_tracker_get_sigma2(const tdlo_tracker *t);
 void tdlo_tracker_set_sigma2(tdlo_tracker *t, double sigma2);
@@ -208,7 +216,8 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N,
 /* ---- plain GMM-EM initial registration ------------------------------------ */
 /* reg(pts, Y, sigma2, M, mu, max_iter), trackdlo/src/utils.cpp:21-82 (declared trackdlo/include/utils.h): M centroids
  * fitted to the cloud with the Euclidean membership only; Y (M x 3 column-major) and sigma2 are pure outputs (the
- * reference overwrites both, :24-29, :45).  Exactly max_iter iterations, no stopping rule, fp64.  pts == NULL: use the
+ * reference overwrites both, :24-29, :45).  Exactly max_iter iterations, no stopping rule, fp64.  M <= 890 (per-wave
+ * accumulators in LDS; more is TDLO_E_INVALID).  pts == NULL: use the
  * cloud resident in `slot`.  A centroid that attracts no probability mass comes back NaN, as in the reference. */
 int tdlo_reg(tdlo_ctx *ctx, int slot, const double *pts, int N, double *Y, double *sigma2, int M, double mu, int max_iter);
 

@@ -49,11 +49,9 @@ public:
         for (int i = 0; i < 11; ++i) params_[i] = o.params_[i];
         if (o.trk_) {
             make_tracker();
-            std::vector<double> y(3 * (size_t)M_);
-            tdlo_tracker_get_tracking_result(o.trk_, y.data());
-            tdlo_tracker_initialize_nodes(trk_, y.data());
-            tdlo_tracker_set_sigma2(trk_, tdlo_tracker_get_sigma2(o.trk_));
-            if (!o.coord_.empty()) tdlo_tracker_initialize_geodesic_coord(trk_, o.coord_.data(), (int)o.coord_.size());
+            // every member of the reference class (trackdlo.h:104-121): Y_, guide_nodes_, sigma2_, the parameters,
+            // geodesic_coord_, correspondence_priors_ -- what the implicit copy assignment of the reference copies
+            if (tdlo_tracker_copy_state(trk_, o.trk_) != TDLO_OK) throw std::runtime_error("trackdlo: tdlo_tracker_copy_state failed");
             coord_ = o.coord_;
         }
         return *this;

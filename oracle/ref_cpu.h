@@ -152,6 +152,13 @@ int ref_depth_to_cloud(const unsigned short *depth, const unsigned char *mask, i
  * full-rank A, trackdlo.cpp:415). A and B are overwritten; solution returned in X (n x nrhs). */
 int ref_solve_qrcp(double *A, int n, double *B, int nrhs, double *X);
 
+/* DIAGNOSTIC (not in the reference): the same system in extended precision (__float128 LU + iterative refinement; A, B
+ * not overwritten).  ref_set_solver(1) makes ref_cpd_lle / ref_tracking_step use it in place of the QR solve, so that the
+ * oracle's own rounding error on an ill-conditioned M-step system can be MEASURED: |Y(solver 0) - Y(solver 1)|. */
+int ref_solve_extended(const double *A, int n, const double *B, int nrhs, double *X);
+void ref_set_solver(int mode);
+int ref_get_solver(void);
+
 #ifdef __cplusplus
 }
 #endif

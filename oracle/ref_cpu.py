@@ -146,6 +146,32 @@ def cpd_lle(X, Y, sigma2, *, beta, lambda_, lle_weight, mu, max_iter=30, tol=1e-
     return out
 
 
+def set_solver(mode: int) -> None:
+    """0 (default): the faithful QR solve of trackdlo.cpp:415.  1: DIAGNOSTIC extended-precision solve of the same system
+    (__float128 LU + iterative refinement) -- the distance between the two runs is the oracle's own rounding error."""
+    lib().ref_set_solver(C.c_int(int(mode)))
+
+
+class extended_solver:
+    """with ref_cpu.extended_solver(): ... -- runs the oracle with the diagnostic extended-precision solve."""
+
+    def __enter__(self):
+        set_solver(1)
+        return self
+
+    def __exit__(self, *exc):
+        set_solver(0)
+        return False
+
+
+def solve_extended(A, B):
+    A = _f(A); B = _f(B)
+    n = A.shape[0]; nrhs = B.shape[1]
+    Xo = np.zeros((n, nrhs), order="F")
+    lib().ref_solve_extended(_dp(A), C.c_int(n), _dp(B), C.c_int(nrhs), _dp(Xo))
+    return Xo
+
+
 def calc_lle_weights(Y, k=6, extended=False):
     Y = _f(Y); M = Y.shape[0]
     L = np.zeros((M, M), order="F")

@@ -99,6 +99,9 @@ class NumpyShard:
     def end(self):
         return dict(Y=self.Y, sigma2=self.sigma2, iters=self.it, converged=self.converged, n_kept=len(self.X))
 
+    def abort(self):
+        self.aborted = True
+
 
 class NumpyDeviceShard(NumpyShard):
     """The same arithmetic behind the enqueue-style interface of trackdlo_amd.nsplit.HipDeviceShard: the exchange buffers are

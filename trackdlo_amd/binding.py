@@ -26,7 +26,7 @@ class TdloError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("max_frames", C.c_int), ("max_points", C.c_int), ("max_nodes", C.c_int),
-                ("use_graph", C.c_int), ("estep_blocks", C.c_int)]
+                ("estep_blocks", C.c_int)]
 
 
 class Params(C.Structure):
@@ -37,7 +37,8 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("iters", C.c_int), ("converged", C.c_int), ("n_kept", C.c_int), ("status", C.c_int),
-                ("sigma2", C.c_double), ("loop_ms", C.c_float), ("total_ms", C.c_float), ("host_ms", C.c_double)]
+                ("sigma2", C.c_double), ("loop_ms", C.c_float), ("total_ms", C.c_float), ("host_ms", C.c_double),
+                ("mstep_retries", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -47,10 +48,10 @@ class Stats(C.Structure):
 SYMBOLS = [
     "tdlo_abi_version", "tdlo_device_count", "tdlo_default_config", "tdlo_create", "tdlo_destroy", "tdlo_last_error",
     "tdlo_stream", "tdlo_synchronize", "tdlo_set_cloud", "tdlo_cpd_lle_resident", "tdlo_cpd_lle", "tdlo_cpd_lle_batch",
-    "tdlo_split_begin", "tdlo_split_set_global", "tdlo_split_dmin", "tdlo_split_estep", "tdlo_split_mstep", "tdlo_split_end",
+    "tdlo_split_begin", "tdlo_split_set_global", "tdlo_split_dmin", "tdlo_split_estep", "tdlo_split_mstep", "tdlo_split_end", "tdlo_split_abort",
     "tdlo_split_bind_exchange", "tdlo_split_dmin_enqueue", "tdlo_split_estep_enqueue", "tdlo_split_mstep_enqueue", "tdlo_split_poll",
     "tdlo_tracker_create", "tdlo_tracker_create_default", "tdlo_tracker_destroy", "tdlo_tracker_set_precision",
-    "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_get_sigma2",
+    "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
     "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
@@ -125,6 +126,7 @@ def load_library(path: str | None = None):
     lib.tdlo_split_estep.argtypes = [vp, vp, vp]
     lib.tdlo_split_mstep.argtypes = [vp, vp, C.POINTER(ci)]
     lib.tdlo_split_end.argtypes = [vp, vp, C.POINTER(cd), C.POINTER(Stats)]
+    lib.tdlo_split_abort.argtypes = [vp]
     lib.tdlo_split_bind_exchange.argtypes = [vp, vp, vp]
     lib.tdlo_split_dmin_enqueue.argtypes = [vp]
     lib.tdlo_split_estep_enqueue.argtypes = [vp]
@@ -138,6 +140,7 @@ def load_library(path: str | None = None):
     lib.tdlo_tracker_set_precision.argtypes = [vp, ci]
     lib.tdlo_tracker_initialize_nodes.argtypes = [vp, vp]
     lib.tdlo_tracker_initialize_geodesic_coord.argtypes = [vp, vp, ci]
+    lib.tdlo_tracker_copy_state.argtypes = [vp, vp]
     lib.tdlo_tracker_get_sigma2.restype = cd
     lib.tdlo_tracker_get_sigma2.argtypes = [vp]
     lib.tdlo_tracker_set_sigma2.argtypes = [vp, cd]
@@ -180,9 +183,9 @@ def make_params(beta, lambda_, lle_weight, mu, max_iter=30, tol=1e-4, include_ll
 class Context:
     """Owns one tdlo_ctx (one GPU, one HIP stream)."""
 
-    def __init__(self, device=0, max_frames=1, max_points=65536, max_nodes=64, estep_blocks=0, use_graph=1):
+    def __init__(self, device=0, max_frames=1, max_points=65536, max_nodes=64, estep_blocks=0):
         self.lib = load_library()
-        cfg = Config(device, max_frames, max_points, max_nodes, use_graph, estep_blocks)
+        cfg = Config(device, max_frames, max_points, max_nodes, estep_blocks)
         err = C.c_int(0)
         self.h = self.lib.tdlo_create(C.byref(cfg), C.byref(err))
         if not self.h:
@@ -237,7 +240,7 @@ class Context:
         if check:
             self._chk(rc)
         return dict(Y=Y, sigma2=s2.value, converged=bool(st.converged), iters=st.iters, n_kept=st.n_kept, rc=rc,
-                    status=st.status, loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms)
+                    status=st.status, loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms, mstep_retries=st.mstep_retries)
 
     def cpd_lle(self, X, Y, sigma2, params: Params, priors=None, visible_nodes=None, H=None, check=True):
         """trackdlo::cpd_lle (trackdlo.cpp:161-441): returns dict(Y, sigma2, converged, ...)."""

@@ -128,8 +128,12 @@ int ensure_xfer(tdlo_ctx *c, size_t doubles) {
 int ensure_points(tdlo_ctx *c, Slot &s, int n) {
     if (n <= s.cap_points) return 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.bucket); hipFree(s.blksum); }
-    s.cap_points = 0;
+    if (s.Xraw) hipFree(s.Xraw);
+    if (s.Xs) hipFree(s.Xs);
+    if (s.bucket) hipFree(s.bucket);
+    if (s.blksum) hipFree(s.blksum);
+    s.Xraw = nullptr; s.Xs = nullptr; s.bucket = nullptr; s.blksum = nullptr;     // a failing hipMalloc below must not leave
+    s.cap_points = 0; s.N0 = 0;                                                      // dangling pointers for tdlo_destroy
     const size_t cap = ((size_t)n + 1023) & ~(size_t)1023;
     const size_t nb = cap / kBlock + 1;
     HIPCHK(c, hipMalloc((void **)&s.Xraw, 3 * cap * sizeof(double)));
@@ -222,6 +226,10 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0) ? 1 : 0;
     (void)vis;
     f.precision = p->precision;
+    {   // test hook: iteration k of the multi-CU M-steps behaves as if a hand-off had timed out (tests/test_parity_gpu.py)
+        static const int force_it = getenv("TDLO_MCU_FORCE_TIMEOUT") ? atoi(getenv("TDLO_MCU_FORCE_TIMEOUT")) : -1;
+        f.force_timeout_it = force_it;
+    }
     // prune / counting-sort workgroups: 256 points each up to 1024 workgroups; larger clouds give every workgroup 2, 4, 8 ...
     // consecutive tiles, so that the one-workgroup scan of the (workgroup, node) histogram in k_setup stays ~1000 rows
     f.prune_tiles = 1;
@@ -256,6 +264,7 @@ size_t upload_doubles(const NodeCarve &nc, const tdlo_params *p) { return p->inc
 
 void fill_stats(tdlo_stats *st, const IterState &is) {
     st->iters = is.it; st->converged = is.converged; st->n_kept = is.N; st->status = is.status; st->sigma2 = is.sigma2;
+    st->mstep_retries = is.retries;
 }
 
 // Shared driver of tdlo_cpd_lle_resident / _batch.
@@ -427,7 +436,7 @@ int tdlo_device_count(void) {
 
 void tdlo_default_config(tdlo_config *cfg) {
     if (!cfg) return;
-    cfg->device = 0; cfg->max_frames = 1; cfg->max_points = 65536; cfg->max_nodes = 64; cfg->use_graph = 1; cfg->estep_blocks = 0;
+    cfg->device = 0; cfg->max_frames = 1; cfg->max_points = 65536; cfg->max_nodes = 64; cfg->estep_blocks = 0;
 }
 
 tdlo_ctx *tdlo_create(const tdlo_config *cfg_in, int *err) {
@@ -469,7 +478,10 @@ void tdlo_destroy(tdlo_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &s : c->slots) {
-        if (s.Xraw) { hipFree(s.Xraw); hipFree(s.Xs); hipFree(s.bucket); hipFree(s.blksum); }
+        if (s.Xraw) hipFree(s.Xraw);
+        if (s.Xs) hipFree(s.Xs);
+        if (s.bucket) hipFree(s.bucket);
+        if (s.blksum) hipFree(s.blksum);
         if (s.hist) hipFree(s.hist);
         if (s.nodeblk) hipFree(s.nodeblk);
         if (s.sync) hipFree(s.sync);
@@ -569,12 +581,14 @@ int tdlo_split_begin(tdlo_ctx *c, const double *Y, int M, double sigma2, const t
 
 int tdlo_split_set_global(tdlo_ctx *c, double n_kept_global, double sum_d2_global) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, launch_split_set_global(c->fd, n_kept_global, sum_d2_global, c->stream));
     return TDLO_OK;
 }
 
 int tdlo_split_dmin(tdlo_ctx *c, double *dmin_sq) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     const FrameDev &f = c->fh[0];
     const int M = f.M;
     if (!f.vis_branch) { for (int m = 0; m < M; ++m) dmin_sq[m] = 0; return TDLO_OK; }
@@ -593,6 +607,7 @@ int tdlo_split_dmin(tdlo_ctx *c, double *dmin_sq) {
 
 int tdlo_split_estep(tdlo_ctx *c, const double *dmin_sq_global, double *sums) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     const FrameDev &f = c->fh[0];
     const int M = f.M;
     hipStream_t s = c->stream;
@@ -614,6 +629,7 @@ int tdlo_split_estep(tdlo_ctx *c, const double *dmin_sq_global, double *sums) {
 
 int tdlo_split_mstep(tdlo_ctx *c, const double *sums_global, int *done) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     const FrameDev &f = c->fh[0];
     const int M = f.M;
     hipStream_t s = c->stream;
@@ -639,6 +655,7 @@ int tdlo_split_bind_exchange(tdlo_ctx *c, double *d_dmin, double *d_sums) {
 
 int tdlo_split_dmin_enqueue(tdlo_ctx *c) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     if (!c->xch_dmin) return fail(c, TDLO_E_INVALID, "no exchange buffers bound");
     if (!c->fh[0].vis_branch) return TDLO_OK;
     HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 1, c->stream));
@@ -648,6 +665,7 @@ int tdlo_split_dmin_enqueue(tdlo_ctx *c) {
 
 int tdlo_split_estep_enqueue(tdlo_ctx *c) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     if (!c->xch_sums) return fail(c, TDLO_E_INVALID, "no exchange buffers bound");
     hipStream_t s = c->stream;
     if (c->fh[0].vis_branch) HIPCHK(c, launch_split_dmin_xch(c->fd, c->fh.data(), c->xch_dmin, 1, s));
@@ -658,6 +676,7 @@ int tdlo_split_estep_enqueue(tdlo_ctx *c) {
 
 int tdlo_split_mstep_enqueue(tdlo_ctx *c) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     if (!c->xch_sums) return fail(c, TDLO_E_INVALID, "no exchange buffers bound");
     HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 4, c->stream));
     return TDLO_OK;
@@ -665,6 +684,7 @@ int tdlo_split_mstep_enqueue(tdlo_ctx *c) {
 
 int tdlo_split_poll(tdlo_ctx *c, int *done, int *iters) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->pin, c->fh[0].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -677,6 +697,7 @@ int tdlo_split_poll(tdlo_ctx *c, int *done, int *iters) {
 
 int tdlo_split_end(tdlo_ctx *c, double *Y, double *sigma2, tdlo_stats *stats) {
     if (!c || !c->split_active) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     const FrameDev &f = c->fh[0];
     const int M = f.M;
     NodeCarve nc(M);
@@ -692,11 +713,21 @@ int tdlo_split_end(tdlo_ctx *c, double *Y, double *sigma2, tdlo_stats *stats) {
     return is.status;
 }
 
-// ---- caller-side visibility pre-pass ------------------------------------------------------------
+int tdlo_split_abort(tdlo_ctx *c) {
+    if (!c) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->split_active = 0;
+    c->xch_dmin = nullptr; c->xch_sums = nullptr;
+    return TDLO_OK;
+}
+
+// ---- plain GMM-EM `reg` ---------------------------------------------------------------------------
 int tdlo_reg(tdlo_ctx *c, int slot, const double *pts, int N, double *Y, double *sigma2, int M, double mu, int max_iter) {
     if (!c) return TDLO_E_INVALID;
     if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
-    if (!Y || !sigma2 || M < 1 || M > 4096 || max_iter < 0 || !(mu >= 0 && mu < 1)) return fail(c, TDLO_E_INVALID, "bad reg arguments");
+    if (!Y || !sigma2 || M < 1 || max_iter < 0 || !(mu >= 0 && mu < 1)) return fail(c, TDLO_E_INVALID, "bad reg arguments");
+    if (M > reg_max_nodes()) return fail(c, TDLO_E_INVALID, "reg: more than " + std::to_string(reg_max_nodes()) + " centroids do not fit the E-step's per-wave accumulators in 160 KB of LDS");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = TDLO_OK;
     if (pts) rc = tdlo_set_cloud(c, slot, pts, N);
@@ -808,6 +839,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     return TDLO_OK;
 }
 
+// ---- caller-side visibility pre-pass ------------------------------------------------------------
 int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, double visibility_threshold, double d_vis,
                             const double *geodesic_coord, double *node_dist, int *visible_nodes, int *n_vis,
                             int *visible_nodes_extended, int *n_vis_ext) {
@@ -1035,6 +1067,15 @@ int tdlo_tracker_initialize_nodes(tdlo_tracker *t, const double *Y_init) {
 int tdlo_tracker_initialize_geodesic_coord(tdlo_tracker *t, const double *coord, int n) {
     if (!t || !coord || n < 0) return TDLO_E_INVALID;
     t->geodesic_coord.insert(t->geodesic_coord.end(), coord, coord + n);
+    return TDLO_OK;
+}
+
+int tdlo_tracker_copy_state(tdlo_tracker *dst, const tdlo_tracker *src) {
+    if (!dst || !src || dst->M != src->M) return TDLO_E_INVALID;
+    if (dst == src) return TDLO_OK;
+    tdlo_ctx *ctx = dst->ctx; const int slot = dst->slot;
+    *dst = *src;                                       // every member of trackdlo.h:104-121 (and the precision switch)
+    dst->ctx = ctx; dst->slot = slot;
     return TDLO_OK;
 }
 

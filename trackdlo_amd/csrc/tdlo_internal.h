@@ -30,7 +30,8 @@ struct IterState {
     int done;           // 1: remaining kernels of the loop are no-ops
     int converged;      // value cpd_lle returns (:440)
     int status;         // 0 or TDLO_E_*
-    int pad;
+    int retry_pending;  // set by the finishing workgroup of a multi-CU M-step after a timed-out hand-off: the one-workgroup kernel that follows redoes the iteration
+    int retries;        // iterations whose multi-CU elimination hit a hand-off time limit and were redone in one workgroup
 };
 
 // Immutable-after-setup description of one frame's registration.
@@ -62,6 +63,7 @@ struct FrameDev {
     unsigned long long *dminbits;  // M: per-node min squared distance, as ordered bits
     double *part;           // nblkE x (4M+1) block partials [P1 | PXx | PXy | PXz | Q]
     double *partM;          // the rows the M-step adds up: part itself, or the kPartGroups group sums behind it (nblkE > kPartDirect)
+    int force_timeout_it;   // test hook (environment TDLO_MCU_FORCE_TIMEOUT=k): iteration k of the multi-CU M-steps behaves as if a hand-off timed out; -1 = off
     int nblkM, prune_tiles; // number of those rows; 256-point tiles one prune workgroup handles (1 up to 262 144 points)
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
@@ -89,6 +91,7 @@ hipError_t launch_mstep_pivot_mcu(const FrameDev *frames_dev, const FrameDev *fr
 bool mstep_pivot_mcu_enabled();
 // tdlo_reg.hip: plain GMM-EM `reg` (utils.cpp:21-82); ws layout: state (8) | Y (3 M) | block partials
 size_t reg_ws_doubles(int M, int nblk);
+int reg_max_nodes();        // the E-step's per-wave accumulators must fit 160 KB of LDS
 hipError_t launch_reg(const double *X, int N, int M, double mu, int max_iter, int nblk, double *ws, hipStream_t s);
 // tdlo_cloud.hip: depth image -> cloud -> voxel grid
 size_t cloud_ws_bytes(int P);

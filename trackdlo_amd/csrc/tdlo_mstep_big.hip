@@ -26,6 +26,8 @@
 //   * U lives in LDS in B-operand order; consecutive tiles of a wave share the row block, so the A operand is reused.
 // Mp = M rounded up to 16 rows (identity padded), Cp = Mp + 16 columns, right-hand sides in columns Mp .. Mp + 2.
 #include "tdlo_devcommon.h"
+#include "tdlo_mstep_generic.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace tdlo {
@@ -53,12 +55,8 @@ __device__ __forceinline__ double block_sum16(double v, double *scratch) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__ frames, int from_sums_in) {
-    const int from_sums = from_sums_in;
-    const FrameDev &f = frames[blockIdx.x];
+__device__ __forceinline__ void mstep_big_body(const FrameDev &f, const int from_sums, char *smem) {
     IterState *st = f.st;
-    if (st->done) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = f.M, t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nS = 4 * M + 1;
     const int Mp = (M + 15) & ~15, Cp = Mp + 16, nrb = Mp >> 4, ncb = Cp >> 4;
@@ -296,6 +294,22 @@ __global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__
     }
 }
 
+// retry_only: the launch that follows every k_mstep_mcu launch -- a no-op unless that kernel's finishing workgroup found
+// a timed-out hand-off and left the iteration to be redone here (IterState::retry_pending)
+template <typename T>
+__global__ __launch_bounds__(kBig) void k_mstep_big(const FrameDev *__restrict__ frames, int from_sums, int retry_only) {
+    const FrameDev &f = frames[blockIdx.x];
+    if (f.st->done) return;
+    if (retry_only) {
+        const int pending = f.st->retry_pending;
+        if (!pending) return;
+        __syncthreads();
+        if (threadIdx.x == 0) f.st->retry_pending = 0;
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    mstep_big_body<T>(f, from_sums, smem);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_mstep_mcu: the same elimination spread over the row blocks' own CUs (one workgroup per 16 rows of the tableau).
 //
@@ -518,9 +532,10 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
                     for (int r = 0; r < 4; ++r) Ab[(cL >> 2) * 64 + (4 * r + gL) + 16 * (cL & 3)] = -C[q][r];
                 }
             }
-            if (t == 0) {
+            if (t == 0 && !flg[1]) {                  // after one time-out this workgroup waits no more: the iteration is redone anyway
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(sync + 16 + pb, TDLO_RLX_AGENT) != epoch) {
+                if (f.force_timeout_it == st->it && rb == nrb - 1) flg[1] = 1;      // test hook (TDLO_MCU_FORCE_TIMEOUT)
+                else while (__hip_atomic_load(sync + 16 + pb, TDLO_RLX_AGENT) != epoch) {
                     __builtin_amdgcn_s_sleep(1);
                     if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) { flg[1] = 1; break; }
                 }
@@ -577,11 +592,11 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
             __hip_atomic_store(tp + 2 * M + i, (unsigned long long)__double_as_longlong(v2 + tmp[1024 + i]), TDLO_RLX_AGENT);
         }
     }
-    singular = __syncthreads_or(singular | timed_out);
+    singular = __syncthreads_or(singular) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-        if (singular) __hip_atomic_fetch_or(sync + 2, 1u, TDLO_RLX_AGENT);
+        if (singular | timed_out) __hip_atomic_fetch_or(sync + 2, (unsigned)singular | (timed_out ? 2u : 0u), TDLO_RLX_AGENT);
         const unsigned old = __hip_atomic_fetch_add(sync + 1, 1u, TDLO_RLX_AGENT);
         flg[0] = (old == (unsigned)nrb - 1u);
         if (flg[0]) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -589,7 +604,23 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
     __syncthreads();
     if (!flg[0]) return;
     MSTAMP(3);
-    singular = (int)__hip_atomic_load(sync + 2, TDLO_RLX_AGENT);
+    {
+        const unsigned fl = __hip_atomic_load(sync + 2, TDLO_RLX_AGENT);
+        singular = (int)(fl & 1u);
+        if (fl & 2u) {
+            // A hand-off ran into its time limit (a workgroup that was not scheduled beside the others: a plain launch gives
+            // no residency guarantee): the row blocks hold garbage.  Nothing is published; the sync words are re-armed and
+            // the iteration is redone from the same sums by the one-workgroup elimination that follows in the stream
+            // (k_mstep_big, retry_only).
+            if (t == 0) {
+                __hip_atomic_store(sync + 1, 0u, TDLO_RLX_AGENT);
+                __hip_atomic_store(sync + 2, 0u, TDLO_RLX_AGENT);
+                __hip_atomic_store(sync + 0, gen + 1u, TDLO_RLX_AGENT);
+                st->retries += 1; st->retry_pending = 1;
+            }
+            return;
+        }
+    }
     // ---- 5. the finishing workgroup: all sums, T = Y0 + sum over the row blocks' shares (fixed order)
     for (int e = t; e < nS; e += kBig) S[e] = f.sums[e];
     for (int e = t; e < 3 * M; e += kBig) {
@@ -793,6 +824,7 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
         int p; bool okp;
         {
             unsigned long long word = 0;
+            if (f.force_timeout_it == st->it && rb == nrb - 1 && lane == 0) flg[1] = 1;       // test hook (TDLO_MCU_FORCE_TIMEOUT)
             if (!flg[1]) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
@@ -850,18 +882,33 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
             __hip_atomic_store(tp + 2 * M + i, (unsigned long long)__double_as_longlong(v2), TDLO_RLX_AGENT);
         }
     }
-    singular = __syncthreads_or(singular | timed_out);
+    singular = __syncthreads_or(singular) ? 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-        if (singular) __hip_atomic_fetch_or(sync + 2, 1u, TDLO_RLX_AGENT);
+        if (singular | timed_out) __hip_atomic_fetch_or(sync + 2, (unsigned)singular | (timed_out ? 2u : 0u), TDLO_RLX_AGENT);
         const unsigned old = __hip_atomic_fetch_add(sync + 1, 1u, TDLO_RLX_AGENT);
         flg[0] = (old == (unsigned)nrb - 1u);
         if (flg[0]) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (!flg[0]) return;
-    singular = (int)__hip_atomic_load(sync + 2, TDLO_RLX_AGENT);
+    {
+        const unsigned fl = __hip_atomic_load(sync + 2, TDLO_RLX_AGENT);
+        singular = (int)(fl & 1u);
+        if (fl & 2u) {
+            // time-out in a hand-off (see k_mstep_mcu): nothing is published, sync words and flags are re-armed, the generic
+            // pivoted elimination that follows in the stream (k_mstep, retry_only) redoes the iteration
+            if (t < 64) __hip_atomic_store(flag64 + t, 0ull, TDLO_RLX_AGENT);
+            if (t == 0) {
+                __hip_atomic_store(sync + 1, 0u, TDLO_RLX_AGENT);
+                __hip_atomic_store(sync + 2, 0u, TDLO_RLX_AGENT);
+                __hip_atomic_store(sync + 0, gen + 1u, TDLO_RLX_AGENT);
+                st->retries += 1; st->retry_pending = 1;
+            }
+            return;
+        }
+    }
 
     // ---- 5. the finishing workgroup: all sums, T = Y0 + sum of the shares (fixed order), sigma2, stopping rule, publish
     for (int e = t; e < nS; e += kPT) S[e] = f.sums[e];
@@ -989,10 +1036,16 @@ hipError_t launch_mstep_big(const FrameDev *fd, const FrameDev *fh, int F, int f
             e = hipFuncSetAttribute((const void *)k_mstep_mcu<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((k_mstep_mcu<double>), grid, dim3(kBig), lds, s, fd, from_sums);
+            e = hipFuncSetAttribute((const void *)k_mstep_big<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds_bytes(M));
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_mstep_big<double>), dim3(F), dim3(kBig), big_lds_bytes(M), s, fd, from_sums, 1);
         } else {
             e = hipFuncSetAttribute((const void *)k_mstep_mcu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((k_mstep_mcu<float>), grid, dim3(kBig), lds, s, fd, from_sums);
+            e = hipFuncSetAttribute((const void *)k_mstep_big<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds_bytes(M));
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_mstep_big<float>), dim3(F), dim3(kBig), big_lds_bytes(M), s, fd, from_sums, 1);
         }
         return hipGetLastError();
     }
@@ -1000,11 +1053,11 @@ hipError_t launch_mstep_big(const FrameDev *fd, const FrameDev *fh, int F, int f
     if (f64) {
         e = hipFuncSetAttribute((const void *)k_mstep_big<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_mstep_big<double>), dim3(F), dim3(kBig), lds, s, fd, from_sums);
+        hipLaunchKernelGGL((k_mstep_big<double>), dim3(F), dim3(kBig), lds, s, fd, from_sums, 0);
     } else {
         e = hipFuncSetAttribute((const void *)k_mstep_big<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_mstep_big<float>), dim3(F), dim3(kBig), lds, s, fd, from_sums);
+        hipLaunchKernelGGL((k_mstep_big<float>), dim3(F), dim3(kBig), lds, s, fd, from_sums, 0);
     }
     return hipGetLastError();
 }

@@ -88,6 +88,9 @@ __global__ __launch_bounds__(kRB) void k_reg_mstep(int N, int M, int nblk, doubl
 
 }  // namespace
 
+// k_reg_estep: 8 (23 M + 4) bytes of dynamic LDS, at most 160 KB per workgroup on gfx950
+int reg_max_nodes() { return (int)((160 * 1024 / sizeof(double) - 4) / 23); }
+
 size_t reg_ws_doubles(int M, int nblk) { return 8 + 3 * (size_t)M + (size_t)nblk * (5 * (size_t)M + 1) + 8; }
 
 hipError_t launch_reg(const double *X, int N, int M, double mu, int max_iter, int nblk, double *ws, hipStream_t s) {

@@ -93,6 +93,10 @@ class HipShard:
             raise B.TdloError(rc, "split registration failed")
         return dict(Y=Y, sigma2=s2.value, iters=st.iters, converged=bool(st.converged), n_kept=st.n_kept)
 
+    def abort(self):
+        """Leaves the registration without results (tdlo_split_abort): the context and the shard stay usable."""
+        self.ctx.lib.tdlo_split_abort(self.ctx.h)
+
 
 def cpd_lle_nsplit(shard, comm, Y, sigma2, params, priors=None, visible_nodes=None, H=None):
     """trackdlo::cpd_lle (trackdlo.cpp:161-441) with the N points sharded over the ranks of `comm`."""
@@ -101,6 +105,7 @@ def cpd_lle_nsplit(shard, comm, Y, sigma2, params, priors=None, visible_nodes=No
     vis_branch = (n_vis != M and n_vis != 0 and params.k_vis != 0)          # trackdlo.cpp:358
     init = comm.all_reduce_sum(shard.begin(Y, sigma2, params, priors, visible_nodes, H))
     if init[0] <= 0:
+        shard.abort()                        # same decision on every rank: the sum is global
         raise B.TdloError(B.TDLO_E_EMPTY, "every point was pruned")
     shard.set_global(init[0], init[1])
     for _ in range(params.max_iter):
@@ -195,6 +200,7 @@ def cpd_lle_nsplit_device(shard, xch, comm_init, Y, sigma2, params, priors=None,
     vis_branch = (n_vis != M and n_vis != 0 and params.k_vis != 0)          # trackdlo.cpp:358
     init = comm_init.all_reduce_sum(shard.begin(Y, sigma2, params, priors, visible_nodes, H))
     if init[0] <= 0:
+        shard.abort()
         raise B.TdloError(B.TDLO_E_EMPTY, "every point was pruned")
     shard.set_global(init[0], init[1])
     polls = poll_points(params.max_iter) if params.tol > 0 else set()
