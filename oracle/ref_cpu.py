@@ -36,6 +36,8 @@ class RefTrace(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("TDLO_ORACLE_LIB"):          # e.g. libref_cpu_asan.so (`make -C oracle asan`), tests/test_oracle_sanitizer.py
+        return os.environ["TDLO_ORACLE_LIB"]
     so = os.path.join(_HERE, "libref_cpu.so")
     src = os.path.join(_HERE, "ref_cpu.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ref_cpu.h"))):
