@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- EM iterations/s of TrackDLO's registration loop on MI355X (BASELINE.json metric).
 
-Workload at N=1 (BASELINE.json configs[1], "C2"): ONE frame, N = 50 000 cloud points, M = 50 nodes,
-50 EM iterations with tol = 0 (so exactly 50 run), launch/trackdlo.launch parameter values, fp32
-E-step + fp64 M-step.  A "step" is one complete trackdlo::cpd_lle call (trackdlo.cpp:161-441: prune,
-setup, 50 iterations, read-back of Y / sigma2) on a cloud that is already resident in HBM.
-    value = steps * frames * 50 / wall time         [EM iterations / s, whole job, all ranks]
-With --gpus N (torch.distributed.run, one rank per GPU, RCCL only for the barrier and the max-over-ranks
-of the time) every rank registers its own frame(s): frames are independent, so scaling is "weak" and
-there is no data-path collective (BASELINE.json configs[2]).
---mode nsplit is BASELINE.json configs[3] instead: ONE frame of 2 000 000 points split over the ranks, per EM
-iteration an RCCL all-reduce of the 4M+2 sums on the context's stream ("scaling": "strong"; its own metric line).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
+
+Workloads (BASELINE.json configs; launch/trackdlo.launch parameter values, tol = 0 so that exactly 50 iterations run):
+  c2 (default; the configuration the metric is quoted on)  ONE frame per GPU, N = 50 000 points, M = 50 nodes, fp32 E-step + fp64 M-step
+  c3  32 frames per GPU registered as one tdlo_cpd_lle_batch call (256 frames on 8 GPUs), otherwise c2
+  c4  ONE frame of N = 2 000 000 points split over the ranks; per EM iteration an RCCL all-reduce of the 4M+2 sums ("strong")
+  c5  ONE frame per GPU, N = 200 000 points, M = 300 nodes, fp64 everywhere
+A "step" is one complete trackdlo::cpd_lle call (trackdlo.cpp:161-441: prune, setup, 50 iterations, read-back of Y / sigma2) on a
+cloud that is already resident in HBM.    value = steps * frames * 50 * ranks / wall time      [EM iterations / s, whole job]
+
+--gpus N > 1 without a torch.distributed environment: this script launches itself as N ranks
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N, one rank per GPU, RCCL).  With WORLD_SIZE already set (the
+driver's launch) it must agree with --gpus.  Frames are independent (c2 / c3 / c5): no data-path collective, "weak" scaling;
+RCCL carries only the closing barrier and the max-over-ranks of the time.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (the fused E-step): algorithmic bytes per launch (3 * 4 B * N, one read of
-               the cloud) / its average dispatch duration, measured live with HIP start/stop
-               events bound to each E-step dispatch of a real E/M loop on the context's stream, vs 8 TB/s
-  cpu_baseline the CPU oracle (a plain-C port of the reference loop; the reference's own Eigen build
-               cannot be produced here) timed on this box's host, single thread like the reference
+  roofline          the per-iteration kernel with the LARGER share of GPU time in this run; roofline_kernels holds both
+                    (E-step: algorithmic bytes 3 * s * N per launch against 8 TB/s HBM, plus its VALU fraction; M-step:
+                    (2/3) M^3 + 14 M^2 flops per launch against the fp64 matrix peak).  Durations are measured live: HIP
+                    start/stop events bound to every E-step and M-step dispatch of real iterations on the context's stream
+                    (tdlo_profile_iteration).  `traffic` is never measured by this script (PMC counters need rocprofv3):
+                    it is copied from the newest committed profiles/*_pmc_hbm.json and labelled with `traffic_source`.
+  cpu_baseline      the CPU oracle (a plain-C port of the reference loop; the reference's own Eigen build cannot be produced
+                    here) timed on this box's host on a bounded sample of the same workload, single thread like the reference
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,186 +38,311 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_POINTS, M_NODES, EM_ITERS = 50000, 50, 50
+EM_ITERS = 50
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VECTOR_TFLOPS = 157.3      # same guide: peak FP32 (vector)
+FP64_TFLOPS = 78.6              # MI355X public specification: fp64 vector = fp64 matrix = half the fp32 vector rate (not in the guide's table)
+
+CONFIGS = {
+    "c2": dict(N=50000, M=50, frames=1, prec="f32", steps=1000, warmup=20, cpu_iters=EM_ITERS, cpu_repeats=5,
+               metric="EM iterations/sec at N=50k cloud pts, M=50 nodes"),
+    "c3": dict(N=50000, M=50, frames=32, prec="f32", steps=400, warmup=10, cpu_iters=EM_ITERS, cpu_repeats=3,
+               metric="EM iterations/sec at N=50k cloud pts, M=50 nodes"),
+    "c5": dict(N=200000, M=300, frames=1, prec="f64", steps=120, warmup=5, cpu_iters=8, cpu_repeats=1,
+               metric="EM iterations/sec at N=200k cloud pts, M=300 nodes, fp64"),
+    "c4": dict(N=2000000, M=50, frames=1, prec="f32", steps=200, warmup=5, cpu_iters=6, cpu_repeats=1,
+               metric="EM iterations/sec at N=2M cloud pts, M=50 nodes, cloud split over the ranks"),
+}
+
+
+def _self_launch(args):
+    """--gpus N > 1 outside torch.distributed.run: become the launcher of N ranks of this very command line."""
+    port = int(os.environ.get("TDLO_BENCH_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _context_class():
+    """binding.Context, or (tests only) a stand-in named by TDLO_BENCH_STUB=module:Class so that the launch / rank logic can run
+    on a box without a GPU.  The product path has no CPU fallback: without the stub variable a missing GPU raises."""
+    stub = os.environ.get("TDLO_BENCH_STUB")
+    if stub:
+        import importlib
+        mod, cls = stub.split(":")
+        return getattr(importlib.import_module(mod), cls)
+    from trackdlo_amd import binding as B
+    return B.Context
+
+
+def _traffic_from_profiles(F):
+    """HBM bytes per E-step launch from the newest committed rocprofv3 PMC summary (separate --pmc passes; scripts/gpu_profile.sh):
+    NOT measured by this run, hence labelled with its source."""
+    try:
+        import glob
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[-1]
+        with open(path) as fh:
+            return round(json.load(fh)["estep"]["traffic_bytes_per_launch"] * F), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=1, help="independent frames registered concurrently per rank (C2: 1)")
-    ap.add_argument("--mode", choices=["frames", "nsplit"], default="frames",
-                    help="frames (default, the BASELINE.json metric): every rank registers its own frame(s); nsplit (BASELINE.json "
-                         "configs[3]): ONE frame of 2 000 000 points split over the ranks, RCCL all-reduce of the 4M+2 sums per iteration")
+    ap.add_argument("--steps", type=int, default=None, help="timed cpd_lle calls (default per config: a timed region of about a second or more)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--frames", type=int, default=None, help="override the frames registered concurrently per rank (c2: 1, c3: 32)")
+    ap.add_argument("--mode", choices=["frames", "nsplit"], default=None, help="deprecated alias: nsplit == --config c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-repeats", type=int, default=5)
     args = ap.parse_args()
+    if args.mode == "nsplit":
+        args.config = "c4"
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(_self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    torch = None
-    backend = "nccl"
+
+    cfg = dict(CONFIGS[args.config])
+    if args.frames:
+        cfg["frames"] = args.frames
+    if args.steps is not None:
+        cfg["steps"] = args.steps
+    if args.warmup is not None:
+        cfg["warmup"] = args.warmup
+
+    dist = torch = None
+    backend = os.environ.get("TDLO_BENCH_BACKEND", "nccl")      # "gloo" only lets the rank logic run on a box with fewer GPUs than ranks
     dev_index = local_rank
-    if world > 1:
+    if world > 1 or args.config == "c4":
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL (backend "nccl") over xGMI on a real multi-GPU node; TDLO_BENCH_BACKEND=gloo exists only so that the
-        # multi-rank code path can be exercised on a box with fewer GPUs than ranks
-        backend = os.environ.get("TDLO_BENCH_BACKEND", "nccl")
-        ngpu = torch.cuda.device_count()
-        dev_index = local_rank % max(ngpu, 1)
-        torch.cuda.set_device(dev_index)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            ngpu = torch.cuda.device_count()
+            if ngpu < world:
+                sys.exit(f"bench.py: --gpus {world} but only {ngpu} GPU(s) are visible")
+            torch.cuda.set_device(dev_index)
+        if world == 1:                     # c4 on one GPU: a one-rank RCCL group, so that the collectives are real launches
+            import tempfile
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            kw = dict(init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="tdlo_pg_"), "store"), rank=0, world_size=1)
         else:
-            dist.init_process_group(backend)
-
-    from trackdlo_amd import binding as B, synth
-    P = synth.LAUNCH_PARAMS
-    if args.mode == "nsplit":
-        return bench_nsplit(args, rank, world, dev_index, dist, torch, backend)
-    F = args.frames
-    ctx = B.Context(device=dev_index, max_frames=F, max_points=N_POINTS, max_nodes=M_NODES)   # raises without a GPU
-    params = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
-                           alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
-    Ys = []
-    for f in range(F):
-        X, Y0, _ = synth.scene(N_POINTS, M_NODES, config=2, frame=rank * F + f)
-        ctx.set_cloud(f, X)                      # inputs resident in HBM before the timed region
-        Ys.append(Y0)
-    X0, Y00, _ = synth.scene(N_POINTS, M_NODES, config=2, frame=rank * F)
-
-    def step():
-        if F == 1:
-            return ctx.cpd_lle_resident(0, Ys[0], 0.0, params)
-        return ctx.cpd_lle_batch(Ys, [0.0] * F, params)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        ctx.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    loop_ms = 0.0
-    for _ in range(args.steps):
-        r = step()
-        loop_ms += (r["loop_ms"] if F == 1 else r["stats"][0]["loop_ms"])
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    iters_total = args.steps * F * EM_ITERS * world
-    value = iters_total / dt
-
-    out = None
-    if rank == 0:
-        # ---- dominant kernel: fused E-step, HIP-event average over back-to-back launches on the ctx stream
-        ctx.cpd_lle_resident(0, Ys[0], 0.0, params) if F == 1 else ctx.cpd_lle_batch(Ys, [0.0] * F, params)
-        est_us = ctx.profile_kernel(10, 200)        # in situ: HIP start/stop events bound to each E-step dispatch of a live E/M loop
-        est_b2b_us = ctx.profile_kernel(0, 300)     # same kernel launched back to back (hot caches): lower bound, reported for reference
-        mst_us = ctx.profile_kernel(2, 100)
-        alg_bytes = 3 * 4 * N_POINTS * F
-        achieved = alg_bytes / (est_us * 1e-6) / 1e9
-        traffic = None
-        try:        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE calibrated, + WRITE_SIZE): the newest
-            # profiles/*_pmc_hbm.json (made by scripts/gpu_profile.sh + scripts/pmc_summary.py from this same command)
-            import glob
-            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))[-1]) as fh:
-                traffic = round(json.load(fh)["estep"]["traffic_bytes_per_launch"] * F)
-        except Exception:
-            traffic = None
-        roof = dict(bound="hbm", kernel="k_estep<float,1,false>", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, avg_launch_us=round(est_us, 3),
-                    algorithmic_bytes_per_launch=alg_bytes, avg_launch_us_back_to_back=round(est_b2b_us, 3), mstep_avg_launch_us=round(mst_us, 3),
-                    note="E-step is VALU/latency-bound at this size (about 100 flop per byte); HBM fraction reported as the metric requires")
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import ref_cpu
-            kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
-                      include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
-            rates = []
-            o = None
-            for _ in range(args.cpu_repeats):
-                o = ref_cpu.cpd_lle(X0, Y00, 0.0, **kw)
-                rates.append(o["iters"] / o["loop_seconds"])
-            g = ctx.cpd_lle_resident(0, Ys[0], 0.0, params) if F == 1 else None
-            cpu = dict(value=round(float(np.median(rates)), 3), unit="EM iterations/s", cores=1, kind="port",
-                       sample=f"the full C2 workload (N={N_POINTS}, M={M_NODES}, {EM_ITERS} iterations), median of {args.cpu_repeats} runs of the loop body",
-                       note="oracle/ref_cpu.c: plain-C fp64 restatement of trackdlo.cpp:275-438, -O3, single thread like the reference")
-            if g is not None:
-                cpu["max_abs_dY_vs_gpu_m"] = float(np.abs(g["Y"] - o["Y"]).max())
-            try:        # secondary column: the same restatement with OpenMP over the points on all host cores
-                # thread count: what the affinity mask / cgroup quota allow, or fewer if that is faster (a container may be
-                # granted fewer cores than it sees); one probing run each, then the median of 3 at the best count
-                hc = ref_cpu.host_cores()
-                probe = {}
-                kwp = dict(kw, max_iter=10)
-                for nt in sorted({hc, min(hc, 64), min(hc, 16), min(hc, 8)}, reverse=True):
-                    ref_cpu.set_threads(nt)
-                    op = ref_cpu.cpd_lle(X0, Y00, 0.0, all_cores=True, **kwp)
-                    probe[nt] = op["iters"] / op["loop_seconds"]
-                ncores = max(probe, key=probe.get)
-                ref_cpu.set_threads(ncores)
-                r2 = []
-                for _ in range(3):
-                    o2 = ref_cpu.cpd_lle(X0, Y00, 0.0, all_cores=True, **kw)
-                    r2.append(o2["iters"] / o2["loop_seconds"])
-                cpu["all_cores"] = dict(value=round(float(np.median(r2)), 3), unit="EM iterations/s", cores=ncores,
-                                        note="same restatement, -fopenmp over the points (the M x M solve stays serial); median of 3 runs at the fastest of the probed thread counts", probed_threads_it_per_s={str(k): round(v, 2) for k, v in probe.items()},
-                                        max_abs_dY_vs_single_thread_m=float(np.abs(o2["Y"] - o["Y"]).max()))
-            except Exception as e:      # the baseline proper is the single-thread figure above
-                cpu["all_cores"] = dict(error=str(e))
-        out = dict(metric="EM iterations/sec at N=50k cloud pts, M=50 nodes", value=round(value, 2), unit="EM iterations/s",
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt * 1e3 / args.steps, 4),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"C2: {F} frame(s) per GPU, N={N_POINTS} points, M={M_NODES} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, trackdlo.launch parameters, fp32 E-step + fp64 M-step",
-                               frames_per_gpu=F, parallelism=f"frames sharded, {world} rank(s), no data-path collective"),
-                   frames_per_s=round(args.steps * F * world / dt, 2),
-                   em_loop_only_iters_per_s=round(args.steps * F * EM_ITERS / (loop_ms * 1e-3), 2),
-                   roofline=roof, cpu_baseline=cpu)
-        if cpu:
-            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
-        print(json.dumps(out), flush=True)
-    ctx.close()
+            kw = {}
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
+        else:
+            dist.init_process_group(backend, **kw)
+    env = dict(rank=rank, world=world, dev_index=dev_index, dist=dist, torch=torch, backend=backend)
+    if args.config == "c4":
+        bench_nsplit(args, cfg, env)
+    else:
+        bench_frames(args, cfg, env)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def bench_nsplit(args, rank, world, dev_index, dist, torch, backend):
-    """BASELINE.json configs[3]: one frame, N = 2 000 000 points, M = 50, contiguous shard per rank; per EM iteration an
-    all-reduce SUM of [P1 | PX | Q | N] (4M+2 doubles) on the context's stream, identical M-step on every rank
-    (trackdlo_amd/nsplit.py, device-resident exchange).  Total work is fixed: "scaling": "strong".  A step is one whole
-    cpd_lle call on shards that are already resident in HBM."""
-    from trackdlo_amd import binding as B, nsplit, synth
+def _rank_table(env):
+    """[{rank, device}] as the process group actually formed it."""
+    dist, torch = env["dist"], env["torch"]
+    if dist is None or env["world"] == 1:
+        return 1, [dict(rank=0, device=env["dev_index"])]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=f"cuda:{env['dev_index']}" if env["backend"] == "nccl" else "cpu")
+    t[dist.get_rank()] = env["dev_index"]
+    dist.all_reduce(t)
+    return dist.get_world_size(), [dict(rank=r, device=int(d)) for r, d in enumerate(t.tolist())]
+
+
+def _max_over_ranks(env, dt):
+    dist, torch = env["dist"], env["torch"]
+    if dist is None or env["world"] == 1:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{env['dev_index']}" if env["backend"] == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b2b_us=None):
+    """Both per-iteration kernels against their rooflines; the one with the larger share of GPU time first."""
+    alg_bytes = 3 * esize * N * F                                   # one read of the cloud (SURVEY.md 8(d)); Pt1 is never materialised
+    e_flops = 24.0 * M * N * F                                      # FMA-class flops of the E-step as SURVEY.md 8(d) counts them
+    m_flops = ((2.0 / 3.0) * M ** 3 + 14.0 * M ** 2) * F            # LU + 3 right-hand sides + G W + assembly, per frame
+    bw = alg_bytes / (est_us * 1e-6) / 1e9
+    traffic, tsrc = _traffic_from_profiles(F) if (N == 50000 and M == 50) else (None, None)
+    vpeak = FP32_VECTOR_TFLOPS if esize == 4 else FP64_TFLOPS
+    est = dict(bound="hbm", kernel=f"k_estep<{'float' if esize == 4 else 'double'}>", achieved=round(bw, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=round(bw / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc, avg_launch_us=round(est_us, 3),
+               algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=e_flops,
+               valu_tflops=round(e_flops / (est_us * 1e-6) / 1e12, 3), valu_peak_tflops=vpeak, valu_frac=round(e_flops / (est_us * 1e-6) / 1e12 / vpeak, 5),
+               note="VALU / latency-bound (about 100 flop per byte at M = 50 against a ridge of 20): the HBM fraction is reported as the metric requires; "
+                    "valu_frac counts every (node, point) pair although the kernel skips the exactly-zero memberships outside the wave's node window")
+    if est_b2b_us is not None:
+        est["avg_launch_us_back_to_back"] = round(est_b2b_us, 3)
+    objs = [est]
+    if mst_us is not None:
+        tf = m_flops / (mst_us * 1e-6) / 1e12
+        objs.append(dict(bound="mfma", kernel=mstep_name, achieved=round(tf, 6), peak=FP64_TFLOPS, unit="TFLOP/s", frac=round(tf / FP64_TFLOPS, 7), traffic=None,
+                         avg_launch_us=round(mst_us, 3), algorithmic_flops_per_launch=m_flops,
+                         note=("one workgroup per frame on ONE CU: a chain of dependent elimination panels, latency-bound" if mstep_name.startswith("k_mstep_fast")
+                               else "one workgroup per 16 rows: bound by the chain of inter-workgroup hand-offs per panel, latency-bound")))
+    tot = sum(o["avg_launch_us"] for o in objs)
+    for o in objs:
+        o["share_of_gpu_time"] = round(o["avg_launch_us"] / tot, 4)
+    objs.sort(key=lambda o: -o["avg_launch_us"])
+    dom = dict(objs[0])
+    dom["iteration_us"] = round(iter_us, 3)
+    return dom, objs
+
+
+def _cpu_baseline(cfg, X0, Y00, kw, g_single):
+    from oracle import ref_cpu
+    kws = dict(kw, max_iter=cfg["cpu_iters"])
+    rates, o = [], None
+    t0 = time.perf_counter()
+    for _ in range(cfg["cpu_repeats"]):
+        o = ref_cpu.cpd_lle(X0, Y00, 0.0, **kws)
+        rates.append(o["iters"] / o["loop_seconds"])
+    cpu = dict(value=round(float(np.median(rates)), 3), unit="EM iterations/s", cores=1, kind="port",
+               sample=f"one frame of the workload (N={cfg['N']}, M={cfg['M']}), the first {cfg['cpu_iters']} of its {EM_ITERS} iterations, median of {cfg['cpu_repeats']} run(s) of the loop body",
+               seconds=round(time.perf_counter() - t0, 2),
+               note="oracle/ref_cpu.c: plain-C fp64 restatement of trackdlo.cpp:275-438, -O3, single thread like the reference")
+    if g_single is not None and cfg["cpu_iters"] == EM_ITERS:
+        cpu["max_abs_dY_vs_gpu_m"] = float(np.abs(g_single["Y"] - o["Y"]).max())
+    try:        # secondary column (SURVEY.md 8(d)): the same restatement with OpenMP over the points on the host cores this process is granted
+        hc = ref_cpu.host_cores()
+        probe = {}
+        kwp = dict(kw, max_iter=max(2, min(10, cfg["cpu_iters"])))
+        for nt in sorted({hc, min(hc, 64), min(hc, 16), min(hc, 8)}, reverse=True):
+            ref_cpu.set_threads(nt)
+            op = ref_cpu.cpd_lle(X0, Y00, 0.0, all_cores=True, **kwp)
+            probe[nt] = op["iters"] / op["loop_seconds"]
+        ncores = max(probe, key=probe.get)
+        ref_cpu.set_threads(ncores)
+        o2 = ref_cpu.cpd_lle(X0, Y00, 0.0, all_cores=True, **kws)
+        cpu["all_cores"] = dict(value=round(o2["iters"] / o2["loop_seconds"], 3), unit="EM iterations/s", cores=ncores,
+                                note="same restatement, -fopenmp over the points (the M x M solve stays serial), at the fastest of the probed thread counts",
+                                probed_threads_it_per_s={str(k): round(v, 2) for k, v in probe.items()},
+                                max_abs_dY_vs_single_thread_m=float(np.abs(o2["Y"] - o["Y"]).max()))
+    except Exception as e:      # the baseline proper is the single-thread figure above
+        cpu["all_cores"] = dict(error=str(e))
+    return cpu
+
+
+def bench_frames(args, cfg, env):
+    """c2 / c3 / c5: every rank registers its own frame(s); no data-path collective."""
+    from trackdlo_amd import binding as B, synth
+    Context = _context_class()
     P = synth.LAUNCH_PARAMS
-    NT, M = 2000000, M_NODES
-    if dist is None:                      # one rank: a one-rank RCCL group, so that the collectives are real launches
-        import torch
-        import torch.distributed as dist
-        import tempfile
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        torch.cuda.set_device(dev_index)
-        dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="tdlo_pg_"), "store"), rank=0, world_size=1,
-                                device_id=torch.device("cuda", dev_index))
-    dev = f"cuda:{dev_index}"
+    rank, world, dev_index, dist, torch = env["rank"], env["world"], env["dev_index"], env["dist"], env["torch"]
+    N, M, F = cfg["N"], cfg["M"], cfg["frames"]
+    prec = B.PREC_F32 if cfg["prec"] == "f32" else B.PREC_F64
+    cfg_id = {"c2": 2, "c3": 2, "c5": 5}[args.config]
+    ctx = Context(device=dev_index, max_frames=F, max_points=N, max_nodes=M)   # raises without a GPU: no CPU fallback
+
+    def mk_params(precision):
+        return B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
+                             alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=precision)
+
+    params = mk_params(prec)
+    Ys = []
+    for f in range(F):
+        X, Y0, _ = synth.scene(N, M, config=cfg_id, frame=rank * F + f)
+        ctx.set_cloud(f, X)                      # inputs resident in HBM before the timed region
+        Ys.append(Y0)
+
+    def step(p=params):
+        if F == 1:
+            return ctx.cpd_lle_resident(0, Ys[0], 0.0, p)
+        return ctx.cpd_lle_batch(Ys, [0.0] * F, p)
+
+    def barrier():
+        if dist is not None and world > 1:
+            dist.barrier()
+            if env["backend"] == "nccl":
+                torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(cfg["warmup"]):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    loop_ms = 0.0
+    for _ in range(cfg["steps"]):
+        r = step()
+        loop_ms += (r["loop_ms"] if F == 1 else r["stats"][0]["loop_ms"])
+    barrier()
+    dt = _max_over_ranks(env, time.perf_counter() - t0)
+    n_ranks, ranks = _rank_table(env)
+    value = cfg["steps"] * F * EM_ITERS * n_ranks / dt
+
+    if rank == 0:
+        # ---- per-iteration kernels, in situ: HIP start/stop events bound to every E-step and M-step dispatch of a live loop
+        step()
+        est_us, mst_us, iter_us, mname = ctx.profile_iteration(200)
+        est_b2b_us = ctx.profile_kernel(0, 300)     # the E-step launched back to back (hot caches): lower bound, reported beside it
+        esize = 4 if cfg["prec"] == "f32" else 8
+        roof, roof_all = _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mname, est_b2b_us)
+        out = dict(metric=cfg["metric"], value=round(value, 2), unit="EM iterations/s", n_gpus=n_ranks, ranks=ranks,
+                   steps=cfg["steps"], warmup=cfg["warmup"], ms_per_step=round(dt * 1e3 / cfg["steps"], 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=cfg["prec"], data="synthetic",
+                   config=dict(workload=f"{args.config.upper()}: {F} frame(s) per GPU, N={N} points, M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, "
+                                        f"trackdlo.launch parameters, {'fp32 E-step + fp64 M-step' if cfg['prec'] == 'f32' else 'fp64 everywhere'}",
+                               frames_per_gpu=F, parallelism=f"frames sharded, {n_ranks} rank(s), no data-path collective"),
+                   timed_region_s=round(dt, 3), frames_per_s=round(cfg["steps"] * F * n_ranks / dt, 2),
+                   em_loop_only_iters_per_s=round(cfg["steps"] * F * EM_ITERS / (loop_ms * 1e-3), 2),
+                   roofline=roof, roofline_kernels=roof_all)
+        if args.config == "c2" and F == 1:
+            # the reference's arithmetic is fp64 throughout: the same workload with TDLO_PREC_F64 (not the headline: BASELINE C2 names fp32)
+            p64 = mk_params(B.PREC_F64)
+            for _ in range(5):
+                step(p64)
+            n64 = max(20, cfg["steps"] // 5)
+            ctx.synchronize(); t1 = time.perf_counter()
+            for _ in range(n64):
+                step(p64)
+            ctx.synchronize()
+            out["em_iters_per_s_f64"] = round(n64 * EM_ITERS / (time.perf_counter() - t1), 2)
+            e64, m64, i64, _ = ctx.profile_iteration(100)
+            out["f64_kernels_us"] = dict(estep=round(e64, 3), mstep=None if m64 is None else round(m64, 3), iteration=round(i64, 3))
+        cpu = None
+        if n_ranks == 1 and not args.no_cpu_baseline:
+            X0, Y00, _ = synth.scene(N, M, config=cfg_id, frame=0)
+            kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
+                      include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+            g = ctx.cpd_lle_resident(0, Ys[0], 0.0, params) if cfg["cpu_iters"] == EM_ITERS else None
+            cpu = _cpu_baseline(cfg, X0, Y00, kw, g)
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    ctx.close()
+
+
+def bench_nsplit(args, cfg, env):
+    """c4 (BASELINE.json configs[3]): one frame, N = 2 000 000 points, M = 50, contiguous shard per rank; per EM iteration an
+    all-reduce SUM of [P1 | PX | Q | N] (4M+2 doubles) on the context's stream, identical M-step on every rank
+    (trackdlo_amd/nsplit.py, device-resident exchange).  Total work is fixed: "scaling": "strong"."""
+    from trackdlo_amd import binding as B, nsplit, synth
+    Context = _context_class()
+    P = synth.LAUNCH_PARAMS
+    rank, world, dev_index, dist, torch, backend = env["rank"], env["world"], env["dev_index"], env["dist"], env["torch"], env["backend"]
+    NT, M = cfg["N"], cfg["M"]
+    dev = f"cuda:{dev_index}" if backend == "nccl" else "cpu"
     X, Y0, _ = synth.scene(NT, M, config=4)
     lo, hi = rank * NT // world, (rank + 1) * NT // world
-    ctx = B.Context(device=dev_index, max_points=hi - lo, max_nodes=M)
+    ctx = Context(device=dev_index, max_points=hi - lo, max_nodes=M)
     params = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
                            alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
-    xch = nsplit.TorchDeviceExchange(M, dev, stream_ptr=ctx.stream_ptr())
+    xch = nsplit.TorchDeviceExchange(M, dev, stream_ptr=ctx.stream_ptr() if backend == "nccl" else None)
     shard = nsplit.HipDeviceShard(ctx, X[lo:hi], xch)          # uploads the shard once; every step re-binds and re-registers
     comm = nsplit.TorchComm(dev if backend == "nccl" else None)
 
@@ -218,35 +351,52 @@ def bench_nsplit(args, rank, world, dev_index, dist, torch, backend):
         return nsplit.cpd_lle_nsplit_device(shard, xch, comm, Y0, 0.0, params)
 
     def barrier():
-        dist.barrier(); torch.cuda.synchronize(); ctx.synchronize()
+        dist.barrier()
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        ctx.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(cfg["warmup"]):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(cfg["steps"]):
         out = step()
     barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = _max_over_ranks(env, time.perf_counter() - t0)
+    n_ranks, ranks = _rank_table(env)
     if rank == 0:
         est_us = ctx.profile_kernel(0, 50)
-        alg = 3 * 4 * (hi - lo)
-        line = dict(metric="EM iterations/sec at N=2M cloud pts, M=50 nodes, cloud split over the ranks", value=round(args.steps * EM_ITERS / dt, 2),
-                    unit="EM iterations/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt * 1e3 / args.steps, 4),
+        mst_us = ctx.profile_kernel(4, 50)          # the M-step from the reduced sums, as every rank runs it
+        roof, roof_all = _roofline_objects(hi - lo, M, 1, 4, est_us, mst_us, dt * 1e6 / (cfg["steps"] * EM_ITERS), "k_mstep_fast<MFMA>")
+        roof["note_durations"] = "back-to-back launches on the shard's state (the split loop interleaves RCCL launches, so per-dispatch events are not bound here)"
+        line = dict(metric=cfg["metric"], value=round(cfg["steps"] * EM_ITERS / dt, 2), unit="EM iterations/s", n_gpus=n_ranks, ranks=ranks,
+                    steps=cfg["steps"], warmup=cfg["warmup"], ms_per_step=round(dt * 1e3 / cfg["steps"], 4),
                     higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload=f"C4: one frame, N={NT} points split over {world} rank(s) ({hi - lo} per rank), M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, fp32 E-step + fp64 M-step",
-                                parallelism=f"points sharded over {world} rank(s); per iteration all-reduce SUM of 4M+2 doubles ({backend}), identical M-step on every rank"),
-                    us_per_iteration=round(dt * 1e6 / (args.steps * EM_ITERS), 2), iters=out["iters"], n_kept_global=out["n_kept_global"],
-                    roofline=dict(bound="hbm", kernel="k_estep<float,1,false>", achieved=round(alg / (est_us * 1e-6) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                  frac=round(alg / (est_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), traffic=None, avg_launch_us_back_to_back=round(est_us, 3),
-                                  algorithmic_bytes_per_launch=alg), cpu_baseline=None)
+                    config=dict(workload=f"C4: one frame, N={NT} points split over {n_ranks} rank(s) ({hi - lo} per rank), M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, fp32 E-step + fp64 M-step",
+                                parallelism=f"points sharded over {n_ranks} rank(s); per iteration all-reduce SUM of 4M+2 doubles ({backend}), identical M-step on every rank"),
+                    timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"], n_kept_global=out["n_kept_global"],
+                    roofline=roof, roofline_kernels=roof_all)
+        cpu = None
+        if n_ranks == 1:
+            # the same cloud through the plain (unsplit) call on this one GPU: what the split costs at one rank
+            ctx.set_cloud(0, X)
+            for _ in range(3):
+                ctx.cpd_lle_resident(0, Y0, 0.0, params)
+            ctx.synchronize(); t1 = time.perf_counter()
+            nun = max(10, cfg["steps"] // 4)
+            for _ in range(nun):
+                ctx.cpd_lle_resident(0, Y0, 0.0, params)
+            ctx.synchronize()
+            line["unsplit_iters_per_s"] = round(nun * EM_ITERS / (time.perf_counter() - t1), 2)
+            if not args.no_cpu_baseline:
+                kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
+                          include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+                cpu = _cpu_baseline(cfg, X, Y0, kw, None)
+                line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
+        line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     ctx.close()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -274,6 +274,13 @@ double tdlo_compute_error(const double *Y_track, int n_track, const double *Y_tr
  * E-step dispatch carrying its own start/stop events (hipExtLaunchKernelGGL) -- the per-dispatch duration a kernel
  * trace reports, measured live on the context's stream. */
 int tdlo_profile_kernel(tdlo_ctx *ctx, int slot, int kind, int reps, float *avg_us);
+/* One EM iteration IN SITU on the state left by the last cpd_lle call (all frames of the last call): `reps` (<= 256) real
+ * iterations on the context's stream; the E-step dispatch and the M-step dispatch of every iteration carry their own HIP
+ * start/stop events (hipExtLaunchKernelGGL) -- the per-dispatch durations a kernel trace reports.  *iter_us = stream time
+ * per whole iteration (dispatch gaps and the small kernels of the visibility / large-cloud paths included).
+ * mstep_kernel receives the name of the M-step kernel these frames dispatch; *mstep_us = -1 when that kernel's dispatch
+ * carries no events (the pivoted paths). */
+int tdlo_profile_iteration(tdlo_ctx *ctx, int reps, float *estep_us, float *mstep_us, float *iter_us, char *mstep_kernel, int name_cap);
 /* Development aid: copies the first n (<= 64) shader-clock stamps that the M-step kernel of the last
  * launch wrote at its phase boundaries (reduce / assemble / eliminate / update / publish). */
 int tdlo_debug_stamps(tdlo_ctx *ctx, int slot, unsigned long long *out, int n);

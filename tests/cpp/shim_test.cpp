@@ -78,6 +78,23 @@ int main() {
             // LLE weights of the pre-processing registration are ill-conditioned: allow 1e-4 m here
             if (dy > 1e-4 || (int)pri.size() != rt->K || G.rows() != M) ++fails;
         }
+        // ---- copy semantics (trackdlo.h:104-121 has no user-defined copy: EVERY member is copied -- Y_, guide_nodes_, sigma2_,
+        //      geodesic_coord_, correspondence_priors_, the parameters).  A copy taken after two steps must answer every getter
+        //      like the original and continue the sequence with the same bits.
+        {
+            trackdlo copy;
+            copy = tracker;
+            MatrixXd Ya = tracker.get_tracking_result(), Yb = copy.get_tracking_result();
+            MatrixXd Ga = tracker.get_guide_nodes(), Gb = copy.get_guide_nodes();
+            std::vector<MatrixXd> Pa = tracker.get_correspondence_pairs(), Pb = copy.get_correspondence_pairs();
+            bool same = Ya.v == Yb.v && Ga.r == Gb.r && Ga.v == Gb.v && Pa.size() == Pb.size() && !Pa.empty() && tracker.get_sigma2() == copy.get_sigma2();
+            for (size_t i = 0; same && i < Pa.size(); ++i) same = Pa[i].v == Pb[i].v;
+            tracker.tracking_step(X, vis, vis_ext, proj, 720, 1280);
+            copy.tracking_step(X, vis, vis_ext, proj, 720, 1280);
+            same = same && tracker.get_tracking_result().v == copy.get_tracking_result().v && tracker.get_sigma2() == copy.get_sigma2();
+            std::printf("copy assignment: state and continuation %s\n", same ? "identical" : "DIFFER");
+            if (!same) ++fails;
+        }
         ref_tracker_destroy(rt);
     }
     std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);

@@ -1,0 +1,67 @@
+"""bench.py --gpus N must really form N ranks (`--gpus` was parsed and ignored).  The launch / rank / JSON logic
+runs here under gloo with the GPU context replaced by tests/bench_stub.py; the product path itself has no CPU fallback."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**extra):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(TDLO_BENCH_BACKEND="gloo", TDLO_BENCH_STUB="bench_stub:StubContext", TDLO_HIP_RUNTIME="system",
+               PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + env.get("PYTHONPATH", ""))
+    env.update(extra)
+    return env
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config,frames", [("c2", 1), ("c3", 32)])
+def test_gpus_2_self_launches_two_ranks(config, frames):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", config,
+                        "--no-cpu-baseline"], env=_env(TDLO_BENCH_PORT="29631"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks"] == [dict(rank=0, device=0), dict(rank=1, device=1)]
+    assert line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak" and line["config"]["frames_per_gpu"] == frames
+    # whole-job value: both ranks' iterations over the max-over-ranks time
+    assert abs(line["value"] - frames * 50 * 2 / (line["ms_per_step"] * 1e-3)) <= 0.01 * line["value"]
+    assert line["roofline"]["kernel"] == "k_mstep_fast<MFMA>" and abs(line["roofline"]["share_of_gpu_time"] - 17 / 24) < 1e-3
+    assert {o["bound"] for o in line["roofline_kernels"]} == {"hbm", "mfma"}
+    assert line["cpu_baseline"] is None and line["vs_baseline"] is None
+
+
+def test_driver_style_launch_and_world_size_mismatch():
+    """The driver's own command (torch.distributed.run ... bench.py --gpus N) and a WORLD_SIZE that disagrees with --gpus."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert _json_line(r.stdout)["n_gpus"] == 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=_env(WORLD_SIZE="4", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "disagrees with WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_single_rank_line_schema():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line
+    assert line["metric"] == "EM iterations/sec at N=50k cloud pts, M=50 nodes" and line["n_gpus"] == 1 and line["dtype"] == "f32"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"]
+    assert "em_iters_per_s_f64" in line

@@ -1077,3 +1077,107 @@ def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F):
                 assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"]
     finally:
         ctx.close()
+
+
+_RETRY_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from trackdlo_amd import binding as B, synth
+P = synth.LAUNCH_PARAMS
+res = {}
+for i, (N, M, iters, lle, F) in enumerate(eval(sys.argv[3])):
+    ctx = B.Context(max_frames=F, max_points=N, max_nodes=M)
+    pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], iters, 0.0, False, precision=1)
+    kw = {}
+    if lle:
+        pr = B.make_params(3.0, 1.0, 10.0, 0.1, iters, 0.0, True, precision=1)
+        kw['H'] = np.eye(M) * 0.1 + 0.01 * np.diag(np.ones(M - 1), 1) + 0.01 * np.diag(np.ones(M - 1), -1)
+    Ys = []
+    for f in range(F):
+        X, Y0, _ = synth.scene(N, M, config=190 + i, frame=f)
+        ctx.set_cloud(f, X); Ys.append(Y0)
+    if F == 1:
+        g = ctx.cpd_lle_resident(0, Ys[0], 2e-5 if lle else 0.0, pr, **kw)
+        res[f'Y{i}'] = g['Y']; res[f's{i}'] = np.array([g['sigma2'], g['iters'], g['status'], g['mstep_retries']])
+    else:
+        out = ctx.cpd_lle_batch(Ys, [2e-5 if lle else 0.0] * F, pr, **kw)
+        res[f'Y{i}'] = np.stack(out['Y']); res[f's{i}'] = np.array([out['sigma2'][0], out['stats'][0]['iters'], max(s['status'] for s in out['stats']),
+                                                                     sum(s['mstep_retries'] for s in out['stats'])])
+    ctx.close()
+np.savez(sys.argv[2], **res)
+"""
+
+
+def test_multi_cu_mstep_redoes_an_iteration_after_a_timed_out_hand_off(tmp_path, oracle):
+    """a hand-off of k_mstep_mcu / k_mstep_pivot_mcu that runs into its time limit (a workgroup not co-resident with
+    the others: a plain launch gives no such guarantee) must not poison the registration.  TDLO_MCU_FORCE_TIMEOUT=k makes the
+    last row block's wait in iteration k behave as timed out: the finishing workgroup then publishes nothing, re-arms the
+    sync words, and the one-workgroup elimination that follows in the stream redoes the iteration from the same sums.  The
+    result must carry status 0, report the retry, and agree with the undisturbed run to rounding (the two eliminations
+    perform the same operations; only G W / the block partials are summed in another fixed order)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(4000, 130, 4, False, 1), (6000, 300, 3, False, 1), (3000, 90, 4, False, 5), (4000, 200, 3, True, 1), (3000, 129, 3, True, 3)]
+    outs = {}
+    for mode in ("plain", "forced"):
+        env = dict(os.environ)
+        env.pop("TDLO_MCU_FORCE_TIMEOUT", None)
+        if mode == "forced": env["TDLO_MCU_FORCE_TIMEOUT"] = "1"          # the second iteration
+        out = tmp_path / f"{mode}.npz"
+        r = subprocess.run([sys.executable, "-c", _RETRY_SCRIPT, root, str(out), repr(cases)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(out)
+    a, b = outs["plain"], outs["forced"]
+    for i, (N, M, iters, lle, F) in enumerate(cases):
+        assert a[f"s{i}"][2] == 0 and b[f"s{i}"][2] == 0                      # status
+        assert a[f"s{i}"][3] == 0 and b[f"s{i}"][3] == F                      # one redone iteration per frame, none undisturbed
+        assert a[f"s{i}"][1] == b[f"s{i}"][1] == iters
+        ty, ts = (1e-9, 1e-7) if lle else (1e-12, 1e-10)
+        assert np.abs(a[f"Y{i}"] - b[f"Y{i}"]).max() <= ty, (i, np.abs(a[f"Y{i}"] - b[f"Y{i}"]).max())
+        assert abs(a[f"s{i}"][0] - b[f"s{i}"][0]) <= ts * a[f"s{i}"][0]
+
+
+def test_reg_rejects_more_centroids_than_fit_the_lds(hip_ctx):
+    """tdlo_reg beyond the LDS-derived limit (890 centroids) is TDLO_E_INVALID, not an opaque launch failure."""
+    from trackdlo_amd import binding as B, synth
+    X, _, _ = synth.scene(4000, 30, config=3)
+    Y, s2 = hip_ctx.reg(X, 890, max_iter=1)
+    assert np.isfinite(s2)
+    with pytest.raises(B.TdloError) as e:
+        hip_ctx.reg(X, 891, max_iter=1)
+    assert e.value.code == B.TDLO_E_INVALID
+    assert hip_ctx.reg(X, 8, max_iter=2)[0].shape == (8, 3)                  # the context stays usable
+
+
+def test_nsplit_empty_cloud_leaves_the_context_reusable(hip_ctx):
+    """an N-split registration whose global kept-point count is 0 raises TDLO_E_EMPTY and ABORTS the split
+    (tdlo_split_abort), so that the same shard / context can register the next frame."""
+    import torch
+    from trackdlo_amd import binding as B, nsplit, synth
+    P = synth.LAUNCH_PARAMS
+
+    class Identity:
+        def all_reduce_sum(self, a): return np.array(a, dtype=np.float64)
+        def all_reduce_min(self, a): return np.array(a, dtype=np.float64)
+
+    class LocalExchange:
+        def __init__(self, M):
+            self.buf = torch.zeros(5 * M + 2, dtype=torch.float64, device="cuda:0"); self.dmin = self.buf[:M]; self.sums = self.buf[M:]
+        def all_reduce_min_dmin(self): pass
+        def all_reduce_sum_sums(self): pass
+
+    M = 40
+    X, Y0, _ = synth.scene(5000, M, config=6)
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 6, 0.0, False)
+    far = X + np.array([0.0, 0.0, 5.0])
+    with pytest.raises(B.TdloError) as e:
+        nsplit.cpd_lle_nsplit(nsplit.HipShard(hip_ctx, far), Identity(), Y0, 0.0, pr)
+    assert e.value.code == B.TDLO_E_EMPTY
+    xch = LocalExchange(M)
+    shard = nsplit.HipDeviceShard(hip_ctx, far, xch)
+    with pytest.raises(B.TdloError):
+        nsplit.cpd_lle_nsplit_device(shard, xch, Identity(), Y0, 0.0, pr)
+    shard2 = nsplit.HipDeviceShard(hip_ctx, X, xch)                           # bind() would fail inside a dangling registration
+    b = nsplit.cpd_lle_nsplit_device(shard2, xch, Identity(), Y0, 0.0, pr)
+    a = hip_ctx.cpd_lle(X, Y0, 0.0, pr)
+    assert b["iters"] == 6 and np.abs(a["Y"] - b["Y"]).max() <= 1e-12

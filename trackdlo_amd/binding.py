@@ -54,7 +54,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -152,6 +152,7 @@ def load_library(path: str | None = None):
     lib.tdlo_line_sphere_intersection.argtypes = [vp, vp, vp, cd, vp]
     lib.tdlo_traverse_euclidean.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
     lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
+    lib.tdlo_profile_iteration.argtypes = [vp, ci, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_char_p, ci]
     lib.tdlo_debug_stamps.argtypes = [vp, ci, vp, ci]
     lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
     lib.tdlo_piecewise_error.restype = cd
@@ -303,6 +304,13 @@ class Context:
         out = np.zeros(n, dtype=np.uint64)
         self._chk(self.lib.tdlo_debug_stamps(self.h, slot, _ptr(out), n))
         return out
+
+    def profile_iteration(self, reps=200):
+        """(E-step us, M-step us or None, whole-iteration us, M-step kernel name): per-dispatch HIP events, in situ."""
+        e = C.c_float(0); m = C.c_float(0); it = C.c_float(0)
+        name = C.create_string_buffer(64)
+        self._chk(self.lib.tdlo_profile_iteration(self.h, int(reps), C.byref(e), C.byref(m), C.byref(it), name, 64))
+        return e.value, (m.value if m.value >= 0 else None), it.value, name.value.decode()
 
     def profile_kernel(self, kind, reps=200, slot=0):
         us = C.c_float(0)

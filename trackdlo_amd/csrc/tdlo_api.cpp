@@ -918,7 +918,7 @@ int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us
         std::vector<hipEvent_t> evs(2 * (size_t)reps, nullptr);
         for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
         for (int w = 0; w < 3; ++w) HIPCHK(c, launch_iteration(c->fd, fh.data(), F, s));
-        for (int r = 0; r < reps; ++r) HIPCHK(c, launch_iteration_timed(c->fd, fh.data(), F, s, evs[2 * r], evs[2 * r + 1]));
+        for (int r = 0; r < reps; ++r) HIPCHK(c, launch_iteration_timed(c->fd, fh.data(), F, s, evs[2 * r], evs[2 * r + 1], nullptr, nullptr));
         HIPCHK(c, hipStreamSynchronize(s));
         double tot = 0;
         for (int r = 0; r < reps; ++r) { float ms = 0; hipEventElapsedTime(&ms, evs[2 * r], evs[2 * r + 1]); tot += ms; }
@@ -935,6 +935,55 @@ int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us
     if (avg_us) *avg_us = ms * 1000.0f / (float)reps;
     }
     // restore
+    for (int i = 0; i < F; ++i) {
+        std::memcpy(c->pin + i * 16, &saved[i], sizeof(IterState));
+        HIPCHK(c, hipMemcpyAsync(c->fh[i].st, c->pin + i * 16, sizeof(IterState), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return TDLO_OK;
+}
+
+int tdlo_profile_iteration(tdlo_ctx *c, int reps, float *estep_us, float *mstep_us, float *iter_us, char *mstep_kernel, int name_cap) {
+    if (!c || c->last_F < 1 || c->fh.empty()) return TDLO_E_INVALID;
+    if (reps < 1 || reps > 256) return fail(c, TDLO_E_INVALID, "bad reps");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int F = c->last_F;
+    std::vector<IterState> saved(F);
+    for (int i = 0; i < F; ++i) HIPCHK(c, hipMemcpyAsync(&saved[i], c->fh[i].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int i = 0; i < F; ++i) {
+        IterState is = saved[i];
+        is.done = 0; is.it = 0;
+        std::memcpy(c->pin + i * 16, &is, sizeof is);
+        HIPCHK(c, hipMemcpyAsync(c->fh[i].st, c->pin + i * 16, sizeof(IterState), hipMemcpyHostToDevice, s));
+    }
+    std::vector<FrameDev> fh = c->fh;
+    for (auto &f : fh) { f.max_iter = 1 << 30; f.tol = -1.0; }
+    HIPCHK(c, hipMemcpyAsync(c->fd, fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
+    std::vector<hipEvent_t> evs(4 * (size_t)reps, nullptr);
+    for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
+    for (int w = 0; w < 3; ++w) HIPCHK(c, launch_iteration(c->fd, fh.data(), F, s));
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    for (int r = 0; r < reps; ++r) HIPCHK(c, launch_iteration_timed(c->fd, fh.data(), F, s, evs[4 * r], evs[4 * r + 1], evs[4 * r + 2], evs[4 * r + 3]));
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    double te = 0, tm = 0;
+    bool m_ok = true;
+    for (int r = 0; r < reps; ++r) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, evs[4 * r], evs[4 * r + 1]); te += ms;
+        if (hipEventElapsedTime(&ms, evs[4 * r + 2], evs[4 * r + 3]) == hipSuccess) tm += ms; else m_ok = false;     // dispatch without events
+    }
+    (void)hipGetLastError();
+    float tot = 0;
+    hipEventElapsedTime(&tot, c->ev[0], c->ev[1]);
+    for (auto &e : evs) hipEventDestroy(e);
+    if (estep_us) *estep_us = (float)(te * 1000.0 / reps);
+    if (mstep_us) *mstep_us = m_ok ? (float)(tm * 1000.0 / reps) : -1.0f;
+    if (iter_us) *iter_us = tot * 1000.0f / (float)reps;
+    if (mstep_kernel && name_cap > 0) { std::strncpy(mstep_kernel, mstep_kernel_name(fh.data(), F), (size_t)name_cap - 1); mstep_kernel[name_cap - 1] = 0; }
     for (int i = 0; i < F; ++i) {
         std::memcpy(c->pin + i * 16, &saved[i], sizeof(IterState));
         HIPCHK(c, hipMemcpyAsync(c->fh[i].st, c->pin + i * 16, sizeof(IterState), hipMemcpyHostToDevice, s));

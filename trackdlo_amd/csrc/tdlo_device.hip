@@ -1246,6 +1246,8 @@ template <typename T, int EB> static size_t estep_lds_bytes(int M, bool single) 
 // measurement aid (tdlo_profile_kernel kind 10): when set, the E-step is launched with start/stop events bound to the
 // dispatch itself (hipExtLaunchKernelGGL), i.e. the same begin/end timestamps a kernel trace reports
 static hipEvent_t g_estep_ev[2] = {nullptr, nullptr};
+// the same for the M-step dispatch (k_mstep_fast here, k_mstep_mcu in tdlo_mstep_big.hip): tdlo_profile_iteration
+hipEvent_t g_mstep_ev[2] = {nullptr, nullptr};
 
 template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
     const int M = fh[0].M, nch = nch_for(M);
@@ -1300,10 +1302,12 @@ template <typename T, int NW, int MC, bool MFMA = false> static hipError_t launc
     const size_t lds = mstep_fast_lds_bytes<T>(fh[0].M, NW);
     if (F == 1) {
         TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true, MFMA>, lds));
-        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
+        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA>), dim3(1), dim3(NW * 64), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
+        else hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
     } else {
         TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, false, MFMA>, lds));
-        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, false, MFMA>), dim3(F), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
+        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_fast<T, NW, MC, false, MFMA>), dim3(F), dim3(NW * 64), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
+        else hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, false, MFMA>), dim3(F), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
     }
     return hipGetLastError();
 }
@@ -1395,11 +1399,26 @@ hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipSt
     return hipSuccess;
 }
 
-hipError_t launch_iteration_timed(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop) {
+hipError_t launch_iteration_timed(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
+                                  hipEvent_t m_start, hipEvent_t m_stop) {
     g_estep_ev[0] = e_start; g_estep_ev[1] = e_stop;
+    g_mstep_ev[0] = m_start; g_mstep_ev[1] = m_stop;
     const hipError_t e = launch_iteration(fd, fh, F, s);
     g_estep_ev[0] = g_estep_ev[1] = nullptr;
+    g_mstep_ev[0] = g_mstep_ev[1] = nullptr;
     return e;
+}
+
+// which kernel the M-step of these frames dispatches (for the bench line): name and whether its dispatch carries the events
+const char *mstep_kernel_name(const FrameDev *fh, int F) {
+    const int M = fh[0].M;
+    bool any_lle = false;
+    for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
+    if (M <= 60 && !any_lle) return "k_mstep_fast<MFMA>";
+    if (!any_lle) return "k_mstep_mcu";
+    if (M <= 64) return "k_mstep_fast<pivoted>";
+    if (M <= kLdsSolveMaxM) return "k_mstep<LDS>";
+    return "k_mstep_pivot_mcu";
 }
 
 // kind: 0 E-step, 1 dmin, 2 M-step (from block partials), 3 M-step export-only (split), 4 M-step from global sums (split)

@@ -76,7 +76,9 @@ struct FrameDev {
 // launchers implemented in tdlo_device.hip
 hipError_t launch_prune_and_setup(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
 hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
-hipError_t launch_iteration_timed(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop);
+hipError_t launch_iteration_timed(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
+                                  hipEvent_t m_start, hipEvent_t m_stop);
+const char *mstep_kernel_name(const FrameDev *frames_host, int F);
 hipError_t launch_estep_only(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int kind, hipStream_t s);
 hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames_host, hipStream_t s);
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);

@@ -29,8 +29,10 @@
 #include "tdlo_mstep_generic.h"
 #include <algorithm>
 #include <cstdlib>
+#include <hip/hip_ext.h>
 
 namespace tdlo {
+extern hipEvent_t g_mstep_ev[2];       // tdlo_device.hip: start/stop events for the M-step dispatch (tdlo_profile_iteration)
 namespace {
 
 constexpr int kBig = 1024;
@@ -1035,14 +1037,16 @@ hipError_t launch_mstep_big(const FrameDev *fd, const FrameDev *fh, int F, int f
         if (f64) {
             e = hipFuncSetAttribute((const void *)k_mstep_mcu<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_mstep_mcu<double>), grid, dim3(kBig), lds, s, fd, from_sums);
+            if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_mcu<double>), grid, dim3(kBig), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, from_sums);
+            else hipLaunchKernelGGL((k_mstep_mcu<double>), grid, dim3(kBig), lds, s, fd, from_sums);
             e = hipFuncSetAttribute((const void *)k_mstep_big<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds_bytes(M));
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((k_mstep_big<double>), dim3(F), dim3(kBig), big_lds_bytes(M), s, fd, from_sums, 1);
         } else {
             e = hipFuncSetAttribute((const void *)k_mstep_mcu<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_mstep_mcu<float>), grid, dim3(kBig), lds, s, fd, from_sums);
+            if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_mcu<float>), grid, dim3(kBig), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, from_sums);
+            else hipLaunchKernelGGL((k_mstep_mcu<float>), grid, dim3(kBig), lds, s, fd, from_sums);
             e = hipFuncSetAttribute((const void *)k_mstep_big<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds_bytes(M));
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL((k_mstep_big<float>), dim3(F), dim3(kBig), big_lds_bytes(M), s, fd, from_sums, 1);
