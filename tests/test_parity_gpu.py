@@ -26,6 +26,26 @@ def _params(kw, prec):
                          kw["alpha"], kw["k_vis"], kw["visibility_threshold"], prec)
 
 
+def _measured_gate(oracle, prec, run, H, o):
+    """Gate for a registration with the (ill-conditioned) LLE term: the stated tolerance, widened ONLY by what the oracle itself is
+    measured to be uncertain by on this very input -- 8 x the larger of (a) its own rounding error: the faithful QR solve
+    against the quadruple-precision solve of the same systems, (b) its sensitivity to the last bit of the data: H perturbed
+    by +-1 ulp per entry (the reference forms H, H G and the sums in another order than any re-implementation can).
+    On all but the pathological draws both are ~1e-12 m and the stated tolerance stands (scripts/gpu_lle_gates.py)."""
+    ty, ts = TOL[prec]
+    with oracle.extended_solver():
+        e = run(H)
+    dy = np.abs(e["Y"] - o["Y"]).max(); ds = abs(e["sigma2"] - o["sigma2"]) / o["sigma2"]
+    rng = np.random.default_rng(4242)
+    for _ in range(2):
+        Hp = np.asarray(H) * (1.0 + 2.220446049250313e-16 * rng.choice([-1.0, 1.0], size=np.shape(H)))
+        p = run(Hp)
+        if p["iters"] != o["iters"]:
+            return np.inf, np.inf                 # the last bit of H moves the stopping decision: nothing can be compared
+        dy = max(dy, np.abs(p["Y"] - o["Y"]).max()); ds = max(ds, abs(p["sigma2"] - o["sigma2"]) / o["sigma2"])
+    return max(ty, 8.0 * dy), max(ts, 8.0 * ds)
+
+
 def _check(g, o, prec):
     ty, ts = TOL[prec]
     assert g["rc"] == 0
@@ -705,19 +725,13 @@ def test_randomised_configurations(hip_ctx, oracle, seed):
         _check(g, o, prec)
         return
     # LLE system A = lambda s2 I + (diag(P1) + s2 gamma H) G: the weights behind H come from rank-deficient local Gram
-    # matrices, so cond(A) ranges from 1e7 to 1e13 depending on the draw (M = 47 on this centreline is such a
-    # case).  Two backward-stable solvers (oracle: Householder QR with column pivoting; device: pivoted Gauss-Jordan; the
-    # reference: Eigen's COD) then agree only to cond(A) x rounding, so the gate scales with a condition estimate, and a
-    # draw beyond 1e10 is only required to run to the same iteration count with finite results.
-    kg = oracle.kernel_G(Y0, kw["beta"]); G = kg[1] if isinstance(kg, tuple) else kg
-    s2e = max(s2, 1.5e-5)
-    kappa = np.linalg.cond(np.diag(np.full(M, o["n_kept"] / M)) @ G + kw["lambda_"] * s2e * np.eye(M) + s2e * kw["lle_weight"] * H @ G)
+    # matrices (entries of H reach 1e10 on a few draws, cond(A) 1e13).  The gate is the stated tolerance unless
+    # the ORACLE ITSELF is measurably less certain on this draw: its own rounding error (QR against the quadruple-precision
+    # solve of the same system) and its sensitivity to the last bit of H (tests/test_solver_error.py explains both).
+    ty, ts = _measured_gate(oracle, prec, lambda H_: oracle.cpd_lle(X, Y0, s2, priors=pri, visible_nodes=vext, H=H_, **kw), H, o)
     assert g["rc"] == 0 and g["iters"] == o["iters"] and g["n_kept"] == o["n_kept"] and np.all(np.isfinite(g["Y"]))
-    if kappa < 1e10:
-        ty, ts = TOL[prec]
-        scale = max(1.0, kappa / (1e5 if prec else 1e9))
-        assert np.abs(g["Y"] - o["Y"]).max() <= ty * scale
-        assert abs(g["sigma2"] - o["sigma2"]) <= ts * scale * o["sigma2"]
+    assert np.abs(g["Y"] - o["Y"]).max() <= ty
+    assert abs(g["sigma2"] - o["sigma2"]) <= ts * o["sigma2"]
 
 
 @pytest.mark.gpu
@@ -786,6 +800,8 @@ def test_randomised_tracking_sequences(hip_ctx, oracle, seed):
             continue                                                                       # the reference needs a chain to register
         Lg = oracle.calc_lle_weights(Ycur[vext], 6)
         Hpre = (np.eye(len(vext)) - Lg).T @ (np.eye(len(vext)) - Lg)
+        Yprev, s2prev = ref.get_tracking_result(), ref.get_sigma2()
+        snap = B.trackdlo(*args, ctx=hip_ctx); snap.copy_state_from(trk)              # the product's state before this frame
         try:
             ref.tracking_step(X, vis, vext, H_pre=Hpre)
         except Exception:
@@ -793,31 +809,49 @@ def test_randomised_tracking_sequences(hip_ctx, oracle, seed):
                 trk.tracking_step(X, vis, vext, None, 0, 0, H_pre=Hpre)                     # the product reports it as an error too
             break
         trk.tracking_step(X, vis, vext, None, 0, 0, H_pre=Hpre)
-        # condition estimate of the pre-processing registration's LLE system (same construction as in
-        # test_randomised_configurations): its H comes from rank-deficient local Gram matrices, cond(A) is 1e6..1e8 for most
-        # draws and 1e13 and beyond for a few (seed 69 of the extended sweep: 3e13, H entries of 1e10).  Two backward-stable
-        # solvers agree to cond(A) x rounding only, so beyond 1e10 the frame is required to finish with finite, converged
-        # results and the sequence is not followed further.
-        kg = oracle.kernel_G(Ycur[vext], P["beta_pre_proc"]); Gp = kg[1] if isinstance(kg, tuple) else kg
-        Mv = len(vext); s2e = max(ref.get_sigma2(), 1.5e-5)
-        kappa = np.linalg.cond(np.diag(np.full(Mv, N / Mv)) @ Gp + P["lambda_pre_proc"] * s2e * np.eye(Mv) + s2e * P["lle_weight"] * Hpre @ Gp)
-        if kappa > 1e10:
+
+        # What the oracle itself is uncertain by on this frame (pre-processing registration with the LLE term, H from
+        # rank-deficient local Gram matrices): its own rounding error (QR against the quadruple-precision solve) and its
+        # sensitivity to the last bit of H -- measured by re-running the frame from the same state.  Gates are the stated
+        # fp32-mode tolerances unless 8 x that measurement is larger.
+        def rerun(Hx, solver):
+            t2 = oracle.Tracker(*args); t2.initialize_nodes(Yprev); t2.initialize_geodesic_coord(coord); t2.set_sigma2(s2prev)
+            oracle.set_solver(solver)
+            try:
+                t2.tracking_step(X, vis, vext, H_pre=Hx)
+            finally:
+                oracle.set_solver(0)
+            return t2
+        prng = np.random.default_rng(777 + seed)
+        alts = [rerun(Hpre, 1)] + [rerun(Hpre * (1.0 + 2.220446049250313e-16 * prng.choice([-1.0, 1.0], size=Hpre.shape)), 0) for _ in range(2)]
+        if any(a.stats_pre.iters != ref.stats_pre.iters or a.stats_main.iters != ref.stats_main.iters or
+               a.get_correspondence_pairs().shape != ref.get_correspondence_pairs().shape for a in alts):
+            # the last bit of H moves a stopping decision of the ORACLE: this frame pins nothing; carry on from the oracle's state
             assert np.all(np.isfinite(trk.get_tracking_result())) and np.isfinite(trk.get_sigma2())
             break
+        unc_y = max(np.abs(a.get_tracking_result() - ref.get_tracking_result()).max() for a in alts)
+        unc_g = max(max(np.abs(a.get_guide_nodes() - ref.get_guide_nodes()).max(), np.abs(a.get_correspondence_pairs() - ref.get_correspondence_pairs()).max()) for a in alts)
+        unc_s = max(abs(a.get_sigma2() - ref.get_sigma2()) / ref.get_sigma2() for a in alts)
+
         if trk.last_stats[0]["iters"] != ref.stats_pre.iters or trk.last_stats[1]["iters"] != ref.stats_main.iters:
-            # The stopping rule (:424) is a threshold on a rounded quantity: when the criterion sits at tol, fp32 E-step and
-            # the ill-conditioned pre-processing solve may stop a few iterations apart (seen in 2 of 160 sequences).  Both
-            # are converged states: they must agree to the stopping tolerance's order; the sequence is not followed further.
+            # The stopping rule (:424) thresholds a rounded quantity: with the fp32 E-step the criterion can pass tol one
+            # iteration apart (2 of 160 sequences).  That it IS the fp32 rounding is shown, not assumed: the same frame from the
+            # same state in TDLO_PREC_F64 must reproduce the oracle's iteration counts and meet the fp64 gates; the sequence
+            # then continues from that state.
+            t64 = B.trackdlo(*args, ctx=hip_ctx); t64.copy_state_from(snap); t64.set_precision(B.PREC_F64)
+            t64.tracking_step(X, vis, vext, None, 0, 0, H_pre=Hpre)
+            assert t64.last_stats[0]["iters"] == ref.stats_pre.iters and t64.last_stats[1]["iters"] == ref.stats_main.iters
+            np.testing.assert_allclose(t64.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=max(1e-9, 8 * unc_y))
             assert trk.last_stats[0]["converged"] and trk.last_stats[1]["converged"]
-            assert np.abs(trk.get_tracking_result() - ref.get_tracking_result()).max() < 2e-3
-            break
+            trk.copy_state_from(t64); trk.set_precision(B.PREC_F32)
+            continue
         kp, kr = trk.get_correspondence_pairs(), ref.get_correspondence_pairs()
         assert kp.shape == kr.shape
-        tol_pre = 1e-5 * max(1.0, kappa / 1e7)            # outputs of the pre-processing registration: guide nodes, priors
+        tol_pre = max(1e-5, 8 * unc_g)                    # outputs of the pre-processing registration: guide nodes, priors
         np.testing.assert_allclose(kp, kr, rtol=0, atol=tol_pre)
         np.testing.assert_allclose(trk.get_guide_nodes(), ref.get_guide_nodes(), rtol=0, atol=tol_pre)
-        np.testing.assert_allclose(trk.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=1e-5)
-        assert abs(trk.get_sigma2() - ref.get_sigma2()) <= 1e-3 * ref.get_sigma2()
+        np.testing.assert_allclose(trk.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=max(1e-5, 8 * unc_y))
+        assert abs(trk.get_sigma2() - ref.get_sigma2()) <= max(1e-3, 8 * unc_s) * ref.get_sigma2()
 
 
 @pytest.mark.gpu
@@ -952,9 +986,9 @@ def test_multi_cu_mstep_matches_one_workgroup_kernel(tmp_path):
     a, b = outs
     for i in range(len(cases)):
         assert a[f"s{i}"][2] == 0 and b[f"s{i}"][2] == 0 and a[f"s{i}"][1] == b[f"s{i}"][1]
-        # the pivoted eliminations of the (ill-conditioned: c = lambda sigma2 ~ 1e-5 against entries of order 100) LLE system
-        # differ in the order of their row operations: two valid solutions of such a system agree to ~1e-7 m
-        ty, ts = (1e-6, 1e-5) if cases[i][5] else (1e-12, 1e-10)
+        # the pivoted eliminations of the LLE system (c = lambda sigma2 ~ 1e-5 against entries of order 100) order their row
+        # operations differently; both are Gaussian elimination with back substitution (backward stable): stated fp64 tolerance
+        ty, ts = (1e-9, 1e-7) if cases[i][5] else (1e-12, 1e-10)
         assert np.abs(a[f"Y{i}"] - b[f"Y{i}"]).max() <= ty
         assert abs(a[f"s{i}"][0] - b[f"s{i}"][0]) <= ts * b[f"s{i}"][0]
 
@@ -1048,10 +1082,9 @@ def test_multi_cu_mstep_hand_offs_under_uneven_load():
 @pytest.mark.parametrize("M,F", [(129, 3), (200, 9), (300, 5)])
 def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F):
     """k_mstep_pivot_mcu (LLE term, more than 128 nodes: 16 rows per workgroup, pivot search across the workgroups, one
-    hand-off per column): against the oracle -- stated tolerance 1e-6 m / 1e-5 relative in sigma2 for this regime: the
-    pre-processing system (lambda = 1, sigma2 ~ 1e-5) is ill-conditioned at these sizes and the oracle's own QR solution
-    carries the same ~1e-8..1e-7 m uncertainty (`scripts/gpu_lle_acc.py`: the one-workgroup kernel sits at the same distance)
-    -- and frames registered concurrently / repeatedly must reproduce the single call bit for bit."""
+    hand-off per column; back substitution by the finishing workgroup): against the oracle at the stated fp64 tolerance
+    (1e-9 m / 1e-7; the oracle's own error on these systems is 1e-11 m, tests/test_solver_error.py) -- and frames registered
+    concurrently / repeatedly must reproduce the single call bit for bit."""
     from trackdlo_amd import binding as B, synth
     rng = np.random.default_rng(9500 + M)
     ctx = B.Context(device=0, max_frames=F, max_points=1 << 14, max_nodes=M)
@@ -1069,7 +1102,7 @@ def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F):
             if f == 0:
                 o = oracle.cpd_lle(X, Y0, 2e-5, H=H, **kw)
                 assert g["status"] == 0 and g["iters"] == o["iters"] and g["n_kept"] == o["n_kept"]
-                assert np.abs(g["Y"] - o["Y"]).max() <= 1e-6 and abs(g["sigma2"] - o["sigma2"]) <= 1e-5 * o["sigma2"]
+                assert np.abs(g["Y"] - o["Y"]).max() <= TOL[1][0] and abs(g["sigma2"] - o["sigma2"]) <= TOL[1][1] * o["sigma2"]
         for rep in range(3):
             out = ctx.cpd_lle_batch(Ys, s2s, pr, H=H)
             for f in range(F):

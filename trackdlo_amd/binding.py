@@ -346,6 +346,13 @@ class trackdlo:
         except Exception:
             pass
 
+    def copy_state_from(self, other: "trackdlo"):
+        """The reference's implicit copy assignment (trackdlo.h:104-121: every member); keeps this object's context and slot."""
+        self.ctx._chk(self.ctx.lib.tdlo_tracker_copy_state(self.h, other.h))
+
+    def set_precision(self, precision):
+        self.ctx._chk(self.ctx.lib.tdlo_tracker_set_precision(self.h, int(precision)))
+
     def get_sigma2(self):
         return self.ctx.lib.tdlo_tracker_get_sigma2(self.h)
 

@@ -770,6 +770,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     double *aux = tmp + 12 * 64;                      // 7 x 64: node - Y0 (3), alpha (Y_ext - Y0) (3), alpha J (1)
     double *Gs = aux + 7 * 64;                        // M x M (column-major, ld = M)
     double *Sg = Gs + (((size_t)M * M + 1) & ~(size_t)1);   // NG x nSp partial-sum groups
+    double *Ut = Sg + (size_t)(MB / npair) * nSp;            // (M + 3) x 64: the eliminated tableau for the back substitution (pivoted variant only)
 
 #define TDLO_STAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     TDLO_STAMP(0);
@@ -1064,9 +1065,10 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                     if (e == 0 || e == 0x7ff) singular = 1;          // zero / denormal / non-finite pivot
                     const double sc = __hiloint2double((2046 - e) << 20, 0);
                     const bool self = (row == pw);
-                    const double ps = self ? 1.0 : pv * sc;
-                    const double ls = self ? 0.0 : aik * sc;
-                    dgv = self ? pv : (mine >= 0 ? dgv * ps : dgv);
+                    const bool upd = !self && mine < 0;       // a row that has served as pivot row is final: Gaussian elimination,
+                    const double ps = upd ? pv * sc : 1.0;    // not Gauss-Jordan (see the back substitution below)
+                    const double ls = upd ? aik * sc : 0.0;
+                    dgv = self ? pv : dgv;
                     mine = self ? k : mine;
 #pragma unroll
                     for (int s2 = sI + 1; s2 < NB; ++s2) pc[s2] = fma(ps, pc[s2], -(ls * readlane_f64(pc[s2], pw)));
@@ -1084,10 +1086,34 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
             }
         }
     }
-    __syncthreads();
-    if (rowok && mine >= 0) {
+    // ---- 3b. back substitution.  The elimination above is Gaussian elimination with partial pivoting (LU), which is backward
+    // stable; Gauss-Jordan (reducing the rows above the pivot as well, as this kernel did) is only forward stable: its error
+    // in W is not of the form A^-1 dA W, the product G W of :417 does not damp it, and on the ill-conditioned systems of
+    // the pre-processing registration it cost ~1e-8 m per solve in T (the oracle's QR: 1e-11, tests/test_solver_error.py).
+    // The finished tableau goes to LDS once (column j = 64 consecutive rows); waves 0..2 take one right-hand side each,
+    // lane = row: the row's entries of U live in registers, x_k comes from the lane that pivots column k (v_readlane),
+    // every row that pivots an earlier column takes b -= U[row][k] x_k.  One LDS round trip, no barrier inside the loop.
+    __syncthreads();                                  // the panel buffers / Sg are dead; Ut has its own area
 #pragma unroll
-        for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j >= M && j < ncol) W[(j - M) * M + mine] = a[c] / dgv; }
+    for (int c = 0; c < MC; ++c) { const int j = slot + c * NSLOT; if (j < ncol) Ut[j * 64 + row] = a[c]; }
+    __syncthreads();
+    if (slot < 3) {
+        constexpr int KMAX = (4 * MC - 3) < 64 ? (4 * MC - 3) : 64;      // M <= 4 MC - 3 for this instantiation
+        double u[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) u[k] = Ut[(k < M ? k : 0) * 64 + row];
+        double b = Ut[(M + slot) * 64 + row];
+        const double rinv = mine >= 0 ? 1.0 / dgv : 0.0;
+#pragma unroll
+        for (int k = KMAX - 1; k >= 0; --k) {
+            if (k < M) {                              // wave-uniform
+                const unsigned long long hit = __ballot(mine == k);
+                const int pl = hit ? (int)__builtin_ctzll(hit) : 0;
+                const double w = readlane_f64(b, pl) * readlane_f64(rinv, pl);
+                b = (mine >= 0 && mine < k) ? fma(-u[k], w, b) : b;
+            }
+        }
+        if (rowok && mine >= 0) W[slot * M + mine] = b * rinv;
     }
     singular = __syncthreads_or(singular);
     }   // !MFMA
@@ -1290,16 +1316,17 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
     return hipGetLastError();
 }
 
-template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW) {
+template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW, bool pivoted) {
     typedef typename PartOf<T>::type PT;
     const int VEC = 16 / (int)sizeof(PT);
     const int nSp = part_stride<PT>(M), npair = nSp / VEC, NG = (NW * 64) / npair;
     size_t d = (size_t)((nSp + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 12 * 64 + 7 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
+    if (pivoted) d += (size_t)(M + 3) * 64;
     return d * sizeof(double);
 }
 
 template <typename T, int NW, int MC, bool MFMA = false> static hipError_t launch_mstep_fast(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
-    const size_t lds = mstep_fast_lds_bytes<T>(fh[0].M, NW);
+    const size_t lds = mstep_fast_lds_bytes<T>(fh[0].M, NW, !MFMA);
     if (F == 1) {
         TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true, MFMA>, lds));
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA>), dim3(1), dim3(NW * 64), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);

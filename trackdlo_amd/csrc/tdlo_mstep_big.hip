@@ -720,7 +720,7 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
     int *used = ib, *kof = ib + 16, *flg = ib + 32;    // flg: [0] last arriver, [1] a spin ran into its time limit
     const auto Gg = TDLO_AS_GLOBAL(double, f.G);
     const auto Cb = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.Ascr;      // [parity][rb][slotsz]
-    const auto Tp = TDLO_AS_GLOBAL_RW(double, f.Ascr) + (size_t)Mp * Cp + (size_t)Mp * 16;          // [rb][d][M]
+    const auto Ur = TDLO_AS_GLOBAL_RW(double, f.Ascr) + (size_t)Mp * Cp + (size_t)Mp * 16 + (size_t)nrb * 3 * Mp;   // [M][NC]: the factor's rows, by pivot column
     gu32 *sync = (gu32 *)(uintptr_t)f.sync;
     // flags: one 64-bit word per (column parity, workgroup) = {column + 1 : 16 | candidate row : 16 | key of |a| : 32}; the key is
     // the upper half of the fp64 pattern (monotone for non-negative values).  The flag IS the candidate's header (no second
@@ -860,8 +860,8 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
             if (16 * rb + r == p) {
                 for (int j = k + cs; j < NC; j += 16) R[r * ld + j] = prow[j];
                 if (cs == 0) { used[r] = 1; kof[r] = k; }
-            } else {
-                const double l = R[r * ld + k];
+            } else if (!used[r]) {                    // a row that has served as pivot row is final (Gaussian elimination, not
+                const double l = R[r * ld + k];       // Gauss-Jordan: see the back substitution of step 5)
                 for (int j = k + 1 + cs; j < NC; j += 16) R[r * ld + j] = fma(-l, prow[j], R[r * ld + j]);
             }
         }
@@ -869,19 +869,13 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
     }
     const int timed_out = flg[1];
 
-    // ---- 4. share of G W: sum over the own pivot rows r (pivot of column kof[r]) of G[:, kof[r]] W[kof[r]]
+    // ---- 4. the own pivot rows (unit diagonal, entries right of it, right-hand sides) go to the finishing workgroup,
+    //         stored by the column they pivot: row kof of the upper-triangular factor
     {
-        auto tp = (__attribute__((address_space(1))) unsigned long long *)(Tp + (size_t)rb * 3 * M);
-        for (int i = t; i < M; i += kPT) {
-            double v0 = 0, v1 = 0, v2 = 0;
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r) {
-                const int kc = kof[r];
-                if (kc >= 0) { const double gk = Gg[(size_t)kc * M + i]; v0 += gk * R[r * ld + M]; v1 += gk * R[r * ld + M + 1]; v2 += gk * R[r * ld + M + 2]; }
-            }
-            __hip_atomic_store(tp + i, (unsigned long long)__double_as_longlong(v0), TDLO_RLX_AGENT);
-            __hip_atomic_store(tp + M + i, (unsigned long long)__double_as_longlong(v1), TDLO_RLX_AGENT);
-            __hip_atomic_store(tp + 2 * M + i, (unsigned long long)__double_as_longlong(v2), TDLO_RLX_AGENT);
+        const int r = t & 15, cs = t >> 4, kc = kof[r];
+        if (kc >= 0) {
+            auto ur = (__attribute__((address_space(1))) unsigned long long *)(Ur + (size_t)kc * NC);
+            for (int j = kc + cs; j < NC; j += 16) __hip_atomic_store(ur + j, (unsigned long long)__double_as_longlong(R[r * ld + j]), TDLO_RLX_AGENT);
         }
     }
     singular = __syncthreads_or(singular) ? 1 : 0;
@@ -912,18 +906,102 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
         }
     }
 
-    // ---- 5. the finishing workgroup: all sums, T = Y0 + sum of the shares (fixed order), sigma2, stopping rule, publish
-    for (int e = t; e < nS; e += kPT) S[e] = f.sums[e];
-    for (int e = t; e < 3 * M; e += kPT) {
-        double a = 0;
-        for (int r0 = 0; r0 < nrb; r0 += 8) {
-            double v[8];
+    // ---- 5. the finishing workgroup: back substitution on the gathered factor (Gaussian elimination is backward stable;
+    //         Gauss-Jordan is only forward stable and its error in W is not damped by the product G W of :417 -- on the
+    //         ill-conditioned systems of the pre-processing registration that cost ~1e-8 m per solve in T, against 1e-11 for the
+    //         oracle's QR, tests/test_solver_error.py).  Row oriented, eight rows per round: the dot products with the part
+    //         of W that is already known are reduced over the workgroup in one go, the 8 x 8 triangle is finished by three
+    //         threads (one per right-hand side).  W lives in the dead row area R.
+    {
+        double *Wl = R;                                // [d][M]
+        double *part = S;                              // [4 waves][8 rows][3]: S is filled afterwards
+        double *tri = part + 96;                       // [8][8]
+        double *rhs = tri + 64;                        // [8][3]
+        const int kb0 = ((M - 1) >> 3) << 3;
+        // thread = column kb + t + 256 q of the block's eight rows (q < 3: M + 3 <= 515 columns); the entries of the NEXT block
+        // are requested before this block's reduction starts (the gathered rows were stored write-through, so every round
+        // would otherwise begin with a round trip to memory)
+        constexpr int QM = 3;
+        double en[8][QM];
+        auto fetch = [&](int kbx) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = Tp[(size_t)(r0 + u < nrb ? r0 + u : nrb - 1) * 3 * M + e];
+            for (int q = 0; q < QM; ++q) {
+                const int j = kbx + t + kPT * q;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (r0 + u < nrb) a += v[u];
+                for (int r = 0; r < 8; ++r) {
+                    const int kk = kbx + r;
+                    const bool on = j < NC && kk < M && j >= kk;
+                    en[r][q] = on ? Ur[(size_t)(kk < M ? kk : 0) * NC + (j < NC ? j : 0)] : 0.0;
+                }
+            }
+        };
+        fetch(kb0);
+        for (int kb = kb0; kb >= 0; kb -= 8) {
+            double e[8][QM];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int q = 0; q < QM; ++q) e[r][q] = en[r][q];
+            if (kb >= 8) fetch(kb - 8);
+            double acc[8][3];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { acc[r][0] = 0; acc[r][1] = 0; acc[r][2] = 0; }
+#pragma unroll
+            for (int q = 0; q < QM; ++q) {
+                const int j = kb + t + kPT * q;
+                if (j < NC) {
+                    if (j >= M) {                                     // the right-hand sides (first: the top block's columns run into them) ...
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) rhs[r * 3 + (j - M)] = e[r][q];
+                    } else if (j < kb + 8) {                          // ... the triangle (unit diagonal) ...
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) tri[r * 8 + (j - kb)] = e[r][q];
+                    } else {                                          // ... the part of W that is already known
+                        const double w0 = Wl[j], w1 = Wl[M + j], w2 = Wl[2 * M + j];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { acc[r][0] += e[r][q] * w0; acc[r][1] += e[r][q] * w1; acc[r][2] += e[r][q] * w2; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { const double v = wave_sum(acc[r][d]); if (lane == 0) part[(w * 8 + r) * 3 + d] = v; }
+            __syncthreads();
+            if (t < 3) {
+                double x[8];
+#pragma unroll
+                for (int r = 7; r >= 0; --r) {
+                    const int kk = kb + r;
+                    double v = 0.0;
+                    if (kk < M) {
+                        v = rhs[r * 3 + t] - (((part[r * 3 + t] + part[(8 + r) * 3 + t]) + part[(16 + r) * 3 + t]) + part[(24 + r) * 3 + t]);
+#pragma unroll
+                        for (int c = 7; c > r; --c) if (kb + c < M) v -= tri[r * 8 + c] * x[c];
+                        Wl[t * M + kk] = v;
+                    }
+                    x[r] = v;
+                }
+            }
+            __syncthreads();
         }
-        Tn[e] = f.Y0[e] + a;
+        // T = Y0 + G W (:417): wave = quarter of the k range, lane = node (+ 64 c); the quarters are added in a fixed order
+        double *tq = R + 3 * M;                        // [4 quarters][3][M], behind W in the dead row area (16 (M + 3) doubles)
+        const int kq = (M + 3) >> 2, kbeg = w * kq, kend = (kbeg + kq) < M ? (kbeg + kq) : M;
+        for (int i = lane; i < M; i += 64) {
+            double v0 = 0, v1 = 0, v2 = 0;
+            for (int k = kbeg; k < kend; k += 8) {
+                double g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g[u] = Gg[(size_t)((k + u) < kend ? (k + u) : (kend - 1)) * M + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (k + u < kend) { v0 += g[u] * Wl[k + u]; v1 += g[u] * Wl[M + k + u]; v2 += g[u] * Wl[2 * M + k + u]; }
+            }
+            tq[(w * 3 + 0) * M + i] = v0; tq[(w * 3 + 1) * M + i] = v1; tq[(w * 3 + 2) * M + i] = v2;
+        }
+        __syncthreads();
+        for (int e = t; e < 3 * M; e += kPT) Tn[e] = f.Y0[e] + (((tq[e] + tq[3 * M + e]) + tq[6 * M + e]) + tq[9 * M + e]);
+        for (int e = t; e < nS; e += kPT) S[e] = f.sums[e];
     }
     __syncthreads();
     const V4<T> *ndq = (const V4<T> *)f.nodes;
@@ -995,7 +1073,8 @@ size_t big_lds_bytes(int M) {
 }  // namespace
 
 // tableau (k_mstep_big) or published pivot rows (k_mstep_mcu) | panel columns | the row blocks' shares of G W
-size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16) + Mp * 16 + (Mp / 16) * 3 * Mp; }
+// k_mstep_pivot_mcu: candidate slots (front) ... | the gathered upper-triangular factor M x (M + 3) (behind everything else)
+size_t mstep_big_scratch_doubles(int M) { const size_t Mp = ((size_t)M + 15) & ~(size_t)15; return Mp * (Mp + 16) + Mp * 16 + (Mp / 16) * 3 * Mp + Mp * (Mp + 4); }
 
 // TDLO_MSTEP_BIG=1wg keeps the whole elimination in one workgroup (k_mstep_big, the comparator of the tests and of
 // scripts/gpu_c5.py); the export-only form of the N-split interface (from_sums == 2) has no elimination and stays there.

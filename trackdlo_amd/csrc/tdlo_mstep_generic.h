@@ -86,7 +86,12 @@ __device__ __forceinline__ void mstep_generic_body(const FrameDev &f, int from_s
     for (int i = t; i < M; i += NT) used[i] = 0;
     __syncthreads();
 
-    // ---- 3. Gauss-Jordan elimination with partial pivoting, rows permuted implicitly (:415)
+    // ---- 3. Gaussian elimination with partial pivoting (rows permuted implicitly) + back substitution (:415).
+    // NOT Gauss-Jordan: a row stops changing once it has served as pivot row, and the right-hand sides are finished by a
+    // back substitution.  Gauss-Jordan is only forward stable; its error in W is not of the form A^-1 dA W, so the product
+    // G W of :417 does not damp it, and on the ill-conditioned systems of the pre-processing registration (beta = 3,
+    // lambda = 1) it cost 1e-8 m per solve in T (the oracle's QR: 1e-11, tests/test_solver_error.py).  LU with back
+    // substitution is backward stable and sits at 1e-12.
     int singular = 0;
     const int Mr = (M + 63) & ~63;                                   // rows rounded up to whole waves
     const int ncs = Mr <= NT ? NT / Mr : 1;                  // column slots: NT / rows
@@ -114,7 +119,7 @@ __device__ __forceinline__ void mstep_generic_body(const FrameDev &f, int from_s
         // thread = (row, column slot): the multiplier of a row is formed once, and no element pays an integer division
         // (M is a run-time value: `e % M, e / M` per element had been most of this kernel's instructions)
         for (int i = ri; i < rend; i += rstep) {
-            if (i != p) {
+            if (i != p && !used[i]) {
                 const double l = A[(size_t)k * ld + i] * rp;
                 int j = k + 1 + cs;
                 for (; j + 7 * ncs < M + 3; j += 8 * ncs) {        // 8 independent element updates in flight (the tableau may be in global memory)
@@ -127,15 +132,34 @@ __device__ __forceinline__ void mstep_generic_body(const FrameDev &f, int from_s
                 for (; j < M + 3; j += ncs) A[(size_t)j * ld + i] -= l * A[(size_t)j * ld + p];
             }
         }
-        if (t == 0) { piv[k] = p; used[p] = 1; }
+        if (t == 0) { piv[k] = p; used[p] = 1; }          // (no thread reads used[p] in this step: the update skips i == p first)
         __syncthreads();
     }
-    for (int e = t; e < 3 * M; e += NT) {
-        const int k = e % M, d = e / M;
-        const int p = piv[k];
-        W[e] = A[(size_t)(M + d) * ld + p] / A[(size_t)k * ld + p];
-    }
+    // back substitution, column oriented: x_k = b[piv k] / U[piv k][k]; every row that pivots an earlier column takes
+    // b_i -= U[i][k] x_k.  used[] is recycled as kof (the column a row pivots); the reciprocals of the pivots are formed once,
+    // in parallel (Tn is free until step 4); a thread keeps its (row, right-hand side) items for the whole loop.
+    for (int k = t; k < M; k += NT) { used[piv[k]] = k; const double ukk = A[(size_t)k * ld + piv[k]]; Tn[k] = ukk != 0.0 ? 1.0 / ukk : 0.0; }
     __syncthreads();
+    {
+        constexpr int NI = (3 * (LDSA ? kLdsSolveMaxM : kMaxNodes) + NT - 1) / NT;        // (row, right-hand side) items per thread
+        int ii[NI], kk[NI]; size_t bo[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int e = t + q * NT;
+            ii[q] = e < 3 * M ? e % M : 0;
+            kk[q] = e < 3 * M ? used[ii[q]] : 0x7fffffff;      // items beyond 3 M never update
+            bo[q] = (size_t)(M + (e < 3 * M ? e / M : 0)) * ld;
+        }
+        for (int k = M - 1; k >= 0; --k) {
+            const int p = piv[k];
+            const double rk = Tn[k];
+#pragma unroll
+            for (int q = 0; q < NI; ++q)
+                if (kk[q] < k) A[bo[q] + ii[q]] -= A[(size_t)k * ld + ii[q]] * (A[bo[q] + p] * rk);
+            if (t < 3) W[t * M + k] = A[(size_t)(M + t) * ld + p] * rk;
+            __syncthreads();
+        }
+    }
 
     // ---- 4. T = Y0 + G W (:417)
     for (int e = t; e < 3 * M; e += NT) {
