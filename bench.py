@@ -6,7 +6,8 @@
 Workloads (BASELINE.json configs; launch/trackdlo.launch parameter values, tol = 0 so that exactly 50 iterations run):
   c2 (default; the configuration the metric is quoted on)  ONE frame per GPU, N = 50 000 points, M = 50 nodes, fp32 E-step + fp64 M-step
   c3  32 frames per GPU registered as one tdlo_cpd_lle_batch call (256 frames on 8 GPUs), otherwise c2
-  c4  ONE frame of N = 2 000 000 points split over the ranks; per EM iteration an RCCL all-reduce of the 4M+2 sums ("strong")
+  c4  ONE frame of N = 2 000 000 points split over the ranks ("strong"); per EM iteration the ranks exchange the 4M+2 sums through
+      the one-shot exchange of tdlo_split_run (peer-written inboxes over xGMI; RCCL all-reduces issued by the library as fallback)
   c5  ONE frame per GPU, N = 200 000 points, M = 300 nodes, fp64 everywhere
 A "step" is one complete trackdlo::cpd_lle call (trackdlo.cpp:161-441: prune, setup, 50 iterations, read-back of Y / sigma2) on a
 cloud that is already resident in HBM.    value = steps * frames * 50 * ranks / wall time      [EM iterations / s, whole job]
@@ -123,7 +124,7 @@ def main():
     dist = torch = None
     backend = os.environ.get("TDLO_BENCH_BACKEND", "nccl")      # "gloo" only lets the rank logic run on a box with fewer GPUs than ranks
     dev_index = local_rank
-    if world > 1 or args.config == "c4":
+    if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -132,16 +133,10 @@ def main():
             if ngpu < world:
                 sys.exit(f"bench.py: --gpus {world} but only {ngpu} GPU(s) are visible")
             torch.cuda.set_device(dev_index)
-        if world == 1:                     # c4 on one GPU: a one-rank RCCL group, so that the collectives are real launches
-            import tempfile
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            kw = dict(init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="tdlo_pg_"), "store"), rank=0, world_size=1)
-        else:
-            kw = {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
-            dist.init_process_group(backend, **kw)
+            dist.init_process_group(backend)
     env = dict(rank=rank, world=world, dev_index=dev_index, dist=dist, torch=torch, backend=backend)
     if args.config == "c4":
         bench_nsplit(args, cfg, env)
@@ -328,32 +323,61 @@ def bench_frames(args, cfg, env):
 
 
 def bench_nsplit(args, cfg, env):
-    """c4 (BASELINE.json configs[3]): one frame, N = 2 000 000 points, M = 50, contiguous shard per rank; per EM iteration an
-    all-reduce SUM of [P1 | PX | Q | N] (4M+2 doubles) on the context's stream, identical M-step on every rank
-    (trackdlo_amd/nsplit.py, device-resident exchange).  Total work is fixed: "scaling": "strong"."""
-    from trackdlo_amd import binding as B, nsplit, synth
+    """c4 (BASELINE.json configs[3]): one frame, N = 2 000 000 points, M = 50, contiguous shard per rank, identical M-step on
+    every rank.  Total work is fixed: "scaling": "strong".  The exchange per EM iteration (per-node minima when visibility
+    weighting is on, and the 4M+2 sums) is the ONE-SHOT EXCHANGE of tdlo_split_run: every rank stores its contribution
+    straight into every peer's inbox (xGMI peer stores; the inboxes travel between the processes as HIP IPC handles) and the
+    M-step kernel reduces the R contributions itself -- no collective, no launch in between.  If the inboxes cannot be
+    shared, the ranks fall back (together) on the RCCL form: the library issues the all-reduces on its stream."""
+    from trackdlo_amd import binding as B, synth
     Context = _context_class()
     P = synth.LAUNCH_PARAMS
     rank, world, dev_index, dist, torch, backend = env["rank"], env["world"], env["dev_index"], env["dist"], env["torch"], env["backend"]
     NT, M = cfg["N"], cfg["M"]
-    dev = f"cuda:{dev_index}" if backend == "nccl" else "cpu"
     X, Y0, _ = synth.scene(NT, M, config=4)
     lo, hi = rank * NT // world, (rank + 1) * NT // world
     ctx = Context(device=dev_index, max_points=hi - lo, max_nodes=M)
-    params = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
-                           alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
-    xch = nsplit.TorchDeviceExchange(M, dev, stream_ptr=ctx.stream_ptr() if backend == "nccl" else None)
-    shard = nsplit.HipDeviceShard(ctx, X[lo:hi], xch)          # uploads the shard once; every step re-binds and re-registers
-    comm = nsplit.TorchComm(dev if backend == "nccl" else None)
 
-    def step():
-        shard.bind()
-        return nsplit.cpd_lle_nsplit_device(shard, xch, comm, Y0, 0.0, params)
+    def mk(vis_on):
+        return B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False, alpha=0.0,
+                             k_vis=P["k_vis"] if vis_on else 0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
+    params = mk(False)
+    ctx.set_cloud(0, X[lo:hi])                      # the shard, resident before the timed region
+
+    # ---- exchange set-up: inboxes shared as IPC handles (one process per GPU), else RCCL made by the library
+    form, comm = "one-shot exchange (peer-written inboxes, reduced inside the M-step kernel)", None
+    try:
+        own = ctx.xch_create(world, 64)
+        if world == 1:
+            ctx.xch_bind(0, [own])
+        else:
+            handles = [None] * world
+            dist.all_gather_object(handles, ctx.xch_export())
+            ctx.xch_bind(rank, [own if r == rank else ctx.xch_open(handles[r]) for r in range(world)])
+        ok = 1
+    except Exception as e:            # pragma: no cover  (needs a node whose GPUs cannot map each other's memory)
+        print(f"bench.py: rank {rank}: one-shot exchange unavailable ({e})", file=sys.stderr)
+        ok = 0
+    if world > 1:
+        t = torch.tensor([ok], dtype=torch.int64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        ctx.lib.tdlo_xch_bind(ctx.h, 0, 0, None)
+        ids = [B.rccl_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = ctx.rccl_comm_init(world, rank, ids[0])
+        form = "RCCL all-reduce MIN / SUM issued by the library on its stream (tdlo_split_run with a communicator)"
+
+    def step(p=params, vis=None):
+        return ctx.split_run(Y0, 0.0, p, comm=comm, visible_nodes=vis)
 
     def barrier():
-        dist.barrier()
-        if backend == "nccl":
-            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize()
         ctx.synchronize()
 
     for _ in range(cfg["warmup"]):
@@ -367,28 +391,47 @@ def bench_nsplit(args, cfg, env):
     n_ranks, ranks = _rank_table(env)
     if rank == 0:
         est_us = ctx.profile_kernel(0, 50)
-        mst_us = ctx.profile_kernel(4, 50)          # the M-step from the reduced sums, as every rank runs it
+        mst_us = ctx.profile_kernel(2, 50)
         roof, roof_all = _roofline_objects(hi - lo, M, 1, 4, est_us, mst_us, dt * 1e6 / (cfg["steps"] * EM_ITERS), "k_mstep_fast<MFMA>")
-        roof["note_durations"] = "back-to-back launches on the shard's state (the split loop interleaves RCCL launches, so per-dispatch events are not bound here)"
+        roof["note_durations"] = "back-to-back launches on the shard's state (in the split loop the M-step kernel also waits for the peers' sums, so its in-situ duration is not a kernel cost)"
         line = dict(metric=cfg["metric"], value=round(cfg["steps"] * EM_ITERS / dt, 2), unit="EM iterations/s", n_gpus=n_ranks, ranks=ranks,
                     steps=cfg["steps"], warmup=cfg["warmup"], ms_per_step=round(dt * 1e3 / cfg["steps"], 4),
                     higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=f"C4: one frame, N={NT} points split over {n_ranks} rank(s) ({hi - lo} per rank), M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, fp32 E-step + fp64 M-step",
-                                parallelism=f"points sharded over {n_ranks} rank(s); per iteration all-reduce SUM of 4M+2 doubles ({backend}), identical M-step on every rank"),
-                    timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"], n_kept_global=out["n_kept_global"],
+                                parallelism=f"points sharded over {n_ranks} rank(s); per iteration: {form}; identical M-step on every rank"),
+                    timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"],
                     roofline=roof, roofline_kernels=roof_all)
         cpu = None
         if n_ranks == 1:
-            # the same cloud through the plain (unsplit) call on this one GPU: what the split costs at one rank
-            ctx.set_cloud(0, X)
-            for _ in range(3):
-                ctx.cpd_lle_resident(0, Y0, 0.0, params)
-            ctx.synchronize(); t1 = time.perf_counter()
+            # what the split costs on one rank: the plain (unsplit) call on the same cloud, the RCCL form of the same call, and one
+            # 250 000-point shard (a rank's share on 8 GPUs) with visibility weighting on, i.e. with the MIN exchange as well
+            def rate(fn, n):
+                for _ in range(3):
+                    fn()
+                ctx.synchronize(); t1 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                ctx.synchronize()
+                return n * EM_ITERS / (time.perf_counter() - t1)
             nun = max(10, cfg["steps"] // 4)
-            for _ in range(nun):
-                ctx.cpd_lle_resident(0, Y0, 0.0, params)
-            ctx.synchronize()
-            line["unsplit_iters_per_s"] = round(nun * EM_ITERS / (time.perf_counter() - t1), 2)
+            line["unsplit_iters_per_s"] = round(rate(lambda: ctx.cpd_lle_resident(0, Y0, 0.0, params), nun), 2)
+            try:
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+                c1 = ctx.rccl_comm_init(1, 0, B.rccl_unique_id())
+                line["rccl_form_iters_per_s"] = round(rate(lambda: ctx.split_run(Y0, 0.0, params, comm=c1), nun), 2)
+            except Exception as e:
+                line["rccl_form_iters_per_s"] = None; line["rccl_form_error"] = str(e)
+            _, _, vis = synth.scene(1000, M, config=4, occlude=(0.4, 0.46))
+            vext = synth.extend_visible(vis, M, synth.geodesic_coord(Y0))
+            ctx.set_cloud(0, X[:NT // 8])
+            pv = mk(True)
+            shard = dict(points=NT // 8)
+            shard["one_shot_vis_us_per_iteration"] = round(1e6 / rate(lambda: step(pv, vext), 60), 2)
+            shard["one_shot_us_per_iteration"] = round(1e6 / rate(lambda: step(params), 60), 2)
+            shard["unsplit_vis_us_per_iteration"] = round(1e6 / rate(lambda: ctx.cpd_lle_resident(0, Y0, 0.0, pv, visible_nodes=vext), 60), 2)
+            if line.get("rccl_form_iters_per_s"):
+                shard["rccl_form_vis_us_per_iteration"] = round(1e6 / rate(lambda: ctx.split_run(Y0, 0.0, pv, comm=c1, visible_nodes=vext), 60), 2)
+            line["shard_of_8"] = shard
             if not args.no_cpu_baseline:
                 kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                           include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])

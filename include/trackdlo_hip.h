@@ -36,7 +36,8 @@ enum {
     TDLO_E_HIP = -3,         /* HIP runtime error, see tdlo_last_error */
     TDLO_E_EMPTY = -4,       /* the prune (trackdlo.cpp:177-195) removed every point */
     TDLO_E_NUMERIC = -5,     /* non-finite sigma2 / Y or singular system encountered */
-    TDLO_E_TRAVERSE = -6     /* traverse_euclidean would read out of bounds in the reference */
+    TDLO_E_TRAVERSE = -6,    /* traverse_euclidean would read out of bounds in the reference */
+    TDLO_E_EXCHANGE = -7     /* N-split: a peer's contribution did not arrive in time / RCCL reported an error */
 };
 
 /* tdlo_params.precision */
@@ -170,6 +171,40 @@ int tdlo_split_dmin_enqueue(tdlo_ctx *ctx);    /* local dmin -> d_dmin */
 int tdlo_split_estep_enqueue(tdlo_ctx *ctx);   /* d_dmin (global) -> E-step on the shard -> local sums -> d_sums */
 int tdlo_split_mstep_enqueue(tdlo_ctx *ctx);   /* d_sums (global) -> M-step (:392-437), identical on every rank */
 int tdlo_split_poll(tdlo_ctx *ctx, int *done, int *iters);   /* synchronises the stream */
+
+/* ---- the split registration driven from C++ (no torch, no Python in the loop) -------------------------------------- */
+/* One whole trackdlo::cpd_lle (trackdlo.cpp:161-441) with the cloud split over the ranks: every rank holds its shard in slot 0
+ * (tdlo_set_cloud / tdlo_depth_to_cloud) and calls this with the same Y, sigma2 and parameters; every rank returns the same
+ * Y, sigma2, iteration count (the replicated M-step solves the same system from the same bits).  stats->n_kept is the
+ * shard's count.  Two forms:
+ *   nccl_comm != NULL  an RCCL communicator (ncclComm_t) over the ranks: per iteration the all-reduce MIN of dmin[M]
+ *       (visibility weighting only) and the all-reduce SUM of the 4M+2 sums, issued by this library on the context's stream
+ *       between its kernels (librccl is bound at run time: an RCCL already mapped into the process -- PyTorch's -- is used,
+ *       else $TDLO_RCCL_LIB / tdlo_rccl_load, else the system's); any chain length.
+ *   nccl_comm == NULL  the ONE-SHOT EXCHANGE bound with tdlo_xch_bind: no collective at all.  Every rank writes its minima /
+ *       sums straight into every peer's inbox (peer stores: xGMI on a multi-GPU node) and raises a flag; the last workgroup of
+ *       the min-distance kernel and the one-workgroup M-step wait for the R flags in their own inbox and reduce the R
+ *       contributions in rank order.  One EM iteration is the three kernels of the unsplit loop, no launch in between.
+ *       Chains up to 60 nodes (64 with the LLE term), up to 8 ranks.
+ * The stopping rule is evaluated on the device and read after iterations 1, 2, 4, 8, 12, ... (tol > 0). */
+int tdlo_split_run(tdlo_ctx *ctx, void *nccl_comm, double *Y, int M, double *sigma2, const tdlo_params *params,
+                   const double *priors, int K, const int *visible_nodes, int n_vis, const double *H_override, tdlo_stats *stats);
+/* One-shot exchange set-up.  tdlo_xch_create allocates this rank's inbox (device memory, zeroed; tdlo_xch_bytes bytes) for
+ * `nranks` ranks and chains up to `max_nodes` nodes.  Ranks in other processes export / open it as a HIP IPC handle (64
+ * bytes, carried by whatever the host application uses to bootstrap: MPI, a file, a socket); ranks in one process pass the
+ * pointers directly.  tdlo_xch_bind takes the device pointers of ALL ranks' inboxes, valid on this context's device, own
+ * inbox at [rank]; nranks == 0 unbinds. */
+size_t tdlo_xch_bytes(int nranks, int max_nodes);
+int tdlo_xch_create(tdlo_ctx *ctx, int nranks, int max_nodes, void **inbox);
+int tdlo_xch_ipc_export(tdlo_ctx *ctx, void *handle64);
+int tdlo_xch_ipc_open(tdlo_ctx *ctx, const void *handle64, void **peer_inbox);
+int tdlo_xch_bind(tdlo_ctx *ctx, int rank, int nranks, void *const *inboxes);
+/* RCCL bootstrap for hosts that have no communicator of their own: rank 0 makes the 128-byte ncclUniqueId and hands it to
+ * the other ranks; every rank then creates its communicator (owned by the context, destroyed with it).  tdlo_rccl_load
+ * names the librccl to bind (NULL: search as described above); returns 0 when RCCL is usable. */
+int tdlo_rccl_load(const char *path);
+int tdlo_rccl_unique_id(void *id128);
+int tdlo_rccl_comm_init(tdlo_ctx *ctx, int nranks, int rank, const void *id128, void **comm_out);
 
 /* ---- tracker object: class trackdlo (trackdlo/include/trackdlo.h:53-130) ---------------------- */
 typedef struct tdlo_tracker tdlo_tracker;

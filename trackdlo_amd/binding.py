@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrackdlo_hip.so")
 
 TDLO_OK = 0
-TDLO_E_NO_DEVICE, TDLO_E_INVALID, TDLO_E_HIP, TDLO_E_EMPTY, TDLO_E_NUMERIC, TDLO_E_TRAVERSE = -1, -2, -3, -4, -5, -6
+TDLO_E_NO_DEVICE, TDLO_E_INVALID, TDLO_E_HIP, TDLO_E_EMPTY, TDLO_E_NUMERIC, TDLO_E_TRAVERSE, TDLO_E_EXCHANGE = -1, -2, -3, -4, -5, -6, -7
 PREC_F32, PREC_F64 = 0, 1
 
 
@@ -49,6 +49,8 @@ SYMBOLS = [
     "tdlo_abi_version", "tdlo_device_count", "tdlo_default_config", "tdlo_create", "tdlo_destroy", "tdlo_last_error",
     "tdlo_stream", "tdlo_synchronize", "tdlo_set_cloud", "tdlo_cpd_lle_resident", "tdlo_cpd_lle", "tdlo_cpd_lle_batch",
     "tdlo_split_begin", "tdlo_split_set_global", "tdlo_split_dmin", "tdlo_split_estep", "tdlo_split_mstep", "tdlo_split_end", "tdlo_split_abort",
+    "tdlo_split_run", "tdlo_xch_bytes", "tdlo_xch_create", "tdlo_xch_ipc_export", "tdlo_xch_ipc_open", "tdlo_xch_bind",
+    "tdlo_rccl_load", "tdlo_rccl_unique_id", "tdlo_rccl_comm_init",
     "tdlo_split_bind_exchange", "tdlo_split_dmin_enqueue", "tdlo_split_estep_enqueue", "tdlo_split_mstep_enqueue", "tdlo_split_poll",
     "tdlo_tracker_create", "tdlo_tracker_create_default", "tdlo_tracker_destroy", "tdlo_tracker_set_precision",
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
@@ -127,6 +129,16 @@ def load_library(path: str | None = None):
     lib.tdlo_split_mstep.argtypes = [vp, vp, C.POINTER(ci)]
     lib.tdlo_split_end.argtypes = [vp, vp, C.POINTER(cd), C.POINTER(Stats)]
     lib.tdlo_split_abort.argtypes = [vp]
+    lib.tdlo_split_run.argtypes = [vp, vp, vp, ci, C.POINTER(cd), C.POINTER(Params), vp, ci, vp, ci, vp, C.POINTER(Stats)]
+    lib.tdlo_xch_bytes.restype = C.c_size_t
+    lib.tdlo_xch_bytes.argtypes = [ci, ci]
+    lib.tdlo_xch_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    lib.tdlo_xch_ipc_export.argtypes = [vp, vp]
+    lib.tdlo_xch_ipc_open.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.tdlo_xch_bind.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    lib.tdlo_rccl_load.argtypes = [C.c_char_p]
+    lib.tdlo_rccl_unique_id.argtypes = [vp]
+    lib.tdlo_rccl_comm_init.argtypes = [vp, ci, ci, vp, C.POINTER(vp)]
     lib.tdlo_split_bind_exchange.argtypes = [vp, vp, vp]
     lib.tdlo_split_dmin_enqueue.argtypes = [vp]
     lib.tdlo_split_estep_enqueue.argtypes = [vp]
@@ -165,6 +177,28 @@ def load_library(path: str | None = None):
     if path is None:
         _lib = lib
     return lib
+
+
+def rccl_load():
+    """Binds RCCL for tdlo_split_run.  One process, one RCCL: with a PyTorch installation present its librccl.so is the one
+    (torch.distributed uses it, and it sits next to the HIP runtime _pin_hip_runtime mapped); otherwise the system's."""
+    lib = load_library()
+    path = None
+    if _hip_runtime not in (None, "system"):
+        cand = os.path.join(os.path.dirname(_hip_runtime), "librccl.so")
+        if os.path.exists(cand):
+            path = cand.encode()
+    if lib.tdlo_rccl_load(path) != 0:
+        raise TdloError(TDLO_E_EXCHANGE, "no usable librccl")
+
+
+def rccl_unique_id() -> bytes:
+    rccl_load()
+    buf = C.create_string_buffer(128)
+    rc = load_library().tdlo_rccl_unique_id(buf)
+    if rc:
+        raise TdloError(rc, "ncclGetUniqueId failed")
+    return bytes(buf.raw)
 
 
 def _f64(a):
@@ -259,6 +293,52 @@ class Context:
                                               _ptr(Hm), C.cast(st, C.c_void_p)))
         Yo = np.ascontiguousarray(Yb.transpose(0, 2, 1))
         return dict(Y=[Yo[i] for i in range(F)], sigma2=s2, stats=[s.as_dict() for s in st])
+
+    # ---- the split registration driven from C++ (tdlo_split_run) -------------------------------------------------------
+    def split_run(self, Y, sigma2, params: Params, comm=None, priors=None, visible_nodes=None, H=None, check=True):
+        """trackdlo::cpd_lle with the cloud split over the ranks; this rank's shard is the cloud resident in slot 0.
+        comm: an ncclComm_t (integer / c_void_p) -> RCCL all-reduces issued by the library; None -> the one-shot exchange
+        bound with xch_bind."""
+        Y = _f64(Y).copy(order="F")
+        M = Y.shape[0]
+        pri, K, vis, nv, Hm = self._opt(priors, visible_nodes, H)
+        s2 = C.c_double(float(sigma2)); st = Stats()
+        rc = self.lib.tdlo_split_run(self.h, C.c_void_p(comm) if comm else None, _ptr(Y), M, C.byref(s2), C.byref(params), _ptr(pri), K,
+                                     _ptr(vis), nv, _ptr(Hm), C.byref(st))
+        if check:
+            self._chk(rc)
+        return dict(Y=Y, sigma2=s2.value, converged=bool(st.converged), iters=st.iters, n_kept=st.n_kept, rc=rc, status=st.status,
+                    loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms)
+
+    def xch_create(self, nranks, max_nodes):
+        """This rank's inbox of the one-shot exchange; returns its device pointer (an integer)."""
+        p = C.c_void_p(0)
+        self._chk(self.lib.tdlo_xch_create(self.h, int(nranks), int(max_nodes), C.byref(p)))
+        return int(p.value)
+
+    def xch_export(self):
+        """The inbox as a 64-byte HIP IPC handle (for ranks in other processes)."""
+        buf = C.create_string_buffer(64)
+        self._chk(self.lib.tdlo_xch_ipc_export(self.h, buf))
+        return bytes(buf.raw)
+
+    def xch_open(self, handle: bytes):
+        p = C.c_void_p(0)
+        buf = C.create_string_buffer(handle, 64)
+        self._chk(self.lib.tdlo_xch_ipc_open(self.h, buf, C.byref(p)))
+        return int(p.value)
+
+    def xch_bind(self, rank, inboxes):
+        arr = (C.c_void_p * len(inboxes))(*[C.c_void_p(int(p)) for p in inboxes])
+        self._chk(self.lib.tdlo_xch_bind(self.h, int(rank), len(inboxes), arr))
+
+    def rccl_comm_init(self, nranks, rank, unique_id: bytes):
+        """An RCCL communicator over `nranks` ranks, owned by the context; returns the ncclComm_t as an integer."""
+        rccl_load()
+        comm = C.c_void_p(0)
+        buf = C.create_string_buffer(unique_id, 128)
+        self._chk(self.lib.tdlo_rccl_comm_init(self.h, int(nranks), int(rank), buf, C.byref(comm)))
+        return int(comm.value)
 
     def visibility_prepass(self, slot, Y, visibility_threshold, d_vis, geodesic_coord):
         """trackdlo_node.cpp:257-277 + :345-360 (distance test and gap fill; no painter test)."""

@@ -4,6 +4,7 @@
 #include "../../include/trackdlo_hip.h"
 #include "tdlo_internal.h"
 #include "tdlo_host.h"
+#include "tdlo_rccl.h"
 
 #include <algorithm>
 #include <chrono>
@@ -89,6 +90,16 @@ struct tdlo_ctx {
     int split_active = 0;
     double *xch_dmin = nullptr;      // caller-owned device memory of the device-resident N-split exchange (tdlo_split_bind_exchange)
     double *xch_sums = nullptr;
+    // tdlo_split_run: the whole split registration driven from C++ (RCCL called directly, or the one-shot exchange)
+    double *split_buf = nullptr;     // RCCL form: [init 2 | dmin M | sums 4M+2], all-reduced in place on the context's stream
+    size_t split_buf_doubles = 0;
+    void *own_comm = nullptr;        // communicator made by tdlo_rccl_comm_init (destroyed with the context)
+    unsigned long long *xch_own = nullptr;     // one-shot exchange: this rank's inbox (tdlo_xch_create)
+    size_t xch_own_words = 0;
+    int xch_rank = 0, xch_nranks = 0, xch_mcap = 0, xch_cap_ranks = 0;
+    unsigned long long *xch_peer[kMaxXchRanks] = {};
+    std::vector<void *> xch_opened;  // peer inboxes opened from IPC handles (closed with the context)
+    unsigned xch_calls = 0;          // epoch of the flags: one per registration, in lockstep on all ranks
 };
 
 namespace {
@@ -317,7 +328,10 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     for (int g = 0; g <= NS; ++g) goff[g] = (int)(((long long)F * g) / NS);
     hipStream_t gs[kBatchStreams];
     gs[0] = s;
-    for (int g = 1; g < NS; ++g) gs[g] = c->stream2[g - 1];
+    for (int g = 1; g < NS; ++g) {            // the further streams are made when a batch first needs them: a context that only ever
+        if (!c->stream2[g - 1]) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2[g - 1], hipStreamNonBlocking));   // registers single frames
+        gs[g] = c->stream2[g - 1];            // (or a shard) occupies one hardware queue, not four
+    }
     bool forked = false;
     auto iterate = [&](int n) -> hipError_t {
         for (int it = 0; it < n; ++it) {
@@ -457,7 +471,6 @@ tdlo_ctx *tdlo_create(const tdlo_config *cfg_in, int *err) {
     c->device = cfg.device; c->cfg = cfg;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
-    for (auto &q : c->stream2) if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
     for (auto &e : c->evx) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
     for (auto &e : c->evj) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return bail(TDLO_E_HIP); }
     c->slots.resize(cfg.max_frames);
@@ -492,6 +505,10 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->pin) hipHostFree(c->pin);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->xfer) hipFree(c->xfer);
+    if (c->split_buf) hipFree(c->split_buf);
+    for (void *p : c->xch_opened) hipIpcCloseMemHandle(p);
+    if (c->xch_own) hipFree(c->xch_own);
+    if (c->own_comm) { const RcclApi *r = rccl_api(nullptr, nullptr); if (r) r->CommDestroy(c->own_comm); }
     for (auto &e : c->evx) if (e) hipEventDestroy(e);
     for (auto &e : c->evj) if (e) hipEventDestroy(e);
     for (auto &q : c->stream2) if (q) hipStreamDestroy(q);
@@ -720,6 +737,221 @@ int tdlo_split_abort(tdlo_ctx *c) {
     c->split_active = 0;
     c->xch_dmin = nullptr; c->xch_sums = nullptr;
     return TDLO_OK;
+}
+
+// ---- tdlo_split_run: the split registration driven from C++ ---------------------------------------------------------
+int tdlo_rccl_load(const char *path) {
+    std::string why;
+    return rccl_api(path, &why) ? TDLO_OK : TDLO_E_EXCHANGE;
+}
+
+int tdlo_rccl_unique_id(void *id128) {
+    std::string why;
+    const RcclApi *r = rccl_api(nullptr, &why);
+    if (!r || !id128) return TDLO_E_EXCHANGE;
+    RcclApi::UniqueId id;
+    if (r->GetUniqueId(&id) != 0) return TDLO_E_EXCHANGE;
+    std::memcpy(id128, &id, sizeof id);
+    return TDLO_OK;
+}
+
+int tdlo_rccl_comm_init(tdlo_ctx *c, int nranks, int rank, const void *id128, void **comm_out) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return TDLO_E_INVALID;
+    std::string why;
+    const RcclApi *r = rccl_api(nullptr, &why);
+    if (!r) return fail(c, TDLO_E_EXCHANGE, "RCCL cannot be loaded: " + why);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->own_comm) { r->CommDestroy(c->own_comm); c->own_comm = nullptr; }
+    RcclApi::UniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    void *comm = nullptr;
+    const int rc = r->CommInitRank(&comm, nranks, id, rank);
+    if (rc != 0) return fail(c, TDLO_E_EXCHANGE, std::string("ncclCommInitRank: ") + r->GetErrorString(rc));
+    c->own_comm = comm;
+    if (comm_out) *comm_out = comm;
+    return TDLO_OK;
+}
+
+size_t tdlo_xch_bytes(int nranks, int max_nodes) {
+    if (nranks < 1 || nranks > kMaxXchRanks || max_nodes < 4) return 0;
+    return xch_words(nranks, max_nodes) * sizeof(unsigned long long);
+}
+
+int tdlo_xch_create(tdlo_ctx *c, int nranks, int max_nodes, void **inbox) {
+    if (!c) return TDLO_E_INVALID;
+    if (nranks < 1 || nranks > kMaxXchRanks || max_nodes < 4 || max_nodes > kMaxNodes) return fail(c, TDLO_E_INVALID, "tdlo_xch_create: 1..8 ranks, 4..512 nodes");
+    if (c->split_active) return fail(c, TDLO_E_INVALID, "tdlo_xch_create inside a split registration");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->xch_own) { hipFree(c->xch_own); c->xch_own = nullptr; }
+    c->xch_nranks = 0;
+    const size_t words = xch_words(nranks, max_nodes);
+    // peers write this buffer over xGMI while this GPU polls it: uncached (fine-grained) device memory where the runtime offers
+    // it; the accesses are system-scope atomics either way
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, words * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(c, hipMalloc(&p, words * sizeof(unsigned long long)));
+    }
+    HIPCHK(c, hipMemset(p, 0, words * sizeof(unsigned long long)));
+    HIPCHK(c, hipDeviceSynchronize());
+    c->xch_own = (unsigned long long *)p; c->xch_own_words = words; c->xch_mcap = max_nodes; c->xch_cap_ranks = nranks;
+    if (inbox) *inbox = p;
+    return TDLO_OK;
+}
+
+int tdlo_xch_ipc_export(tdlo_ctx *c, void *handle64) {
+    if (!c || !handle64) return TDLO_E_INVALID;
+    if (!c->xch_own) return fail(c, TDLO_E_INVALID, "tdlo_xch_ipc_export before tdlo_xch_create");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    HIPCHK(c, hipIpcGetMemHandle(&h, c->xch_own));
+    std::memcpy(handle64, &h, sizeof h);
+    return TDLO_OK;
+}
+
+int tdlo_xch_ipc_open(tdlo_ctx *c, const void *handle64, void **peer_inbox) {
+    if (!c || !handle64 || !peer_inbox) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, sizeof h);
+    void *p = nullptr;
+    HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    c->xch_opened.push_back(p);
+    *peer_inbox = p;
+    return TDLO_OK;
+}
+
+int tdlo_xch_bind(tdlo_ctx *c, int rank, int nranks, void *const *inboxes) {
+    if (!c) return TDLO_E_INVALID;
+    if (c->split_active) return fail(c, TDLO_E_INVALID, "tdlo_xch_bind inside a split registration");
+    if (nranks == 0) { c->xch_nranks = 0; return TDLO_OK; }
+    if (!c->xch_own || !inboxes || nranks != c->xch_cap_ranks || rank < 0 || rank >= nranks) return fail(c, TDLO_E_INVALID, "tdlo_xch_bind: create the inbox for this many ranks first");
+    for (int r = 0; r < nranks; ++r) if (!inboxes[r]) return fail(c, TDLO_E_INVALID, "tdlo_xch_bind: null peer inbox");
+    if (inboxes[rank] != (void *)c->xch_own) return fail(c, TDLO_E_INVALID, "tdlo_xch_bind: inboxes[rank] is not this context's own inbox");
+    for (int r = 0; r < kMaxXchRanks; ++r) c->xch_peer[r] = r < nranks ? (unsigned long long *)inboxes[r] : nullptr;
+    c->xch_rank = rank; c->xch_nranks = nranks;
+    return TDLO_OK;
+}
+
+int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma2, const tdlo_params *p, const double *priors, int K,
+                   const int *vis, int n_vis, const double *H_override, tdlo_stats *stats) {
+    if (!c) return TDLO_E_INVALID;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    if (!Y || !sigma2) return fail(c, TDLO_E_INVALID, "null Y / sigma2");
+    if (c->split_active) return fail(c, TDLO_E_INVALID, "tdlo_split_run inside a split registration");
+    int rc = check_params(c, M, p);
+    if (rc) return rc;
+    const bool oneshot = nccl_comm == nullptr;
+    const RcclApi *R = nullptr;
+    if (oneshot) {
+        if (c->xch_nranks < 1) return fail(c, TDLO_E_INVALID, "tdlo_split_run without a communicator needs the one-shot exchange (tdlo_xch_create / tdlo_xch_bind)");
+        if (M > c->xch_mcap) return fail(c, TDLO_E_INVALID, "more nodes than the inbox was created for");
+        if (!((!p->include_lle && M <= 60) || (p->include_lle && M <= 64)))
+            return fail(c, TDLO_E_INVALID, "the one-shot exchange lives in the one-workgroup M-step (up to 60 nodes, 64 with the LLE term): pass an RCCL communicator for longer chains");
+    } else {
+        std::string why;
+        R = rccl_api(nullptr, &why);
+        if (!R) return fail(c, TDLO_E_EXCHANGE, "RCCL cannot be loaded: " + why);
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    NodeCarve nc(M);
+    rc = ensure_pin(c, std::max(nc.upload, nc.readback + 2) + 8 * (size_t)M + 16);
+    if (rc) return rc;
+    c->fh.assign(1, FrameDev{});
+    rc = prepare_frame(c, 0, Y, M, *sigma2, p, priors, K, vis, n_vis, H_override, c->pin, c->fh[0]);
+    if (rc) return rc;
+    FrameDev &f = c->fh[0];
+    hipStream_t s = c->stream;
+    double *b_init = nullptr, *b_dmin = nullptr, *b_sums = nullptr;
+    if (oneshot) {
+        for (int r = 0; r < kMaxXchRanks; ++r) f.xch_inbox[r] = c->xch_peer[r];
+        f.xch_rank = c->xch_rank; f.xch_nranks = c->xch_nranks; f.xch_mcap = c->xch_mcap; f.xch_epoch = ++c->xch_calls;
+    } else {
+        const size_t need = 2 + (size_t)M + 4 * (size_t)M + 2 + 2;
+        if (need > c->split_buf_doubles) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->split_buf) hipFree(c->split_buf);
+            c->split_buf = nullptr; c->split_buf_doubles = 0;
+            HIPCHK(c, hipMalloc((void **)&c->split_buf, need * sizeof(double)));
+            c->split_buf_doubles = need;
+        }
+        b_init = c->split_buf; b_dmin = b_init + 2; b_sums = b_dmin + ((M + 1) & ~1);
+        f.sums = b_sums;                                 // the export-only M-step writes, and the M-step from sums reads, this buffer
+    }
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev), hipMemcpyHostToDevice, s));
+    HIPCHK(c, launch_split_setup(c->fd, c->fh.data(), s));
+    auto nccl = [&](int e, const char *what) -> int {
+        if (e == 0) return 0;
+        return fail(c, TDLO_E_EXCHANGE, std::string(what) + ": " + R->GetErrorString(e));
+    };
+    // once per call: kept points and the sigma2-initialisation sum over all shards (trackdlo.cpp:195, :263-273)
+    if (oneshot) HIPCHK(c, launch_xch_init(c->fd, s));
+    else {
+        HIPCHK(c, launch_split_init_pack(c->fd, b_init, s));
+        if ((rc = nccl(R->AllReduce(b_init, b_init, 2, kNcclFloat64, kNcclSum, nccl_comm, s), "ncclAllReduce(init)"))) return rc;
+        HIPCHK(c, launch_split_set_global_dev(c->fd, b_init, s));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    const bool visb = f.vis_branch != 0;
+    auto iteration = [&]() -> int {
+        if (oneshot) {
+            if (visb) HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 1, s));      // k_dmin: its last workgroup exchanges the minima
+            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
+            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 5, s));                // M-step with the exchange of the sums inside
+        } else {
+            int e;
+            if (visb) {
+                HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 1, s));
+                HIPCHK(c, launch_split_dmin_xch(c->fd, c->fh.data(), b_dmin, 0, s));
+                if ((e = nccl(R->AllReduce(b_dmin, b_dmin, (size_t)M, kNcclFloat64, kNcclMin, nccl_comm, s), "ncclAllReduce(dmin)"))) return e;
+                HIPCHK(c, launch_split_dmin_xch(c->fd, c->fh.data(), b_dmin, 1, s));
+            }
+            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
+            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));                // block partials -> b_sums
+            if ((e = nccl(R->AllReduce(b_sums, b_sums, 4 * (size_t)M + 2, kNcclFloat64, kNcclSum, nccl_comm, s), "ncclAllReduce(sums)"))) return e;
+            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 4, s));
+        }
+        return 0;
+    };
+    IterState is{};
+    bool have_state = false;
+    for (int it = 1; it <= p->max_iter; ++it) {
+        if ((rc = iteration())) return rc;
+        // the stopping rule lives on the device (the same flag on every rank: they solve the same system); it is read after
+        // iterations 1, 2, 4, 8, 12, ... -- a tracker in steady state converges within a couple of iterations
+        const bool poll = p->tol > 0.0 && it < p->max_iter && (it == 1 || it == 2 || it == 4 || (it >= 8 && it % 4 == 0));
+        if (poll) {
+            HIPCHK(c, hipMemcpyAsync(c->pin, f.st, sizeof(IterState), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            std::memcpy(&is, c->pin, sizeof is);
+            if (is.done) { have_state = true; break; }
+        }
+    }
+    (void)have_state;
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[0].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::memcpy(&is, c->pin + (nc.st - nc.Yout), sizeof is);
+    c->last_F = 1;
+    if ((is.status == 0 || is.status == TDLO_E_NUMERIC) && is.it > 0) { std::memcpy(Y, c->pin, sizeof(double) * 3 * M); }
+    if (is.status == 0 || is.status == TDLO_E_NUMERIC) *sigma2 = is.sigma2;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        fill_stats(stats, is);
+        if (p->max_iter == 0) stats->converged = 1;
+        hipEventElapsedTime(&stats->loop_ms, c->ev[1], c->ev[2]);
+        hipEventElapsedTime(&stats->total_ms, c->ev[0], c->ev[3]);
+        stats->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    }
+    if (is.status == TDLO_E_EMPTY) return fail(c, is.status, "every point of every shard was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
+    if (is.status == TDLO_E_NUMERIC) return fail(c, is.status, "non-finite or non-positive sigma2, or singular M-step system");
+    if (is.status == TDLO_E_EXCHANGE) return fail(c, is.status, "a peer's contribution to the one-shot exchange did not arrive within its time limit");
+    return is.status;
 }
 
 // ---- plain GMM-EM `reg` ---------------------------------------------------------------------------

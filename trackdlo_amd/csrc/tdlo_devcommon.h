@@ -130,4 +130,26 @@ __device__ __forceinline__ double fast_rcp(double v) {
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f64_16x16x4_f64
 
+// ---- one-shot exchange of the N-split: peer-written inboxes (xGMI peer stores on a multi-GPU node), system scope ---------
+// payload: relaxed system-scope stores -> release fence (system) -> flag store; reader: relaxed poll of the flag ->
+// acquire fence (system) -> relaxed system-scope loads of the payload.
+typedef __attribute__((address_space(1))) unsigned long long xch_word;
+__device__ __forceinline__ xch_word *xch_ptr(unsigned long long *p) { return (xch_word *)(uintptr_t)p; }
+__device__ __forceinline__ void xch_store(xch_word *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void xch_store_f64(xch_word *p, double v) { xch_store(p, (unsigned long long)__double_as_longlong(v)); }
+__device__ __forceinline__ unsigned long long xch_load(const xch_word *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double xch_load_f64(const xch_word *p) { return __longlong_as_double((long long)xch_load(p)); }
+__device__ __forceinline__ void xch_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+__device__ __forceinline__ void xch_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
+constexpr unsigned long long kXchSpinTicks = 200000000ull;      // 2 s of the 100 MHz real-time clock: a peer that is this late is gone
+// waits until *flag == tag; false when the time limit passed
+__device__ __forceinline__ bool xch_wait(const xch_word *flag, unsigned long long tag) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (xch_load(flag) != tag) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kXchSpinTicks) return false;
+    }
+    return true;
+}
+
 }  // namespace tdlo

@@ -274,63 +274,173 @@ __global__ void k_split_set_global(const FrameDev *__restrict__ frames, double N
     }
 }
 
+// the same with the two numbers in device memory (tdlo_split_run with an RCCL communicator: the all-reduce of the kept-point
+// count and the sigma2-initialisation sum runs on the stream, no host round trip)
+__global__ void k_split_init_pack(const FrameDev *__restrict__ frames, double *__restrict__ init2) {
+    const IterState *st = frames[0].st;
+    if (threadIdx.x == 0) { init2[0] = (double)st->N; init2[1] = st->sum_d2; }
+}
+__global__ void k_split_set_global_dev(const FrameDev *__restrict__ frames, const double *__restrict__ init2) {
+    const FrameDev &f = frames[0];
+    IterState *st = f.st;
+    if (threadIdx.x == 0) {
+        const double Nglob = init2[0], Sglob = init2[1];
+        if (Nglob <= 0) { st->status = TDLO_E_EMPTY; st->done = 1; return; }
+        double sigma2 = f.sigma2_in;
+        if (sigma2 == 0) sigma2 = Sglob / (3.0 * (double)f.M * Nglob);
+        set_iter_consts(f, st, sigma2, Nglob);
+    }
+}
+
+// One-shot exchange, once per registration: every rank writes its [kept points, sum d2] into every peer's inbox (peer
+// stores over xGMI on a multi-GPU node), raises its flag there, waits for all flags in its own inbox and adds the R
+// contributions in rank order -- the same bits on every rank.  One wave; lane = peer.
+__global__ void k_xch_init(const FrameDev *__restrict__ frames) {
+    const FrameDev &f = frames[0];
+    IterState *st = f.st;
+    const int R = f.xch_nranks, me = f.xch_rank, lane = threadIdx.x;
+    const unsigned long long tag = ((unsigned long long)f.xch_epoch << 32) | 0x80000000ull;
+    if (lane < R) {
+        xch_word *peer = xch_ptr(f.xch_inbox[lane]);
+        xch_store_f64(peer + xch_off_init(R) + 2 * me, (double)st->N);
+        xch_store_f64(peer + xch_off_init(R) + 2 * me + 1, st->sum_d2);
+        xch_release();
+        xch_store(peer + xch_off_flag_init(R) + me, tag);
+    }
+    const xch_word *own = xch_ptr(f.xch_inbox[me]);
+    bool ok = true;
+    if (lane < R) ok = xch_wait(own + xch_off_flag_init(R) + lane, tag);
+    ok = __all(ok);
+    xch_acquire();
+    if (lane == 0) {
+        if (!ok) { st->status = TDLO_E_EXCHANGE; st->done = 1; return; }
+        double Nglob = 0, Sglob = 0;
+        for (int r = 0; r < R; ++r) { Nglob += xch_load_f64(own + xch_off_init(R) + 2 * r); Sglob += xch_load_f64(own + xch_off_init(R) + 2 * r + 1); }
+        if (Nglob <= 0) { st->status = TDLO_E_EMPTY; st->done = 1; return; }
+        double sigma2 = f.sigma2_in;
+        if (sigma2 == 0) sigma2 = Sglob / (3.0 * (double)f.M * Nglob);
+        set_iter_consts(f, st, sigma2, Nglob);
+    }
+}
+
+// four consecutive nodes {x, y, z, coord} by ONE scalar load (s_load_dwordx16; two of them in fp64)
+template <typename T> struct Node4 { T v[16]; };
+template <typename T> __device__ __forceinline__ Node4<T> load_node4(const void *nodes, int m0) {
+    typedef T vec16 __attribute__((ext_vector_type(16)));
+    typedef vec16 __attribute__((aligned(16))) vec16a;
+    const vec16 r = *(const __attribute__((address_space(4))) vec16a *)((uintptr_t)nodes + (size_t)m0 * 4 * sizeof(T));
+    Node4<T> o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o.v[i] = r[i];
+    return o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-node shortest distance to the cloud, trackdlo.cpp:278-296 (only consumed by :358-372)
 // ------------------------------------------------------------------------------------------------
+// thread = point, one wave per batch of 64 points (grid stride); nodes arrive through scalar loads, four at a time.  Every lane
+// keeps the running minimum of ITS point sequence for each of 64 nodes in registers -- one v_min per (point, node) pair, no
+// LDS in the loop (the former version went through a 64 x 64 transposition tile per batch: one LDS write and one LDS read per
+// pair, 30 us at 250 000 points against 5 us now) -- and the 64 lanes are reduced once per wave at the end (DPP), then the four
+// waves through LDS, then one atomicMin per node and workgroup.  Chains beyond 64 nodes take one pass over the points per 64.
 template <typename T, int NCH>
 __global__ __launch_bounds__(kBlock) void k_dmin(const FrameDev *__restrict__ frames, int nblk) {
     const FrameDev &f = frames[blockIdx.y];
     IterState *st = f.st;
     if (!f.vis_branch || st->done) return;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ T red[4 * 64];
     const int N = st->N, M = f.M;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rows = M < kChunk ? M : kChunk;
-    T *pb = (T *)smem + (size_t)wave * rows * kPStride;
-    const auto nodes = TDLO_AS_CONST(V4<T>, f.nodes);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const auto xs = TDLO_AS_GLOBAL(T, f.Xs);
     const size_t ld = f.ldx;
-    T rmin[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) rmin[c] = Num<T>::inf();
     const int nbatch = (N + 63) >> 6;
-    for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += nblk * 4) {
-        const int n = batch * 64 + lane;
-        const bool valid = n < N;
-        T x = 0, y = 0, z = 0;
-        if (valid) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int m0 = c * kChunk, m1 = min(M, m0 + kChunk);
-            for (int m = m0; m < m1; ++m) {
-                V4<T> q; q.x = nodes[m].x; q.y = nodes[m].y; q.z = nodes[m].z; q.w = nodes[m].w;
-                const T dx = x - q.x, dy = y - q.y, dz = z - q.z;
-                const T d2 = dx * dx + dy * dy + dz * dz;
-                pb[(m - m0) * kPStride + lane] = valid ? d2 : Num<T>::inf();
-            }
-            wave_lds_sync();
-            if (m0 + lane < m1) {
-                T r = rmin[c];
-#pragma unroll 16
-                for (int j = 0; j < 64; ++j) r = tmin(r, pb[lane * kPStride + j]);
-                rmin[c] = r;
-            }
-            wave_lds_sync();
-        }
-    }
-    // block-level min over the 4 waves, then one atomicMin per node and workgroup
-    __syncthreads();
-    T *red = (T *)smem;                                   // 4 x 64 (the tiles are dead)
-#pragma unroll
+#pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
-        red[wave * 64 + lane] = rmin[c];
+        const int mb = c * kChunk;
+        if (mb >= M) break;                                // block-uniform
+        const int ng = ((M - mb < kChunk ? M - mb : kChunk) + 3) >> 2;      // groups of four nodes in this chunk
+        T rmin[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) rmin[j] = Num<T>::inf();
+        for (int batch = blockIdx.x * 4 + wave; batch < nbatch; batch += nblk * 4) {
+            const int n = batch * 64 + lane;
+            T x = Num<T>::inf(), y = Num<T>::inf(), z = Num<T>::inf();      // a lane without a point: every distance comes out +inf
+            if (n < N) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }
+            // the node loads do not depend on the batch: left alone, the compiler hoists all 16 of them out of this loop (256 SGPRs),
+            // spills them to vector lanes and pays a v_readlane per operand; an opaque copy of the base address per batch keeps
+            // them where they are
+            unsigned long long nbase = (unsigned long long)(uintptr_t)f.nodes;
+            asm volatile("" : "+s"(nbase));
+#pragma unroll
+            for (int g = 0; g < kChunk / 4; ++g) {
+                if (g < ng) {                              // wave-uniform; entries behind the last node stay inside the slot's node block
+                    const Node4<T> q4 = load_node4<T>((const void *)(uintptr_t)nbase, mb + 4 * g);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {          // (entries behind the last node of a partial group give a minimum nobody reads)
+                        const T dx = x - q4.v[4 * k], dy = y - q4.v[4 * k + 1], dz = z - q4.v[4 * k + 2];
+                        rmin[4 * g + k] = tmin(rmin[4 * g + k], dx * dx + dy * dy + dz * dz);
+                    }
+                }
+                if (g & 1) __builtin_amdgcn_sched_barrier(0);      // at most two groups' nodes (32 SGPRs) in flight: hoisting all 16 loads spills
+            }
+        }
+        // the wave's minimum of node mb + j goes to lane j
+        T mine = Num<T>::inf();
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {                 // (nodes behind the chain's end: a minimum nobody reads)
+            const T r = wave_min_nonneg(rmin[j]);
+            mine = lane == j ? r : mine;
+        }
+        // block-level min over the 4 waves, then one atomicMin per node and workgroup
+        red[wave * 64 + lane] = mine;
         __syncthreads();
         if (wave == 0) {
             const T r = tmin(tmin(red[lane], red[64 + lane]), tmin(red[128 + lane], red[192 + lane]));
-            const int m = c * kChunk + lane;
+            const int m = mb + lane;
             if (m < M && r < Num<T>::inf()) atomicMin(&f.dminbits[m], Num<T>::bits(r));
         }
         __syncthreads();
+    }
+    // N-split with the one-shot exchange: the workgroup that finishes last hands the shard's minima to every peer, waits
+    // for theirs and leaves the global minimum in dminbits for the E-step (what the MIN all-reduce does in the RCCL form).
+    // One workgroup waits, so that shards sharing a GPU (tests) cannot starve each other of CUs.
+    if (f.xch_nranks > 0) {
+        __shared__ int s_last;
+        // the atomicMins are device-scope read-modify-writes: once they are acknowledged (vmcnt) they are performed where every
+        // CU's device-scope atomics meet, so the ticket needs no cache write-back in front of it (an agent-scope fence per
+        // workgroup had cost 16 us per launch at 250 000 points)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(f.sync + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == gridDim.x - 1u);
+            if (s_last) __hip_atomic_store(f.sync + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const int R = f.xch_nranks, me = f.xch_rank, Mc = f.xch_mcap, par = st->it & 1, t = threadIdx.x;
+        const unsigned long long tag = ((unsigned long long)f.xch_epoch << 32) | (unsigned)(st->it + 1);
+        for (int m = t; m < M; m += kBlock) {
+            const unsigned long long b = atomicMin(&f.dminbits[m], ~0ull);      // a device-scope read of the value all atomicMins produced
+            const double v = b == ~0ull ? 1e300 : Num<T>::from_bits(b);      // ~0: no point on this shard
+            for (int q = 0; q < R; ++q) xch_store_f64(xch_ptr(f.xch_inbox[q]) + xch_off_dmin(R, Mc) + ((size_t)par * R + me) * Mc + m, v);
+        }
+        xch_release();
+        __syncthreads();
+        if (t < R) xch_store(xch_ptr(f.xch_inbox[t]) + xch_off_flag_dmin(R) + par * R + me, tag);
+        const xch_word *own = xch_ptr(f.xch_inbox[me]);
+        __shared__ int s_ok;
+        if (t == 0) s_ok = 1;
+        __syncthreads();
+        if (t < R && !xch_wait(own + xch_off_flag_dmin(R) + par * R + t, tag)) s_ok = 0;
+        __syncthreads();
+        xch_acquire();
+        if (!s_ok) { if (t == 0) { st->status = TDLO_E_EXCHANGE; st->done = 1; } return; }
+        for (int m = t; m < M; m += kBlock) {
+            double mn = 1e300;
+            for (int r = 0; r < R; ++r) mn = ::fmin(mn, xch_load_f64(own + xch_off_dmin(R, Mc) + ((size_t)par * R + r) * Mc + m));
+            f.dminbits[m] = Num<T>::bits((T)mn);
+        }
     }
 }
 
@@ -388,8 +498,8 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const int rows = M < RT ? M : RT;
     // LDS carve (every offset a multiple of 16 bytes)
     V4<T> *nodesL = (V4<T> *)smem;                                    // M
-    V4<T> *pts = nodesL + M;                                          // NWE x 64
-    T *lvL = (T *)(pts + NWE * 64);                                   // M rounded up to 4
+    V4<T> *pts = nodesL + M;                                          // NWE x kPtsStride: point i of a wave at i + (i >> 4), see the column sums
+    T *lvL = (T *)(pts + NWE * kPtsStride);                           // M rounded up to 4
     T *pbase = lvL + ((M + 3) & ~3);
     T *pb = pbase + (size_t)wave * rows * kPStride;
     double *scratch = (double *)(pbase + (((size_t)NWE * rows * kPStride + 7) & ~(size_t)3));   // 16-byte aligned, stays an LDS pointer
@@ -488,16 +598,26 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         int a = plo;
         // candidates in groups of 4: the group's scalar loads are issued together (index clamped to phi), the evaluations
         // beyond phi are skipped by wave-uniform branches -- one scalar-memory latency per group instead of one per node
-        for (int m0 = plo; m0 <= phi; m0 += 4) {
-            V4<T> q[4];
+        {
+            int m0 = plo;
+            for (; m0 + 3 <= phi; m0 += 4) {             // whole groups: ONE scalar load of four nodes, no per-node index clamp or test
+                const Node4<T> q4 = load_node4<T>(f.nodes, m0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int mk = (m0 + k) < phi ? (m0 + k) : phi; q[k].x = nodes[mk].x; q[k].y = nodes[mk].y; q[k].z = nodes[mk].z; q[k].w = nodes[mk].w; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (m0 + k <= phi) {
-                    const T dx = x - q[k].x, dy = y - q[k].y, dz = z - q[k].z;
+                for (int k = 0; k < 4; ++k) {
+                    const T dx = x - q4.v[4 * k], dy = y - q4.v[4 * k + 1], dz = z - q4.v[4 * k + 2];
                     const T d2 = dx * dx + dy * dy + dz * dz;
                     if (d2 < best) { best = d2; a = m0 + k; }
+                }
+            }
+            if (m0 <= phi) {                             // the last, partial group: the same load (entries behind the last node stay inside
+                const Node4<T> q4 = load_node4<T>(f.nodes, m0);          // the slot's node block), evaluations beyond phi skipped wave-uniformly
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (m0 + k <= phi) {
+                        const T dx = x - q4.v[4 * k], dy = y - q4.v[4 * k + 1], dz = z - q4.v[4 * k + 2];
+                        const T d2 = dx * dx + dy * dy + dz * dz;
+                        if (d2 < best) { best = d2; a = m0 + k; }
+                    }
                 }
             }
         }
@@ -557,12 +677,24 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         };
         // [from, to] in groups of 4 nodes: scalar loads first (clamped index), evaluations beyond `to` skipped wave-uniformly
         auto span = [&](int from, int to, auto ADJ, auto STORE) {
-            for (int m0 = from; m0 <= to; m0 += 4) {
-                V4<T> q[4];
+            int m0 = from;
+            for (; m0 + 3 <= to; m0 += 4) {              // whole groups: one scalar load of four nodes (the scalar unit is shared by the
+                const Node4<T> q4 = load_node4<T>(f.nodes, m0);          // CU's four SIMDs: index clamps, address arithmetic and a
+#pragma unroll                                                           // wave-uniform branch per node had cost one scalar instruction
+                for (int k = 0; k < 4; ++k) {                            // per two vector ones, SQ_INSTS_SALU 8.15 M : VALU 15.1 M)
+                    V4<T> q; q.x = q4.v[4 * k]; q.y = q4.v[4 * k + 1]; q.z = q4.v[4 * k + 2]; q.w = q4.v[4 * k + 3];
+                    member(q, m0 + k, ADJ, STORE);
+                }
+            }
+            if (m0 <= to) {                              // the last, partial group: the same load, evaluations beyond `to` skipped
+                const Node4<T> q4 = load_node4<T>(f.nodes, m0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const int mk = (m0 + k) < to ? (m0 + k) : to; q[k].x = nodes[mk].x; q[k].y = nodes[mk].y; q[k].z = nodes[mk].z; q[k].w = nodes[mk].w; }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (m0 + k <= to) member(q[k], m0 + k, ADJ, STORE);
+                for (int k = 0; k < 4; ++k) {
+                    if (m0 + k <= to) {
+                        V4<T> q; q.x = q4.v[4 * k]; q.y = q4.v[4 * k + 1]; q.z = q4.v[4 * k + 2]; q.w = q4.v[4 * k + 3];
+                        member(q, m0 + k, ADJ, STORE);
+                    }
+                }
             }
         };
         {
@@ -578,7 +710,11 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         // small numbers, so fp32 tile sums and fp32 block partials lose nothing that matters
         const T ox = bcast_first(x), oy = bcast_first(y), oz = bcast_first(z);
         V4<T> pw; pw.x = inv; pw.y = inv * (x - ox); pw.z = inv * (y - oy); pw.w = inv * (z - oz);     // (s0, sx) and (sy, sz) pair up for v_pk_fma
-        pts[wave * 64 + lane] = pw;
+        // one entry of padding after every 16 points: the column sums below read 16-point slices with all lanes of a slice on one
+        // address (broadcast), and a ds_read_b128 serves 16 lanes that straddle two slices at a time -- 256 bytes apart they fall
+        // on the same banks (2-way conflict on every read, SQ_LDS_BANK_CONFLICT = 69 % of the LDS cycles at N = 2 000 000),
+        // 272 bytes apart they do not
+        pts[wave * kPtsStride + lane + (lane >> 4)] = pw;
 
         {
             // ---- column sums (:386-389): lane = (node of the window, slice of the 64 points).  The window is summed in
@@ -607,13 +743,16 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const int nj = 1 << shift;                                   // points per slice: 16 / 32
             T s0 = 0, sx = 0, sy = 0, sz = 0;
             if (wl < Wn) {
-                const T *prow = pb + (rbase + wl) * kPStride + sl * nj;
-                const V4<T> *pw_ = pts + wave * 64 + sl * nj;
+                for (int h = 0; h < nj; h += 16) {                       // 16 points at a time (same order as one loop over nj)
+                    const int i0 = sl * nj + h;
+                    const T *prow = pb + (rbase + wl) * kPStride + i0;
+                    const V4<T> *pw_ = pts + wave * kPtsStride + i0 + (i0 >> 4);
 #pragma unroll 8
-                for (int j = 0; j < nj; ++j) {
-                    const T p = prow[j];
-                    const V4<T> w = pw_[j];
-                    s0 += p * w.x; sx += p * w.y; sy += p * w.z; sz += p * w.w;
+                    for (int j = 0; j < 16; ++j) {
+                        const T p = prow[j];
+                        const V4<T> w = pw_[j];
+                        s0 += p * w.x; sx += p * w.y; sy += p * w.z; sz += p * w.w;
+                    }
                 }
             }
             s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
@@ -746,7 +885,9 @@ __device__ __forceinline__ double sel_by_group(double a0, double a1, double a2, 
     return __hiloint2double(hi, lo);
 }
 
-template <typename T, int NW, int MC, bool SINGLE, bool MFMA>
+// XCH: the instantiation that carries the one-shot exchange of the N-split (from_sums == 3); the plain loop's kernel is compiled
+// without it (its presence alone moved the register allocation: +0.7 us per launch at C2)
+template <typename T, int NW, int MC, bool SINGLE, bool MFMA, bool XCH = false>
 __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
     static_assert(!MFMA || NW == 4, "the MFMA elimination maps one 16-column block to each of 4 waves");
     constexpr int MB = NW * 64, NSLOT = NW;
@@ -855,6 +996,34 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         for (int i = t; i < nS; i += MB) f.sums[i] = S[i];
         if (t == 0) f.sums[nS] = (double)stg->N;
         return;
+    }
+    if (XCH && from_sums == 3) {
+        // N-split with the one-shot exchange: the shard's sums go to every peer's inbox (peer stores), the flag follows; then
+        // this workgroup waits for the R flags in its own inbox and adds the R contributions in rank order (the same bits
+        // on every rank) -- the SUM all-reduce of the RCCL form, inside the M-step, without a launch in between.
+        const int R = f.xch_nranks, me = f.xch_rank, Mc = f.xch_mcap, it = stg->it, par = it & 1;
+        const unsigned long long tag = ((unsigned long long)f.xch_epoch << 32) | (unsigned)(it + 1);
+        const size_t so = xch_off_sums(R, Mc), sl = 4 * (size_t)Mc + 2;
+        for (int i = t; i < nS; i += MB) {
+            const double v = S[i];
+            for (int q = 0; q < R; ++q) xch_store_f64(xch_ptr(f.xch_inbox[q]) + so + ((size_t)par * R + me) * sl + i, v);
+        }
+        xch_release();
+        __syncthreads();
+        if (t < R) xch_store(xch_ptr(f.xch_inbox[t]) + xch_off_flag_sums(R) + par * R + me, tag);
+        const xch_word *own = xch_ptr(f.xch_inbox[me]);
+        if (t == 0) red[7] = 1.0;
+        __syncthreads();
+        if (t < R && !xch_wait(own + xch_off_flag_sums(R) + par * R + t, tag)) red[7] = 0.0;
+        __syncthreads();
+        xch_acquire();
+        if (red[7] == 0.0) { if (t == 0) { st->status = TDLO_E_EXCHANGE; st->done = 1; st->converged = 0; } return; }
+        for (int i = t; i < nS; i += MB) {
+            double a = 0;
+            for (int r = 0; r < R; ++r) a += xch_load_f64(own + so + ((size_t)par * R + r) * sl + i);
+            S[i] = a;
+        }
+        __syncthreads();
     }
 
     // ---- 2. assemble [A | B] (:392-413) straight into registers: wave = column slot, lane = row,
@@ -1238,11 +1407,6 @@ hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, 
 // ------------------------------------------------------------------------------------------------
 static inline int nch_for(int M) { const int c = (M + kChunk - 1) / kChunk; return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }
 
-template <typename T> static size_t dmin_lds_bytes(int M) {
-    const int rows = M < kChunk ? M : kChunk;
-    const size_t tile = sizeof(T) * (size_t)4 * rows * kPStride, red = sizeof(T) * 256;
-    return tile > red ? tile : red;
-}
 size_t mstep_lds_bytes(int M) {
     const int nS = 4 * M + 1, ld = M | 1;
     size_t b = sizeof(double) * (size_t)(((nS + 1) & ~1) + 6 * M + 16) + sizeof(int) * 2 * (size_t)((M + 3) & ~3) + 16;
@@ -1263,7 +1427,7 @@ template <typename T, int EB> static size_t estep_lds_bytes(int M, bool single) 
     constexpr int NWE = EB / 64;
     const size_t tile = sizeof(T) * (((size_t)NWE * rows * kPStride + 7) & ~(size_t)3);
     const size_t red = (size_t)NWE * 64 * 4 * sizeof(double);
-    size_t b = sizeof(V4<T>) * (size_t)M + sizeof(V4<T>) * NWE * 64 + sizeof(T) * (size_t)((M + 3) & ~3);
+    size_t b = sizeof(V4<T>) * (size_t)M + sizeof(V4<T>) * NWE * kPtsStride + sizeof(T) * (size_t)((M + 3) & ~3);
     b += (tile > red ? tile : red) + 16 * sizeof(double) + 64;
     if (M <= kChunk) b += sizeof(double) * (size_t)NWE * M * 4;     // per-wave accumulators of the windowed variant
     return b;
@@ -1299,18 +1463,21 @@ template <typename T> static hipError_t launch_estep_T(const FrameDev *fd, const
     return launch_estep_TE<T, 256>(fd, fh, F, s);
 }
 
+// workgroups of k_dmin (4 waves, a wave = a grid-stride sequence of 64-point batches): a wave pays a fixed epilogue (64 nodes x
+// a cross-lane minimum, about two batches' worth of instructions), so large clouds give every wave several batches
 static inline int dmin_blocks(const FrameDev *fh, int F) {
-    int gx = 0;
-    for (int i = 0; i < F; ++i) gx = fh[i].nblkE > gx ? fh[i].nblkE : gx;
-    return gx;
+    int nb = 1;
+    for (int i = 0; i < F; ++i) { const int b = (fh[i].N0 + 63) / 64; nb = b > nb ? b : nb; }
+    const int per_wave = nb >= 8192 ? 8 : (nb >= 2048 ? 4 : (nb >= 512 ? 2 : 1));
+    const int gx = (nb + 4 * per_wave - 1) / (4 * per_wave);
+    return gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
 }
 
 template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
     const int M = fh[0].M, nch = nch_for(M);
     const int gx = dmin_blocks(fh, F);
     const dim3 grid(gx, F), block(kBlock);
-    const size_t lds = dmin_lds_bytes<T>(M);
-#define TDLO_D(NCH) do { TDLO_TRY(set_lds(k_dmin<T, NCH>, lds)); hipLaunchKernelGGL((k_dmin<T, NCH>), grid, block, lds, s, fd, gx); } while (0)
+#define TDLO_D(NCH) do { hipLaunchKernelGGL((k_dmin<T, NCH>), grid, block, 0, s, fd, gx); } while (0)
     switch (nch) { case 1: TDLO_D(1); break; case 2: TDLO_D(2); break; case 4: TDLO_D(4); break; default: TDLO_D(8); }
 #undef TDLO_D
     return hipGetLastError();
@@ -1327,7 +1494,11 @@ template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW, bool piv
 
 template <typename T, int NW, int MC, bool MFMA = false> static hipError_t launch_mstep_fast(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
     const size_t lds = mstep_fast_lds_bytes<T>(fh[0].M, NW, !MFMA);
-    if (F == 1) {
+    if (from_sums == 3) {          // one frame (a shard of the split cloud), exchange inside the kernel
+        if (F != 1) return hipErrorInvalidValue;
+        TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true, MFMA, true>, lds));
+        hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA, true>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
+    } else if (F == 1) {
         TDLO_TRY(set_lds(k_mstep_fast<T, NW, MC, true, MFMA>, lds));
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA>), dim3(1), dim3(NW * 64), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
         else hipLaunchKernelGGL((k_mstep_fast<T, NW, MC, true, MFMA>), dim3(1), dim3(NW * 64), lds, s, fd, fh[0], from_sums);
@@ -1448,7 +1619,8 @@ const char *mstep_kernel_name(const FrameDev *fh, int F) {
     return "k_mstep_pivot_mcu";
 }
 
-// kind: 0 E-step, 1 dmin, 2 M-step (from block partials), 3 M-step export-only (split), 4 M-step from global sums (split)
+// kind: 0 E-step, 1 dmin, 2 M-step (from block partials), 3 M-step export-only (split), 4 M-step from global sums (split),
+// 5 M-step from block partials with the one-shot exchange of the split inside (k_mstep_fast only: the caller checks M)
 hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int kind, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     switch (kind) {
@@ -1457,6 +1629,7 @@ hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int 
         case 2: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s);
         case 3: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 2, s) : launch_mstep_T<float>(fd, fh, F, 2, s);
         case 4: return f64 ? launch_mstep_T<double>(fd, fh, F, 1, s) : launch_mstep_T<float>(fd, fh, F, 1, s);
+        case 5: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 3, s) : launch_mstep_T<float>(fd, fh, F, 3, s);   // M-step with the one-shot exchange inside
         default: return hipErrorInvalidValue;
     }
 }
@@ -1486,6 +1659,19 @@ hipError_t launch_split_dmin_xch(const FrameDev *fd, const FrameDev *fh, double 
     const dim3 grid((fh[0].M + 63) / 64), block(64);
     if (fh[0].precision == TDLO_PREC_F64) hipLaunchKernelGGL((k_split_dmin_xch<double>), grid, block, 0, s, fd, xch, import);
     else hipLaunchKernelGGL((k_split_dmin_xch<float>), grid, block, 0, s, fd, xch, import);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_init_pack(const FrameDev *fd, double *init2, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_init_pack, dim3(1), dim3(64), 0, s, fd, init2);
+    return hipGetLastError();
+}
+hipError_t launch_split_set_global_dev(const FrameDev *fd, const double *init2, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_set_global_dev, dim3(1), dim3(64), 0, s, fd, init2);
+    return hipGetLastError();
+}
+hipError_t launch_xch_init(const FrameDev *fd, hipStream_t s) {
+    hipLaunchKernelGGL(k_xch_init, dim3(1), dim3(64), 0, s, fd);
     return hipGetLastError();
 }
 

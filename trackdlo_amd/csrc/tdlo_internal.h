@@ -9,12 +9,14 @@ constexpr int kBlock = 256;          // workgroup size of the point-parallel ker
 constexpr int kWave = 64;
 constexpr int kChunk = 64;           // nodes handled per lane-transposed tile
 constexpr int kPStride = 65;         // LDS row stride of the 64 x 64 transposition tile (conflict-free)
+constexpr int kPtsStride = 68;       // E-step: a wave's 64 normalised points in LDS, one entry of padding after every 16
 constexpr int kPartDirect = 256;    // up to this many block partials go straight to the M-step (80 KB of fp32 at M = 50) ...
 constexpr int kPartGroups = 32;     // ... more are first summed in this many groups of consecutive blocks by k_part_reduce
 constexpr int kTileRows = 24;        // rows of the E-step's transposition tile when M <= 64: the node window is processed
                                      // in chunks of this many nodes (6 KB of LDS per wave -> two workgroups per CU)
 constexpr int kMaxNodes = 512;       // E-step template covers ceil(M/64) in {1,2,4,8}
 constexpr int kLdsSolveMaxM = 128;   // M-step keeps [A|B] in LDS up to this M
+constexpr int kMaxXchRanks = 8;      // ranks of the one-shot N-split exchange (one node: 8 GPUs)
 
 // Mutable per-iteration state of one registration, device resident (trackdlo.cpp:275-438 loop state).
 struct IterState {
@@ -71,7 +73,23 @@ struct FrameDev {
     unsigned long long *dbg; // 64 shader-clock stamps written by the M-step (tdlo_debug_stamps)
     unsigned *sync;         // 256 words, zeroed when the slot is created: generation / arrivals / flags of the multi-CU M-steps' hand-offs
     IterState *st;
+    // one-shot exchange of the N-split (tdlo_xch_*, tdlo_split_run without a communicator): every rank's inbox as a device
+    // pointer valid on THIS device (own inbox included); xch_nranks == 0: no exchange
+    unsigned long long *xch_inbox[kMaxXchRanks];
+    int xch_rank, xch_nranks, xch_mcap;
+    unsigned xch_epoch;     // tag of this registration: flags carry (epoch << 32 | iteration + 1)
 };
+
+// Inbox layout in 64-bit words (R ranks, node capacity Mc); rank r writes the [r] entries of every peer's inbox:
+//   flags: init [R] | dmin [2][R] | sums [2][R]      (parity = iteration & 1)
+//   init [R][2] (kept points, sum d2)  |  dmin [2][R][Mc]  |  sums [2][R][4 Mc + 2]
+__host__ __device__ inline size_t xch_off_flag_init(int R) { (void)R; return 0; }
+__host__ __device__ inline size_t xch_off_flag_dmin(int R) { return (size_t)R; }
+__host__ __device__ inline size_t xch_off_flag_sums(int R) { return 3 * (size_t)R; }
+__host__ __device__ inline size_t xch_off_init(int R) { return (5 * (size_t)R + 7) & ~(size_t)7; }
+__host__ __device__ inline size_t xch_off_dmin(int R, int Mc) { (void)Mc; return xch_off_init(R) + 2 * (size_t)R; }
+__host__ __device__ inline size_t xch_off_sums(int R, int Mc) { return xch_off_dmin(R, Mc) + 2 * (size_t)R * Mc; }
+__host__ __device__ inline size_t xch_words(int R, int Mc) { return xch_off_sums(R, Mc) + 2 * (size_t)R * (4 * (size_t)Mc + 2); }
 
 // launchers implemented in tdlo_device.hip
 hipError_t launch_prune_and_setup(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
@@ -82,6 +100,9 @@ const char *mstep_kernel_name(const FrameDev *frames_host, int F);
 hipError_t launch_estep_only(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int kind, hipStream_t s);
 hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames_host, hipStream_t s);
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
+hipError_t launch_split_init_pack(const FrameDev *frames_dev, double *init2, hipStream_t s);        // [kept points, sum d2] of the shard -> device buffer (for the all-reduce)
+hipError_t launch_split_set_global_dev(const FrameDev *frames_dev, const double *init2, hipStream_t s);   // ... and back, reduced
+hipError_t launch_xch_init(const FrameDev *frames_dev, hipStream_t s);                             // one-shot exchange of the same two numbers
 hipError_t launch_split_dmin_xch(const FrameDev *frames_dev, const FrameDev *frames_host, double *xch, int import, hipStream_t s);
 hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s);
 size_t mstep_lds_bytes(int M);
