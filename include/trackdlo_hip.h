@@ -319,6 +319,11 @@ int tdlo_profile_iteration(tdlo_ctx *ctx, int reps, float *estep_us, float *mste
 /* Development aid: copies the first n (<= 64) shader-clock stamps that the M-step kernel of the last
  * launch wrote at its phase boundaries (reduce / assemble / eliminate / update / publish). */
 int tdlo_debug_stamps(tdlo_ctx *ctx, int slot, unsigned long long *out, int n);
+/* Test aid: which M-step serves registrations WITHOUT the LLE term from now on, process-wide.  0 (default): the chain smoother
+ * (csrc/tdlo_mstep_chain.hip: the system of trackdlo.cpp:405-413 solved in O(M) through the state-space form of the kernel G);
+ * 1: the dense eliminations of the same system (k_mstep_fast / k_mstep_mcu), kept as comparators.  Returns the previous
+ * setting.  The initial setting is 1 when the environment holds TDLO_MSTEP=dense. */
+int tdlo_debug_mstep_dense(int on);
 /* Development aid: copies the pruned, centred, node-sorted cloud of the last call (N x 3 column-major, widened to
  * double) and the centring offset; returns N. */
 int tdlo_debug_read_cloud(tdlo_ctx *ctx, int slot, double *out, int max_points, double *ctr);

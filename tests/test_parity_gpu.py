@@ -978,6 +978,7 @@ def test_multi_cu_mstep_matches_one_workgroup_kernel(tmp_path):
         env = dict(os.environ)
         env.pop("TDLO_MSTEP_BIG", None)
         env.pop("TDLO_MSTEP_LLE", None)
+        env["TDLO_MSTEP"] = "dense"              # the dense eliminations (comparators since round 2: the product path without LLE is the chain smoother)
         if mode == "1wg": env["TDLO_MSTEP_BIG"] = "1wg"; env["TDLO_MSTEP_LLE"] = "1wg"
         out = tmp_path / f"{mode}.npz"
         r = subprocess.run([sys.executable, "-c", _ONE_WG_SCRIPT, root, str(out), repr(cases)], env=env, capture_output=True, text=True, timeout=600)
@@ -1016,6 +1017,15 @@ def test_multi_cu_mstep_nsplit_and_oracle_at_c5_nodes(hip_ctx, oracle):
 
 
 def test_multi_cu_mstep_hand_offs_under_uneven_load():
+    from trackdlo_amd import binding as B
+    prev_dense = B.mstep_dense(True)           # the multi-CU dense elimination (comparator since round 2: the product path is the chain smoother)
+    try:
+        _hand_offs_under_uneven_load()
+    finally:
+        B.mstep_dense(prev_dense)
+
+
+def _hand_offs_under_uneven_load():
     """The in-launch hand-offs of k_mstep_mcu (write-through pivot rows + flag, L1-bypassing loads) must not depend on
     timing or placement: batches of M = 130 / 300 frames are registered while a second context (its own stream, driven from
     another thread) keeps the GPU busy with the E-steps of a 1 000 000-point cloud, and every frame of every repetition
@@ -1155,6 +1165,7 @@ def test_multi_cu_mstep_redoes_an_iteration_after_a_timed_out_hand_off(tmp_path,
     for mode in ("plain", "forced"):
         env = dict(os.environ)
         env.pop("TDLO_MCU_FORCE_TIMEOUT", None)
+        env["TDLO_MSTEP"] = "dense"              # the multi-CU dense elimination (comparator since round 2)
         if mode == "forced": env["TDLO_MCU_FORCE_TIMEOUT"] = "1"          # the second iteration
         out = tmp_path / f"{mode}.npz"
         r = subprocess.run([sys.executable, "-c", _RETRY_SCRIPT, root, str(out), repr(cases)], env=env, capture_output=True, text=True, timeout=900)

@@ -49,7 +49,7 @@ struct NodeCarve {
     // back with one copy.
     size_t Yin, aJ, aYd, H, upload;
     size_t Yout, st, readback;
-    size_t ctr, Y, Y0, nodes, coord, G, HG, HY0, dmin, sums, dbg, Ascr, part, total;
+    size_t ctr, Y, Y0, nodes, coord, G, chain, HG, HY0, dmin, sums, dbg, Ascr, part, total;
     explicit NodeCarve(int M) {
         const size_t m = (size_t)M, mm = m * m;
         size_t o = 0;
@@ -57,7 +57,7 @@ struct NodeCarve {
         Yin = take(3 * m); aJ = take(m); aYd = take(3 * m); H = take(mm); upload = o;
         Yout = take(3 * m); st = take((sizeof(IterState) + 7) / 8); readback = o - Yout;
         ctr = take(4); Y = take(3 * m); Y0 = take(3 * m); nodes = take(4 * m); coord = take(m);
-        G = take(mm); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2); dbg = take(64);
+        G = take(mm); chain = take(8 * (m + 1)); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2); dbg = take(64);
         Ascr = take(std::max((size_t)(M | 1) * (m + 3), mstep_big_scratch_doubles(M)));
         part = take((size_t)(kMaxEstepBlocks + kPartGroups) * (4 * m + 2));     // block partials + their group sums
         total = o;
@@ -260,7 +260,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     }
     f.Xraw = s.Xraw; f.Xs = s.Xs; f.bucket = s.bucket; f.hist = s.hist; f.blksum = s.blksum;
     f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
-    f.coord = blk + nc.coord; f.G = blk + nc.G; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
+    f.coord = blk + nc.coord; f.G = blk + nc.G; f.chain = blk + nc.chain; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
     f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
     // M-step input: the block partials themselves, or (large clouds) kPartGroups group sums stored behind the last block row
     f.partM = blk + nc.part; f.nblkM = f.nblkE;
@@ -1241,6 +1241,8 @@ int tdlo_debug_read_cloud(tdlo_ctx *c, int slot, double *out, int max_points, do
     if (ctr) HIPCHK(c, hipMemcpy(ctr, f.ctr, 3 * sizeof(double), hipMemcpyDeviceToHost));
     return N;
 }
+
+int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 
 int tdlo_debug_stamps(tdlo_ctx *c, int slot, unsigned long long *out, int n) {
     if (!c || slot < 0 || slot >= (int)c->slots.size() || !out || n < 1 || n > 64 || c->fh.empty()) return TDLO_E_INVALID;

@@ -128,6 +128,29 @@ __device__ __forceinline__ double fast_rcp(double v) {
     return r;
 }
 
+// State-space form of the kernel G of trackdlo.cpp:233 (Matern-3/2 in the chain coordinate; see tdlo_mstep_chain.hip): the link
+// over a gap h >= 0 between consecutive nodes, o = {Phi11, Phi12, Phi21, Phi22, Q11, Q12, Q22, 0},
+//   Phi = e^-x [[1 + x, h], [-s^2 h, 1 - x]],  x = s h,  s = sqrt2 / beta,
+//   Q   = Pinf - Phi Pinf Phi^T,  Pinf = sf2 diag(1, s^2),  sf2 = 1 / (2 sqrt2 beta):
+//   Q11 = sf2 (1 - e^-2x (1 + 2x + 2x^2)),  Q12 = 2 sf2 s^3 h^2 e^-2x,  Q22 = sf2 s^2 (1 - e^-2x (1 - 2x + 2x^2)).
+// For small gaps 1 - e^-2x (1 + 2x + 2x^2) is O(x^3) out of terms of size 1; the series e^-2x sum_{n >= 3} (2x)^n / n! has
+// only positive terms (Q22 likewise: e^-2x (4x + sum_{n >= 3})), so every entry keeps full relative accuracy.
+__device__ __forceinline__ void chain_link(double beta, double h, double *o) {
+    const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta);
+    const double x = s * h, e = ::exp(-x), e2 = e * e;
+    o[0] = e * (1.0 + x); o[1] = e * h; o[2] = -s * s * h * e; o[3] = e * (1.0 - x);
+    double u11, u22;
+    if (x < 1.0) {
+        const double tt = 2.0 * x;
+        double term = tt * tt * tt / 6.0, sum = term;
+        for (int n = 4; n < 48; ++n) { term = term * tt / (double)n; sum += term; }
+        u11 = e2 * sum; u22 = e2 * (4.0 * x + sum);
+    } else {
+        u11 = 1.0 - e2 * (1.0 + 2.0 * x + 2.0 * x * x); u22 = 1.0 - e2 * (1.0 - 2.0 * x + 2.0 * x * x);
+    }
+    o[4] = sf2 * u11; o[5] = 2.0 * sf2 * s * s * s * h * h * e2; o[6] = sf2 * s * s * u22; o[7] = 0.0;
+}
+
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f64_16x16x4_f64
 
 // ---- one-shot exchange of the N-split: peer-written inboxes (xGMI peer stores on a multi-GPU node), system scope ---------

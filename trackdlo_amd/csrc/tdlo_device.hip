@@ -172,6 +172,14 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         f.dminbits[m] = ~0ull;
     }
     const double beta = f.beta;
+    // state-space form of G for the chain smoother (tdlo_mstep_chain.hip): one link per pair of consecutive nodes
+    for (int i = t; i < M; i += kBlock) {
+        double o[8];
+        if (i == 0) { const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta); o[0] = sf2; o[1] = s * s * sf2; o[2] = o[3] = o[4] = o[5] = o[6] = o[7] = 0.0; }
+        else chain_link(beta, sc[i] - sc[i - 1], o);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f.chain[8 * (size_t)i + q] = o[q];
+    }
     {
         const auto Gw = TDLO_AS_GLOBAL_RW(double, f.G);
         for (int e = t; e < M * M; e += kBlock) {
@@ -1515,6 +1523,7 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
     const int M = fh[0].M;
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
+    if (!any_lle && mstep_chain_enabled()) return launch_mstep_chain(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     if (M <= 60 && !any_lle) return launch_mstep_fast<T, 4, 1, true>(fd, fh, F, from_sums, s);
     // (M = 61..64 without LLE: the 64-column register tableau has no room for the right-hand sides; the tracer-column
     //  variant of the register path is an order of magnitude less accurate at weak regularisation, so these sizes take
@@ -1612,6 +1621,7 @@ const char *mstep_kernel_name(const FrameDev *fh, int F) {
     const int M = fh[0].M;
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
+    if (!any_lle && mstep_chain_enabled()) return "k_mstep_chain";
     if (M <= 60 && !any_lle) return "k_mstep_fast<MFMA>";
     if (!any_lle) return "k_mstep_mcu";
     if (M <= 64) return "k_mstep_fast<pivoted>";

@@ -57,6 +57,7 @@ struct FrameDev {
     void *nodes;            // M x {x,y,z,coord} in compute precision (float4 / double4)
     double *coord;          // M cumulative arc length (:214-223)
     double *G;              // M x M kernel (:233)
+    double *chain;          // (M + 1) x 8: state-space form of G for the chain smoother (tdlo_mstep_chain.hip): [0] = {sf2, s^2 sf2}, [i] = link between nodes i-1 and i {Phi (4), Q (3)}
     const double *H;        // M x M LLE regulariser (host supplied) or nullptr
     double *HG;             // M x M  H*G   (include_lle)
     double *HY0;            // M x 3  H*Yin (include_lle)
@@ -112,6 +113,10 @@ size_t mstep_big_scratch_doubles(int M);
 // M-step with the LLE term for M > kLdsSolveMaxM: 16 rows per workgroup, partial pivoting across the workgroups
 hipError_t launch_mstep_pivot_mcu(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
 bool mstep_pivot_mcu_enabled();
+// tdlo_mstep_chain.hip: M-step without the LLE term as a Kalman / Rauch-Tung-Striebel smoother along the chain, any M
+hipError_t launch_mstep_chain(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
+bool mstep_chain_enabled();
+int mstep_set_dense(int on);      // returns the previous setting
 // tdlo_reg.hip: plain GMM-EM `reg` (utils.cpp:21-82); ws layout: state (8) | Y (3 M) | block partials
 size_t reg_ws_doubles(int M, int nblk);
 int reg_max_nodes();        // the E-step's per-wave accumulators must fit 160 KB of LDS

@@ -1,0 +1,465 @@
+// tdlo_mstep_chain.hip -- M-step (trackdlo.cpp:392-437) without the LLE term as a smoother along the chain: O(M), any M <= 512.
+//
+// What the reference solves each iteration (:405-413, include_lle == false):
+//     (c I + D G) W = B,   T = Y0 + G W,      c = lambda sigma2,  D = diag(P1) + alpha J  (diagonal, >= 0),
+// with the kernel of :233
+//     G_ij = 1/(4 beta^2) exp(-sqrt2 |c_i - c_j| / beta) (2 |c_i - c_j| + sqrt2 beta)
+//          = sf2 (1 + s d) exp(-s d),        d = |c_i - c_j|,  s = sqrt2 / beta,  sf2 = 1 / (2 sqrt2 beta)
+// over the chain coordinates c_0 <= c_1 <= ... (:219-223, a running sum, i.e. sorted).  Only T is used afterwards (:417-431).
+// With V = G W the system reads (c G^-1 + D) V = B: V is the posterior mean of a Gaussian process with covariance G / c
+// observed at the nodes with precisions D_i ("observation" B_i / D_i).  G is the Matern-3/2 kernel in one dimension, and the
+// process with that covariance is Markov in the state x = (f, f'):
+//     x_{i+1} = Phi(h_i) x_i + noise,  Phi(h) = e^{-sh} [[1 + sh, h], [-s^2 h, 1 - sh]],  Q(h) = Pinf - Phi Pinf Phi^T,
+//     Pinf = sf2 diag(1, s^2),  h_i = c_{i+1} - c_i.
+// The posterior mean of a Markov chain is a Kalman filter pass plus a Rauch-Tung-Striebel smoothing pass: M dependent steps
+// on 2 x 2 matrices instead of the M dependent column eliminations on an M x M tableau of the dense kernels (k_mstep_fast:
+// 13 panels, 10 us at M = 50; k_mstep_mcu: 19 workgroups, 131 us at M = 300).  No M x M matrix is touched at all: neither G
+// (20 KB at M = 50, 2 MB at M = 512) nor the product G W.  It is the same linear system, so the result is the reference's up
+// to rounding -- and the rounding is smaller: the dense system has condition number ~ P1 G / c (1e5 ... 1e8 as sigma2 falls), the
+// filter's quantities are all O(1) ratios (measured against an 80-bit solve of the dense system: 1e-17 ... 1e-14 m where
+// partial-pivot LU / QR of the dense system leave 1e-14 ... 1e-9 m; tests/test_mstep_chain.py).
+//
+// Mapping: ONE wave runs the chain (the other three waves of the workgroup only help with the block partials and the
+// sigma2 sums).  The chain is walked from BOTH ends at once: lanes 0..31 filter nodes 0 .. j, lanes 32..63 filter nodes
+// M-1 .. j of the time-reversed process (same Phi and Q: the process is stationary and reversible in (f, -f')), j = (M-1)/2.
+// At node j the two Gaussians are fused (information form, the prior counted once), and both halves smooth outwards.  That
+// halves the dependent chain for free: a wave64 fp64 instruction costs 4 cycles whether 3 or 64 lanes are active.  Inside a
+// half, lane & 3 = coordinate (x, y, z) for the means; the covariance recursion is the same in every lane.
+// Per forward step: 2 x 2 predict (Phi P Phi^T + Q), one reciprocal, update; the smoother gain C_k = P_k Phi^T (P^-_{k+1})^-1
+// is NOT on that chain: the loop stores P_k, and one lane-parallel pass (lane = step) forms all C_k afterwards.
+// Backward step: x_k = e_k + C_k x_{k+1}, two dependent FMAs.
+//
+// The dense kernels stay in the tree: with the LLE term (include_lle, the pre-processing registration of tracking_step) the
+// system is not of this form, and TDLO_MSTEP=dense selects them as comparators for the tests.
+#include "tdlo_devcommon.h"
+#include <atomic>
+#include <cstdlib>
+#include <hip/hip_ext.h>
+
+namespace tdlo {
+extern hipEvent_t g_mstep_ev[2];       // tdlo_device.hip: start/stop events for the M-step dispatch (tdlo_profile_iteration)
+namespace {
+
+constexpr int kCB = 256;               // workgroup size
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+}  // namespace
+
+// Step slots.  Both directions have nB = M - j steps; direction A (nodes 0 .. j) starts with nB - nA in {0, 1} dummy steps
+// (identity link, no observation), so that both directions reach the junction in their LAST step and the loops need no
+// per-direction bookkeeping.  Slot sl = dir * nB + k.  One slot = kSlot doubles of LDS:
+//   [ 0.. 7] record of the step  {f11 f12 | f21 f22 | q11/c q12/c | q22/c p}   (Phi and Q of the link INTO the step, observation precision)
+//   [ 8..13] right-hand side     {bx - | by - | bz -}
+//   [14..19] mean                {mx0 mx1 | my0 my1 | mz0 mz1}   filtered -> e_k -> smoothed
+//   [20..23] posterior           {a b | d g}
+//   [24..27] smoother gain       {C11 C12 | C21 C22}
+constexpr int kSlot = 28;
+constexpr int kAhead = 6;             // slots behind the last one that the software-pipelined loops may read
+constexpr int kDump = 32;              // doubles per lane of the dump area (lanes that have nothing to store write there)
+
+struct ChainCarve {
+    int nSp, npair, NG, jn, nA, nB, nSl;
+    size_t S, red, dump, slots, total;
+    __host__ __device__ ChainCarve(int M, int vec, int nSp_) {
+        nSp = nSp_; npair = nSp / vec; NG = npair >= kCB ? 1 : kCB / npair;
+        jn = (M - 1) >> 1; nA = jn + 1; nB = M - jn; nSl = 2 * nB;
+        size_t o = 0;
+        S = o; o += (size_t)((nSp + 1) & ~1);           // [P1 | Rx | Ry | Rz | Q]
+        red = o; o += 32;                               // [0..15] wave sums, [24] exchange flag
+        dump = o; o += (size_t)64 * kDump;
+        slots = o;                                      // first: the NG partial-sum groups of the fetch
+        {
+            const size_t a = (size_t)kSlot * (nSl + kAhead), b = (size_t)NG * nSp;      // the loops read up to kAhead slots ahead
+            o += ((a > b ? a : b) + 1) & ~(size_t)1;
+        }
+        total = o;
+    }
+};
+
+template <typename T, bool SINGLE, bool XCH>
+__global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
+    constexpr int MB = kCB;
+    const FrameDev &f = SINGLE ? f0 : frames[blockIdx.x];
+    IterState *st = f.st;
+    const int M = f.M, t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    typedef typename PartOf<T>::type PT;
+    constexpr int VEC = 16 / (int)sizeof(PT);
+    const int nS = 4 * M + 1;
+    const ChainCarve cv(M, VEC, part_stride<PT>(M));
+    const int nSp = cv.nSp, npair = cv.npair, NG = cv.NG, nA = cv.nA, nB = cv.nB, nSl = cv.nSl, sh = nB - nA;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *S = (double *)smem + cv.S, *red = (double *)smem + cv.red, *dump = (double *)smem + cv.dump, *slots = (double *)smem + cv.slots;
+    double *Sg = slots;
+
+#define CSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    CSTAMP(0);
+    const auto stg = TDLO_AS_GLOBAL(IterState, st);
+    const int done = stg->done;
+    const double sigma2 = stg->sigma2;
+    const int pri = f.has_priors;
+    const double ctr0 = f.ctr[0], ctr1 = f.ctr[1], ctr2 = f.ctr[2];
+    const auto ndg = TDLO_AS_GLOBAL(V4<T>, f.nodes);
+    const auto Yg = TDLO_AS_GLOBAL(double, f.Y);
+    const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
+    const auto aJg = TDLO_AS_GLOBAL(double, f.aJ);
+    const auto aYg = TDLO_AS_GLOBAL(double, f.aYd);
+    const auto chg = TDLO_AS_GLOBAL(dbl2, f.chain);
+
+    // slot -> (node, link into the step, does the step observe its node).  The junction node's data belong to direction A.
+    auto slot_info = [&](int sl, int &node, int &li, bool &obs) __attribute__((always_inline)) {
+        const int dir = sl >= nB, k = dir ? sl - nB : sl;
+        const bool real = dir || k >= sh;
+        node = real ? (dir ? M - 1 - k : k - sh) : 0;
+        li = dir ? (k > 0 ? M - k : 0) : (k > sh ? k - sh : 0);      // 0: identity (first step of a direction, dummy step)
+        obs = real && !(dir && k == nB - 1);
+    };
+    // ---- 1. everything that comes from memory is requested up front: this thread's step slot (its link, its node), the block partials
+    struct SlotQ { dbl2 l[4]; double y[3], y0[3], yp[3], ay[3], aj, w; int node, li; bool obs; };
+    auto load_slot = [&](int sl) __attribute__((always_inline)) {
+        SlotQ q;
+        slot_info(sl < nSl ? sl : 0, q.node, q.li, q.obs);
+        const int lc = q.li > 0 ? q.li : 1, mc = q.node;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q.l[i] = chg[4 * (size_t)lc + i];
+        q.y[0] = (double)ndg[mc].x; q.y[1] = (double)ndg[mc].y; q.y[2] = (double)ndg[mc].z; q.w = (double)ndg[mc].w;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { q.y0[d] = Y0g[d * M + mc]; q.yp[d] = Yg[d * M + mc]; q.ay[d] = pri ? aYg[d * M + mc] : 0.0; }
+        q.aj = pri ? aJg[mc] : 0.0;
+        return q;
+    };
+    const SlotQ q0 = load_slot(t);
+    const double pinf0 = chg[0].x, pinf1 = chg[0].y;  // sf2, s^2 sf2
+    const double c2 = f.lambda * sigma2, rc2 = 1.0 / c2;
+    if (from_sums != 1) {
+        typedef PT pvec __attribute__((ext_vector_type(VEC)));
+        const auto part = TDLO_AS_GLOBAL(pvec, f.partM);
+        const int nb = f.nblkM;
+        constexpr int UL = 20;                        // loads in flight per thread
+        for (int u0 = 0; u0 < npair; u0 += MB) {      // one trip for M <= 255
+            const int pe = u0 + (NG == 1 ? t : t % npair), g = NG == 1 ? 0 : t / npair;
+            if (pe < npair && g < NG) {
+                double acc[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
+                for (int b = g; b < nb; b += UL * NG) {
+                    pvec v[UL];
+#pragma unroll
+                    for (int u = 0; u < UL; ++u) { const int bb = b + u * NG; v[u] = part[(size_t)(bb < nb ? bb : nb - 1) * npair + pe]; }
+#pragma unroll
+                    for (int u = 0; u < UL; ++u) {
+                        if (b + u * NG < nb) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) acc[i] += (double)v[u][i];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) Sg[(size_t)g * nSp + VEC * pe + i] = acc[i];
+            }
+        }
+    }
+    if (done) return;
+    CSTAMP(1);
+    __syncthreads();
+    if (from_sums != 1) {
+        for (int i = t; i < nS; i += MB) { double a = 0; for (int q = 0; q < NG; ++q) a += Sg[(size_t)q * nSp + i]; S[i] = a; }
+    } else {
+        const auto sums = TDLO_AS_GLOBAL(double, f.sums);
+        for (int i = t; i < nS; i += MB) S[i] = sums[i];
+    }
+    __syncthreads();
+    if (from_sums == 2) {       // split mode, export only
+        for (int i = t; i < nS; i += MB) f.sums[i] = S[i];
+        if (t == 0) f.sums[nS] = (double)stg->N;
+        return;
+    }
+    if (XCH && from_sums == 3) {
+        // N-split with the one-shot exchange (see k_mstep_fast): sums to every peer's inbox, flag, wait for the R flags in the
+        // own inbox, add the R contributions in rank order
+        const int R = f.xch_nranks, me = f.xch_rank, Mc = f.xch_mcap, it = stg->it, par = it & 1;
+        const unsigned long long tag = ((unsigned long long)f.xch_epoch << 32) | (unsigned)(it + 1);
+        const size_t so = xch_off_sums(R, Mc), sl = 4 * (size_t)Mc + 2;
+        for (int i = t; i < nS; i += MB) {
+            const double v = S[i];
+            for (int q = 0; q < R; ++q) xch_store_f64(xch_ptr(f.xch_inbox[q]) + so + ((size_t)par * R + me) * sl + i, v);
+        }
+        xch_release();
+        __syncthreads();
+        if (t < R) xch_store(xch_ptr(f.xch_inbox[t]) + xch_off_flag_sums(R) + par * R + me, tag);
+        const xch_word *own = xch_ptr(f.xch_inbox[me]);
+        if (t == 0) red[24] = 1.0;
+        __syncthreads();
+        if (t < R && !xch_wait(own + xch_off_flag_sums(R) + par * R + t, tag)) red[24] = 0.0;
+        __syncthreads();
+        xch_acquire();
+        if (red[24] == 0.0) { if (t == 0) { st->status = TDLO_E_EXCHANGE; st->done = 1; st->converged = 0; } return; }
+        for (int i = t; i < nS; i += MB) {
+            double a = 0;
+            for (int r = 0; r < R; ++r) a += xch_load_f64(own + so + ((size_t)par * R + r) * sl + i);
+            S[i] = a;
+        }
+        __syncthreads();
+    }
+    CSTAMP(2);
+
+    // ---- 2. thread = step slot: the step's record and right-hand side  B = PX - P1 Y0 (+ alpha (Y_ext - Y0)) = R + P1 (y - Y0) (+ ...)
+    //         (the E-step delivers R = PX - P1 y, y = the nodes as it saw them)
+    for (int sl = t, r = 0; sl < nSl + kAhead; sl += MB, ++r) {
+        dbl2 *o = (dbl2 *)(slots + (size_t)kSlot * sl);
+        if (sl >= nSl) {        // the slots the loops read ahead into
+            o[0] = dbl2{1.0, 0.0}; o[1] = dbl2{0.0, 1.0}; o[2] = dbl2{0.0, 0.0}; o[3] = dbl2{0.0, 0.0}; o[4] = dbl2{0.0, 0.0}; o[5] = dbl2{0.0, 0.0}; o[6] = dbl2{0.0, 0.0};
+            continue;
+        }
+        const SlotQ q = r == 0 ? q0 : load_slot(sl);
+        const bool idl = q.li == 0;
+        const double p1 = q.obs ? S[q.node] : 0.0;
+        o[0] = idl ? dbl2{1.0, 0.0} : q.l[0];
+        o[1] = idl ? dbl2{0.0, 1.0} : q.l[1];
+        o[2] = idl ? dbl2{0.0, 0.0} : q.l[2] * rc2;
+        o[3] = dbl2{idl ? 0.0 : q.l[3].x * rc2, q.obs ? p1 + q.aj : 0.0};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[4 + d] = dbl2{q.obs ? S[(1 + d) * M + q.node] + (p1 * (q.y[d] - q.y0[d]) + q.ay[d]) : 0.0, 0.0};
+    }
+    __syncthreads();
+    CSTAMP(3);
+
+    // ---- 3. the chain (wave 0): lanes 0..31 direction A, 32..63 direction B; lane & 31 < 3 = coordinate for the means
+    if (wv == 0) {
+        const int dir = lane >> 5, hl = lane & 31;
+        const bool wr = hl < 3;
+        // LDS addresses (bytes from the slot area): ra = the direction's current slot (the same in every lane of a half);
+        // la = the lane's own cells: slot + 16 hl for the three coordinate lanes, else the lane's dump area (stride 0);
+        // qa = the posterior's cells for lane 0 of the half, else the dump area
+        char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
+        constexpr int SB = kSlot * 8;
+        char *ra = sb + (size_t)SB * dir * nB;
+        char *la = wr ? ra + 16 * hl : db;
+        char *qa = hl == 0 ? ra : db;
+        const int lstep = wr ? SB : 0, qstep = hl == 0 ? SB : 0;
+        double m0 = 0.0, m1 = 0.0, a = pinf0 * rc2, b = 0.0, d = pinf1 * rc2;
+        struct Rec { dbl2 r0, r1, r2, r3; double bb; };
+        auto fetch = [&](int ahead) __attribute__((always_inline)) {       // operands of the step `ahead` slots further on
+            Rec r;
+            const char *rp = ra + SB * ahead, *lp = la + lstep * ahead;
+            r.r0 = *(const dbl2 *)(rp); r.r1 = *(const dbl2 *)(rp + 16); r.r2 = *(const dbl2 *)(rp + 32); r.r3 = *(const dbl2 *)(rp + 48);
+            r.bb = *(const double *)(lp + 64);
+            return r;
+        };
+        auto step = [&](const Rec &r, int at) __attribute__((always_inline)) {   // one step on the slot `at` slots further on
+            const double f11 = r.r0.x, f12 = r.r0.y, f21 = r.r1.x, f22 = r.r1.y, q11 = r.r2.x, q12 = r.r2.y, q22 = r.r3.x, p = r.r3.y;
+            // predict: m^- = Phi m,  P^- = Phi P Phi^T + Q / c
+            const double pm0 = fma(f12, m1, f11 * m0), pm1 = fma(f22, m1, f21 * m0);
+            const double t1 = fma(f12, b, f11 * a), t2 = fma(f12, d, f11 * b);
+            const double t3 = fma(f22, b, f21 * a), t4 = fma(f22, d, f21 * b);
+            const double pa = fma(t2, f12, fma(t1, f11, q11));
+            const double pb = fma(t2, f22, fma(t1, f21, q12));
+            const double pd = fma(t4, f22, fma(t3, f21, q22));
+            // update with observation precision p: gain K = P^- e1 / (1 + p P^-_11) = (a, b) of the posterior
+            const double g = fast_rcp(fma(p, pa, 1.0));
+            const double npb = -(p * pb), innov = fma(-p, pm0, r.bb);
+            a = pa * g; b = pb * g; d = fma(npb, b, pd);
+            m0 = fma(a, innov, pm0); m1 = fma(b, innov, pm1);
+            *(dbl2 *)(la + lstep * at + 112) = dbl2{m0, m1};
+            *(dbl2 *)(qa + qstep * at + 160) = dbl2{a, b};
+            *(dbl2 *)(qa + qstep * at + 176) = dbl2{d, g};
+        };
+        // four steps per trip on four register sets: every operand is requested two steps (>= one LDS latency) before its use and
+        // nothing is copied; the slots behind a direction's last one are readable (look-ahead slots / the other direction)
+        int k = 0;
+        if (nB >= 4) {
+            Rec rA = fetch(0), rB = fetch(1);
+            for (; k + 3 < nB; k += 4) {
+                const Rec rC = fetch(2), rD = fetch(3);
+                step(rA, 0); step(rB, 1);
+                rA = fetch(4); rB = fetch(5);
+                step(rC, 2); step(rD, 3);
+                ra += 4 * SB; la += 4 * lstep; qa += 4 * qstep;
+            }
+        }
+        for (; k < nB; ++k) {
+            const Rec r = fetch(0);
+            step(r, 0);
+            ra += SB; la += lstep; qa += qstep;
+        }
+    }
+    __syncthreads();
+    CSTAMP(4);
+    // ---- 4. thread = step slot: smoother gain C_k = P_k Phi'^T (Phi' P_k Phi'^T + Q')^-1 with the link of step k + 1 (the next
+    //         slot's record), and e_k = m_k - C_k Phi' m_k, so that the backward step is x_k = e_k + C_k x_{k+1}
+    for (int sl = t; sl < nSl; sl += MB) {
+        const int k = sl >= nB ? sl - nB : sl;
+        if (k < nB - 1) {
+            double *o = slots + (size_t)kSlot * sl;
+            const dbl2 *np = (const dbl2 *)(o + kSlot);
+            const double h11 = np[0].x, h12 = np[0].y, h21 = np[1].x, h22 = np[1].y, q11 = np[2].x, q12 = np[2].y, q22 = np[3].x;
+            const dbl2 ab = *(const dbl2 *)(o + 20);
+            const double a = ab.x, b = ab.y, d = o[22];
+            const double t1 = fma(h12, b, h11 * a), t2 = fma(h12, d, h11 * b);       // (P Phi^T) column 1 = (t1, t2)
+            const double t3 = fma(h22, b, h21 * a), t4 = fma(h22, d, h21 * b);       // (P Phi^T) column 2 = (t3, t4)
+            const double pa = fma(t2, h12, fma(t1, h11, q11)), pb = fma(t2, h22, fma(t1, h21, q12)), pd = fma(t4, h22, fma(t3, h21, q22));
+            const double rdet = fast_rcp(fma(pa, pd, -(pb * pb)));
+            const double ia = pd * rdet, ib = -pb * rdet, id = pa * rdet;
+            const double C11 = fma(t1, ia, t3 * ib), C12 = fma(t1, ib, t3 * id), C21 = fma(t2, ia, t4 * ib), C22 = fma(t2, ib, t4 * id);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                dbl2 *mp = (dbl2 *)(o + 14 + 2 * q);
+                const dbl2 mm = *mp;
+                const double pm0 = fma(h12, mm.y, h11 * mm.x), pm1 = fma(h22, mm.y, h21 * mm.x);
+                *mp = dbl2{mm.x - fma(C11, pm0, C12 * pm1), mm.y - fma(C21, pm0, C22 * pm1)};
+            }
+            *(dbl2 *)(o + 24) = dbl2{C11, C12};
+            *(dbl2 *)(o + 26) = dbl2{C21, C22};
+        }
+    }
+    __syncthreads();
+    CSTAMP(5);
+    if (wv == 0) {
+        const int dir = lane >> 5, hl = lane & 31;
+        const bool wr = hl < 3;
+        constexpr int SB = kSlot * 8;
+        char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
+        // fuse at the junction (both directions' last slot): posterior of A (data of nodes 0 .. j) and prediction of B (data of nodes
+        // j+1 .. M-1), the prior counted once; every lane forms the fused state of its coordinate, in A's frame (f, f'): B's f' has the
+        // opposite sign
+        double xs0, xs1;
+        {
+            const int dd = wr ? hl : 2;
+            const double *sA = slots + (size_t)kSlot * (nB - 1), *sB = slots + (size_t)kSlot * (2 * nB - 1);
+            const dbl2 mA = *(const dbl2 *)(sA + 14 + 2 * dd), mB = *(const dbl2 *)(sB + 14 + 2 * dd);
+            const dbl2 abA = *(const dbl2 *)(sA + 20), abB = *(const dbl2 *)(sB + 20);
+            const double Aa = abA.x, Ab = abA.y, Ad = sA[22], Ba = abB.x, Bb = -abB.y, Bd = sB[22];
+            const double rA = fast_rcp(fma(Aa, Ad, -(Ab * Ab))), rB = fast_rcp(fma(Ba, Bd, -(Bb * Bb)));
+            const double ia = Ad * rA, ib = -Ab * rA, id = Aa * rA, ja = Bd * rB, jb = -Bb * rB, jd = Ba * rB;
+            const double Bm1 = -mB.y;
+            const double e0 = fma(ia, mA.x, ib * mA.y) + fma(ja, mB.x, jb * Bm1);
+            const double e1 = fma(ib, mA.x, id * mA.y) + fma(jb, mB.x, jd * Bm1);
+            const double La = ia + ja - c2 / pinf0, Lb = ib + jb, Ld = id + jd - c2 / pinf1;
+            const double rL = fast_rcp(fma(La, Ld, -(Lb * Lb)));
+            xs0 = (Ld * e0 - Lb * e1) * rL; xs1 = (La * e1 - Lb * e0) * rL;
+            if (dir) xs1 = -xs1;
+        }
+        // backward: both halves walk from the junction to their end of the chain; the smoothed state replaces e_k
+        char *ra = sb + (size_t)SB * (dir * nB + nB - 1);
+        char *la = wr ? ra + 16 * hl : db;
+        const int lstep = wr ? SB : 0;
+        *(dbl2 *)(la + 112) = dbl2{xs0, xs1};
+        ra -= SB; la -= lstep;
+        struct BRec { dbl2 e, C0, C1; };
+        auto bfetch = [&](int back) __attribute__((always_inline)) {       // operands of the step `back` slots towards the chain's end
+            BRec r;                                                        // (the slots in front of a direction's first one are readable)
+            r.e = *(const dbl2 *)(la - lstep * back + 112); r.C0 = *(const dbl2 *)(ra - SB * back + 192); r.C1 = *(const dbl2 *)(ra - SB * back + 208);
+            return r;
+        };
+        auto bstep = [&](const BRec &r, int back) __attribute__((always_inline)) {
+            const double y0 = fma(r.C0.x, xs0, fma(r.C0.y, xs1, r.e.x));
+            const double y1 = fma(r.C1.x, xs0, fma(r.C1.y, xs1, r.e.y));
+            xs0 = y0; xs1 = y1;
+            *(dbl2 *)(la - lstep * back + 112) = dbl2{xs0, xs1};
+        };
+        int k = nB - 2;                                                   // steps k, k-1, ..., 0
+        if (k >= 3) {
+            BRec bA = bfetch(0), bB = bfetch(1);
+            for (; k >= 3; k -= 4) {
+                const BRec bC = bfetch(2), bD = bfetch(3);
+                bstep(bA, 0); bstep(bB, 1);
+                bA = bfetch(4); bB = bfetch(5);
+                bstep(bC, 2); bstep(bD, 3);
+                ra -= 4 * SB; la -= 4 * lstep;
+            }
+        }
+        for (; k >= 0; --k) {
+            const BRec r = bfetch(0);
+            bstep(r, 0);
+            ra -= SB; la -= lstep;
+        }
+    }
+    __syncthreads();
+    CSTAMP(6);
+
+    // ---- 5. T = Y0 + V, sigma2 (residual form of :418-422) and the convergence criterion (:424); publish Y and the nodes.  thread = step slot
+    V4<T> *nodes_w = (V4<T> *)f.nodes;
+    double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
+    for (int sl = t, r = 0; sl < nSl; sl += MB, ++r) {
+        const SlotQ q = r == 0 ? q0 : load_slot(sl);
+        if (!q.obs) continue;
+        const int m = q.node;
+        const double *o = slots + (size_t)kSlot * sl;
+        const double p1 = S[m];
+        double Td[3], cr2 = 0, dr = 0, pd2 = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            Td[d] = q.y0[d] + o[14 + 2 * d];
+            const double del = Td[d] - q.y[d], ex = q.yp[d] - Td[d];
+            dr = fma(del, S[(1 + d) * M + m], dr); pd2 = fma(del, del, pd2); cr2 = fma(ex, ex, cr2);
+        }
+        s_np += p1; s_dr += dr; s_pd += p1 * pd2; s_cr += ::sqrt(cr2);
+        V4<T> w; w.x = (T)Td[0]; w.y = (T)Td[1]; w.z = (T)Td[2]; w.w = (T)q.w;      // .w = chain coordinate, unchanged
+        nodes_w[m] = w;
+        f.dminbits[m] = ~0ull;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { f.Y[d * M + m] = Td[d]; f.Yout[d * M + m] = Td[d] + (d == 0 ? ctr0 : (d == 1 ? ctr1 : ctr2)); }
+    }
+    if (wv * 64 < nSl) {                               // waves without slots contribute nothing (uniform per wave)
+        s_np = wave_sum(s_np); s_dr = wave_sum(s_dr); s_pd = wave_sum(s_pd); s_cr = wave_sum(s_cr);
+    }
+    if (lane == 0) { red[4 * wv] = s_np; red[4 * wv + 1] = s_dr; red[4 * wv + 2] = s_pd; red[4 * wv + 3] = s_cr; }
+    __syncthreads();
+    CSTAMP(7);
+    if (t == 0) {
+        const double t_np = ((red[0] + red[4]) + red[8]) + red[12], t_dr = ((red[1] + red[5]) + red[9]) + red[13];
+        const double t_pd = ((red[2] + red[6]) + red[10]) + red[14], t_cr = ((red[3] + red[7]) + red[11]) + red[15];
+        const double new_sigma2 = (S[4 * M] - 2.0 * t_dr + t_pd) / (t_np * 3.0);
+        const double crit = t_cr / (double)M;
+        const int it = stg->it + 1;
+        st->it = it; st->crit = crit; st->Np = t_np;
+        const double Nc = stg->Nc;
+        const bool finite_ok = (new_sigma2 == new_sigma2) && (fabs(new_sigma2) < 1e300) && (new_sigma2 > 0) && (crit == crit);
+        if (finite_ok) set_iter_consts(f, st, new_sigma2, Nc);
+        else { st->sigma2 = new_sigma2; st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
+        if (crit < f.tol) st->done = 1;                                   // :424-428
+        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+    }
+#undef CSTAMP
+}
+
+static size_t mstep_chain_lds_bytes(int M, bool f64) {
+    const ChainCarve cv(M, f64 ? 2 : 4, f64 ? part_stride<double>(M) : part_stride<float>(M));
+    return cv.total * sizeof(double);
+}
+
+template <typename K> static hipError_t set_lds_c(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+
+template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
+    const size_t lds = mstep_chain_lds_bytes(fh[0].M, sizeof(T) == 8);
+    hipError_t e;
+    if (from_sums == 3) {          // one frame (a shard of the split cloud), exchange inside the kernel
+        if (F != 1) return hipErrorInvalidValue;
+        if ((e = set_lds_c(k_mstep_chain<T, true, true>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_mstep_chain<T, true, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
+    } else if (F == 1) {
+        if ((e = set_lds_c(k_mstep_chain<T, true, false>, lds)) != hipSuccess) return e;
+        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
+        else hipLaunchKernelGGL((k_mstep_chain<T, true, false>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
+    } else {
+        if ((e = set_lds_c(k_mstep_chain<T, false, false>, lds)) != hipSuccess) return e;
+        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, false, false>), dim3(F), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
+        else hipLaunchKernelGGL((k_mstep_chain<T, false, false>), dim3(F), dim3(kCB), lds, s, fd, fh[0], from_sums);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mstep_chain(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, bool f64, hipStream_t s) {
+    return f64 ? launch_mstep_chain_T<double>(fd, fh, F, from_sums, s) : launch_mstep_chain_T<float>(fd, fh, F, from_sums, s);
+}
+
+// Which M-step serves registrations without the LLE term: 0 the chain smoother (default), 1 the dense eliminations
+// (k_mstep_fast<MFMA> / k_mstep_mcu), kept as comparators.  Process-wide; initial value from TDLO_MSTEP=dense.
+static std::atomic<int> g_mstep_dense{[] { const char *e = getenv("TDLO_MSTEP"); return (e && e[0] == 'd') ? 1 : 0; }()};
+bool mstep_chain_enabled() { return g_mstep_dense.load(std::memory_order_relaxed) == 0; }
+int mstep_set_dense(int on) { return g_mstep_dense.exchange(on ? 1 : 0); }
+
+}  // namespace tdlo
