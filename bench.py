@@ -185,18 +185,16 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
         est["avg_launch_us_back_to_back"] = round(est_b2b_us, 3)
     objs = [est]
     if mst_us is not None and mstep_name == "k_mstep_chain":
-        # the chain smoother: O(M) work on ONE wave; what it reads is the E-step's block partial rows (or their 32 group sums), the
-        # links and the node block -- bytes and flops are both negligible against any roofline: the kernel is a dependent recursion
-        eb = 512 if (esize == 4 and M <= 64) else 256
-        rows = -(-(-(-N // 64)) // (eb // 64))
-        rows = 32 if rows > 256 else rows
-        m_bytes = (rows * (4 * M + 1) * esize + (M + 1) * 64 + M * (4 * esize + 10 * 8)) * F
+        # the chain smoother: O(M) work on ONE wave; what it reads is the E-step's sums (2 parities x 8 replica rows of 64-bit fixed-point
+        # accumulators), the links and the node block -- bytes and flops are both negligible against any roofline: the kernel is a
+        # dependent recursion
+        m_bytes = (2 * 8 * (4 * M + 2) * 8 + (M + 1) * 64 + M * (4 * esize + 10 * 8)) * F
         c_flops = (2 * (31 + 14) + 60) * M * F                  # filter step + backward step per node (both directions share the chain), gain pass
         bwm = m_bytes / (mst_us * 1e-6) / 1e9
         objs.append(dict(bound="hbm", kernel=mstep_name, achieved=round(bwm, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(bwm / HBM_PEAK_GBS, 7), traffic=None,
                          avg_launch_us=round(mst_us, 3), algorithmic_bytes_per_launch=m_bytes, algorithmic_flops_per_launch=c_flops,
                          note="one workgroup per frame; the solve is a Kalman filter / RTS smoother along the chain (M/2 dependent 2 x 2 steps from both ends "
-                              "on one wave, ~8 cycles per instruction), preceded by the fetch of the block partial rows through one CU: latency-bound, "
+                              "on one wave, ~8 cycles per instruction), preceded by one memory round trip for the sums: latency-bound, "
                               "neither bytes nor flops are near a roofline"))
     elif mst_us is not None:
         tf = m_flops / (mst_us * 1e-6) / 1e12

@@ -104,11 +104,44 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
-// partial rows written by the E-step have an even stride so that the M-step can fetch them 16 bytes at a time
-// (fp32 mode: fp32 partials, stride a multiple of 4 floats; fp64 mode: fp64 partials, even stride)
-// block partial element type for compute precision T
-template <typename T> struct PartOf { typedef T type; };     // fp32 mode: fp32 partials (half the M-step's load); fp64 mode: fp64
-template <typename PT> __host__ __device__ inline int part_stride(int M) { return sizeof(PT) == 4 ? ((4 * M + 1 + 3) & ~3) : (4 * M + 2); }
+// ---- the E-step's sums [P1 | Rx | Ry | Rz | Q] (trackdlo.cpp:386-389 in residual form) as 64-bit fixed-point accumulators ----------------
+// Every E-step workgroup adds its share with integer atomics into one of kAccRows replica rows; integer addition is associative, so
+// the sums do not depend on the order in which the workgroups arrive (batches, repetitions and shards reproduce bit for bit), and the
+// M-step fetches kAccRows short rows instead of one row per workgroup (98 rows = 80 KB through one CU took 3 us at N = 50 000;
+// 512 rows needed a reduction kernel of their own).  Resolution 2^-sh: sh is chosen per quantity from the cloud size and the
+// extent of the scene so that the total stays below 2^62 (prepare_frame); at N = 50 000 that is 1e-14 on P1 ~ 1000 -- finer than the fp32
+// rows it replaces by eight decimal digits, and at the level of fp64 rounding.
+__host__ __device__ inline int acc_stride(int M) { return 4 * M + 2; }
+__device__ __forceinline__ int acc_shift(const FrameDev &f, int i) { const int M = f.M; return i < M ? f.acc_sh[0] : (i < 4 * M ? f.acc_sh[1] : f.acc_sh[2]); }
+__device__ __forceinline__ void acc_add(long long *row, int i, double v, int sh) {
+    if (v != 0.0) __hip_atomic_fetch_add(row + i, __double2ll_rn(::ldexp(v, sh)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exact zeros (nodes outside the window) add nothing
+}
+__device__ __forceinline__ const long long *acc_rows(const FrameDev &f, int it) { return f.acc + (size_t)(it & 1) * kAccRows * acc_stride(f.M); }
+// element i of the sums of iteration `it`: the replica rows are added as integers (exact), one conversion
+__device__ __forceinline__ double acc_read(const FrameDev &f, const long long *rows, int i) {
+    const auto a = TDLO_AS_GLOBAL(long long, rows);
+    const int st = acc_stride(f.M);
+    long long s = 0;
+#pragma unroll
+    for (int r = 0; r < kAccRows; ++r) s += a[(size_t)r * st + i];
+    return ::ldexp((double)s, -acc_shift(f, i));
+}
+// the same without a load that depends on the iteration counter (both parities are fetched, one is kept): for the one-workgroup M-steps,
+// whose first memory round trip is on the critical path of every iteration
+__device__ __forceinline__ double acc_read_both(const FrameDev &f, int i, int it) {
+    const auto a = TDLO_AS_GLOBAL(long long, f.acc);
+    const int st = acc_stride(f.M);
+    long long s0 = 0, s1 = 0;
+#pragma unroll
+    for (int r = 0; r < kAccRows; ++r) { s0 += a[(size_t)r * st + i]; s1 += a[(size_t)(kAccRows + r) * st + i]; }
+    return ::ldexp((double)((it & 1) ? s1 : s0), -acc_shift(f, i));
+}
+// the rows of the other parity are cleared for the next E-step (nobody touches them while an M-step runs)
+template <int NT> __device__ __forceinline__ void acc_clear_other(const FrameDev &f, int it, int t) {
+    long long *z = f.acc + (size_t)((it + 1) & 1) * kAccRows * acc_stride(f.M);
+    const int n = kAccRows * acc_stride(f.M);
+    for (int i = t; i < n; i += NT) z[i] = 0;
+}
 
 __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
     // c of trackdlo.cpp:300 (or c' of :378 when visibility weighting is active)

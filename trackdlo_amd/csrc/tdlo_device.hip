@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         f.coord[m] = sc[m];
         f.dminbits[m] = ~0ull;
     }
+    for (int i = t; i < 2 * kAccRows * acc_stride(M); i += kBlock) f.acc[i] = 0;      // the E-step's accumulators, both parities
     const double beta = f.beta;
     // state-space form of G for the chain smoother (tdlo_mstep_chain.hip): one link per pair of consecutive nodes
     for (int i = t; i < M; i += kBlock) {
@@ -811,8 +812,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     __syncthreads();
     ESTAMP(6);
-    typedef typename PartOf<T>::type PT;
-    PT *part = (PT *)f.part + (size_t)blockIdx.x * part_stride<PT>(M);
+    // into the fixed-point accumulators of this iteration's parity, replica row = workgroup % kAccRows (integer atomics: the order in
+    // which the workgroups arrive does not matter)
+    long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (blockIdx.x % kAccRows)) * acc_stride(M);
+    const int shP = f.acc_sh[0], shR = f.acc_sh[1];
     if (NCH == 1) {
         const double *accAll = scratch + 16;
         for (int i = tid; i < 4 * M; i += EB) {
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             double v = 0;
 #pragma unroll
             for (int w = 0; w < NWE; ++w) v += accAll[(size_t)w * M * 4 + i];
-            part[k * M + m] = (PT)v;
+            acc_add(arow, k * M + m, v, k == 0 ? shP : shR);
         }
     } else {
     double *red = (double *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 double v = 0;
 #pragma unroll
                 for (int w = 0; w < NWE; ++w) v += red[(w * 64 + l) * 4 + k];
-                part[k * M + m] = (PT)v;
+                acc_add(arow, k * M + m, v, k == 0 ? shP : shR);
             }
         }
         __syncthreads();
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         double q = 0;
 #pragma unroll
         for (int w = 0; w < NWE; ++w) q += scratch[w];
-        part[4 * M] = (PT)q;
+        acc_add(arow, 4 * M, q, f.acc_sh[2]);
     }
     ESTAMP(7);
 #ifdef TDLO_ESTEP_STAMPS
@@ -905,9 +908,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     const int slot = __builtin_amdgcn_readfirstlane(t >> 6);      // wave index, wave-uniform
     const int row = lane;
     const bool rowok = row < M;
-    typedef typename PartOf<T>::type PT;
-    constexpr int VEC = 16 / (int)sizeof(PT);         // partial elements per 16-byte load
-    const int nS = 4 * M + 1, nSp = part_stride<PT>(M), npair = nSp / VEC;
+    const int nS = 4 * M + 1, nSp = (nS + 1) & ~1;
     const int ncol = M + 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *S = (double *)smem;                       // nSp
@@ -918,8 +919,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     double *tmp = colb + 2 * 8 * 64;                  // 12 x 64: G W slices
     double *aux = tmp + 12 * 64;                      // 7 x 64: node - Y0 (3), alpha (Y_ext - Y0) (3), alpha J (1)
     double *Gs = aux + 7 * 64;                        // M x M (column-major, ld = M)
-    double *Sg = Gs + (((size_t)M * M + 1) & ~(size_t)1);   // NG x nSp partial-sum groups
-    double *Ut = Sg + (size_t)(MB / npair) * nSp;            // (M + 3) x 64: the eliminated tableau for the back substitution (pivoted variant only)
+    double *Ut = Gs + (((size_t)M * M + 1) & ~(size_t)1);    // (M + 3) x 64: the eliminated tableau for the back substitution (pivoted variant only)
 
 #define TDLO_STAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     TDLO_STAMP(0);
@@ -948,34 +948,17 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         }
     }
     const double ctr0 = f.ctr[0], ctr1 = f.ctr[1], ctr2 = f.ctr[2];
-    // ---- 1. everything that comes from memory is requested up front: block partials (16 B per load,
-    //         NG thread groups striding over the blocks, fixed summation order), G
-    typedef PT pvec __attribute__((ext_vector_type(VEC)));
-    const int NG = MB / npair;                        // >= 1 for M <= 64
-    const int pe = t % npair, g = t / npair;
-    double acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
-    constexpr int GQ = (64 * 64 + MB - 1) / MB;       // G (M <= 64) goes through registers: requested before the partials
+    // ---- 1. everything that comes from memory is requested up front: the E-step's sums (kAccRows replica rows of fixed-point
+    //         accumulators, both iteration parities so that no load waits for the iteration counter), G
+    constexpr int GQ = (64 * 64 + MB - 1) / MB;       // G (M <= 64) goes through registers
     double gq[GQ];
 #pragma unroll
     for (int u = 0; u < GQ; ++u) { const int i = t + u * MB; gq[u] = i < M * M ? Gg[i] : 0.0; }
-    if (from_sums != 1 && g < NG) {
-        const auto part = TDLO_AS_GLOBAL(pvec, f.partM);
-        const int nb = f.nblkM;
-        constexpr int UL = 20;                        // loads in flight per thread; no scalar remainder loop (a
-        for (int b = g; b < nb; b += UL * NG) {       // dependent load per trip costs a full memory latency each)
-            pvec v[UL];
-#pragma unroll
-            for (int u = 0; u < UL; ++u) { const int bb = b + u * NG; v[u] = part[(size_t)(bb < nb ? bb : nb - 1) * npair + pe]; }
-#pragma unroll
-            for (int u = 0; u < UL; ++u) {
-                if (b + u * NG < nb) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] += (double)v[u][i];
-                }
-            }
-        }
+    const int itn = stg->it;
+    double sq0 = 0, sq1 = 0;
+    if (from_sums != 1) {
+        if (t < nS) sq0 = acc_read_both(f, t, itn);
+        if (t + MB < nS) sq1 = acc_read_both(f, t + MB, itn);
     }
     if (slot < 4) f.dbg[8 + slot] = __builtin_amdgcn_s_memtime();
 #pragma unroll
@@ -985,16 +968,11 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         aux[row] = (double)nq.x - y0q[0]; aux[64 + row] = (double)nq.y - y0q[1]; aux[128 + row] = (double)nq.z - y0q[2];
         aux[192 + row] = ayq[0]; aux[256 + row] = ayq[1]; aux[320 + row] = ayq[2]; aux[384 + row] = ajq;
     }
-    if (from_sums != 1) {
-        if (g < NG) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) Sg[g * nSp + VEC * pe + i] = acc[i];
-        }
-    }
     TDLO_STAMP(1);
-    __syncthreads();
     if (from_sums != 1) {
-        for (int i = t; i < nS; i += MB) { double a = 0; for (int q = 0; q < NG; ++q) a += Sg[q * nSp + i]; S[i] = a; }
+        if (t < nS) S[t] = sq0;
+        if (t + MB < nS) S[t + MB] = sq1;
+        acc_clear_other<MB>(f, itn, t);
     } else {
         const auto sums = TDLO_AS_GLOBAL(double, f.sums);
         for (int i = t; i < nS; i += MB) S[i] = sums[i];
@@ -1492,11 +1470,10 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
 }
 
 template <typename T> static size_t mstep_fast_lds_bytes(int M, int NW, bool pivoted) {
-    typedef typename PartOf<T>::type PT;
-    const int VEC = 16 / (int)sizeof(PT);
-    const int nSp = part_stride<PT>(M), npair = nSp / VEC, NG = (NW * 64) / npair;
-    size_t d = (size_t)((nSp + 1) & ~1) + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 12 * 64 + 7 * 64 + (((size_t)M * M + 1) & ~(size_t)1) + (size_t)NG * nSp;
+    const int nSp = (4 * M + 2) & ~1;
+    size_t d = (size_t)nSp + 2 * (size_t)((3 * M + 1) & ~1) + 8 + 2 * 8 * 64 + 12 * 64 + 7 * 64 + (((size_t)M * M + 1) & ~(size_t)1);
     if (pivoted) d += (size_t)(M + 3) * 64;
+    (void)NW;
     return d * sizeof(double);
 }
 
@@ -1562,46 +1539,10 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     return hipGetLastError();
 }
 
-// Large clouds (more than kPartDirect E-step workgroups): the block partials are first summed in kPartGroups groups of
-// consecutive blocks, spread over kPartGroups CUs, so that the single-workgroup M-step fetches 32 rows instead of 512
-// (400 KB through one CU took 25 us).  Fixed order inside a group, fp64 accumulation, one rounding to the partial type.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_part_reduce(const FrameDev *__restrict__ frames) {
-    const FrameDev &f = frames[blockIdx.y];
-    if (f.nblkE <= kPartDirect || f.st->done) return;
-    typedef typename PartOf<T>::type PT;
-    const int M = f.M, nS = 4 * M + 1, nSp = part_stride<PT>(M), nb = f.nblkE;
-    const int per = (nb + kPartGroups - 1) / kPartGroups;
-    const int b0 = blockIdx.x * per, b1 = (b0 + per) < nb ? (b0 + per) : nb;
-    const auto src = TDLO_AS_GLOBAL(PT, f.part);
-    PT *dst = (PT *)f.partM + (size_t)blockIdx.x * nSp;
-    for (int e = threadIdx.x; e < nS; e += kBlock) {
-        double a = 0;
-        for (int b = b0; b < b1; b += 16) {
-            PT v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { const int bb = (b + u) < b1 ? (b + u) : (b1 - 1); v[u] = src[(size_t)bb * nSp + e]; }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) if (b + u < b1) a += (double)v[u];
-        }
-        dst[e] = (PT)a;                  // an empty group (b0 >= nb) writes zeros
-    }
-}
-
-static hipError_t launch_part_reduce(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
-    bool any = false;
-    for (int i = 0; i < F; ++i) any = any || fh[i].nblkE > kPartDirect;
-    if (!any) return hipSuccess;
-    if (fh[0].precision == TDLO_PREC_F64) hipLaunchKernelGGL((k_part_reduce<double>), dim3(kPartGroups, F), dim3(kBlock), 0, s, fd);
-    else hipLaunchKernelGGL((k_part_reduce<float>), dim3(kPartGroups, F), dim3(kBlock), 0, s, fd);
-    return hipGetLastError();
-}
-
 hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     if (fh[0].vis_branch) TDLO_TRY(f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s));
-    TDLO_TRY(launch_part_reduce(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s));
     return hipSuccess;
 }
@@ -1636,10 +1577,10 @@ hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int 
     switch (kind) {
         case 0: return f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s);
         case 1: return f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s);
-        case 2: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s);
-        case 3: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 2, s) : launch_mstep_T<float>(fd, fh, F, 2, s);
+        case 2: return f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s);
+        case 3: return f64 ? launch_mstep_T<double>(fd, fh, F, 2, s) : launch_mstep_T<float>(fd, fh, F, 2, s);
         case 4: return f64 ? launch_mstep_T<double>(fd, fh, F, 1, s) : launch_mstep_T<float>(fd, fh, F, 1, s);
-        case 5: TDLO_TRY(launch_part_reduce(fd, fh, F, s)); return f64 ? launch_mstep_T<double>(fd, fh, F, 3, s) : launch_mstep_T<float>(fd, fh, F, 3, s);   // M-step with the one-shot exchange inside
+        case 5: return f64 ? launch_mstep_T<double>(fd, fh, F, 3, s) : launch_mstep_T<float>(fd, fh, F, 3, s);   // M-step with the one-shot exchange inside
         default: return hipErrorInvalidValue;
     }
 }

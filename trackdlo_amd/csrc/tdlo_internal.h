@@ -10,8 +10,7 @@ constexpr int kWave = 64;
 constexpr int kChunk = 64;           // nodes handled per lane-transposed tile
 constexpr int kPStride = 65;         // LDS row stride of the 64 x 64 transposition tile (conflict-free)
 constexpr int kPtsStride = 68;       // E-step: a wave's 64 normalised points in LDS, one entry of padding after every 16
-constexpr int kPartDirect = 256;    // up to this many block partials go straight to the M-step (80 KB of fp32 at M = 50) ...
-constexpr int kPartGroups = 32;     // ... more are first summed in this many groups of consecutive blocks by k_part_reduce
+constexpr int kAccRows = 8;          // replica rows of the E-step's fixed-point accumulators (workgroup b adds to row b % 8: spreads the atomics)
 constexpr int kTileRows = 24;        // rows of the E-step's transposition tile when M <= 64: the node window is processed
                                      // in chunks of this many nodes (6 KB of LDS per wave -> two workgroups per CU)
 constexpr int kMaxNodes = 512;       // E-step template covers ceil(M/64) in {1,2,4,8}
@@ -64,10 +63,11 @@ struct FrameDev {
     const double *aJ;       // M: alpha * J_mm (:240-260, :406)
     const double *aYd;      // M x 3: alpha * (Y_extended - Y0) (:407)
     unsigned long long *dminbits;  // M: per-node min squared distance, as ordered bits
-    double *part;           // nblkE x (4M+1) block partials [P1 | PXx | PXy | PXz | Q]
-    double *partM;          // the rows the M-step adds up: part itself, or the kPartGroups group sums behind it (nblkE > kPartDirect)
+    long long *acc;         // [2 (iteration parity)][kAccRows][4M+2]: the E-step's sums [P1 | Rx | Ry | Rz | Q] in 64-bit fixed point, added with
+                            // integer atomics (order-independent, i.e. reproducible); the M-step of iteration `it` reads parity it & 1 and zeroes the other
+    int acc_sh[3];          // binary exponents of the fixed point: value = integer * 2^-sh for P1 / R / Q
     int force_timeout_it;   // test hook (environment TDLO_MCU_FORCE_TIMEOUT=k): iteration k of the multi-CU M-steps behaves as if a hand-off timed out; -1 = off
-    int nblkM, prune_tiles; // number of those rows; 256-point tiles one prune workgroup handles (1 up to 262 144 points)
+    int prune_tiles;        // 256-point tiles one prune workgroup handles (1 up to 262 144 points)
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result

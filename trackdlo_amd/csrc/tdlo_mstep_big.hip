@@ -74,22 +74,12 @@ __device__ __forceinline__ void mstep_big_body(const FrameDev &f, const int from
 
 #define BSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     BSTAMP(0);
-    // ---- 1. reduce the E-step block partials in a fixed order
+    // ---- 1. the E-step's sums (fixed-point accumulators, kAccRows replica rows)
     if (from_sums != 1) {
-        typedef typename PartOf<T>::type PT;
-        const int nb = f.nblkM, nSp = part_stride<PT>(M);
-        const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
-        for (int e = t; e < nS; e += kBig) {
-            double a0 = 0;
-            for (int b = 0; b < nb; b += 32) {            // 32 loads in flight, block order kept
-                PT v[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) { const int bb = b + u < nb ? b + u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
-#pragma unroll
-                for (int u = 0; u < 32; ++u) if (b + u < nb) a0 += (double)v[u];
-            }
-            S[e] = a0;
-        }
+        const int itn = st->it;
+        const long long *rows = acc_rows(f, itn);
+        for (int e = t; e < nS; e += kBig) S[e] = acc_read(f, rows, e);
+        acc_clear_other<kBig>(f, itn, t);
     } else {
         for (int e = t; e < nS; e += kBig) S[e] = f.sums[e];
     }
@@ -379,32 +369,16 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
         const int e = kk * M + (valid ? irow : 0);
         auto sums_g = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.sums;
         if (from_sums != 1) {
-            typedef typename PartOf<T>::type PT;
-            const int nb = f.nblkM, nSp = part_stride<PT>(M);
-            const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
-            double a0 = 0;
-            for (int b = w; b < nb; b += 256) {
-                PT v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) { const int bb = b + 16 * u < nb ? b + 16 * u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) if (b + 16 * u < nb) a0 += (double)v[u];
-            }
-            double *red = Ul;
-            red[w * 64 + lane] = a0;
-            __syncthreads();
+            const int itn = st->it;
+            const long long *rows = acc_rows(f, itn);
             if (w == 0) {
-                double a = 0;
-#pragma unroll
-                for (int g = 0; g < 16; ++g) a += red[g * 64 + lane];
-                Sown[lane] = valid ? a : 0.0;
+                const double a = valid ? acc_read(f, rows, e) : 0.0;
+                Sown[lane] = a;
                 if (valid) __hip_atomic_store(sums_g + e, (unsigned long long)__double_as_longlong(a), TDLO_RLX_AGENT);
             }
-            if (rb == 0) {                     // Q = sum P |x - y|^2, only needed for sigma2
-                double q = 0;
-                for (int b = t; b < nb; b += kBig) q += (double)partT[(size_t)b * nSp + 4 * M];
-                q = block_sum16(q, scratch);
-                if (t == 0) __hip_atomic_store(sums_g + 4 * M, (unsigned long long)__double_as_longlong(q), TDLO_RLX_AGENT);
+            if (rb == 0) {                     // Q = sum P |x - y|^2, only needed for sigma2; the other parity's rows are cleared for the next E-step
+                if (t == 0) __hip_atomic_store(sums_g + 4 * M, (unsigned long long)__double_as_longlong(acc_read(f, rows, 4 * M)), TDLO_RLX_AGENT);
+                acc_clear_other<kBig>(f, itn, t);
             }
         } else if (w == 0) Sown[lane] = valid ? f.sums[e] : 0.0;
     }
@@ -737,30 +711,16 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
         const int e = kk * M + (valid ? irow : 0);
         auto sums_g = (__attribute__((address_space(1))) unsigned long long *)(uintptr_t)f.sums;
         if (from_sums != 1) {
-            typedef typename PartOf<T>::type PT;
-            const int nb = f.nblkM, nSp = part_stride<PT>(M);
-            const auto partT = TDLO_AS_GLOBAL(PT, f.partM);
-            double a0 = 0;
-            for (int b = w; b < nb; b += 64) {
-                PT v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) { const int bb = b + 4 * u < nb ? b + 4 * u : nb - 1; v[u] = partT[(size_t)bb * nSp + e]; }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) if (b + 4 * u < nb) a0 += (double)v[u];
-            }
-            double *red = R;
-            red[w * 64 + lane] = a0;
-            __syncthreads();
+            const int itn = st->it;
+            const long long *rows = acc_rows(f, itn);
             if (w == 0) {
-                const double a = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
-                Sown[lane] = valid ? a : 0.0;
+                const double a = valid ? acc_read(f, rows, e) : 0.0;
+                Sown[lane] = a;
                 if (valid) __hip_atomic_store(sums_g + e, (unsigned long long)__double_as_longlong(a), TDLO_RLX_AGENT);
             }
             if (rb == 0) {
-                double q = 0;
-                for (int b = t; b < nb; b += kPT) q += (double)partT[(size_t)b * nSp + 4 * M];
-                q = block_sum(q, scratch);
-                if (t == 0) __hip_atomic_store(sums_g + 4 * M, (unsigned long long)__double_as_longlong(q), TDLO_RLX_AGENT);
+                if (t == 0) __hip_atomic_store(sums_g + 4 * M, (unsigned long long)__double_as_longlong(acc_read(f, rows, 4 * M)), TDLO_RLX_AGENT);
+                acc_clear_other<kPT>(f, itn, t);
             }
         } else if (w == 0) Sown[lane] = valid ? f.sums[e] : 0.0;
     }

@@ -58,20 +58,16 @@ constexpr int kAhead = 6;             // slots behind the last one that the soft
 constexpr int kDump = 32;              // doubles per lane of the dump area (lanes that have nothing to store write there)
 
 struct ChainCarve {
-    int nSp, npair, NG, jn, nA, nB, nSl;
+    int nSp, jn, nA, nB, nSl;
     size_t S, red, dump, slots, total;
-    __host__ __device__ ChainCarve(int M, int vec, int nSp_) {
-        nSp = nSp_; npair = nSp / vec; NG = npair >= kCB ? 1 : kCB / npair;
+    __host__ __device__ explicit ChainCarve(int M) {
+        nSp = 4 * M + 2;
         jn = (M - 1) >> 1; nA = jn + 1; nB = M - jn; nSl = 2 * nB;
         size_t o = 0;
         S = o; o += (size_t)((nSp + 1) & ~1);           // [P1 | Rx | Ry | Rz | Q]
         red = o; o += 32;                               // [0..15] wave sums, [24] exchange flag
         dump = o; o += (size_t)64 * kDump;
-        slots = o;                                      // first: the NG partial-sum groups of the fetch
-        {
-            const size_t a = (size_t)kSlot * (nSl + kAhead), b = (size_t)NG * nSp;      // the loops read up to kAhead slots ahead
-            o += ((a > b ? a : b) + 1) & ~(size_t)1;
-        }
+        slots = o; o += (size_t)kSlot * (nSl + kAhead);  // the loops read up to kAhead slots ahead
         total = o;
     }
 };
@@ -83,14 +79,11 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     IterState *st = f.st;
     const int M = f.M, t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    typedef typename PartOf<T>::type PT;
-    constexpr int VEC = 16 / (int)sizeof(PT);
     const int nS = 4 * M + 1;
-    const ChainCarve cv(M, VEC, part_stride<PT>(M));
-    const int nSp = cv.nSp, npair = cv.npair, NG = cv.NG, nA = cv.nA, nB = cv.nB, nSl = cv.nSl, sh = nB - nA;
+    const ChainCarve cv(M);
+    const int nA = cv.nA, nB = cv.nB, nSl = cv.nSl, sh = nB - nA;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *S = (double *)smem + cv.S, *red = (double *)smem + cv.red, *dump = (double *)smem + cv.dump, *slots = (double *)smem + cv.slots;
-    double *Sg = slots;
 
 #define CSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
     CSTAMP(0);
@@ -131,39 +124,18 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     const SlotQ q0 = load_slot(t);
     const double pinf0 = chg[0].x, pinf1 = chg[0].y;  // sf2, s^2 sf2
     const double c2 = f.lambda * sigma2, rc2 = 1.0 / c2;
-    if (from_sums != 1) {
-        typedef PT pvec __attribute__((ext_vector_type(VEC)));
-        const auto part = TDLO_AS_GLOBAL(pvec, f.partM);
-        const int nb = f.nblkM;
-        constexpr int UL = 20;                        // loads in flight per thread
-        for (int u0 = 0; u0 < npair; u0 += MB) {      // one trip for M <= 255
-            const int pe = u0 + (NG == 1 ? t : t % npair), g = NG == 1 ? 0 : t / npair;
-            if (pe < npair && g < NG) {
-                double acc[VEC];
+    // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
+    // for the iteration counter (M <= 512: at most 9 elements per thread)
+    const int itn = stg->it;
+    double sq[9];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
-                for (int b = g; b < nb; b += UL * NG) {
-                    pvec v[UL];
-#pragma unroll
-                    for (int u = 0; u < UL; ++u) { const int bb = b + u * NG; v[u] = part[(size_t)(bb < nb ? bb : nb - 1) * npair + pe]; }
-#pragma unroll
-                    for (int u = 0; u < UL; ++u) {
-                        if (b + u * NG < nb) {
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) acc[i] += (double)v[u][i];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) Sg[(size_t)g * nSp + VEC * pe + i] = acc[i];
-            }
-        }
-    }
+    for (int u = 0; u < 9; ++u) { const int i = t + u * MB; sq[u] = (from_sums != 1 && i < nS) ? acc_read_both(f, i, itn) : 0.0; }
     if (done) return;
     CSTAMP(1);
-    __syncthreads();
     if (from_sums != 1) {
-        for (int i = t; i < nS; i += MB) { double a = 0; for (int q = 0; q < NG; ++q) a += Sg[(size_t)q * nSp + i]; S[i] = a; }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) { const int i = t + u * MB; if (i < nS) S[i] = sq[u]; }
+        acc_clear_other<MB>(f, itn, t);
     } else {
         const auto sums = TDLO_AS_GLOBAL(double, f.sums);
         for (int i = t; i < nS; i += MB) S[i] = sums[i];
@@ -423,10 +395,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 #undef CSTAMP
 }
 
-static size_t mstep_chain_lds_bytes(int M, bool f64) {
-    const ChainCarve cv(M, f64 ? 2 : 4, f64 ? part_stride<double>(M) : part_stride<float>(M));
-    return cv.total * sizeof(double);
-}
+static size_t mstep_chain_lds_bytes(int M) { return ChainCarve(M).total * sizeof(double); }
 
 template <typename K> static hipError_t set_lds_c(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -434,7 +403,7 @@ template <typename K> static hipError_t set_lds_c(K kernel, size_t bytes) {
 }
 
 template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
-    const size_t lds = mstep_chain_lds_bytes(fh[0].M, sizeof(T) == 8);
+    const size_t lds = mstep_chain_lds_bytes(fh[0].M);
     hipError_t e;
     if (from_sums == 3) {          // one frame (a shard of the split cloud), exchange inside the kernel
         if (F != 1) return hipErrorInvalidValue;

@@ -38,21 +38,12 @@ __device__ __forceinline__ void mstep_generic_body(const FrameDev &f, int from_s
     double *Alds = (double *)(used + ((M + 3) & ~3));
     double *A = LDSA ? Alds : f.Ascr;         // ld x (M+3)
 
-    // ---- 1. reduce the E-step block partials in a fixed order
+    // ---- 1. the E-step's sums (fixed-point accumulators, kAccRows replica rows)
     if (from_sums != 1) {
-        typedef typename PartOf<T>::type PT;
-        const int nb = f.nblkM, nSp = part_stride<PT>(M);
-        const PT *partT = (const PT *)f.partM;
-        for (int e = t; e < nS; e += NT) {
-            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            int b = 0;
-            for (; b + 3 < nb; b += 4) {
-                a0 += (double)partT[(size_t)b * nSp + e]; a1 += (double)partT[(size_t)(b + 1) * nSp + e];
-                a2 += (double)partT[(size_t)(b + 2) * nSp + e]; a3 += (double)partT[(size_t)(b + 3) * nSp + e];
-            }
-            for (; b < nb; ++b) a0 += (double)partT[(size_t)b * nSp + e];
-            S[e] = (a0 + a1) + (a2 + a3);
-        }
+        const int itn = st->it;
+        const long long *rows = acc_rows(f, itn);
+        for (int e = t; e < nS; e += NT) S[e] = acc_read(f, rows, e);
+        acc_clear_other<NT>(f, itn, t);
     } else {
         for (int e = t; e < nS; e += NT) S[e] = f.sums[e];
     }
