@@ -145,7 +145,8 @@ template <int NT> __device__ __forceinline__ void acc_clear_other(const FrameDev
 
 __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
     // c of trackdlo.cpp:300 (or c' of :378 when visibility weighting is active)
-    double c = pow(2.0 * M_PI * sigma2, 1.5) * f.mu / (1.0 - f.mu);
+    const double tp = 2.0 * M_PI * sigma2;
+    double c = tp * ::sqrt(tp) * f.mu / (1.0 - f.mu);          // (2 pi sigma2)^(3/2): one square root instead of pow() at the end of every M-step
     c = f.vis_branch ? c / Nc : c * (double)f.M / Nc;
     st->sigma2 = sigma2;
     st->Nc = Nc;

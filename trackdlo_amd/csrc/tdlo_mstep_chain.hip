@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         const int lc = q.li > 0 ? q.li : 1, mc = q.node;
 #pragma unroll
         for (int i = 0; i < 4; ++i) q.l[i] = chg[4 * (size_t)lc + i];
+        if (q.li == 0) { q.l[0] = dbl2{1.0, 0.0}; q.l[1] = dbl2{0.0, 1.0}; q.l[2] = dbl2{0.0, 0.0}; q.l[3] = dbl2{0.0, 0.0}; }     // identity link
         q.y[0] = (double)ndg[mc].x; q.y[1] = (double)ndg[mc].y; q.y[2] = (double)ndg[mc].z; q.w = (double)ndg[mc].w;
 #pragma unroll
         for (int d = 0; d < 3; ++d) { q.y0[d] = Y0g[d * M + mc]; q.yp[d] = Yg[d * M + mc]; q.ay[d] = pri ? aYg[d * M + mc] : 0.0; }
@@ -123,7 +124,11 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     };
     const SlotQ q0 = load_slot(t);
     const double pinf0 = chg[0].x, pinf1 = chg[0].y;  // sf2, s^2 sf2
-    const double c2 = f.lambda * sigma2, rc2 = 1.0 / c2;
+    const double c2 = f.lambda * sigma2, rc2 = fast_rcp(c2);
+    // what the kernel's last thread needs of set_iter_consts, formed while the loads are in flight: c of :300 / c' of :378 is
+    // (2 pi sigma2)^(3/2) times this factor
+    const double Nc = stg->Nc;
+    const double kc = f.mu / (1.0 - f.mu) * (f.vis_branch ? 1.0 / Nc : (double)M / Nc);
     // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
     // for the iteration counter (M <= 512: at most 9 elements per thread)
     const int itn = stg->it;
@@ -177,21 +182,18 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 
     // ---- 2. thread = step slot: the step's record and right-hand side  B = PX - P1 Y0 (+ alpha (Y_ext - Y0)) = R + P1 (y - Y0) (+ ...)
     //         (the E-step delivers R = PX - P1 y, y = the nodes as it saw them)
-    for (int sl = t, r = 0; sl < nSl + kAhead; sl += MB, ++r) {
+    for (int sl = t, r = 0; sl < nSl; sl += MB, ++r) {
         dbl2 *o = (dbl2 *)(slots + (size_t)kSlot * sl);
-        if (sl >= nSl) {        // the slots the loops read ahead into
-            o[0] = dbl2{1.0, 0.0}; o[1] = dbl2{0.0, 1.0}; o[2] = dbl2{0.0, 0.0}; o[3] = dbl2{0.0, 0.0}; o[4] = dbl2{0.0, 0.0}; o[5] = dbl2{0.0, 0.0}; o[6] = dbl2{0.0, 0.0};
-            continue;
-        }
         const SlotQ q = r == 0 ? q0 : load_slot(sl);
-        const bool idl = q.li == 0;
         const double p1 = q.obs ? S[q.node] : 0.0;
-        o[0] = idl ? dbl2{1.0, 0.0} : q.l[0];
-        o[1] = idl ? dbl2{0.0, 1.0} : q.l[1];
-        o[2] = idl ? dbl2{0.0, 0.0} : q.l[2] * rc2;
-        o[3] = dbl2{idl ? 0.0 : q.l[3].x * rc2, q.obs ? p1 + q.aj : 0.0};
+        o[0] = q.l[0]; o[1] = q.l[1]; o[2] = q.l[2] * rc2;
+        o[3] = dbl2{q.l[3].x * rc2, q.obs ? p1 + q.aj : 0.0};
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[4 + d] = dbl2{q.obs ? S[(1 + d) * M + q.node] + (p1 * (q.y[d] - q.y0[d]) + q.ay[d]) : 0.0, 0.0};
+    }
+    if (t >= MB - kAhead) {     // the slots the loops read ahead into: identity, nothing observed
+        dbl2 *o = (dbl2 *)(slots + (size_t)kSlot * (nSl + (t - (MB - kAhead))));
+        o[0] = dbl2{1.0, 0.0}; o[1] = dbl2{0.0, 1.0}; o[2] = dbl2{0.0, 0.0}; o[3] = dbl2{0.0, 0.0}; o[4] = dbl2{0.0, 0.0}; o[5] = dbl2{0.0, 0.0}; o[6] = dbl2{0.0, 0.0};
     }
     __syncthreads();
     CSTAMP(3);
@@ -381,14 +383,17 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     if (t == 0) {
         const double t_np = ((red[0] + red[4]) + red[8]) + red[12], t_dr = ((red[1] + red[5]) + red[9]) + red[13];
         const double t_pd = ((red[2] + red[6]) + red[10]) + red[14], t_cr = ((red[3] + red[7]) + red[11]) + red[15];
-        const double new_sigma2 = (S[4 * M] - 2.0 * t_dr + t_pd) / (t_np * 3.0);
+        const double new_sigma2 = (S[4 * M] - 2.0 * t_dr + t_pd) * fast_rcp(t_np * 3.0);
         const double crit = t_cr / (double)M;
-        const int it = stg->it + 1;
+        const int it = itn + 1;
         st->it = it; st->crit = crit; st->Np = t_np;
-        const double Nc = stg->Nc;
         const bool finite_ok = (new_sigma2 == new_sigma2) && (fabs(new_sigma2) < 1e300) && (new_sigma2 > 0) && (crit == crit);
-        if (finite_ok) set_iter_consts(f, st, new_sigma2, Nc);
-        else { st->sigma2 = new_sigma2; st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
+        st->sigma2 = new_sigma2;
+        if (finite_ok) {        // set_iter_consts with the sigma2-independent factor formed up front
+            const double tp = 2.0 * M_PI * new_sigma2;
+            st->k2 = -1.4426950408889634 * 0.5 * fast_rcp(new_sigma2);
+            st->c_norm = tp * ::sqrt(tp) * kc;
+        } else { st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
         if (crit < f.tol) st->done = 1;                                   // :424-428
         else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
     }
