@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[4 + d] = dbl2{q.obs ? S[(1 + d) * M + q.node] + (p1 * (q.y[d] - q.y0[d]) + q.ay[d]) : 0.0, 0.0};
     }
+    if (t == 0) *(int *)(red + 28) = 0;      // progress counter of the covariance pass
     if (t >= MB - kAhead) {     // the slots the loops read ahead into: identity, nothing observed
         dbl2 *o = (dbl2 *)(slots + (size_t)kSlot * (nSl + (t - (MB - kAhead))));
         o[0] = dbl2{1.0, 0.0}; o[1] = dbl2{0.0, 1.0}; o[2] = dbl2{0.0, 0.0}; o[3] = dbl2{0.0, 0.0}; o[4] = dbl2{0.0, 0.0}; o[5] = dbl2{0.0, 0.0}; o[6] = dbl2{0.0, 0.0};
@@ -198,48 +199,48 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     __syncthreads();
     CSTAMP(3);
 
-    // ---- 3. the chain (wave 0): lanes 0..31 direction A, 32..63 direction B; lane & 31 < 3 = coordinate for the means
+    // ---- 3. forward pass, two waves in a pipeline.  A lone wave issues one instruction per ~8 cycles whatever the instruction is
+    //         (scripts/ubench/lat.hip), so the pass is bound by its instruction count: wave 0 runs the covariance recursion (which
+    //         does not depend on the data), wave 1 follows with the means as the posteriors appear.  Both: lanes 0..31 direction A,
+    //         32..63 direction B.  Hand-over through LDS: wave 0 stores a step's posterior and then the number of finished steps --
+    //         a wave's LDS operations execute in order, the reader loads the counter before the posterior; the inline asm keeps the
+    //         compiler from reordering across the two.
+    constexpr int SB = kSlot * 8;
+    const unsigned prog_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(red + 28);
     if (wv == 0) {
         const int dir = lane >> 5, hl = lane & 31;
-        const bool wr = hl < 3;
-        // LDS addresses (bytes from the slot area): ra = the direction's current slot (the same in every lane of a half);
-        // la = the lane's own cells: slot + 16 hl for the three coordinate lanes, else the lane's dump area (stride 0);
-        // qa = the posterior's cells for lane 0 of the half, else the dump area
         char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
-        constexpr int SB = kSlot * 8;
-        char *ra = sb + (size_t)SB * dir * nB;
-        char *la = wr ? ra + 16 * hl : db;
-        char *qa = hl == 0 ? ra : db;
-        const int lstep = wr ? SB : 0, qstep = hl == 0 ? SB : 0;
-        double m0 = 0.0, m1 = 0.0, a = pinf0 * rc2, b = 0.0, d = pinf1 * rc2;
-        struct Rec { dbl2 r0, r1, r2, r3; double bb; };
-        auto fetch = [&](int ahead) __attribute__((always_inline)) {       // operands of the step `ahead` slots further on
+        char *ra = sb + (size_t)SB * dir * nB;          // the direction's current slot (the same in every lane of a half)
+        char *qa = hl == 0 ? ra : db;                   // the posterior's cells for lane 0 of the half, else the lane's dump area
+        const int qstep = hl == 0 ? SB : 0;
+        double a = pinf0 * rc2, b = 0.0, d = pinf1 * rc2;
+        struct Rec { dbl2 r0, r1, r2, r3; };
+        auto fetch = [&](int ahead) __attribute__((always_inline)) {       // record of the step `ahead` slots further on
             Rec r;
-            const char *rp = ra + SB * ahead, *lp = la + lstep * ahead;
+            const char *rp = ra + SB * ahead;
             r.r0 = *(const dbl2 *)(rp); r.r1 = *(const dbl2 *)(rp + 16); r.r2 = *(const dbl2 *)(rp + 32); r.r3 = *(const dbl2 *)(rp + 48);
-            r.bb = *(const double *)(lp + 64);
             return r;
         };
-        auto step = [&](const Rec &r, int at) __attribute__((always_inline)) {   // one step on the slot `at` slots further on
+        int kdone = 0;
+        auto step = [&](const Rec &r, int at) __attribute__((always_inline)) {
             const double f11 = r.r0.x, f12 = r.r0.y, f21 = r.r1.x, f22 = r.r1.y, q11 = r.r2.x, q12 = r.r2.y, q22 = r.r3.x, p = r.r3.y;
-            // predict: m^- = Phi m,  P^- = Phi P Phi^T + Q / c
-            const double pm0 = fma(f12, m1, f11 * m0), pm1 = fma(f22, m1, f21 * m0);
+            // predict: P^- = Phi P Phi^T + Q / c
             const double t1 = fma(f12, b, f11 * a), t2 = fma(f12, d, f11 * b);
             const double t3 = fma(f22, b, f21 * a), t4 = fma(f22, d, f21 * b);
             const double pa = fma(t2, f12, fma(t1, f11, q11));
             const double pb = fma(t2, f22, fma(t1, f21, q12));
             const double pd = fma(t4, f22, fma(t3, f21, q22));
-            // update with observation precision p: gain K = P^- e1 / (1 + p P^-_11) = (a, b) of the posterior
+            // update with observation precision p: P = P^- - P^- e1 e1^T P^- p / (1 + p P^-_11); the gain of the mean is (a, b) of the posterior
             const double g = fast_rcp(fma(p, pa, 1.0));
-            const double npb = -(p * pb), innov = fma(-p, pm0, r.bb);
+            const double npb = -(p * pb);
             a = pa * g; b = pb * g; d = fma(npb, b, pd);
-            m0 = fma(a, innov, pm0); m1 = fma(b, innov, pm1);
-            *(dbl2 *)(la + lstep * at + 112) = dbl2{m0, m1};
             *(dbl2 *)(qa + qstep * at + 160) = dbl2{a, b};
-            *(dbl2 *)(qa + qstep * at + 176) = dbl2{d, g};
+            *(double *)(qa + qstep * at + 176) = d;
+            ++kdone;
+            asm volatile("ds_write_b32 %0, %1" :: "v"(prog_addr), "v"(kdone) : "memory");
         };
-        // four steps per trip on four register sets: every operand is requested two steps (>= one LDS latency) before its use and
-        // nothing is copied; the slots behind a direction's last one are readable (look-ahead slots / the other direction)
+        // four steps per trip on four register sets: every record is requested two steps before its use, nothing is copied; the
+        // slots behind a direction's last one are readable (look-ahead slots / the other direction)
         int k = 0;
         if (nB >= 4) {
             Rec rA = fetch(0), rB = fetch(1);
@@ -248,14 +249,54 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
                 step(rA, 0); step(rB, 1);
                 rA = fetch(4); rB = fetch(5);
                 step(rC, 2); step(rD, 3);
-                ra += 4 * SB; la += 4 * lstep; qa += 4 * qstep;
+                ra += 4 * SB; qa += 4 * qstep;
             }
         }
         for (; k < nB; ++k) {
             const Rec r = fetch(0);
             step(r, 0);
-            ra += SB; la += lstep; qa += qstep;
+            ra += SB; qa += qstep;
         }
+    } else if (wv == 1) {
+        const int dir = lane >> 5, hl = lane & 31;
+        const bool wr = hl < 3;
+        char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
+        char *ra = sb + (size_t)SB * dir * nB;
+        char *la = wr ? ra + 16 * hl : db;              // the lane's own cells: slot + 16 hl for the three coordinate lanes, else its dump area
+        const int lstep = wr ? SB : 0;
+        double m0 = 0.0, m1 = 0.0;
+        int have = 0;                                   // steps whose posterior is known to be in LDS
+        auto wait_for = [&](int need) __attribute__((always_inline)) {
+            while (have < need) {
+                int v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(prog_addr) : "memory");
+                have = __builtin_amdgcn_readfirstlane(v);
+                if (have < need) __builtin_amdgcn_s_sleep(1);
+            }
+        };
+        struct MRec { dbl2 r0, r1, ab; double p, bb; };
+        auto mfetch = [&](int ahead) __attribute__((always_inline)) {
+            MRec r;
+            const char *rp = ra + SB * ahead;
+            r.r0 = *(const dbl2 *)(rp); r.r1 = *(const dbl2 *)(rp + 16); r.p = *(const double *)(rp + 56); r.ab = *(const dbl2 *)(rp + 160);
+            r.bb = *(const double *)(la + lstep * ahead + 64);
+            return r;
+        };
+        auto mstep = [&](const MRec &r, int at) __attribute__((always_inline)) {
+            // m^- = Phi m;  m = m^- + K (b - p m^-_0),  K = (a, b) of the step's posterior
+            const double pm0 = fma(r.r0.y, m1, r.r0.x * m0), pm1 = fma(r.r1.y, m1, r.r1.x * m0);
+            const double innov = fma(-r.p, pm0, r.bb);
+            m0 = fma(r.ab.x, innov, pm0); m1 = fma(r.ab.y, innov, pm1);
+            *(dbl2 *)(la + lstep * at + 112) = dbl2{m0, m1};
+        };
+        int k = 0;
+        for (; k + 1 < nB; k += 2) {
+            wait_for(k + 2);
+            const MRec rA = mfetch(0), rB = mfetch(1);
+            mstep(rA, 0); mstep(rB, 1);
+            ra += 2 * SB; la += 2 * lstep;
+        }
+        if (k < nB) { wait_for(nB); const MRec r = mfetch(0); mstep(r, 0); }
     }
     __syncthreads();
     CSTAMP(4);
@@ -286,67 +327,91 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             *(dbl2 *)(o + 26) = dbl2{C21, C22};
         }
     }
+    // meanwhile wave 1 (its threads hold no slot up to 63 nodes) fuses the two directions at the junction, both directions' last
+    // slot: posterior of A (data of nodes 0 .. j) and prediction of B (data of nodes j+1 .. M-1), the prior counted once; every lane
+    // forms the fused state of its coordinate, in A's frame (f, f'): B's f' has the opposite sign.  It replaces the junction's means.
+    if (wv == 1) {
+        const int dir = lane >> 5, hl = lane & 31, dd = hl < 3 ? hl : 2;
+        double *sA = slots + (size_t)kSlot * (nB - 1), *sB = slots + (size_t)kSlot * (2 * nB - 1);
+        const dbl2 mA = *(const dbl2 *)(sA + 14 + 2 * dd), mB = *(const dbl2 *)(sB + 14 + 2 * dd);
+        const dbl2 abA = *(const dbl2 *)(sA + 20), abB = *(const dbl2 *)(sB + 20);
+        const double Aa = abA.x, Ab = abA.y, Ad = sA[22], Ba = abB.x, Bb = -abB.y, Bd = sB[22];
+        const double rA = fast_rcp(fma(Aa, Ad, -(Ab * Ab))), rB = fast_rcp(fma(Ba, Bd, -(Bb * Bb)));
+        const double ia = Ad * rA, ib = -Ab * rA, id = Aa * rA, ja = Bd * rB, jb = -Bb * rB, jd = Ba * rB;
+        const double Bm1 = -mB.y;
+        const double e0 = fma(ia, mA.x, ib * mA.y) + fma(ja, mB.x, jb * Bm1);
+        const double e1 = fma(ib, mA.x, id * mA.y) + fma(jb, mB.x, jd * Bm1);
+        const double La = ia + ja - c2 / pinf0, Lb = ib + jb, Ld = id + jd - c2 / pinf1;
+        const double rL = fast_rcp(fma(La, Ld, -(Lb * Lb)));
+        const double xs0 = (Ld * e0 - Lb * e1) * rL, xs1 = (La * e1 - Lb * e0) * rL;
+        wave_lds_sync();                                // every lane has read the junction's means
+        if (hl < 3) *(dbl2 *)((dir ? sB : sA) + 14 + 2 * hl) = dbl2{xs0, dir ? -xs1 : xs1};
+    }
     __syncthreads();
     CSTAMP(5);
+    // ---- 5. backward pass in strides of four.  thread = step slot: the slot's step composed with the steps between it and the next
+    //         ANCHOR above it (the slots a multiple of four below the junction): x_k = eh + Ch x_anchor.  The composites go where the
+    //         records and right-hand sides were (dead by now): Ch -> [0..3], eh -> [8..13].
+    for (int sl = t; sl < nSl; sl += MB) {
+        const int k = sl >= nB ? sl - nB : sl;
+        if (k < nB - 1) {
+            double *o = slots + (size_t)kSlot * sl;
+            const int r4 = (nB - 1 - k) & 3, j = r4 ? r4 : 4;       // steps k .. k + j - 1
+            const double *top = o + (size_t)kSlot * (j - 1);
+            dbl2 c0 = *(const dbl2 *)(top + 24), c1 = *(const dbl2 *)(top + 26);
+            dbl2 ev[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ev[q] = *(const dbl2 *)(top + 14 + 2 * q);
+            for (int i = j - 2; i >= 0; --i) {
+                const double *s = o + (size_t)kSlot * i;
+                const dbl2 d0 = *(const dbl2 *)(s + 24), d1 = *(const dbl2 *)(s + 26);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const dbl2 eq = *(const dbl2 *)(s + 14 + 2 * q);
+                    ev[q] = dbl2{fma(d0.x, ev[q].x, fma(d0.y, ev[q].y, eq.x)), fma(d1.x, ev[q].x, fma(d1.y, ev[q].y, eq.y))};
+                }
+                const dbl2 n0 = dbl2{fma(d0.x, c0.x, d0.y * c1.x), fma(d0.x, c0.y, d0.y * c1.y)};
+                const dbl2 n1 = dbl2{fma(d1.x, c0.x, d1.y * c1.x), fma(d1.x, c0.y, d1.y * c1.y)};
+                c0 = n0; c1 = n1;
+            }
+            // (written after every thread's reads of the raw cells: the composites live in other cells)
+            *(dbl2 *)(o + 0) = c0; *(dbl2 *)(o + 2) = c1;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *(dbl2 *)(o + 8 + 2 * q) = ev[q];
+        }
+    }
+    __syncthreads();
+    // the anchors, one after the other (wave 0; lane = (direction, coordinate)): x_anchor = eh + Ch x_(anchor above), starting at the junction
     if (wv == 0) {
         const int dir = lane >> 5, hl = lane & 31;
         const bool wr = hl < 3;
-        constexpr int SB = kSlot * 8;
         char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
-        // fuse at the junction (both directions' last slot): posterior of A (data of nodes 0 .. j) and prediction of B (data of nodes
-        // j+1 .. M-1), the prior counted once; every lane forms the fused state of its coordinate, in A's frame (f, f'): B's f' has the
-        // opposite sign
-        double xs0, xs1;
-        {
-            const int dd = wr ? hl : 2;
-            const double *sA = slots + (size_t)kSlot * (nB - 1), *sB = slots + (size_t)kSlot * (2 * nB - 1);
-            const dbl2 mA = *(const dbl2 *)(sA + 14 + 2 * dd), mB = *(const dbl2 *)(sB + 14 + 2 * dd);
-            const dbl2 abA = *(const dbl2 *)(sA + 20), abB = *(const dbl2 *)(sB + 20);
-            const double Aa = abA.x, Ab = abA.y, Ad = sA[22], Ba = abB.x, Bb = -abB.y, Bd = sB[22];
-            const double rA = fast_rcp(fma(Aa, Ad, -(Ab * Ab))), rB = fast_rcp(fma(Ba, Bd, -(Bb * Bb)));
-            const double ia = Ad * rA, ib = -Ab * rA, id = Aa * rA, ja = Bd * rB, jb = -Bb * rB, jd = Ba * rB;
-            const double Bm1 = -mB.y;
-            const double e0 = fma(ia, mA.x, ib * mA.y) + fma(ja, mB.x, jb * Bm1);
-            const double e1 = fma(ib, mA.x, id * mA.y) + fma(jb, mB.x, jd * Bm1);
-            const double La = ia + ja - c2 / pinf0, Lb = ib + jb, Ld = id + jd - c2 / pinf1;
-            const double rL = fast_rcp(fma(La, Ld, -(Lb * Lb)));
-            xs0 = (Ld * e0 - Lb * e1) * rL; xs1 = (La * e1 - Lb * e0) * rL;
-            if (dir) xs1 = -xs1;
-        }
-        // backward: both halves walk from the junction to their end of the chain; the smoothed state replaces e_k
         char *ra = sb + (size_t)SB * (dir * nB + nB - 1);
         char *la = wr ? ra + 16 * hl : db;
         const int lstep = wr ? SB : 0;
-        *(dbl2 *)(la + 112) = dbl2{xs0, xs1};
-        ra -= SB; la -= lstep;
-        struct BRec { dbl2 e, C0, C1; };
-        auto bfetch = [&](int back) __attribute__((always_inline)) {       // operands of the step `back` slots towards the chain's end
-            BRec r;                                                        // (the slots in front of a direction's first one are readable)
-            r.e = *(const dbl2 *)(la - lstep * back + 112); r.C0 = *(const dbl2 *)(ra - SB * back + 192); r.C1 = *(const dbl2 *)(ra - SB * back + 208);
+        const dbl2 xj = *(const dbl2 *)(la + 112);
+        double xs0 = xj.x, xs1 = xj.y;
+        const int na = (nB - 1) >> 2;                   // anchors below the junction
+        struct ARec { dbl2 e, C0, C1; };
+        auto afetch = [&](int i) __attribute__((always_inline)) {           // the i-th anchor below the current position
+            ARec r;                                                         // (slots in front of a direction's first one are readable)
+            r.e = *(const dbl2 *)(la - 4 * lstep * i + 64); r.C0 = *(const dbl2 *)(ra - 4 * SB * i); r.C1 = *(const dbl2 *)(ra - 4 * SB * i + 16);
             return r;
         };
-        auto bstep = [&](const BRec &r, int back) __attribute__((always_inline)) {
+        auto astep = [&](const ARec &r, int i) __attribute__((always_inline)) {
             const double y0 = fma(r.C0.x, xs0, fma(r.C0.y, xs1, r.e.x));
             const double y1 = fma(r.C1.x, xs0, fma(r.C1.y, xs1, r.e.y));
             xs0 = y0; xs1 = y1;
-            *(dbl2 *)(la - lstep * back + 112) = dbl2{xs0, xs1};
+            *(dbl2 *)(la - 4 * lstep * i + 112) = dbl2{xs0, xs1};
         };
-        int k = nB - 2;                                                   // steps k, k-1, ..., 0
-        if (k >= 3) {
-            BRec bA = bfetch(0), bB = bfetch(1);
-            for (; k >= 3; k -= 4) {
-                const BRec bC = bfetch(2), bD = bfetch(3);
-                bstep(bA, 0); bstep(bB, 1);
-                bA = bfetch(4); bB = bfetch(5);
-                bstep(bC, 2); bstep(bD, 3);
-                ra -= 4 * SB; la -= 4 * lstep;
-            }
+        int i = 0;
+        ARec rA = afetch(1), rB = afetch(2);
+        for (; i + 1 < na; i += 2) {
+            astep(rA, 1); astep(rB, 2);
+            ra -= 8 * SB; la -= 8 * lstep;
+            rA = afetch(1); rB = afetch(2);
         }
-        for (; k >= 0; --k) {
-            const BRec r = bfetch(0);
-            bstep(r, 0);
-            ra -= SB; la -= lstep;
-        }
+        if (i < na) astep(rA, 1);
     }
     __syncthreads();
     CSTAMP(6);
@@ -360,10 +425,22 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         const int m = q.node;
         const double *o = slots + (size_t)kSlot * sl;
         const double p1 = S[m];
+        // smoothed state: junction and anchors hold it; every other slot is one composite step below its anchor
+        const int ks = sl >= nB ? sl - nB : sl, r4 = (nB - 1 - ks) & 3;
+        double Vd[3];
+        if (r4 == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) Vd[d] = o[14 + 2 * d];
+        } else {
+            const double *an = o + (size_t)kSlot * r4;
+            const dbl2 c0 = *(const dbl2 *)(o + 0);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { const dbl2 xa = *(const dbl2 *)(an + 14 + 2 * d); Vd[d] = fma(c0.x, xa.x, fma(c0.y, xa.y, o[8 + 2 * d])); }
+        }
         double Td[3], cr2 = 0, dr = 0, pd2 = 0;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            Td[d] = q.y0[d] + o[14 + 2 * d];
+            Td[d] = q.y0[d] + Vd[d];
             const double del = Td[d] - q.y[d], ex = q.yp[d] - Td[d];
             dr = fma(del, S[(1 + d) * M + m], dr); pd2 = fma(del, del, pd2); cr2 = fma(ex, ex, cr2);
         }
