@@ -185,7 +185,7 @@ int tdlo_split_poll(tdlo_ctx *ctx, int *done, int *iters);   /* synchronises the
  *       sums straight into every peer's inbox (peer stores: xGMI on a multi-GPU node) and raises a flag; the last workgroup of
  *       the min-distance kernel and the one-workgroup M-step wait for the R flags in their own inbox and reduce the R
  *       contributions in rank order.  One EM iteration is the three kernels of the unsplit loop, no launch in between.
- *       Chains up to 60 nodes (64 with the LLE term), up to 8 ranks.
+ *       Any chain length without the LLE term (the chain smoother carries the exchange), up to 64 nodes with it; up to 8 ranks.
  * The stopping rule is evaluated on the device and read after iterations 1, 2, 4, 8, 12, ... (tol > 0). */
 int tdlo_split_run(tdlo_ctx *ctx, void *nccl_comm, double *Y, int M, double *sigma2, const tdlo_params *params,
                    const double *priors, int K, const int *visible_nodes, int n_vis, const double *H_override, tdlo_stats *stats);

@@ -99,8 +99,8 @@ for ci, (R, N, M, cfg, vis_on, tol, prec, max_iter, empty_first) in enumerate(ev
         X = X.copy(); X[:n // R] += np.array([0.0, 0.0, 5.0])      # the first shard loses every point to the prune
     pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter, tol, False, 0.0, P["k_vis"] if vis_on else 0.0,
                        P["visibility_threshold"], precision=prec)
-    ctxs = [B.Context(device=0, max_frames=1, max_points=max(1024, n // R + 1), max_nodes=64) for _ in range(R)]
-    inboxes = [c.xch_create(R, 64) for c in ctxs]
+    ctxs = [B.Context(device=0, max_frames=1, max_points=max(1024, n // R + 1), max_nodes=max(64, M)) for _ in range(R)]
+    inboxes = [c.xch_create(R, max(64, M)) for c in ctxs]
     out = queue.Queue()
     def work(r):
         try:
@@ -153,6 +153,8 @@ def test_one_shot_exchange_R_shards_against_the_oracle(tmp_path, oracle):
              (8, 24000, 45, 14, True, 0.0, 0, 8, False), (8, 24000, 45, 14, False, 0.0, 1, 8, False), (3, 24000, 45, 14, True, 0.0, 1, 8, False),
              # a shard that loses every point to the prune: its minima stay 'no point', its sums are zero
              (3, 9000, 40, 15, True, 0.0, 0, 6, True),
+             # long chains: the chain smoother carries the exchange for any chain length (one or several step slots per thread)
+             (2, 30000, 150, 16, False, 0.0, 1, 5, False), (4, 40000, 300, 17, True, 0.0, 0, 4, False),
              # BASELINE.json configs[3] at full size: N = 2 000 000 as eight 250 000-point shards, visibility weighting on
              (8, 2000000, 50, 4, True, 0.0, 0, 3, False)]
     z = _run_shard_cases(tmp_path, cases)

@@ -866,8 +866,9 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     if (oneshot) {
         if (c->xch_nranks < 1) return fail(c, TDLO_E_INVALID, "tdlo_split_run without a communicator needs the one-shot exchange (tdlo_xch_create / tdlo_xch_bind)");
         if (M > c->xch_mcap) return fail(c, TDLO_E_INVALID, "more nodes than the inbox was created for");
-        if (!((!p->include_lle && M <= 60) || (p->include_lle && M <= 64)))
-            return fail(c, TDLO_E_INVALID, "the one-shot exchange lives in the one-workgroup M-step (up to 60 nodes, 64 with the LLE term): pass an RCCL communicator for longer chains");
+        // the exchange lives in the one-workgroup M-steps: the chain smoother (any chain length, no LLE term) and k_mstep_fast
+        if (!((!p->include_lle && (mstep_chain_enabled() || M <= 60)) || (p->include_lle && M <= 64)))
+            return fail(c, TDLO_E_INVALID, "the one-shot exchange with the LLE term lives in the one-workgroup M-step (up to 64 nodes): pass an RCCL communicator for longer chains");
     } else {
         std::string why;
         R = rccl_api(nullptr, &why);
