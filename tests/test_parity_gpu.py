@@ -1225,3 +1225,33 @@ def test_nsplit_empty_cloud_leaves_the_context_reusable(hip_ctx):
     b = nsplit.cpd_lle_nsplit_device(shard2, xch, Identity(), Y0, 0.0, pr)
     a = hip_ctx.cpd_lle(X, Y0, 0.0, pr)
     assert b["iters"] == 6 and np.abs(a["Y"] - b["Y"]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_results_do_not_depend_on_the_estep_launch_geometry(prec):
+    """The E-step's sums are converted to 64-bit fixed point at the grain of one wave x one 64-point batch and are integers from there
+    on (csrc/tdlo_devcommon.h: acc_fix): however the batches are dealt out to waves and workgroups -- 196 workgroups of one batch per
+    wave, 7 workgroups of 28 -- and in whatever order the workgroups' atomics arrive, every bit of the result is the same.  With
+    visibility weighting, priors, and a chain of 130 nodes (the register-accumulator variant of the E-step) as well."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    for N, M, occ in ((50000, 50, None), (20000, 45, (0.3, 0.5)), (30000, 130, None)):
+        X, Y0, vis = synth.scene(N, M, config=410 + M, occlude=occ)
+        pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 12, 0.0, False, P["alpha"], P["k_vis"] if occ else 0.0,
+                           P["visibility_threshold"], prec)
+        idx = np.arange(2, M, 9)
+        opt = dict(priors=np.column_stack([idx, Y0[idx] + 0.002]))
+        if occ:
+            opt["visible_nodes"] = np.asarray(synth.extend_visible(vis, M, synth.geodesic_coord(Y0)), dtype=np.int32)
+        ref = None
+        for blocks in (0, 131, 64, 7):
+            ctx = B.Context(device=0, max_points=N, max_nodes=M, estep_blocks=blocks)
+            try:
+                g = ctx.cpd_lle(X, Y0, 0.0, pr, **opt)
+            finally:
+                ctx.close()
+            assert g["rc"] == 0 and g["iters"] == 12
+            if ref is None:
+                ref = g
+            else:
+                assert np.array_equal(g["Y"], ref["Y"]) and g["sigma2"] == ref["sigma2"], (N, M, blocks)

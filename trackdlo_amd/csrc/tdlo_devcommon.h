@@ -105,16 +105,25 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 }
 
 // ---- the E-step's sums [P1 | Rx | Ry | Rz | Q] (trackdlo.cpp:386-389 in residual form) as 64-bit fixed-point accumulators ----------------
-// Every E-step workgroup adds its share with integer atomics into one of kAccRows replica rows; integer addition is associative, so
-// the sums do not depend on the order in which the workgroups arrive (batches, repetitions and shards reproduce bit for bit), and the
-// M-step fetches kAccRows short rows instead of one row per workgroup (98 rows = 80 KB through one CU took 3 us at N = 50 000;
-// 512 rows needed a reduction kernel of their own).  Resolution 2^-sh: sh is chosen per quantity from the cloud size and the
-// extent of the scene so that the total stays below 2^62 (prepare_frame); at N = 50 000 that is 1e-14 on P1 ~ 1000 -- finer than the fp32
-// rows it replaces by eight decimal digits, and at the level of fp64 rounding.
+// The conversion happens at the finest grain: one wave's share of one 64-point batch.  Everything after it -- the wave's running sums over
+// its batches, the workgroup's sum over its waves, the atomics of the workgroups into one of kAccRows replica rows -- is INTEGER addition,
+// which is associative: the totals depend neither on the order in which workgroups arrive nor on how the batches are dealt out to waves
+// and workgroups.  Batches, repetitions and any launch geometry give the same bits; and the M-step fetches kAccRows short rows instead
+// of one row per workgroup (98 rows = 80 KB through one CU took 3 us at N = 50 000; 512 rows needed a reduction kernel of their own).
+// Resolution 2^-sh: sh is chosen per quantity from the cloud size and the extent of the scene so that totals stay below 2^62 and a
+// batch's share below 2^51 (prepare_frame); at N = 50 000 that is 6e-14 on P1 ~ 1000 -- finer than the fp32 rows it replaces by
+// seven decimal digits, and at the level of fp64 rounding.
 __host__ __device__ inline int acc_stride(int M) { return 4 * M + 2; }
 __device__ __forceinline__ int acc_shift(const FrameDev &f, int i) { const int M = f.M; return i < M ? f.acc_sh[0] : (i < 4 * M ? f.acc_sh[1] : f.acc_sh[2]); }
-__device__ __forceinline__ void acc_add(long long *row, int i, double v, int sh) {
-    if (v != 0.0) __hip_atomic_fetch_add(row + i, __double2ll_rn(::ldexp(v, sh)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exact zeros (nodes outside the window) add nothing
+// double -> fixed point, round to nearest, |v * 2^sh| < 2^51 (guaranteed for one wave's share of one 64-point batch by the exponents
+// prepare_frame chooses): the sum v * 2^sh + 1.5 * 2^52 has unit spacing, so its low mantissa bits ARE the integer -- one FMA and
+// one 64-bit subtraction instead of the ~12 instructions of a double -> int64 conversion
+__device__ __forceinline__ double acc_scale(int sh) { return __hiloint2double((1023 + sh) << 20, 0); }
+__device__ __forceinline__ long long acc_fix(double v, double scale) {
+    return __double_as_longlong(::fma(v, scale, 6755399441055744.0)) - 0x4338000000000000ll;
+}
+__device__ __forceinline__ void acc_add(long long *row, int i, long long iv) {
+    if (iv != 0) __hip_atomic_fetch_add(row + i, iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exact zeros (nodes outside the window) add nothing
 }
 __device__ __forceinline__ const long long *acc_rows(const FrameDev &f, int it) { return f.acc + (size_t)(it & 1) * kAccRows * acc_stride(f.M); }
 // element i of the sums of iteration `it`: the replica rows are added as integers (exact), one conversion

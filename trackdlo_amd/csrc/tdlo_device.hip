@@ -549,17 +549,19 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     __syncthreads();
     ESTAMP(1);
 
-    double accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
+    // running sums in 64-bit fixed point (acc_fix at the grain of one wave x one batch; integer from there on: tdlo_devcommon.h)
+    long long accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { accP[c] = 0; accX[c] = 0; accY[c] = 0; accZ[c] = 0; }
-    double accQ = 0;
+    long long accQ = 0;
+    const double scP = acc_scale(f.acc_sh[0]), scR = acc_scale(f.acc_sh[1]), scQ = acc_scale(f.acc_sh[2]);
     // NCH == 1 (M <= 64): windowed variant.  The cloud is sorted by nearest node, so the 64 points of a
     // wave sit on a short piece of the chain, and every membership whose exponent is below -151 (fp32;
     // -1080 in fp64) is EXACTLY zero: only the nodes inside an arc-length window around the wave's
     // nearest-pair range can contribute, the others are skipped -- same sums, bit for bit.
-    double *accL = scratch + 16 + (size_t)wave * M * 4;    // per-wave [M][4] accumulators (NCH == 1)
+    long long *accL = (long long *)(scratch + 16) + (size_t)wave * M * 4;    // per-wave [M][4] accumulators (NCH == 1)
     if (NCH == 1) {
-        for (int i = lane; i < M * 4; i += 64) accL[i] = 0.0;
+        for (int i = lane; i < M * 4; i += 64) accL[i] = 0;
     }
     constexpr double kCut = sizeof(T) == 4 ? 151.0 : 1080.0;
     const T Rwin = (T)(1.01 * ::sqrt(kCut / fabs((double)k2)));
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         }
         ESTAMP(4);
         const T inv = valid ? Num<T>::rcp_fast(sum + cn) : T(0);
-        accQ += (double)(inv * qs);
+        accQ += acc_fix((double)(inv * qs), scQ);
         // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
         // wave's points within centimetres) and leave as the residual R_m = sum_n P_mn (x_n - y_m):
         // small numbers, so fp32 tile sums and fp32 block partials lose nothing that matters
@@ -768,25 +770,26 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
             if (NCH == 1) {
                 if (lane < Wn) {
-                    double *ac = accL + (size_t)(wlo_c + lane) * 4;
+                    long long *ac = accL + (size_t)(wlo_c + lane) * 4;
                     const V4<T> ym = nodesL[wlo_c + lane];
                     const double w0 = (double)s0;
-                    ac[0] += w0;
-                    ac[1] += (double)sx + ((double)ox - (double)ym.x) * w0;
-                    ac[2] += (double)sy + ((double)oy - (double)ym.y) * w0;
-                    ac[3] += (double)sz + ((double)oz - (double)ym.z) * w0;
+                    ac[0] += acc_fix(w0, scP);
+                    ac[1] += acc_fix((double)sx + ((double)ox - (double)ym.x) * w0, scR);
+                    ac[2] += acc_fix((double)sy + ((double)oy - (double)ym.y) * w0, scR);
+                    ac[3] += acc_fix((double)sz + ((double)oz - (double)ym.z) * w0, scR);
                 }
                 wave_lds_sync();
             } else {
                 // M > 64: the sums of node wlo_c + lane go to the lane that owns that node in the register accumulators
                 // (lane = node - 64 c) by cross-lane reads; a window touches at most two node chunks
-                double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
                 if (lane < Wn) {
                     const V4<T> ym = nodesL[wlo_c + lane];
-                    v0 = (double)s0;
-                    v1 = (double)sx + ((double)ox - (double)ym.x) * v0;
-                    v2 = (double)sy + ((double)oy - (double)ym.y) * v0;
-                    v3 = (double)sz + ((double)oz - (double)ym.z) * v0;
+                    const double w0 = (double)s0;
+                    v0 = acc_fix(w0, scP);
+                    v1 = acc_fix((double)sx + ((double)ox - (double)ym.x) * w0, scR);
+                    v2 = acc_fix((double)sy + ((double)oy - (double)ym.y) * w0, scR);
+                    v3 = acc_fix((double)sz + ((double)oz - (double)ym.z) * w0, scR);
                 }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                         const int idx = c * kChunk + lane - wlo_c;
                         const bool ok = idx >= 0 && idx < Wn;
                         const int src = ok ? idx : 0;
-                        const double g0 = __shfl(v0, src), g1 = __shfl(v1, src), g2 = __shfl(v2, src), g3 = __shfl(v3, src);
+                        const long long g0 = __shfl(v0, src), g1 = __shfl(v1, src), g2 = __shfl(v2, src), g3 = __shfl(v3, src);
                         if (ok) { accP[c] += g0; accX[c] += g1; accY[c] += g2; accZ[c] += g3; }
                     }
                 }
@@ -805,28 +808,29 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
 
     ESTAMP(5);
-    // ---- block partial: sum the waves in a fixed order, write [P1 | PXx | PXy | PXz | Q]
+    // ---- the workgroup's share: its waves' integer sums added up, then into the accumulators of this iteration's parity, replica row =
+    //      workgroup % kAccRows (integer atomics: neither the order of the waves nor that of the workgroups matters)
+    long long *iscr = (long long *)scratch;
     {
-        const double qw = wave_sum(accQ);             // Q rides on the same barrier as the node sums
-        if (lane == 0) scratch[wave] = qw;
+        long long qw = accQ;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qw += __shfl_xor(qw, o);
+        if (lane == 0) iscr[wave] = qw;
     }
     __syncthreads();
     ESTAMP(6);
-    // into the fixed-point accumulators of this iteration's parity, replica row = workgroup % kAccRows (integer atomics: the order in
-    // which the workgroups arrive does not matter)
     long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (blockIdx.x % kAccRows)) * acc_stride(M);
-    const int shP = f.acc_sh[0], shR = f.acc_sh[1];
     if (NCH == 1) {
-        const double *accAll = scratch + 16;
+        const long long *accAll = (const long long *)(scratch + 16);
         for (int i = tid; i < 4 * M; i += EB) {
             const int m = i >> 2, k = i & 3;
-            double v = 0;
+            long long v = 0;
 #pragma unroll
             for (int w = 0; w < NWE; ++w) v += accAll[(size_t)w * M * 4 + i];
-            acc_add(arow, k * M + m, v, k == 0 ? shP : shR);
+            acc_add(arow, k * M + m, v);
         }
     } else {
-    double *red = (double *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
+    long long *red = (long long *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         red[(wave * 64 + lane) * 4 + 0] = accP[c];
@@ -838,20 +842,20 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             const int l = tid >> 2, k = tid & 3;     // 64 lanes x 4 values
             const int m = c * kChunk + l;
             if (m < M) {
-                double v = 0;
+                long long v = 0;
 #pragma unroll
                 for (int w = 0; w < NWE; ++w) v += red[(w * 64 + l) * 4 + k];
-                acc_add(arow, k * M + m, v, k == 0 ? shP : shR);
+                acc_add(arow, k * M + m, v);
             }
         }
         __syncthreads();
     }
     }
     if (tid == 0) {
-        double q = 0;
+        long long q = 0;
 #pragma unroll
-        for (int w = 0; w < NWE; ++w) q += scratch[w];
-        acc_add(arow, 4 * M, q, f.acc_sh[2]);
+        for (int w = 0; w < NWE; ++w) q += iscr[w];
+        acc_add(arow, 4 * M, q);
     }
     ESTAMP(7);
 #ifdef TDLO_ESTEP_STAMPS
