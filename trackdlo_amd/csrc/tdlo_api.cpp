@@ -219,19 +219,18 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     std::memset(&f, 0, sizeof f);
     f.N0 = s.N0; f.M = M; f.ldx = s.cap_points;
     const int nbatch = (s.N0 + 63) / 64;
-    // fp32, large clouds: 8 waves per workgroup; clouds of up to 2048 wave batches (131 072 points) and fp64 (tiles twice as
-    // large): 4 waves, i.e. twice the workgroups -- such a cloud cannot fill the GPU, and spread over more CUs every wave has a
-    // SIMD's issue slots to itself (C2: 5.6 -> 5.3 us per E-step; at N = 2 000 000 the 8-wave form is 25 % faster)
-    f.eb = (p->precision == TDLO_PREC_F32 && M <= 64 && nbatch > 2048) ? 512 : 256;
+    // 4 waves per workgroup (fp64 tiles are twice as large anyway; fp32: a cloud that cannot fill the GPU gets twice the workgroups of the
+    // 8-wave form, one wave per SIMD -- C2: 5.6 -> 5.2 us per E-step -- and at N = 2 000 000 1024 workgroups of 4 waves beat 512 of 8 by
+    // 4 %).  The results do not depend on this choice: the sums are integers from the grain of one wave x one batch on.
+    f.eb = 256;
     { static const int eb_env = getenv("TDLO_ESTEP_EB") ? atoi(getenv("TDLO_ESTEP_EB")) : 0; if (eb_env == 256 || (eb_env == 512 && M <= 64 && p->precision == TDLO_PREC_F32)) f.eb = eb_env; }
     const int wpb = f.eb / 64;
     int nblk = (nbatch + wpb - 1) / wpb;
-    // One frame of moderate size keeps its whole node window in a 64-row tile (133 KB of LDS: one workgroup per CU, which
-    // such a frame cannot fill anyway).  A cloud that needs 512 workgroups or more is VALU-bound instead: it takes the 24-row
-    // tile of the batch path (three workgroups per CU hide the LDS / scalar-load latencies: 47 -> 36 us at N = 2 000 000) and
-    // twice the block partials.  Batches (run_frames, F > 1) always use the small tile.
-    f.wide_tile = (M > kChunk || nblk < 512) ? 1 : 0;
-    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : (f.wide_tile ? 256 : 512);
+    // One frame of moderate size (up to 262 144 points) keeps its whole node window in a 64-row tile (67 KB of LDS per 4-wave
+    // workgroup).  A larger cloud is VALU-bound instead: it takes the 24-row tile of the batch path (more workgroups per CU hide the
+    // LDS / scalar-load latencies: 47 -> 36 us at N = 2 000 000).  Batches (run_frames, F > 1) always use the small tile.
+    f.wide_tile = (M > kChunk || nbatch < 4096) ? 1 : 0;
+    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : (f.wide_tile ? (M > kChunk ? 256 : 512) : 1024);      // (more than 64 nodes: 256 -- C5 30 vs 34 us per E-step)
     { static const int cap_env = getenv("TDLO_ESTEP_BLOCKS") ? atoi(getenv("TDLO_ESTEP_BLOCKS")) : 0; if (cap_env > 0) cap = cap_env; }
     cap = std::min(cap, kMaxEstepBlocks);
     f.nblkE = std::max(1, std::min(nblk, cap));
