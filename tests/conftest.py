@@ -19,7 +19,7 @@ def pytest_sessionstart(session):
     step does (hipcc cross-compiles gfx950 without a GPU).  Nothing is built when everything is already there, e.g. on the
     GPU box, where the in-tree libraries arrive with the snapshot."""
     need = [os.path.join(ROOT, "trackdlo_amd", "libtrackdlo_hip.so"), os.path.join(ROOT, "oracle", "libref_cpu.so"),
-            os.path.join(ROOT, "tests", "cpp", "shim_test")]
+            os.path.join(ROOT, "tests", "cpp", "shim_test"), os.path.join(ROOT, "tests", "cpp", "split_run_test")]
     if all(os.path.exists(f) for f in need):
         return
     import shutil

@@ -250,3 +250,19 @@ def test_one_shot_exchange_between_two_processes_over_hip_ipc(oracle):
         assert it == o["iters"] and np.abs(Y - o["Y"]).max() <= 1e-5 and abs(s2 - o["sigma2"]) <= 1e-3 * o["sigma2"]
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     assert outs[0][3] + outs[1][3] == o["n_kept"]
+
+
+def test_cpp_driver_without_python_or_torch():
+    """tests/cpp/split_run_test.cpp: the N-split through the C ABI from a plain C++ program (built by __graft_entry__.build()): the
+    RCCL form with a communicator the library makes itself (librccl bound at run time) must reproduce the plain call bit for bit;
+    the one-shot exchange with two ranks on two host threads must give both ranks the same bits and the plain call's result to
+    the fp32-mode tolerance."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "split_run_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    env = dict(os.environ)
+    # a process without torch: the system's HIP runtime and RCCL (the library finds librccl.so.1 itself; TDLO_RCCL_LIB overrides)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout and "bit for bit" in r.stdout
