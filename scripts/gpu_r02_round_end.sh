@@ -37,7 +37,7 @@ bash scripts/gpu_estep_pmc.sh $tag 2000000 50 0 2>&1 | grep -v amdgpu.ids > $O/e
   echo "== lle (M-step with the LLE term over M)"; timeout 200 python scripts/gpu_lle_time.py
   echo "== track"; timeout 200 python scripts/gpu_track.py
   echo "== pcie"; timeout 200 python scripts/gpu_pcie.py
-  echo "== instruction latencies of a lone wave"; timeout 60 ./scripts/ubench/lat
+  echo "== instruction latencies of a lone wave"; [ -x scripts/ubench/lat ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench/lat.hip -o scripts/ubench/lat 2>/dev/null; timeout 60 ./scripts/ubench/lat
 } 2>&1 | grep -v amdgpu.ids > $O/measured.log
 ls -la $O
 head -5 $O/kernel_stats_c2.csv
