@@ -4,18 +4,20 @@
 // translation of that code: the reference materialises five dense M x N fp64 matrices per
 // iteration on one CPU thread; here no M x N matrix ever exists.
 //
-// Kernels (one EM iteration = [k_dmin] -> k_estep -> k_mstep, all on one stream, no host sync):
+// Kernels (one EM iteration = [k_dmin] -> k_estep -> M-step, all on one stream, no host sync):
 //   k_prune_pass1 / k_setup / k_prune_scatter   once per call   (:177-273)
 //   k_dmin    per-node minimum distance to the cloud (visibility weighting only, :278-296, :358-372)
 //   k_estep   fused distances + nearest-node + geodesic membership + normalisation + column sums
 //             (:278-389): thread = point, nodes via scalar loads, 64x64 lane-transposed LDS tile so
 //             that lane = node accumulates P1 / PX without cross-lane reductions
-//   k_mstep   block-partial reduction, A/B assembly, dense solve, T, sigma2, convergence (:392-437)
+//             -- the sums leave the kernel as 64-bit fixed-point integers added with atomics (tdlo_devcommon.h: acc_*)
+//   k_mstep*  the M-step (:392-437): without the LLE term the chain smoother of tdlo_mstep_chain.hip (O(M)); with it -- and as
+//             comparators -- the dense eliminations here (k_mstep_fast), in tdlo_mstep_generic.h and tdlo_mstep_big.hip
 //
 // Numerics: all device geometry lives in a frame centred on the centroid of the incoming nodes
 // (every formula of the path is translation invariant).  In TDLO_PREC_F32 the E-step works in fp32
-// on fp32-rounded centred coordinates; sums leave each 64-point tile in fp32 and are accumulated in
-// fp64 from there on.  sigma2 uses the algebraically identical residual form
+// on fp32-rounded centred coordinates; sums leave each 64-point tile in fp32, are converted to fixed point per
+// wave and batch, and are integers from there on (exact, order-independent).  sigma2 uses the algebraically identical residual form
 //   sum_mn P_mn |x_n - T_m|^2 = Q - 2 sum_m d_m.R_m + sum_m P1_m |d_m|^2,
 //   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m (accumulated directly by the E-step),  d_m = T_m - y_m
 // instead of :418-422's difference of three large traces, which would cancel catastrophically in fp32.

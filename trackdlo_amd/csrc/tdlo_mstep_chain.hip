@@ -19,15 +19,24 @@
 // filter's quantities are all O(1) ratios (measured against an 80-bit solve of the dense system: 1e-17 ... 1e-14 m where
 // partial-pivot LU / QR of the dense system leave 1e-14 ... 1e-9 m; tests/test_mstep_chain.py).
 //
-// Mapping: ONE wave runs the chain (the other three waves of the workgroup only help with the block partials and the
-// sigma2 sums).  The chain is walked from BOTH ends at once: lanes 0..31 filter nodes 0 .. j, lanes 32..63 filter nodes
-// M-1 .. j of the time-reversed process (same Phi and Q: the process is stationary and reversible in (f, -f')), j = (M-1)/2.
-// At node j the two Gaussians are fused (information form, the prior counted once), and both halves smooth outwards.  That
-// halves the dependent chain for free: a wave64 fp64 instruction costs 4 cycles whether 3 or 64 lanes are active.  Inside a
-// half, lane & 3 = coordinate (x, y, z) for the means; the covariance recursion is the same in every lane.
-// Per forward step: 2 x 2 predict (Phi P Phi^T + Q), one reciprocal, update; the smoother gain C_k = P_k Phi^T (P^-_{k+1})^-1
-// is NOT on that chain: the loop stores P_k, and one lane-parallel pass (lane = step) forms all C_k afterwards.
-// Backward step: x_k = e_k + C_k x_{k+1}, two dependent FMAs.
+// What bounds it: O(M) flops on a handful of lanes -- a chain of dependent instructions.  A lone wave on gfx950 issues one instruction
+// per ~8 cycles when it depends on its predecessor (~5 when it does not), scalar ALU, fp64 and fp32 alike; a dependent v_rcp_f64
+// is 20 cycles, an LDS round trip 76, a store behind an exec-mask branch 38 (scripts/ubench/lat.hip).  So the kernel is designed by
+// instruction count on the critical wave, and independent instruction streams go to different waves.  Phases (one workgroup of
+// four waves per frame; thread = step slot in the parallel ones):
+//   1. fetch: the E-step's sums (16 short rows of fixed-point accumulators, both parities: no load waits for the iteration
+//      counter), this thread's slot (link, node); the slot records are prepared while the loads are in flight;
+//   2. the chain is walked from BOTH ends at once: lanes 0..31 filter nodes 0 .. j, lanes 32..63 filter nodes M-1 .. j of the
+//      time-reversed process (same Phi and Q: the process is stationary and reversible in (f, -f')), j = (M-1)/2 -- a wave64 fp64
+//      instruction costs the same whether 3 or 64 lanes are active, so the dependent chain is halved for free;
+//   3. forward pass as a two-wave pipeline: wave 0 runs the covariance recursion (2 x 2 predict Phi P Phi^T + Q, one reciprocal,
+//      update -- it does not depend on the data), wave 1 follows with the means (lane & 31 < 3 = coordinate) as the posteriors
+//      appear, behind a progress counter in LDS;
+//   4. gains C_k = P_k Phi^T (P^-_{k+1})^-1 and e_k = m_k - C_k Phi m_k, lane = step (the backward step is x_k = e_k + C_k x_{k+1});
+//      meanwhile wave 1 fuses the two Gaussians at node j (information form, the prior counted once);
+//   5. backward pass in strides of four: every slot composes its step with those up to the next anchor above it (affine maps
+//      compose), one wave walks the anchors, the slots between are filled in parallel;
+//   6. T = Y0 + V, sigma2 (residual form), stopping rule, the next E-step's constants.
 //
 // The dense kernels stay in the tree: with the LLE term (include_lle, the pre-processing registration of tracking_step) the
 // system is not of this form, and TDLO_MSTEP=dense selects them as comparators for the tests.
