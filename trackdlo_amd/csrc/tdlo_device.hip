@@ -1213,11 +1213,13 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
                     const double aik = pc[sI];
                     int pw;
                     {
-                        double bv = (rowok && !((usedmask >> row) & 1ull)) ? fabs(aik) : -1.0;
-                        double mx = bv;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-                        const unsigned long long hit = __ballot(bv == mx);
+                        // largest |a_ik| among the rows not yet used, judged by the upper 32 bits of the double (sign off: non-negative
+                        // doubles order like their bit patterns; any entry within 2^-20 of the largest is as good a pivot), first lane
+                        // among equals: a wave-wide max on v_max_u32 with DPP operands (7 instructions) instead of six dependent
+                        // ds_bpermute round trips on the column's critical path (~600 cycles per column)
+                        const unsigned key = (rowok && !((usedmask >> row) & 1ull)) ? ((unsigned)__double2hiint(aik) & 0x7fffffffu) + 1u : 0u;
+                        const unsigned mx = wave_minmax_u32<true>(key);
+                        const unsigned long long hit = __ballot(key == mx);
                         pw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
                         usedmask |= 1ull << pw;
                     }
