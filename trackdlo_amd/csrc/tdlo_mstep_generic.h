@@ -5,6 +5,10 @@
 #include "tdlo_devcommon.h"
 
 namespace tdlo {
+__device__ __forceinline__ double readlane_f64_g(double v, int src_lane) {     // src_lane wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
 
 template <int NW> __device__ __forceinline__ double block_sum_n(double v, double *scratch) {
     v = wave_sum(v);
@@ -97,13 +101,14 @@ __device__ __forceinline__ void mstep_generic_body(const FrameDev &f, int from_s
                 if (v > bv) { bv = v; bi = i; }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(bv, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        const int p = bi;
+        // across the lanes: judged by the upper 32 bits of |a| (non-negative doubles order like their bit patterns; any entry within
+        // 2^-20 of the largest is as good a pivot), first lane among equals -- a DPP wave max (7 instructions) instead of six
+        // dependent rounds of three ds_bpermute each on every column's critical path
+        const unsigned key = bi != 0x7fffffff ? ((unsigned)__double2hiint(bv) & 0x7fffffffu) + 1u : 0u;
+        const unsigned mxk = wave_minmax_u32<true>(key);
+        const int pl = (int)__builtin_ctzll(__ballot(key == mxk));
+        const int p = __builtin_amdgcn_readlane(bi, pl);
+        bv = readlane_f64_g(bv, pl);
         const double pv = A[(size_t)k * ld + p];
         if (!(bv > 0.0)) singular = 1;
         const double rp = (bv > 0.0) ? 1.0 / pv : 0.0;
