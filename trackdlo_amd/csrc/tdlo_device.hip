@@ -775,10 +775,11 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                     long long *ac = accL + (size_t)(wlo_c + lane) * 4;
                     const V4<T> ym = nodesL[wlo_c + lane];
                     const double w0 = (double)s0;
-                    ac[0] += acc_fix(w0, scP);
-                    ac[1] += acc_fix((double)sx + ((double)ox - (double)ym.x) * w0, scR);
-                    ac[2] += acc_fix((double)sy + ((double)oy - (double)ym.y) * w0, scR);
-                    ac[3] += acc_fix((double)sz + ((double)oz - (double)ym.z) * w0, scR);
+                    // (ds_add_u64 without return: one LDS instruction per value instead of read, 64-bit add, write)
+                    __hip_atomic_fetch_add(ac + 0, acc_fix(w0, scP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ac + 1, acc_fix((double)sx + ((double)ox - (double)ym.x) * w0, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ac + 2, acc_fix((double)sy + ((double)oy - (double)ym.y) * w0, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ac + 3, acc_fix((double)sz + ((double)oz - (double)ym.z) * w0, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 wave_lds_sync();
             } else {
