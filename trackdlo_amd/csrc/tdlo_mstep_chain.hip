@@ -149,13 +149,13 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     if (from_sums != 1) {
 #pragma unroll
         for (int u = 0; u < 9; ++u) { const int i = t + u * MB; if (i < nS) S[i] = sq[u]; }
-        acc_clear_other<MB>(f, itn, t);
     } else {
         const auto sums = TDLO_AS_GLOBAL(double, f.sums);
         for (int i = t; i < nS; i += MB) S[i] = sums[i];
     }
     __syncthreads();
     if (from_sums == 2) {       // split mode, export only
+        acc_clear_other<MB>(f, itn, t);
         for (int i = t; i < nS; i += MB) f.sums[i] = S[i];
         if (t == 0) f.sums[nS] = (double)stg->N;
         return;
@@ -306,6 +306,9 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             ra += 2 * SB; la += 2 * lstep;
         }
         if (k < nB) { wait_for(nB); const MRec r = mfetch(0); mstep(r, 0); }
+    } else if (from_sums != 1) {
+        // waves 2 and 3 have nothing to do in this phase: they clear the other parity's accumulator rows for the next E-step
+        acc_clear_other<MB - 128>(f, itn, t - 128);
     }
     __syncthreads();
     CSTAMP(4);
