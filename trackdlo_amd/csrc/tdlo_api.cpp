@@ -239,6 +239,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0) ? 1 : 0;
     (void)vis;
     f.precision = p->precision;
+    f.need_G = (p->include_lle || !mstep_chain_enabled()) ? 1 : 0;
     {   // test hook: iteration k of the multi-CU M-steps behaves as if a hand-off had timed out (tests/test_parity_gpu.py)
         static const int force_it = getenv("TDLO_MCU_FORCE_TIMEOUT") ? atoi(getenv("TDLO_MCU_FORCE_TIMEOUT")) : -1;
         f.force_timeout_it = force_it;

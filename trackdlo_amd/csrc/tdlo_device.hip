@@ -138,8 +138,9 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     __syncthreads();
     {
         const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);
-#pragma unroll 8
-        for (int i = t; i < nb * M; i += kBlock) hg[i] += stot[i % M];
+        // (wave = every 4th prune block, lane = node: no integer modulo per element -- that loop had been a third of this kernel)
+        for (int b = t >> 6; b < nb; b += kBlock / 64)
+            for (int m = t & 63; m < M; m += 64) hg[(size_t)b * M + m] += stot[m];
     }
     // centring offset, chain coordinate: the node block is staged in LDS first -- the serial sums below (same
     // left-to-right order as the reference) would otherwise pay a global-memory round trip per term
@@ -183,13 +184,13 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
 #pragma unroll
         for (int q = 0; q < 8; ++q) f.chain[8 * (size_t)i + q] = o[q];
     }
-    {
+    if (f.need_G) {         // the dense M-steps only (LLE term, comparators): the chain smoother works from the links above
         const auto Gw = TDLO_AS_GLOBAL_RW(double, f.G);
-        for (int e = t; e < M * M; e += kBlock) {
-            const int i = e % M, j = e / M;
-            const double dd = fabs(sc[i] - sc[j]);
-            Gw[e] = 1.0 / (2 * beta * 2 * beta) * ::exp(-::sqrt(2.0) * dd / beta) * (2 * dd + ::sqrt(2.0) * beta);
-        }
+        for (int j = t >> 6; j < M; j += kBlock / 64)
+            for (int i = t & 63; i < M; i += 64) {
+                const double dd = fabs(sc[i] - sc[j]);
+                Gw[(size_t)j * M + i] = 1.0 / (2 * beta * 2 * beta) * ::exp(-::sqrt(2.0) * dd / beta) * (2 * dd + ::sqrt(2.0) * beta);
+            }
     }
     __syncthreads();
     if (f.include_lle) {

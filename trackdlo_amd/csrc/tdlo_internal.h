@@ -68,6 +68,7 @@ struct FrameDev {
     int acc_sh[3];          // binary exponents of the fixed point: value = integer * 2^-sh for P1 / R / Q
     int force_timeout_it;   // test hook (environment TDLO_MCU_FORCE_TIMEOUT=k): iteration k of the multi-CU M-steps behaves as if a hand-off timed out; -1 = off
     int prune_tiles;        // 256-point tiles one prune workgroup handles (1 up to 262 144 points)
+    int need_G;             // the M x M kernel matrix is built at setup (dense M-steps: LLE term, comparators); the chain smoother does not read it
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
