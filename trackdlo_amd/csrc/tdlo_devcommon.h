@@ -186,7 +186,8 @@ __device__ __forceinline__ void chain_link(double beta, double h, double *o) {
     if (x < 1.0) {
         const double tt = 2.0 * x;
         double term = tt * tt * tt / 6.0, sum = term;
-        for (int n = 4; n < 48; ++n) { term = term * tt / (double)n; sum += term; }
+#pragma unroll
+        for (int n = 4; n < 34; ++n) { term *= tt * (1.0 / (double)n); sum += term; }      // tt < 2: the 34th term is below 2^34 / 34! = 6e-29 of the first
         u11 = e2 * sum; u22 = e2 * (4.0 * x + sum);
     } else {
         u11 = 1.0 - e2 * (1.0 + 2.0 * x + 2.0 * x * x); u22 = 1.0 - e2 * (1.0 - 2.0 * x + 2.0 * x * x);

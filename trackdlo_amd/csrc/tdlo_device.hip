@@ -139,8 +139,16 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     {
         const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);
         // (wave = every 4th prune block, lane = node: no integer modulo per element -- that loop had been a third of this kernel)
-        for (int b = t >> 6; b < nb; b += kBlock / 64)
-            for (int m = t & 63; m < M; m += 64) hg[(size_t)b * M + m] += stot[m];
+        for (int m = t & 63; m < M; m += 64) {
+            const int add = stot[m];
+            for (int b = t >> 6; b < nb; b += 8 * (kBlock / 64)) {          // 8 independent read-modify-writes in flight
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int bb = b + u * (kBlock / 64); v[u] = hg[(size_t)(bb < nb ? bb : b) * M + m]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int bb = b + u * (kBlock / 64); if (bb < nb) hg[(size_t)bb * M + m] = v[u] + add; }
+            }
+        }
     }
     // centring offset, chain coordinate: the node block is staged in LDS first -- the serial sums below (same
     // left-to-right order as the reference) would otherwise pay a global-memory round trip per term
