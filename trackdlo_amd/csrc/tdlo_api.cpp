@@ -662,7 +662,7 @@ int tdlo_split_estep(tdlo_ctx *c, const double *dmin_sq_global, double *sums) {
         HIPCHK(c, hipMemcpyAsync(f.dminbits, c->pin, sizeof(double) * M, hipMemcpyHostToDevice, s));
     }
     HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
-    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));        // reduce block partials -> sums
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));        // the shard's accumulators -> sums
     HIPCHK(c, hipMemcpyAsync(c->pin + M, f.sums, sizeof(double) * (4 * M + 2), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     std::memcpy(sums, c->pin + M, sizeof(double) * (4 * M + 2));
@@ -712,7 +712,7 @@ int tdlo_split_estep_enqueue(tdlo_ctx *c) {
     hipStream_t s = c->stream;
     if (c->fh[0].vis_branch) HIPCHK(c, launch_split_dmin_xch(c->fd, c->fh.data(), c->xch_dmin, 1, s));
     HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
-    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));        // block partials -> the bound sums buffer
+    HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));        // the shard's accumulators -> the bound sums buffer
     return TDLO_OK;
 }
 
@@ -937,7 +937,7 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
                 HIPCHK(c, launch_split_dmin_xch(c->fd, c->fh.data(), b_dmin, 1, s));
             }
             HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
-            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));                // block partials -> b_sums
+            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 3, s));                // the shard's accumulators -> b_sums
             if ((e = nccl(R->AllReduce(b_sums, b_sums, 4 * (size_t)M + 2, kNcclFloat64, kNcclSum, nccl_comm, s), "ncclAllReduce(sums)"))) return e;
             HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 4, s));
         }

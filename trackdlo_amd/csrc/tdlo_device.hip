@@ -729,7 +729,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         accQ += acc_fix((double)(inv * qs), scQ);
         // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
         // wave's points within centimetres) and leave as the residual R_m = sum_n P_mn (x_n - y_m):
-        // small numbers, so fp32 tile sums and fp32 block partials lose nothing that matters
+        // small numbers, so fp32 tile sums lose nothing that matters (everything after a tile's sums is 64-bit fixed point)
         const T ox = bcast_first(x), oy = bcast_first(y), oz = bcast_first(z);
         V4<T> pw; pw.x = inv; pw.y = inv * (x - ox); pw.z = inv * (y - oy); pw.w = inv * (z - oz);     // (s0, sx) and (sy, sz) pair up for v_pk_fma
         // one entry of padding after every 16 points: the column sums below read 16-point slices with all lanes of a slice on one
@@ -1588,8 +1588,8 @@ const char *mstep_kernel_name(const FrameDev *fh, int F) {
     return "k_mstep_pivot_mcu";
 }
 
-// kind: 0 E-step, 1 dmin, 2 M-step (from block partials), 3 M-step export-only (split), 4 M-step from global sums (split),
-// 5 M-step from block partials with the one-shot exchange of the split inside (k_mstep_fast only: the caller checks M)
+// kind: 0 E-step, 1 dmin, 2 M-step (from the E-step's accumulators), 3 M-step export-only (split), 4 M-step from global sums (split),
+// 5 M-step from the accumulators with the one-shot exchange of the split inside (chain smoother / k_mstep_fast: the caller checks M)
 hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int kind, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     switch (kind) {

@@ -360,8 +360,8 @@ __global__ __launch_bounds__(kBig) void k_mstep_mcu(const FrameDev *__restrict__
 #endif
     if (rb == 0) MSTAMP(0);
 
-    // ---- 1. block partials -> the 4 x 16 sums this row block needs (P1, PX of its 16 nodes): wave = group of every 16th
-    //         partial row, lane = (quantity, node); the 16 groups are added in a fixed order.  The sums go to f.sums for the
+    // ---- 1. the E-step's accumulators -> the 4 x 16 sums this row block needs (P1, R of its 16 nodes), lane = (quantity, node).
+    //         The sums go to f.sums for the
     //         workgroup that finishes the iteration (every workgroup reading all 256 rows cost 35 us at N >= 64 000).
     {
         const int ii = lane & 15, kk = lane >> 4, irow = 16 * rb + ii;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kPT) void k_mstep_pivot_mcu(const FrameDev *__restr
     if (t < 4) flg[t] = 0;
     if (t < 16) { used[t] = (16 * rb + t < M) ? 0 : 1; kof[t] = -1; }      // padding rows never pivot
 
-    // ---- 1. block partials -> the own 4 x 16 sums (wave = every 4th partial row; groups added in a fixed order)
+    // ---- 1. the E-step's accumulators -> the own 4 x 16 sums
     {
         const int ii = lane & 15, kk = lane >> 4, irow = 16 * rb + ii;
         const bool valid = irow < M;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         li = dir ? (k > 0 ? M - k : 0) : (k > sh ? k - sh : 0);      // 0: identity (first step of a direction, dummy step)
         obs = real && !(dir && k == nB - 1);
     };
-    // ---- 1. everything that comes from memory is requested up front: this thread's step slot (its link, its node), the block partials
+    // ---- 1. everything that comes from memory is requested up front: this thread's step slot (its link, its node), the E-step's sums
     struct SlotQ { dbl2 l[4]; double y[3], y0[3], yp[3], ay[3], aj, w; int node, li; bool obs; };
     auto load_slot = [&](int sl) __attribute__((always_inline)) {
         SlotQ q;
