@@ -209,6 +209,22 @@ def mstep_dense(on: bool) -> bool:
     return bool(load_library().tdlo_debug_mstep_dense(1 if on else 0))
 
 
+class _StatsView:
+    """The per-frame tdlo_stats of a batch call; a frame's dict is built when it is asked for (32 frames x 11 fields of ctypes
+    attribute reads cost more than a tenth of a 32-frame call)."""
+    def __init__(self, st):
+        self._st = st
+
+    def __len__(self):
+        return len(self._st)
+
+    def __getitem__(self, i):
+        return self._st[i].as_dict()
+
+    def __iter__(self):
+        return (s.as_dict() for s in self._st)
+
+
 def _f64(a):
     return np.asfortranarray(np.asarray(a, dtype=np.float64))
 
@@ -299,8 +315,8 @@ class Context:
         pri, K, vis, nv, Hm = self._opt(priors, visible_nodes, H)
         self._chk(self.lib.tdlo_cpd_lle_batch(self.h, F, _ptr(Yb), M, _ptr(s2), C.byref(params), _ptr(pri), K, _ptr(vis), nv,
                                               _ptr(Hm), C.cast(st, C.c_void_p)))
-        Yo = np.ascontiguousarray(Yb.transpose(0, 2, 1))
-        return dict(Y=[Yo[i] for i in range(F)], sigma2=s2, stats=[s.as_dict() for s in st])
+        Yo = Yb.transpose(0, 2, 1)                                 # views: frame i is Yo[i] (M x 3, column-major storage)
+        return dict(Y=Yo, sigma2=s2, stats=_StatsView(st))
 
     # ---- the split registration driven from C++ (tdlo_split_run) -------------------------------------------------------
     def split_run(self, Y, sigma2, params: Params, comm=None, priors=None, visible_nodes=None, H=None, check=True):
