@@ -1,0 +1,38 @@
+"""Ad-hoc sweep of the chain-smoother M-step against the oracle (fp64 mode, no LLE term): random sizes, parameters, priors,
+visibility weighting, carried-over sigma2; prints the worst deviations.  usage: python scripts/gpu_fuzz_chain.py [n_cases]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from trackdlo_amd import binding as B, synth
+from oracle import ref_cpu
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+worst = (0, None); worst_s = (0, None); bad = 0
+ctx = B.Context(device=0, max_points=1 << 14, max_nodes=512)
+for seed in range(n):
+    rng = np.random.default_rng(77000 + seed)
+    M = int(rng.choice([rng.integers(4, 65), rng.integers(65, 200), rng.integers(200, 513)], p=[0.7, 0.2, 0.1]))
+    N = int(rng.integers(200, 9000)); iters = int(rng.integers(1, 12))
+    vis = bool(rng.integers(0, 2)) and M >= 12
+    use_pri = bool(rng.integers(0, 2))
+    X, Y0, v = synth.scene(N, M, config=500 + seed, frame=seed, noise=float(rng.choice([0.0005, 0.002, 0.004])), occlude=(0.35, 0.55) if vis else None,
+                           outliers=int(rng.integers(0, 20)), shift=(0.0, float(rng.uniform(0, 0.008)), float(rng.uniform(-0.003, 0.003))))
+    vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0)) if vis else None
+    kw = dict(beta=float(rng.choice([0.1, 0.35, 0.6, 3.0])), lambda_=float(rng.choice([1.0, 500.0, 50000.0])), lle_weight=10.0,
+              mu=float(rng.choice([0.05, 0.1, 0.3])), max_iter=iters, tol=float(rng.choice([0.0, 2e-4])), include_lle=False, alpha=0.0,
+              k_vis=50.0 if vis else 0.0, visibility_threshold=0.008)
+    pri = None
+    if use_pri:
+        idx = np.sort(rng.choice(M, size=max(1, M // 4), replace=False))
+        pri = np.concatenate([idx[:, None].astype(float), Y0[idx] + rng.normal(0, 0.003, size=(len(idx), 3))], axis=1)
+        kw["alpha"] = float(rng.choice([1.0, 3.0]))
+    s2 = float(rng.choice([0.0, 1e-4, 2e-5]))
+    o = ref_cpu.cpd_lle(X, Y0, s2, priors=pri, visible_nodes=vext, **kw)
+    g = ctx.cpd_lle(X, Y0, s2, B.make_params(kw["beta"], kw["lambda_"], kw["lle_weight"], kw["mu"], kw["max_iter"], kw["tol"], False, kw["alpha"], kw["k_vis"], kw["visibility_threshold"], 1),
+                    priors=pri, visible_nodes=vext, check=False)
+    dy = float(np.abs(g["Y"] - o["Y"]).max()); ds = abs(g["sigma2"] - o["sigma2"]) / o["sigma2"]
+    ok = g["rc"] == 0 and g["iters"] == o["iters"] and g["n_kept"] == o["n_kept"] and dy <= 1e-9 and ds <= 1e-7
+    if not ok:
+        bad += 1; print("MISMATCH seed", seed, "M", M, "N", N, "iters", g["iters"], o["iters"], "rc", g["rc"], "dY %.2e ds %.2e" % (dy, ds), kw)
+    if dy > worst[0]: worst = (dy, (seed, M, N, kw["beta"], kw["lambda_"]))
+    if ds > worst_s[0]: worst_s = (ds, (seed, M, N, kw["beta"], kw["lambda_"]))
+print(f"{n} cases, {bad} outside the fp64 gate (1e-9 m, 1e-7); worst |dY| {worst[0]:.2e} m at {worst[1]}; worst d sigma2 {worst_s[0]:.2e} at {worst_s[1]}")
