@@ -154,13 +154,17 @@ template <int NT> __device__ __forceinline__ void acc_clear_other(const FrameDev
 
 __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st, double sigma2, double Nc) {
     // c of trackdlo.cpp:300 (or c' of :378 when visibility weighting is active)
-    const double tp = 2.0 * M_PI * sigma2;
-    double c = tp * ::sqrt(tp) * f.mu / (1.0 - f.mu);          // (2 pi sigma2)^(3/2): one square root instead of pow() at the end of every M-step
+    const double tp = 2.0 * M_PI * sigma2, rtp = ::sqrt(tp);
+    double c = tp * rtp * f.mu / (1.0 - f.mu);                 // (2 pi sigma2)^(3/2): one square root instead of pow() at the end of every M-step
     c = f.vis_branch ? c / Nc : c * (double)f.M / Nc;
     st->sigma2 = sigma2;
     st->Nc = Nc;
     st->k2 = -1.4426950408889634 / (2.0 * sigma2);
     st->c_norm = c;
+    // the E-step's node window: 2^(k2 t^2) rounds to zero below an exponent of -151 (fp32; -1080 in fp64), i.e. beyond
+    // t = sqrt(151 / |k2|) = sqrt(151 * 2 / (2 pi log2 e)) * sqrt(2 pi sigma2); 1 % of margin, the same square root as above
+    st->rwin32 = 1.01 * 5.7720 * rtp;
+    st->rwin64 = 1.01 * 15.4366 * rtp;
 }
 
 

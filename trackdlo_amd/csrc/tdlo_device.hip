@@ -505,6 +505,13 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 #else
 #define ESTAMP(i) do { } while (0)
 #endif
+    // -DTDLO_ESTEP_PHASES: shader clocks per phase, summed over the batches of wave 0 of the middle workgroup (scripts/gpu_ephases.py)
+#ifdef TDLO_ESTEP_PHASES
+    unsigned long long ph_prev = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define EPHASE(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_prev; ph_prev = t_; } while (0)
+#else
+#define EPHASE(i) do { } while (0)
+#endif
     ESTAMP(0);
     const auto stg = TDLO_AS_GLOBAL(IterState, f.st);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -559,6 +566,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     __syncthreads();
     ESTAMP(1);
+    EPHASE(0);
 
     // running sums in 64-bit fixed point (acc_fix at the grain of one wave x one batch; integer from there on: tdlo_devcommon.h)
     long long accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
@@ -574,15 +582,16 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     if (NCH == 1) {
         for (int i = lane; i < M * 4; i += 64) accL[i] = 0;
     }
-    constexpr double kCut = sizeof(T) == 4 ? 151.0 : 1080.0;
-    const T Rwin = (T)(1.01 * ::sqrt(kCut / fabs((double)k2)));
+    const T Rwin = (T)(sizeof(T) == 4 ? stg->rwin32 : stg->rwin64);      // 1.01 sqrt(151 / |k2|) (fp32; 1080 in fp64), left by the M-step
 
     const int nbatch = (N + 63) >> 6;
     for (int batch = batch0; batch < nbatch; batch += f.nblkE * NWE) {
         const int n = batch * 64 + lane;
         const bool valid = n < N;
+        EPHASE(6);
         if (batch != batch0) { x = 0; y = 0; z = 0; if (valid) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; } }
         else if (!valid) { x = 0; y = 0; z = 0; }     // the speculative first load may have read past the kept points
+        EPHASE(1);
         // ---- nearest node: argmax of the Euclidean membership (:298-310) == argmin of d2, first index
         // The cloud is sorted by nearest node, so the wave's points sit in a small ball (centre = lane 0's point, radius
         // rw).  With D_m = |y_m - centre|: every point is within min_m D_m + rw of some node and at least D_m - rw away
@@ -644,6 +653,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             }
         }
         ESTAMP(2);
+        EPHASE(2);
         // ---- second node by distance (:313-329)
         const int c1 = (a == 0) ? 2 : a - 1;
         const int c2 = (a == M - 1) ? M - 3 : a + 1;
@@ -683,6 +693,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         }
 
         ESTAMP(3);
+        EPHASE(3);
         // ---- unnormalised membership, column sum, Q (:354-383)
         // adj: no point of this wave has the end-node gap (hi == lo + 2), the cheaper form of the exponent applies
         const bool adj = __ballot(valid && hi - lo != 1) == 0;
@@ -725,6 +736,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             else { span(wlo, wst, std::false_type(), std::true_type()); span(wst + 1, whi, std::false_type(), std::false_type()); }
         }
         ESTAMP(4);
+        EPHASE(4);
         const T inv = valid ? Num<T>::rcp_fast(sum + cn) : T(0);
         accQ += acc_fix((double)(inv * qs), scQ);
         // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
@@ -817,6 +829,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             }
             }
         }
+        EPHASE(5);
     }
 
     ESTAMP(5);
@@ -870,6 +883,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         acc_add(arow, 4 * M, q);
     }
     ESTAMP(7);
+    EPHASE(7);
+#ifdef TDLO_ESTEP_PHASES
+    if (tid == 0 && (int)blockIdx.x == f.nblkE / 2) { for (int i = 0; i < 10; ++i) f.dbg[48 + i] = ph_acc[i]; }
+#endif
 #ifdef TDLO_ESTEP_STAMPS
     if (tid == 0) atomicMax(&f.dbg[33], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

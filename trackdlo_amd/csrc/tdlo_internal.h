@@ -26,6 +26,7 @@ struct IterState {
     double Np;          // last Np (:388)
     double sum_d2;      // sum over kept points and nodes of |Y0_m - x_n|^2 (:263-273)
     double Nc;          // N used in the denominator constant c (global N when the cloud is split)
+    double rwin32, rwin64;  // E-step: arc-length radius beyond which a membership is exactly zero in fp32 / fp64 (with 1 % of margin)
     int N;              // points kept by the prune (:195)
     int it;             // iterations completed
     int done;           // 1: remaining kernels of the loop are no-ops
