@@ -1297,7 +1297,9 @@ int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 
 int tdlo_debug_stamps(tdlo_ctx *c, int slot, unsigned long long *out, int n) {
     if (!c || slot < 0 || slot >= (int)c->slots.size() || !out || n < 1 || n > 64 || c->fh.empty()) return TDLO_E_INVALID;
-    HIPCHK(c, hipMemcpyAsync(c->pin, c->fh[0].dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+    const int dbg_frame = getenv("TDLO_DEBUG_FRAME") ? atoi(getenv("TDLO_DEBUG_FRAME")) : 0;      // which frame of the last batch
+    if (dbg_frame < 0 || dbg_frame >= (int)c->fh.size()) return TDLO_E_INVALID;
+    HIPCHK(c, hipMemcpyAsync(c->pin, c->fh[dbg_frame].dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(out, c->pin, sizeof(unsigned long long) * n);
     return TDLO_OK;

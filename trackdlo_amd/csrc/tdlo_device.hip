@@ -490,6 +490,13 @@ __device__ __forceinline__ T geo_arg_adj(int m, int lo, T cm, T c_lo, T d_lo, T 
     return t * t;
 }
 
+// the value of the lane 8 away in the same row of 16 (DPP row_ror:8)
+__device__ __forceinline__ float row_ror8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true)); }
+__device__ __forceinline__ double row_ror8(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x128, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x128, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // EB = threads per workgroup (256 or 512); SINGLE: the frame descriptor arrives by value in the
 // kernarg segment (no dependent loads before the first useful one).
 template <typename T, int NCH, bool VIS, int EB, bool SINGLE>
@@ -514,6 +521,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 #endif
     ESTAMP(0);
     const auto stg = TDLO_AS_GLOBAL(IterState, f.st);
+#ifdef TDLO_TIMELINE      // wall-clock (100 MHz) begin of the first workgroup / end of the last one, iterations 20..27 (scripts/gpu_timeline.py)
+    const int tl_it = stg->it - 20;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && tl_it >= 0 && tl_it < 8) f.dbg[4 * tl_it] = __builtin_amdgcn_s_memrealtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = f.M;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -772,17 +783,19 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 }
             }
             wave_lds_sync();
-            const int shift = Wn <= 16 ? 4 : 5;                          // wave-uniform
+            // (a converged window is 5 to 8 nodes: with 8 lanes per slice a lane sums 8 points instead of 16, and the extra
+            // level of the slice reduction is one DPP add per sum)
+            const int shift = Wn <= 8 ? 3 : (Wn <= 16 ? 4 : 5);          // wave-uniform
             const int wl = lane & ((1 << shift) - 1), sl = lane >> shift;
-            const int nj = 1 << shift;                                   // points per slice: 16 / 32
+            const int nj = 1 << shift;                                   // points per slice (= lanes per slice): 8 / 16 / 32
             T s0 = 0, sx = 0, sy = 0, sz = 0;
             if (wl < Wn) {
-                for (int h = 0; h < nj; h += 16) {                       // 16 points at a time (same order as one loop over nj)
+                for (int h = 0; h < nj; h += 8) {                        // 8 points at a time (same order as one loop over nj)
                     const int i0 = sl * nj + h;
                     const T *prow = pb + (rbase + wl) * kPStride + i0;
                     const V4<T> *pw_ = pts + wave * kPtsStride + i0 + (i0 >> 4);
-#pragma unroll 8
-                    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
                         const T p = prow[j];
                         const V4<T> w = pw_[j];
                         s0 += p * w.x; sx += p * w.y; sy += p * w.z; sz += p * w.w;
@@ -791,6 +804,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             }
             s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
             if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
+            if (shift <= 3) { s0 += row_ror8(s0); sx += row_ror8(sx); sy += row_ror8(sy); sz += row_ror8(sz); }
             if (NCH == 1) {
                 if (lane < Wn) {
                     long long *ac = accL + (size_t)(wlo_c + lane) * 4;
@@ -884,6 +898,9 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     ESTAMP(7);
     EPHASE(7);
+#ifdef TDLO_TIMELINE
+    if (tid == 0 && tl_it >= 0 && tl_it < 8) atomicMax(&f.dbg[4 * tl_it + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 #ifdef TDLO_ESTEP_PHASES
     if (tid == 0 && (int)blockIdx.x == f.nblkE / 2) { for (int i = 0; i < 10; ++i) f.dbg[48 + i] = ph_acc[i]; }
 #endif

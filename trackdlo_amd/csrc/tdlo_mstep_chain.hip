@@ -141,6 +141,9 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
     // for the iteration counter (M <= 512: at most 9 elements per thread)
     const int itn = stg->it;
+#ifdef TDLO_TIMELINE      // wall-clock (100 MHz) begin / end of iterations 20..27, scripts/gpu_timeline.py
+    if (t == 0 && itn >= 20 && itn < 28) f.dbg[4 * (itn - 20) + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     double sq[9];
 #pragma unroll
     for (int u = 0; u < 9; ++u) { const int i = t + u * MB; sq[u] = (from_sums != 1 && i < nS) ? acc_read_both(f, i, itn) : 0.0; }
@@ -486,6 +489,9 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         } else { st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
         if (crit < f.tol) st->done = 1;                                   // :424-428
         else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+#ifdef TDLO_TIMELINE
+        if (itn >= 20 && itn < 28) f.dbg[4 * (itn - 20) + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 #undef CSTAMP
 }
