@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     // state-space form of G for the chain smoother (tdlo_mstep_chain.hip): one link per pair of consecutive nodes
     for (int i = t; i < M; i += kBlock) {
         double o[8];
-        if (i == 0) { const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta); o[0] = sf2; o[1] = s * s * sf2; o[2] = o[3] = o[4] = o[5] = o[6] = o[7] = 0.0; }
+        if (i == 0) { const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta); o[0] = sf2; o[1] = s * s * sf2; o[2] = 1.0 / o[0]; o[3] = 1.0 / o[1]; o[4] = o[5] = o[6] = o[7] = 0.0; }      // Pinf and its inverse
         else chain_link(beta, sc[i] - sc[i - 1], o);
 #pragma unroll
         for (int q = 0; q < 8; ++q) f.chain[8 * (size_t)i + q] = o[q];

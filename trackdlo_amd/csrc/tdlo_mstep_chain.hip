@@ -52,6 +52,13 @@ namespace {
 constexpr int kCB = 256;               // workgroup size
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
+// the value of lane L of the own row of 16 lanes (DPP row_newbcast, two 32-bit halves)
+template <int L> __device__ __forceinline__ double row_bcast_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + L, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + L, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 }  // namespace
 
 // Step slots.  Both directions have nB = M - j steps; direction A (nodes 0 .. j) starts with nB - nA in {0, 1} dummy steps
@@ -60,22 +67,38 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 //   [ 0.. 7] record of the step  {f11 f12 | f21 f22 | q11/c q12/c | q22/c p}   (Phi and Q of the link INTO the step, observation precision)
 //   [ 8..13] right-hand side     {bx - | by - | bz -}
 //   [14..19] mean                {mx0 mx1 | my0 my1 | mz0 mz1}   filtered -> e_k -> smoothed
-//   [20..23] posterior           {a b | d g}
+//   [20..23] posterior           {a b | d -}
 //   [24..27] smoother gain       {C11 C12 | C21 C22}
-constexpr int kSlot = 28;
+//   [28..31] spike means         {F00 F10 | F01 F11}   inner directions: the mean's dependence on the direction's start state
+constexpr int kSlot = 34;             // (272 bytes: consecutive slots start 4 banks apart, so a 128-bit access of 16 lanes -- thread = slot -- covers the
+                                      //  64 banks exactly once; a stride of 256 bytes would put every lane on the same four banks)
 constexpr int kAhead = 6;             // slots behind the last one that the software-pipelined loops may read
-constexpr int kDump = 32;              // doubles per lane of the dump area (lanes that have nothing to store write there)
+constexpr int kBehind = 9;            // slots in front of the first one that the anchor walk may read (values unused)
+constexpr int kDump = 32;              // doubles of the dump area (lanes that have nothing to store write there; never read for a result)
+constexpr int kRed = 112;              // [0..15] wave sums, [24] exchange flag, [26, 27] zeros, [28] progress counter,
+                                       // [32..71] likelihood sums of the four directions (5 columns x 2), [72..77] junction state x2,
+                                       // [80..93], [96..109] junction matrices of the left / right half
+constexpr int kND = 4;                 // directions
 
+// Four directions, nQ steps each (leading dummy steps -- identity link, nothing observed -- make all four end in their last step):
+//   0: nodes 0 .. j1 of the process, from the stationary prior             2: nodes j2 .. j3 of the process, from the state AT j2
+//   1: nodes j2-1 .. j1 of the reversed process, from the state AT j2      3: nodes M-1 .. j3 of the reversed process, from the prior
+// j2 = the middle node, j1 and j3 the quarter points.  The junction nodes' data belong to directions 0 (j1), 2 (j2) and 3 (j3).
 struct ChainCarve {
-    int nSp, jn, nA, nB, nSl;
+    int nSp, j1, j2, j3, n0, n1, n2, n3, nQ, nSl;      // (scalars, no array: an indexed member keeps the whole object in scratch memory)
     size_t S, red, dump, slots, total;
     __host__ __device__ explicit ChainCarve(int M) {
         nSp = 4 * M + 2;
-        jn = (M - 1) >> 1; nA = jn + 1; nB = M - jn; nSl = 2 * nB;
+        j2 = (M - 1) >> 1; j1 = j2 >> 1; j3 = (j2 + M) >> 1;
+        n0 = j1 + 1; n1 = j2 - j1; n2 = j3 - j2 + 1; n3 = M - j3;
+        const int a = n0 > n1 ? n0 : n1, b = n2 > n3 ? n2 : n3;
+        nQ = a > b ? a : b;
+        nSl = kND * nQ;
         size_t o = 0;
         S = o; o += (size_t)((nSp + 1) & ~1);           // [P1 | Rx | Ry | Rz | Q]
-        red = o; o += 32;                               // [0..15] wave sums, [24] exchange flag
-        dump = o; o += (size_t)64 * kDump;
+        red = o; o += kRed;
+        dump = o; o += kDump;
+        o += (size_t)kSlot * kBehind;
         slots = o; o += (size_t)kSlot * (nSl + kAhead);  // the loops read up to kAhead slots ahead
         total = o;
     }
@@ -90,7 +113,10 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nS = 4 * M + 1;
     const ChainCarve cv(M);
-    const int nA = cv.nA, nB = cv.nB, nSl = cv.nSl, sh = nB - nA;
+    const int nQ = cv.nQ, nSl = cv.nSl, j1 = cv.j1, j2 = cv.j2, j3 = cv.j3;
+    // leading dummy steps per direction (0 .. 3 of them), one nibble each: shifts instead of a select chain over four values,
+    // which the compiler turns into a table in scratch memory
+    const int padbits = (nQ - cv.n0) | ((nQ - cv.n1) << 4) | ((nQ - cv.n2) << 8) | ((nQ - cv.n3) << 12);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *S = (double *)smem + cv.S, *red = (double *)smem + cv.red, *dump = (double *)smem + cv.dump, *slots = (double *)smem + cv.slots;
 
@@ -108,13 +134,19 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     const auto aYg = TDLO_AS_GLOBAL(double, f.aYd);
     const auto chg = TDLO_AS_GLOBAL(dbl2, f.chain);
 
-    // slot -> (node, link into the step, does the step observe its node).  The junction node's data belong to direction A.
+    // slot -> (node, link into the step, does the step observe its node); li == 0: identity (a direction's first step from the prior or
+    // at j2, dummy steps).  A junction node is observed (and written back) by one direction only.
+    auto slot_dir = [&](int sl) __attribute__((always_inline)) { return (sl >= 2 * nQ) ? (sl >= 3 * nQ ? 3 : 2) : (sl >= nQ ? 1 : 0); };
     auto slot_info = [&](int sl, int &node, int &li, bool &obs) __attribute__((always_inline)) {
-        const int dir = sl >= nB, k = dir ? sl - nB : sl;
-        const bool real = dir || k >= sh;
-        node = real ? (dir ? M - 1 - k : k - sh) : 0;
-        li = dir ? (k > 0 ? M - k : 0) : (k > sh ? k - sh : 0);      // 0: identity (first step of a direction, dummy step)
-        obs = real && !(dir && k == nB - 1);
+        const int dir = slot_dir(sl), k = sl - dir * nQ;
+        const int kk = k - ((padbits >> (4 * dir)) & 15);
+        const bool real = kk >= 0;
+        int nd, l; bool ob;
+        if (dir == 0)      { nd = kk;         l = kk > 0 ? kk : 0;     ob = true; }
+        else if (dir == 1) { nd = j2 - 1 - kk; l = nd + 1;             ob = nd != j1; }
+        else if (dir == 2) { nd = j2 + kk;    l = kk > 0 ? nd : 0;     ob = nd != j3 && !(kk == 0 && j1 == j2); }
+        else               { nd = M - 1 - kk; l = kk > 0 ? nd + 1 : 0; ob = true; }
+        node = real ? nd : 0; li = real ? l : 0; obs = real && ob;
     };
     // ---- 1. everything that comes from memory is requested up front: this thread's step slot (its link, its node), the E-step's sums
     struct SlotQ { dbl2 l[4]; double y[3], y0[3], yp[3], ay[3], aj, w; int node, li; bool obs; };
@@ -131,22 +163,24 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         q.aj = pri ? aJg[mc] : 0.0;
         return q;
     };
+    // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
+    // for the iteration counter (M <= 512: at most 9 elements per thread).  Requested before the slot: its index arithmetic
+    // runs while these are in flight.
+    const int itn = stg->it;
+    double sq[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) { const int i = t + u * MB; sq[u] = (from_sums != 1 && i < nS) ? acc_read_both(f, i, itn) : 0.0; }
     const SlotQ q0 = load_slot(t);
     const double pinf0 = chg[0].x, pinf1 = chg[0].y;  // sf2, s^2 sf2
     const double c2 = f.lambda * sigma2, rc2 = fast_rcp(c2);
+    const double cp0 = c2 * chg[1].x, cp1 = c2 * chg[1].y;  // Pinf^-1 in the units of the filter (P = covariance / c); reciprocals from k_setup
     // what the kernel's last thread needs of set_iter_consts, formed while the loads are in flight: c of :300 / c' of :378 is
     // (2 pi sigma2)^(3/2) times this factor
     const double Nc = stg->Nc;
     const double kc = f.mu / (1.0 - f.mu) * (f.vis_branch ? 1.0 / Nc : (double)M / Nc);
-    // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
-    // for the iteration counter (M <= 512: at most 9 elements per thread)
-    const int itn = stg->it;
 #ifdef TDLO_TIMELINE      // wall-clock (100 MHz) begin / end of iterations 20..27, scripts/gpu_timeline.py
     if (t == 0 && itn >= 20 && itn < 28) f.dbg[4 * (itn - 20) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-    double sq[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) { const int i = t + u * MB; sq[u] = (from_sums != 1 && i < nS) ? acc_read_both(f, i, itn) : 0.0; }
     if (done) return;
     CSTAMP(1);
     if (from_sums != 1) {
@@ -203,7 +237,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[4 + d] = dbl2{q.obs ? S[(1 + d) * M + q.node] + (p1 * (q.y[d] - q.y0[d]) + q.ay[d]) : 0.0, 0.0};
     }
-    if (t == 0) *(int *)(red + 28) = 0;      // progress counter of the covariance pass
+    if (t == 0) { *(int *)(red + 28) = 0; red[26] = 0.0; red[27] = 0.0; }      // progress counter of the covariance pass; the spike columns' right-hand side
     if (t >= MB - kAhead) {     // the slots the loops read ahead into: identity, nothing observed
         dbl2 *o = (dbl2 *)(slots + (size_t)kSlot * (nSl + (t - (MB - kAhead))));
         o[0] = dbl2{1.0, 0.0}; o[1] = dbl2{0.0, 1.0}; o[2] = dbl2{0.0, 0.0}; o[3] = dbl2{0.0, 0.0}; o[4] = dbl2{0.0, 0.0}; o[5] = dbl2{0.0, 0.0}; o[6] = dbl2{0.0, 0.0};
@@ -213,19 +247,20 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 
     // ---- 3. forward pass, two waves in a pipeline.  A lone wave issues one instruction per ~8 cycles whatever the instruction is
     //         (scripts/ubench/lat.hip), so the pass is bound by its instruction count: wave 0 runs the covariance recursion (which
-    //         does not depend on the data), wave 1 follows with the means as the posteriors appear.  Both: lanes 0..31 direction A,
-    //         32..63 direction B.  Hand-over through LDS: wave 0 stores a step's posterior and then the number of finished steps --
+    //         does not depend on the data), wave 1 follows with the means as the posteriors appear.  Both: 16 lanes per direction.
+    //         Hand-over through LDS: wave 0 stores a step's posterior and then the number of finished steps --
     //         a wave's LDS operations execute in order, the reader loads the counter before the posterior; the inline asm keeps the
     //         compiler from reordering across the two.
     constexpr int SB = kSlot * 8;
     const unsigned prog_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(red + 28);
     if (wv == 0) {
-        const int dir = lane >> 5, hl = lane & 31;
-        char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
-        char *ra = sb + (size_t)SB * dir * nB;          // the direction's current slot (the same in every lane of a half)
-        char *qa = hl == 0 ? ra : db;                   // the posterior's cells for lane 0 of the half, else the lane's dump area
+        const int dir = lane >> 4, hl = lane & 15;
+        const bool inner = dir == 1 || dir == 2;
+        char *const sb = (char *)slots, *const db = (char *)dump;
+        char *ra = sb + (size_t)SB * dir * nQ;          // the direction's current slot (the same in every lane of a quarter)
+        char *qa = hl == 0 ? ra : db;                   // the posterior's cells for lane 0 of the quarter, else the dump area
         const int qstep = hl == 0 ? SB : 0;
-        double a = pinf0 * rc2, b = 0.0, d = pinf1 * rc2;
+        double a = inner ? 0.0 : pinf0 * rc2, b = 0.0, d = inner ? 0.0 : pinf1 * rc2;      // an inner direction starts from a known state
         struct Rec { dbl2 r0, r1, r2, r3; };
         auto fetch = [&](int ahead) __attribute__((always_inline)) {       // record of the step `ahead` slots further on
             Rec r;
@@ -254,9 +289,9 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         // four steps per trip on four register sets: every record is requested two steps before its use, nothing is copied; the
         // slots behind a direction's last one are readable (look-ahead slots / the other direction)
         int k = 0;
-        if (nB >= 4) {
+        if (nQ >= 4) {
             Rec rA = fetch(0), rB = fetch(1);
-            for (; k + 3 < nB; k += 4) {
+            for (; k + 3 < nQ; k += 4) {
                 const Rec rC = fetch(2), rD = fetch(3);
                 step(rA, 0); step(rB, 1);
                 rA = fetch(4); rB = fetch(5);
@@ -264,19 +299,28 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
                 ra += 4 * SB; qa += 4 * qstep;
             }
         }
-        for (; k < nB; ++k) {
+        for (; k < nQ; ++k) {
             const Rec r = fetch(0);
             step(r, 0);
             ra += SB; qa += qstep;
         }
     } else if (wv == 1) {
-        const int dir = lane >> 5, hl = lane & 31;
-        const bool wr = hl < 3;
-        char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
-        char *ra = sb + (size_t)SB * dir * nB;
-        char *la = wr ? ra + 16 * hl : db;              // the lane's own cells: slot + 16 hl for the three coordinate lanes, else its dump area
+        // lane = (direction, column): columns 0..2 the coordinates, 3 and 4 the SPIKE columns -- the mean of an inner direction is
+        // affine in its unknown start state x, m_k = g_k + F_k x: the coordinate columns carry g (start 0), the spike columns F (start
+        // I, nothing observed: right-hand side 0).  The same lanes sum the likelihood of the direction's data as a function of x,
+        //   -1/2 x^T J x + x^T eta,  J = sum_k p g_k h_k h_k^T,  eta = sum_k g_k innov_k h_k,   h_k = row 0 of Phi F_{k-1}, g_k = 1 - p a_k:
+        // with w = +-g_k innov (innov of a spike column is -p h) every lane adds w h_0 and w h_1 -- columns 0..2 end with eta, 3 and 4 with J.
+        const int dir = lane >> 4, hl = lane & 15;
+        const bool wr = hl < 5;
+        char *const sb = (char *)slots, *const db = (char *)dump;
+        char *ra = sb + (size_t)SB * dir * nQ;
+        char *la = wr ? (hl < 3 ? ra + 16 * hl : ra + 112 + 16 * (hl - 3)) : db;    // the lane's mean cell is la + 112: [14 + 2 hl], spike columns [28 + 2 (hl - 3)]
         const int lstep = wr ? SB : 0;
-        double m0 = 0.0, m1 = 0.0;
+        const char *ba = hl < 3 ? ra + 64 + 16 * hl : (const char *)(red + 26);     // right-hand side: the slot's, zero for the spike columns
+        const int bstep = hl < 3 ? SB : 0;
+        double m0 = hl == 3 ? 1.0 : 0.0, m1 = hl == 4 ? 1.0 : 0.0;
+        const double sgl = hl < 3 ? 1.0 : -1.0;
+        double acc0 = 0.0, acc1 = 0.0;
         int have = 0;                                   // steps whose posterior is known to be in LDS
         auto wait_for = [&](int need) __attribute__((always_inline)) {
             while (have < need) {
@@ -291,35 +335,68 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             MRec r;
             const char *rp = ra + SB * ahead;
             r.r0 = *(const dbl2 *)(rp); r.r1 = *(const dbl2 *)(rp + 16); r.p = *(const double *)(rp + 56); r.ab = *(const dbl2 *)(rp + 160);
-            r.bb = *(const double *)(la + lstep * ahead + 64);
+            r.bb = *(const double *)(ba + bstep * ahead);
             return r;
         };
         auto mstep = [&](const MRec &r, int at) __attribute__((always_inline)) {
             // m^- = Phi m;  m = m^- + K (b - p m^-_0),  K = (a, b) of the step's posterior
             const double pm0 = fma(r.r0.y, m1, r.r0.x * m0), pm1 = fma(r.r1.y, m1, r.r1.x * m0);
             const double innov = fma(-r.p, pm0, r.bb);
+            const double w = (sgl * fma(-r.p, r.ab.x, 1.0)) * innov;
+            const double h0 = row_bcast_f64<3>(pm0), h1 = row_bcast_f64<4>(pm0);
+            acc0 = fma(w, h0, acc0); acc1 = fma(w, h1, acc1);
             m0 = fma(r.ab.x, innov, pm0); m1 = fma(r.ab.y, innov, pm1);
             *(dbl2 *)(la + lstep * at + 112) = dbl2{m0, m1};
         };
         int k = 0;
-        for (; k + 1 < nB; k += 2) {
+        for (; k + 3 < nQ; k += 2) {                    // in pairs while the covariance pass is far ahead ...
             wait_for(k + 2);
             const MRec rA = mfetch(0), rB = mfetch(1);
             mstep(rA, 0); mstep(rB, 1);
-            ra += 2 * SB; la += 2 * lstep;
+            ra += 2 * SB; la += 2 * lstep; ba += 2 * bstep;
         }
-        if (k < nB) { wait_for(nB); const MRec r = mfetch(0); mstep(r, 0); }
-    } else if (from_sums != 1) {
+        for (; k < nQ; ++k) {                           // ... one by one at the end: the pass is over one step after the covariances
+            wait_for(k + 1);
+            const MRec r = mfetch(0);
+            mstep(r, 0);
+            ra += SB; la += lstep; ba += bstep;
+        }
+        if (wr) *(dbl2 *)(red + 32 + 2 * (dir * 5 + hl)) = dbl2{acc0, acc1};
+    } else {
         // waves 2 and 3 have nothing to do in this phase: they clear the other parity's accumulator rows for the next E-step
-        acc_clear_other<MB - 128>(f, itn, t - 128);
+        if (from_sums != 1) acc_clear_other<MB - 128>(f, itn, t - 128);
+        if (wv == 2) {
+            // ... and wave 2 prepares what the junction solve (4., below) needs of the covariances alone, while the means finish:
+            // per half (lanes 0..31 left, 32..63 right) P_outer^-1, Lam, A = (I + Lam Pc)^-1, W = A Lam
+            int have = 0;
+            while (have < nQ) {
+                int v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(prog_addr) : "memory");
+                have = __builtin_amdgcn_readfirstlane(v);
+                if (have < nQ) __builtin_amdgcn_s_sleep(4);
+            }
+            const int hf = lane >> 5, dO = hf ? 3 : 0, dI = hf ? 2 : 1;
+            const double *sO = slots + (size_t)kSlot * (dO * nQ + nQ - 1), *sI = slots + (size_t)kSlot * (dI * nQ + nQ - 1);
+            const dbl2 abO = *(const dbl2 *)(sO + 20), abI = *(const dbl2 *)(sI + 20);
+            const double Oa = abO.x, Ob = -abO.y, Od = sO[22], pa = abI.x, pb = abI.y, pd = sI[22];      // outer posterior in the half's frame
+            const double rO = fast_rcp(fma(Oa, Od, -(Ob * Ob)));
+            const double ia = Od * rO, ib = -Ob * rO, id = Oa * rO;
+            const double La = ia - cp0, Lb = ib, Ld = id - cp1;
+            const double n00 = fma(La, pa, fma(Lb, pb, 1.0)), n01 = fma(La, pb, Lb * pd), n10 = fma(Lb, pa, Ld * pb), n11 = fma(Lb, pb, fma(Ld, pd, 1.0));
+            const double rn = fast_rcp(fma(n00, n11, -(n01 * n10)));
+            const double A00 = n11 * rn, A01 = -n01 * rn, A10 = -n10 * rn, A11 = n00 * rn;
+            const double W00 = fma(A00, La, A01 * Lb), W01 = fma(A00, Lb, A01 * Ld), W11 = fma(A10, Lb, A11 * Ld);      // (W is symmetric)
+            dbl2 *jo = (dbl2 *)((lane & 31) == 0 ? red + 80 + 16 * hf : dump);
+            jo[0] = dbl2{ia, ib}; jo[1] = dbl2{id, La}; jo[2] = dbl2{Lb, Ld}; jo[3] = dbl2{A00, A01}; jo[4] = dbl2{A10, A11}; jo[5] = dbl2{W00, W01}; jo[6] = dbl2{W11, 0.0};
+        }
     }
     __syncthreads();
     CSTAMP(4);
     // ---- 4. thread = step slot: smoother gain C_k = P_k Phi'^T (Phi' P_k Phi'^T + Q')^-1 with the link of step k + 1 (the next
     //         slot's record), and e_k = m_k - C_k Phi' m_k, so that the backward step is x_k = e_k + C_k x_{k+1}
     for (int sl = t; sl < nSl; sl += MB) {
-        const int k = sl >= nB ? sl - nB : sl;
-        if (k < nB - 1) {
+        const int dir = slot_dir(sl), k = sl - dir * nQ;
+        if (k < nQ - 1) {
             double *o = slots + (size_t)kSlot * sl;
             const dbl2 *np = (const dbl2 *)(o + kSlot);
             const double h11 = np[0].x, h12 = np[0].y, h21 = np[1].x, h22 = np[1].y, q11 = np[2].x, q12 = np[2].y, q22 = np[3].x;
@@ -328,39 +405,76 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             const double t1 = fma(h12, b, h11 * a), t2 = fma(h12, d, h11 * b);       // (P Phi^T) column 1 = (t1, t2)
             const double t3 = fma(h22, b, h21 * a), t4 = fma(h22, d, h21 * b);       // (P Phi^T) column 2 = (t3, t4)
             const double pa = fma(t2, h12, fma(t1, h11, q11)), pb = fma(t2, h22, fma(t1, h21, q12)), pd = fma(t4, h22, fma(t3, h21, q22));
-            const double rdet = fast_rcp(fma(pa, pd, -(pb * pb)));
+            const double det = fma(pa, pd, -(pb * pb));
+            // (an inner direction starts from a known state: while its covariance is still exactly zero -- dummy steps, coincident
+            // nodes -- the smoothed state IS the filtered mean, C = 0)
+            const double rdet = det > 0.0 ? fast_rcp(det) : 0.0;
             const double ia = pd * rdet, ib = -pb * rdet, id = pa * rdet;
             const double C11 = fma(t1, ia, t3 * ib), C12 = fma(t1, ib, t3 * id), C21 = fma(t2, ia, t4 * ib), C22 = fma(t2, ib, t4 * id);
+            const int nq = (dir == 1 || dir == 2) ? 5 : 3;      // the spike columns go through the same map: E_k = F_k - C_k Phi' F_k
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                dbl2 *mp = (dbl2 *)(o + 14 + 2 * q);
-                const dbl2 mm = *mp;
-                const double pm0 = fma(h12, mm.y, h11 * mm.x), pm1 = fma(h22, mm.y, h21 * mm.x);
-                *mp = dbl2{mm.x - fma(C11, pm0, C12 * pm1), mm.y - fma(C21, pm0, C22 * pm1)};
+            for (int q = 0; q < 5; ++q) {
+                if (q < nq) {
+                    dbl2 *mp = (dbl2 *)(o + (q < 3 ? 14 + 2 * q : 22 + 2 * q));
+                    const dbl2 mm = *mp;
+                    const double pm0 = fma(h12, mm.y, h11 * mm.x), pm1 = fma(h22, mm.y, h21 * mm.x);
+                    *mp = dbl2{mm.x - fma(C11, pm0, C12 * pm1), mm.y - fma(C21, pm0, C22 * pm1)};
+                }
             }
             *(dbl2 *)(o + 24) = dbl2{C11, C12};
             *(dbl2 *)(o + 26) = dbl2{C21, C22};
         }
     }
-    // meanwhile wave 1 (its threads hold no slot up to 63 nodes) fuses the two directions at the junction, both directions' last
-    // slot: posterior of A (data of nodes 0 .. j) and prediction of B (data of nodes j+1 .. M-1), the prior counted once; every lane
-    // forms the fused state of its coordinate, in A's frame (f, f'): B's f' has the opposite sign.  It replaces the junction's means.
+    CSTAMP(12);
+    // meanwhile wave 1 (its threads hold no slot up to 32 nodes) solves for the junction states.  Lanes 0..31: the left half (outer
+    // direction 0 + inner direction 1, in the frame of the reversed process), lanes 32..63 the right half (3 + 2, frame of the process);
+    // lane & 31 = coordinate.  Per half, with (m, P) the outer direction's posterior at its junction node brought into the half's
+    // frame (f' changes sign), (F, g, Pc) the inner direction's last step (state there = F x + g + noise(Pc), x = state at j2):
+    //   Lam = P^-1 - Pinf^-1, xi = P^-1 m            the outer data as a likelihood of the junction state (prior counted once)
+    //   A = (I + Lam Pc)^-1,  W = A Lam,  w = A xi   ... seen through the inner direction's noise
+    //   J = F^T W F + J_in,  eta = F^T (w - W g) + eta_in      the half's message to x (J_in, eta_in: the inner direction's own data)
+    // x = (Pinf^-1 + J_left' + J_right)^-1 (eta_left' + eta_right)  (' = back in the frame of the process), then per half the junction
+    // state u + Pc A (xi - Lam u), u = F x + g.  The junction states replace the four last slots' means, x goes to red[72..77].
     if (wv == 1) {
-        const int dir = lane >> 5, hl = lane & 31, dd = hl < 3 ? hl : 2;
-        double *sA = slots + (size_t)kSlot * (nB - 1), *sB = slots + (size_t)kSlot * (2 * nB - 1);
-        const dbl2 mA = *(const dbl2 *)(sA + 14 + 2 * dd), mB = *(const dbl2 *)(sB + 14 + 2 * dd);
-        const dbl2 abA = *(const dbl2 *)(sA + 20), abB = *(const dbl2 *)(sB + 20);
-        const double Aa = abA.x, Ab = abA.y, Ad = sA[22], Ba = abB.x, Bb = -abB.y, Bd = sB[22];
-        const double rA = fast_rcp(fma(Aa, Ad, -(Ab * Ab))), rB = fast_rcp(fma(Ba, Bd, -(Bb * Bb)));
-        const double ia = Ad * rA, ib = -Ab * rA, id = Aa * rA, ja = Bd * rB, jb = -Bb * rB, jd = Ba * rB;
-        const double Bm1 = -mB.y;
-        const double e0 = fma(ia, mA.x, ib * mA.y) + fma(ja, mB.x, jb * Bm1);
-        const double e1 = fma(ib, mA.x, id * mA.y) + fma(jb, mB.x, jd * Bm1);
-        const double La = ia + ja - c2 / pinf0, Lb = ib + jb, Ld = id + jd - c2 / pinf1;
-        const double rL = fast_rcp(fma(La, Ld, -(Lb * Lb)));
-        const double xs0 = (Ld * e0 - Lb * e1) * rL, xs1 = (La * e1 - Lb * e0) * rL;
-        wave_lds_sync();                                // every lane has read the junction's means
-        if (hl < 3) *(dbl2 *)((dir ? sB : sA) + 14 + 2 * hl) = dbl2{xs0, dir ? -xs1 : xs1};
+        const int hf = lane >> 5, hl = lane & 31, dd = hl < 3 ? hl : 2;
+        const int dO = hf ? 3 : 0, dI = hf ? 2 : 1;
+        double *sO = slots + (size_t)kSlot * (dO * nQ + nQ - 1), *sI = slots + (size_t)kSlot * (dI * nQ + nQ - 1);
+        const dbl2 mO = *(const dbl2 *)(sO + 14 + 2 * dd), gI = *(const dbl2 *)(sI + 14 + 2 * dd);
+        const dbl2 abI = *(const dbl2 *)(sI + 20);
+        const dbl2 *jm = (const dbl2 *)(red + 80 + 16 * hf);                            // wave 2's part (phase 3)
+        const dbl2 j0 = jm[0], j1v = jm[1], j2v = jm[2], j3v = jm[3], j4v = jm[4], j5v = jm[5];
+        const double W11 = red[80 + 16 * hf + 12];
+        const dbl2 Fc0 = *(const dbl2 *)(sI + 28), Fc1 = *(const dbl2 *)(sI + 30);      // columns of F: (F00, F10), (F01, F11)
+        const dbl2 aE = *(const dbl2 *)(red + 32 + 2 * (dI * 5 + dd)), aJ0 = *(const dbl2 *)(red + 32 + 2 * (dI * 5 + 3)), aJ1 = *(const dbl2 *)(red + 32 + 2 * (dI * 5 + 4));
+        const double m0 = mO.x, m1 = -mO.y;                                              // outer mean in the half's frame
+        const double pa = abI.x, pb = abI.y, pd = sI[22];
+        const double F00 = Fc0.x, F10 = Fc0.y, F01 = Fc1.x, F11 = Fc1.y, g0 = gI.x, g1 = gI.y;
+        const double ia = j0.x, ib = j0.y, id = j1v.x, La = j1v.y, Lb = j2v.x, Ld = j2v.y, A00 = j3v.x, A01 = j3v.y, A10 = j4v.x, A11 = j4v.y;
+        const double W00 = j5v.x, W01 = j5v.y, W10 = j5v.y;
+        const double xi0 = fma(ia, m0, ib * m1), xi1 = fma(ib, m0, id * m1);
+        const double w0 = fma(A00, xi0, A01 * xi1), w1 = fma(A10, xi0, A11 * xi1);
+        const double v0 = w0 - fma(W00, g0, W01 * g1), v1 = w1 - fma(W10, g0, W11 * g1);
+        const double WF00 = fma(W00, F00, W01 * F10), WF01 = fma(W00, F01, W01 * F11), WF10 = fma(W10, F00, W11 * F10), WF11 = fma(W10, F01, W11 * F11);
+        // the half's message in the frame of the process: the left half's off-diagonal and second component change sign
+        const double sg = hf ? 1.0 : -1.0;
+        double J00 = fma(F00, WF00, F10 * WF10) + aJ0.x, J01 = sg * (fma(F00, WF01, F10 * WF11) + aJ0.y), J11 = fma(F01, WF01, F11 * WF11) + aJ1.y;
+        double e0 = fma(F00, v0, F10 * v1) + aE.x, e1 = sg * (fma(F01, v0, F11 * v1) + aE.y);
+        J00 += __shfl_xor(J00, 32); J01 += __shfl_xor(J01, 32); J11 += __shfl_xor(J11, 32); e0 += __shfl_xor(e0, 32); e1 += __shfl_xor(e1, 32);
+        J00 += cp0; J11 += cp1;
+        const double rJ = fast_rcp(fma(J00, J11, -(J01 * J01)));
+        const double x0 = (J11 * e0 - J01 * e1) * rJ, x1 = (J00 * e1 - J01 * e0) * rJ;      // state at j2, frame of the process
+        const double s0 = x0, s1 = sg * x1;                                               // ... in the half's frame
+        const double u0 = fma(F00, s0, fma(F01, s1, g0)), u1 = fma(F10, s0, fma(F11, s1, g1));
+        const double r0 = xi0 - fma(La, u0, Lb * u1), r1 = xi1 - fma(Lb, u0, Ld * u1);
+        const double z0 = fma(A00, r0, A01 * r1), z1 = fma(A10, r0, A11 * r1);
+        const double y0 = fma(pa, z0, fma(pb, z1, u0)), y1 = fma(pb, z0, fma(pd, z1, u1));  // junction state, the half's (= the inner direction's) frame
+        wave_lds_sync();                                // every lane has read the last slots' means
+        if (hl < 3) {
+            *(dbl2 *)(sI + 14 + 2 * hl) = dbl2{y0, y1};
+            *(dbl2 *)(sO + 14 + 2 * hl) = dbl2{y0, -y1};
+            if (hf) *(dbl2 *)(red + 72 + 2 * hl) = dbl2{x0, x1};
+        }
+        if (t == 64) f.dbg[13] = __builtin_amdgcn_s_memtime();
     }
     __syncthreads();
     CSTAMP(5);
@@ -368,23 +482,36 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     //         ANCHOR above it (the slots a multiple of four below the junction): x_k = eh + Ch x_anchor.  The composites go where the
     //         records and right-hand sides were (dead by now): Ch -> [0..3], eh -> [8..13].
     for (int sl = t; sl < nSl; sl += MB) {
-        const int k = sl >= nB ? sl - nB : sl;
-        if (k < nB - 1) {
+        const int k = sl - slot_dir(sl) * nQ;
+        if (k < nQ - 1) {
             double *o = slots + (size_t)kSlot * sl;
-            const int r4 = (nB - 1 - k) & 3, j = r4 ? r4 : 4;       // steps k .. k + j - 1
+            const int r4 = (nQ - 1 - k) & 3, j = r4 ? r4 : 4;       // steps k .. k + j - 1
             const double *top = o + (size_t)kSlot * (j - 1);
             dbl2 c0 = *(const dbl2 *)(top + 24), c1 = *(const dbl2 *)(top + 26);
-            dbl2 ev[3];
+            // an inner direction's e_k so far lacks the start state: e_k + E_k x, x = the state at j2 (red[72..77]) in the direction's frame
+            const int dir = slot_dir(sl);
+            const bool inner = dir == 1 || dir == 2;
+            dbl2 xs[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) ev[q] = *(const dbl2 *)(top + 14 + 2 * q);
+            for (int q = 0; q < 3; ++q) { xs[q] = inner ? *(const dbl2 *)(red + 72 + 2 * q) : dbl2{0.0, 0.0}; if (dir == 1) xs[q].y = -xs[q].y; }
+            auto e_of = [&](const double *s, dbl2 (&e)[3]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) e[q] = *(const dbl2 *)(s + 14 + 2 * q);
+                if (inner) {
+                    const dbl2 E0 = *(const dbl2 *)(s + 28), E1 = *(const dbl2 *)(s + 30);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) e[q] = dbl2{fma(E0.x, xs[q].x, fma(E1.x, xs[q].y, e[q].x)), fma(E0.y, xs[q].x, fma(E1.y, xs[q].y, e[q].y))};
+                }
+            };
+            dbl2 ev[3];
+            e_of(top, ev);
             for (int i = j - 2; i >= 0; --i) {
                 const double *s = o + (size_t)kSlot * i;
                 const dbl2 d0 = *(const dbl2 *)(s + 24), d1 = *(const dbl2 *)(s + 26);
+                dbl2 es[3];
+                e_of(s, es);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const dbl2 eq = *(const dbl2 *)(s + 14 + 2 * q);
-                    ev[q] = dbl2{fma(d0.x, ev[q].x, fma(d0.y, ev[q].y, eq.x)), fma(d1.x, ev[q].x, fma(d1.y, ev[q].y, eq.y))};
-                }
+                for (int q = 0; q < 3; ++q) ev[q] = dbl2{fma(d0.x, ev[q].x, fma(d0.y, ev[q].y, es[q].x)), fma(d1.x, ev[q].x, fma(d1.y, ev[q].y, es[q].y))};
                 const dbl2 n0 = dbl2{fma(d0.x, c0.x, d0.y * c1.x), fma(d0.x, c0.y, d0.y * c1.y)};
                 const dbl2 n1 = dbl2{fma(d1.x, c0.x, d1.y * c1.x), fma(d1.x, c0.y, d1.y * c1.y)};
                 c0 = n0; c1 = n1;
@@ -398,15 +525,15 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     __syncthreads();
     // the anchors, one after the other (wave 0; lane = (direction, coordinate)): x_anchor = eh + Ch x_(anchor above), starting at the junction
     if (wv == 0) {
-        const int dir = lane >> 5, hl = lane & 31;
+        const int dir = lane >> 4, hl = lane & 15;
         const bool wr = hl < 3;
-        char *const sb = (char *)slots, *const db = (char *)(dump + (size_t)lane * kDump);
-        char *ra = sb + (size_t)SB * (dir * nB + nB - 1);
+        char *const sb = (char *)slots, *const db = (char *)dump;
+        char *ra = sb + (size_t)SB * (dir * nQ + nQ - 1);
         char *la = wr ? ra + 16 * hl : db;
         const int lstep = wr ? SB : 0;
         const dbl2 xj = *(const dbl2 *)(la + 112);
         double xs0 = xj.x, xs1 = xj.y;
-        const int na = (nB - 1) >> 2;                   // anchors below the junction
+        const int na = (nQ - 1) >> 2;                   // anchors below the direction's last slot
         struct ARec { dbl2 e, C0, C1; };
         auto afetch = [&](int i) __attribute__((always_inline)) {           // the i-th anchor below the current position
             ARec r;                                                         // (slots in front of a direction's first one are readable)
@@ -441,7 +568,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         const double *o = slots + (size_t)kSlot * sl;
         const double p1 = S[m];
         // smoothed state: junction and anchors hold it; every other slot is one composite step below its anchor
-        const int ks = sl >= nB ? sl - nB : sl, r4 = (nB - 1 - ks) & 3;
+        const int ks = sl - slot_dir(sl) * nQ, r4 = (nQ - 1 - ks) & 3;
         double Vd[3];
         if (r4 == 0) {
 #pragma unroll
