@@ -16,5 +16,5 @@ for M in (30, 50, 64, 100, 200, 300, 512):
     g = ctx.cpd_lle_resident(0, Y0, 0.0, pr)
     st = ctx.debug_stamps(64).astype(np.int64)
     d = st[:8] - st[0]
-    print(f"M={M:4d} stamps {d.tolist()}  fetch {d[1]} rec {d[3]-d[1]} fwd {d[4]-d[3]} gains {d[5]-d[4]} bwd {d[6]-d[5]} final {d[7]-d[6]} | in gains: loop {st[12]-st[4]} junction {st[13]-st[4]} barrier {st[14]-st[4]} | mstep_us {ctx.profile_kernel(2, 200):.2f}")
+    print(f"M={M:4d} stamps {d.tolist()}  fetch {d[1]} rec {d[3]-d[1]} fwd {d[4]-d[3]} gains {d[5]-d[4]} bwd {d[6]-d[5]} final {d[7]-d[6]}  mstep_us {ctx.profile_kernel(2, 200):.2f}")
     ctx.close()

@@ -26,7 +26,7 @@ def _system(M, spacing, beta, lam, sigma2, seed, zero_frac, npts=50000, dup=Fals
     return coord, p, B, lam * sigma2
 
 
-@pytest.mark.parametrize("M,spacing", [(4, 0.1), (5, 0.1), (7, 0.05), (30, 0.02), (50, 0.012), (51, 0.001), (300, 0.003), (512, 0.002)])
+@pytest.mark.parametrize("M,spacing", [(2, 0.1), (3, 0.1), (4, 0.1), (5, 0.1), (6, 0.08), (7, 0.05), (9, 0.05), (30, 0.02), (50, 0.012), (51, 0.001), (300, 0.003), (512, 0.002)])
 def test_chain_formulation_against_80bit_dense_solve(M, spacing):
     worst_chain, worst_dense = 0.0, 0.0
     for sigma2 in (1e-2, 1e-5, 1e-8):
@@ -81,7 +81,7 @@ def _params(kw, prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [4, 5, 6, 7, 31, 50, 51, 64, 65, 127, 128, 129, 254, 255, 256, 300, 511, 512])
+@pytest.mark.parametrize("M", [4, 5, 6, 7, 8, 9, 10, 11, 13, 31, 50, 51, 52, 53, 64, 65, 127, 128, 129, 254, 255, 256, 300, 511, 512])
 def test_chain_mstep_against_oracle_over_chain_lengths(oracle, M):
     """fp64 mode at the stated tolerance (1e-9 m, 1e-7 in sigma2; equal iteration counts): even / odd chains (a dummy first step in
     one direction or not), one or several step slots per thread (M + 1 > 256), partial rows fetched in one or several trips."""

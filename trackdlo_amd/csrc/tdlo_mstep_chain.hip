@@ -22,21 +22,33 @@
 // What bounds it: O(M) flops on a handful of lanes -- a chain of dependent instructions.  A lone wave on gfx950 issues one instruction
 // per ~8 cycles when it depends on its predecessor (~5 when it does not), scalar ALU, fp64 and fp32 alike; a dependent v_rcp_f64
 // is 20 cycles, an LDS round trip 76, a store behind an exec-mask branch 38 (scripts/ubench/lat.hip).  So the kernel is designed by
-// instruction count on the critical wave, and independent instruction streams go to different waves.  Phases (one workgroup of
-// four waves per frame; thread = step slot in the parallel ones):
+// instruction count on the critical wave, and independent instruction streams go to different waves.
+//
+// The chain is walked from FOUR ends at once, 16 lanes of a wave per direction (a wave64 fp64 instruction costs the same whether 3
+// or 64 lanes are active, so the dependent chain is quartered for the price of a small junction solve).  With j2 the middle node
+// and j1, j3 the quarter points:
+//   0: nodes 0 .. j1, a Kalman filter from the stationary prior                 3: nodes M-1 .. j3, the same for the time-reversed
+//   2: nodes j2 .. j3, a filter started AT j2 from the exact but unknown            process (same Phi and Q: the process is stationary
+//      state x there (covariance 0)                                                 and reversible in (f, -f'))
+//   1: nodes j2-1 .. j1 of the reversed process, likewise from x.
+// The covariances of an inner direction (1, 2) do not depend on x; its means are affine in x, m_k = g_k + F_k x, so it carries two
+// more mean columns (the SPIKE columns F, started at the identity) next to the three coordinates g, and sums the likelihood of its
+// data as a function of x along the way.  At j1 (and j3) the outer direction's posterior meets the inner direction's last step:
+// eliminating the junction state leaves a 2 x 2 message for x per half, x follows from the two messages and the prior, the
+// junction states by back-substitution.  From there every direction is smoothed backwards from its last step exactly as before
+// (Rauch-Tung-Striebel), the inner ones with x inserted.  Phases (one workgroup of four waves per frame; thread = step slot in the parallel ones):
 //   1. fetch: the E-step's sums (16 short rows of fixed-point accumulators, both parities: no load waits for the iteration
 //      counter), this thread's slot (link, node); the slot records are prepared while the loads are in flight;
-//   2. the chain is walked from BOTH ends at once: lanes 0..31 filter nodes 0 .. j, lanes 32..63 filter nodes M-1 .. j of the
-//      time-reversed process (same Phi and Q: the process is stationary and reversible in (f, -f')), j = (M-1)/2 -- a wave64 fp64
-//      instruction costs the same whether 3 or 64 lanes are active, so the dependent chain is halved for free;
+//   2. records and right-hand sides of the step slots;
 //   3. forward pass as a two-wave pipeline: wave 0 runs the covariance recursion (2 x 2 predict Phi P Phi^T + Q, one reciprocal,
-//      update -- it does not depend on the data), wave 1 follows with the means (lane & 31 < 3 = coordinate) as the posteriors
-//      appear, behind a progress counter in LDS;
+//      update -- it does not depend on the data), wave 1 follows with the means (lane & 15 < 5 = coordinate / spike column) as the
+//      posteriors appear, behind a progress counter in LDS; wave 2 then prepares the junction solve's covariance-only part;
 //   4. gains C_k = P_k Phi^T (P^-_{k+1})^-1 and e_k = m_k - C_k Phi m_k, lane = step (the backward step is x_k = e_k + C_k x_{k+1});
-//      meanwhile wave 1 fuses the two Gaussians at node j (information form, the prior counted once);
+//      meanwhile wave 1 solves for x and the junction states;
 //   5. backward pass in strides of four: every slot composes its step with those up to the next anchor above it (affine maps
-//      compose), one wave walks the anchors, the slots between are filled in parallel;
+//      compose; an inner direction's e_k gets its E_k x here), one wave walks the anchors, the slots between are filled in parallel;
 //   6. T = Y0 + V, sigma2 (residual form), stopping rule, the next E-step's constants.
+// M / 4 dependent steps instead of M / 2 from two ends (the former version): 8.8 instead of 10.3 us at M = 50, 21 instead of 36 us at M = 300.
 //
 // The dense kernels stay in the tree: with the LLE term (include_lle, the pre-processing registration of tracking_step) the
 // system is not of this form, and TDLO_MSTEP=dense selects them as comparators for the tests.
@@ -61,13 +73,13 @@ template <int L> __device__ __forceinline__ double row_bcast_f64(double v) {
 
 }  // namespace
 
-// Step slots.  Both directions have nB = M - j steps; direction A (nodes 0 .. j) starts with nB - nA in {0, 1} dummy steps
-// (identity link, no observation), so that both directions reach the junction in their LAST step and the loops need no
-// per-direction bookkeeping.  Slot sl = dir * nB + k.  One slot = kSlot doubles of LDS:
+// Step slots.  All directions have nQ steps, the shorter ones start with dummy steps (identity link, no observation), so that every
+// direction reaches its junction in its LAST step and the loops need no per-direction bookkeeping.  Slot sl = dir * nQ + k.  One slot =
+// kSlot doubles of LDS:
 //   [ 0.. 7] record of the step  {f11 f12 | f21 f22 | q11/c q12/c | q22/c p}   (Phi and Q of the link INTO the step, observation precision)
 //   [ 8..13] right-hand side     {bx - | by - | bz -}
 //   [14..19] mean                {mx0 mx1 | my0 my1 | mz0 mz1}   filtered -> e_k -> smoothed
-//   [20..23] posterior           {a b | d -}
+//   [20..23] posterior           {a b | d g}           g = 1 / (1 + p P^-_11)
 //   [24..27] smoother gain       {C11 C12 | C21 C22}
 //   [28..31] spike means         {F00 F10 | F01 F11}   inner directions: the mean's dependence on the direction's start state
 constexpr int kSlot = 34;             // (272 bytes: consecutive slots start 4 banks apart, so a 128-bit access of 16 lanes -- thread = slot -- covers the
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             const double npb = -(p * pb);
             a = pa * g; b = pb * g; d = fma(npb, b, pd);
             *(dbl2 *)(qa + qstep * at + 160) = dbl2{a, b};
-            *(double *)(qa + qstep * at + 176) = d;
+            *(dbl2 *)(qa + qstep * at + 176) = dbl2{d, g};       // (g for the likelihood sums of the means wave: 1 - p a would cancel)
             ++kdone;
             asm volatile("ds_write_b32 %0, %1" :: "v"(prog_addr), "v"(kdone) : "memory");
         };
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         // lane = (direction, column): columns 0..2 the coordinates, 3 and 4 the SPIKE columns -- the mean of an inner direction is
         // affine in its unknown start state x, m_k = g_k + F_k x: the coordinate columns carry g (start 0), the spike columns F (start
         // I, nothing observed: right-hand side 0).  The same lanes sum the likelihood of the direction's data as a function of x,
-        //   -1/2 x^T J x + x^T eta,  J = sum_k p g_k h_k h_k^T,  eta = sum_k g_k innov_k h_k,   h_k = row 0 of Phi F_{k-1}, g_k = 1 - p a_k:
+        //   -1/2 x^T J x + x^T eta,  J = sum_k p g_k h_k h_k^T,  eta = sum_k g_k innov_k h_k,   h_k = row 0 of Phi F_{k-1}, g_k = 1 / (1 + p P^-_11):
         // with w = +-g_k innov (innov of a spike column is -p h) every lane adds w h_0 and w h_1 -- columns 0..2 end with eta, 3 and 4 with J.
         const int dir = lane >> 4, hl = lane & 15;
         const bool wr = hl < 5;
@@ -330,19 +342,20 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
                 if (have < need) __builtin_amdgcn_s_sleep(1);
             }
         };
-        struct MRec { dbl2 r0, r1, ab; double p, bb; };
+        struct MRec { dbl2 r0, r1, ab; double p, bb, g; };
         auto mfetch = [&](int ahead) __attribute__((always_inline)) {
             MRec r;
             const char *rp = ra + SB * ahead;
             r.r0 = *(const dbl2 *)(rp); r.r1 = *(const dbl2 *)(rp + 16); r.p = *(const double *)(rp + 56); r.ab = *(const dbl2 *)(rp + 160);
             r.bb = *(const double *)(ba + bstep * ahead);
+            r.g = *(const double *)(rp + 184);
             return r;
         };
         auto mstep = [&](const MRec &r, int at) __attribute__((always_inline)) {
             // m^- = Phi m;  m = m^- + K (b - p m^-_0),  K = (a, b) of the step's posterior
             const double pm0 = fma(r.r0.y, m1, r.r0.x * m0), pm1 = fma(r.r1.y, m1, r.r1.x * m0);
             const double innov = fma(-r.p, pm0, r.bb);
-            const double w = (sgl * fma(-r.p, r.ab.x, 1.0)) * innov;
+            const double w = (sgl * r.g) * innov;
             const double h0 = row_bcast_f64<3>(pm0), h1 = row_bcast_f64<4>(pm0);
             acc0 = fma(w, h0, acc0); acc1 = fma(w, h1, acc1);
             m0 = fma(r.ab.x, innov, pm0); m1 = fma(r.ab.y, innov, pm1);
@@ -425,7 +438,6 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             *(dbl2 *)(o + 26) = dbl2{C21, C22};
         }
     }
-    CSTAMP(12);
     // meanwhile wave 1 (its threads hold no slot up to 32 nodes) solves for the junction states.  Lanes 0..31: the left half (outer
     // direction 0 + inner direction 1, in the frame of the reversed process), lanes 32..63 the right half (3 + 2, frame of the process);
     // lane & 31 = coordinate.  Per half, with (m, P) the outer direction's posterior at its junction node brought into the half's
@@ -474,7 +486,6 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             *(dbl2 *)(sO + 14 + 2 * hl) = dbl2{y0, -y1};
             if (hf) *(dbl2 *)(red + 72 + 2 * hl) = dbl2{x0, x1};
         }
-        if (t == 64) f.dbg[13] = __builtin_amdgcn_s_memtime();
     }
     __syncthreads();
     CSTAMP(5);
