@@ -193,7 +193,7 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
         bwm = m_bytes / (mst_us * 1e-6) / 1e9
         objs.append(dict(bound="hbm", kernel=mstep_name, achieved=round(bwm, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(bwm / HBM_PEAK_GBS, 7), traffic=None,
                          avg_launch_us=round(mst_us, 3), algorithmic_bytes_per_launch=m_bytes, algorithmic_flops_per_launch=c_flops,
-                         note="one workgroup per frame; the solve is a Kalman filter / RTS smoother along the chain (M/2 dependent 2 x 2 steps from both ends "
+                         note="one workgroup per frame; the solve is a Kalman filter / RTS smoother along the chain (M/4 dependent 2 x 2 steps from four ends "
                               "on one wave, ~8 cycles per instruction), preceded by one memory round trip for the sums: latency-bound, "
                               "neither bytes nor flops are near a roofline"))
     elif mst_us is not None:
