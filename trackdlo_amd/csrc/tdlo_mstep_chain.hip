@@ -64,6 +64,32 @@ namespace {
 constexpr int kCB = 256;               // workgroup size
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
+// Four wave-wide sums at once by a halving butterfly: v_permlane32_swap puts the lower halves of two values side by side and their upper
+// halves side by side (one add folds lanes 32 apart of BOTH values), v_permlane16_swap does the same for rows 16 apart, four DPP
+// rotations finish inside the rows.  Every lane of row 0 returns sum(a), row 1 sum(c), row 2 sum(b), row 3 sum(d).
+__device__ __forceinline__ double swap_add32(double x, double y) {      // lanes 0..31: x[l] + x[l + 32], lanes 32..63: y[l - 32] + y[l]
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double x, double y) {      // rows 0, 2: x's rows (0, 1), (2, 3) folded; rows 1, 3: y's
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum4(double a, double b, double c, double d) {
+    double z = swap_add16(swap_add32(a, b), swap_add32(c, d));
+    z += dpp_f64<0x128>(z);      // row_ror:8
+    z += dpp_f64<0x124>(z);      // row_ror:4
+    z += dpp_f64<0x122>(z);      // row_ror:2
+    z += dpp_f64<0x121>(z);      // row_ror:1
+    return z;
+}
+
 // the value of lane L of the own row of 16 lanes (DPP row_newbcast, two 32-bit halves)
 template <int L> __device__ __forceinline__ double row_bcast_f64(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + L, 0xf, 0xf, false);
@@ -604,10 +630,14 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 #pragma unroll
         for (int d = 0; d < 3; ++d) { f.Y[d * M + m] = Td[d]; f.Yout[d * M + m] = Td[d] + (d == 0 ? ctr0 : (d == 1 ? ctr1 : ctr2)); }
     }
-    if (wv * 64 < nSl) {                               // waves without slots contribute nothing (uniform per wave)
-        s_np = wave_sum(s_np); s_dr = wave_sum(s_dr); s_pd = wave_sum(s_pd); s_cr = wave_sum(s_cr);
+    // the wave's four sums at once (wave_sum4: 21 instructions, no LDS round trips); rows 0..3 of the wave end up with sums 0, 2, 1, 3
+    // (waves without slots contribute zeros)
+    {
+        const double tot = wave_sum4(s_np, s_dr, s_pd, s_cr);
+        const int row = lane >> 4, which = ((row & 1) << 1) | (row >> 1);
+        double *dst = (lane & 15) == 0 ? red + 4 * wv + which : dump;
+        *dst = tot;
     }
-    if (lane == 0) { red[4 * wv] = s_np; red[4 * wv + 1] = s_dr; red[4 * wv + 2] = s_pd; red[4 * wv + 3] = s_cr; }
     __syncthreads();
     CSTAMP(7);
     if (t == 0) {
