@@ -85,11 +85,11 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     // counting sort by nearest node: hist[block][node] -> start offset of that (node, block) run.
     // 256 threads = 64 nodes x 4 chunks of blocks; per node an exclusive scan over the blocks in block order.
     const int nb = f.nprune_blocks;
-    __shared__ int stot[kMaxNodes];
-    __shared__ int csum[4][64];
+    __shared__ int stot[kMaxNodes];               // kept points per node -> first index of the node's run
+    __shared__ int csum[kMaxNodes / 64][4][64];   // kept points per (node, quarter of the prune blocks)
+    const int ml = t & 63, ch = t >> 6;
+    const int cb0 = (int)((long long)nb * ch / 4), cb1 = (int)((long long)nb * (ch + 1) / 4);
     {
-        const int ml = t & 63, ch = t >> 6;
-        const int cb0 = (int)((long long)nb * ch / 4), cb1 = (int)((long long)nb * (ch + 1) / 4);
         const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);       // (global address space and 16 independent loads per trip:
         for (int mg = 0; mg < M; mg += 64) {                  //  a load-add chain over ~50 blocks costs a memory latency each)
             const int m = mg + ml;
@@ -103,22 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
                 for (int u = 0; u < 16; ++u) if (b + u < cb1) run += v[u];
             }
             if (cb1 <= cb0 || m >= M) run = 0;
-            csum[ch][ml] = run;
-            __syncthreads();
-            int start = 0;
-            for (int c2 = 0; c2 < ch; ++c2) start += csum[c2][ml];
-            if (ch == 3 && m < M) stot[m] = start + run;
-            if (m < M) {
-                int r2 = start;
-                for (int b = cb0; b < cb1; b += 16) {
-                    int v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + m];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) if (b + u < cb1) { hg[(size_t)(b + u) * M + m] = r2; r2 += v[u]; }
-                }
-            }
-            __syncthreads();
+            csum[mg >> 6][ch][ml] = run;
         }
     }
     {
@@ -129,24 +114,34 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         sd[t] = s;
     }
     __syncthreads();
+    // the two serial sums on two waves: first index of every node's run (thread 0), the sigma2 initialisation sum in its fixed order (thread 64)
     if (t == 0) {
-        int run = 0; double tot = 0;
-        for (int m = 0; m < M; ++m) { const int v = stot[m]; stot[m] = run; run += v; }
+        int run = 0;
+        for (int m = 0; m < M; ++m) { const int g = m >> 6, l = m & 63; const int v = (csum[g][0][l] + csum[g][1][l]) + (csum[g][2][l] + csum[g][3][l]); stot[m] = run; run += v; }
+        sN = run;
+    }
+    if (t == 64) {
+        double tot = 0;
         for (int i = 0; i < kBlock; ++i) tot += sd[i];
-        sN = run; sS = tot;
+        sS = tot;
     }
     __syncthreads();
     {
+        // second pass over the counts: (node, block) count -> where that run starts = node's first index + the earlier quarters + the
+        // earlier blocks of this quarter, written in place (one pass instead of a scan within the node plus a pass adding the node's base)
         const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);
-        // (wave = every 4th prune block, lane = node: no integer modulo per element -- that loop had been a third of this kernel)
-        for (int m = t & 63; m < M; m += 64) {
-            const int add = stot[m];
-            for (int b = t >> 6; b < nb; b += 8 * (kBlock / 64)) {          // 8 independent read-modify-writes in flight
-                int v[8];
+        for (int mg = 0; mg < M; mg += 64) {
+            const int m = mg + ml;
+            if (m < M) {
+                int r2 = stot[m];
+                for (int c2 = 0; c2 < ch; ++c2) r2 += csum[mg >> 6][c2][ml];
+                for (int b = cb0; b < cb1; b += 16) {
+                    int v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int bb = b + u * (kBlock / 64); v[u] = hg[(size_t)(bb < nb ? bb : b) * M + m]; }
+                    for (int u = 0; u < 16; ++u) v[u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + m];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int bb = b + u * (kBlock / 64); if (bb < nb) hg[(size_t)bb * M + m] = v[u] + add; }
+                    for (int u = 0; u < 16; ++u) if (b + u < cb1) { hg[(size_t)(b + u) * M + m] = r2; r2 += v[u]; }
+                }
             }
         }
     }
