@@ -77,8 +77,8 @@ typedef struct {
     int n_kept;           /* N after the prune, trackdlo.cpp:195 */
     int status;           /* 0, or TDLO_E_NUMERIC / TDLO_E_EMPTY */
     double sigma2;        /* final sigma2 (also written through the in/out pointer) */
-    float loop_ms;        /* HIP-event time of the EM loop body on the context's stream (trackdlo.cpp:275-438) */
-    float total_ms;       /* HIP-event time of the whole device-side call (prune + setup + loop + readback) */
+    float loop_ms;        /* HIP-event time of the EM loop body on the context's stream (trackdlo.cpp:275-438); 0 unless tdlo_set_timing(ctx, 1) */
+    float total_ms;       /* HIP-event time of the whole device-side call (prune + setup + loop + readback); 0 unless tdlo_set_timing(ctx, 1) */
     double host_ms;       /* host wall time of the call including uploads and the final synchronise */
     int mstep_retries;    /* iterations whose multi-CU elimination (more than 60 nodes) ran into the time limit of an
                            * inter-workgroup hand-off and were redone by the one-workgroup elimination (normally 0) */
@@ -324,6 +324,10 @@ int tdlo_debug_stamps(tdlo_ctx *ctx, int slot, unsigned long long *out, int n);
  * 1: the dense eliminations of the same system (k_mstep_fast / k_mstep_mcu), kept as comparators.  Returns the previous
  * setting.  The initial setting is 1 when the environment holds TDLO_MSTEP=dense. */
 int tdlo_debug_mstep_dense(int on);
+/* Whether the registrations of this context record the four stream events behind tdlo_stats.loop_ms / total_ms.  Off by default: the
+ * reference has no such figures, and the markers cost about 15 us per call (2 % of a 50-iteration call at N = 50 000).  Returns the
+ * previous setting (or TDLO_E_INVALID). */
+int tdlo_set_timing(tdlo_ctx *ctx, int on);
 /* Development aid: copies the pruned, centred, node-sorted cloud of the last call (N x 3 column-major, widened to
  * double) and the centring offset; returns N. */
 int tdlo_debug_read_cloud(tdlo_ctx *ctx, int slot, double *out, int max_points, double *ctr);

@@ -12,6 +12,9 @@ class StubContext:
     def set_cloud(self, slot, X):
         pass
 
+    def set_timing(self, on):
+        return True
+
     def synchronize(self):
         pass
 

@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_mstep_dense", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_mstep_dense", "tdlo_set_timing", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -168,6 +168,8 @@ def load_library(path: str | None = None):
     lib.tdlo_debug_stamps.argtypes = [vp, ci, vp, ci]
     lib.tdlo_debug_mstep_dense.argtypes = [ci]
     lib.tdlo_debug_mstep_dense.restype = ci
+    lib.tdlo_set_timing.argtypes = [vp, ci]
+    lib.tdlo_set_timing.restype = ci
     lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
     lib.tdlo_piecewise_error.restype = cd
     lib.tdlo_piecewise_error.argtypes = [vp, ci, vp, ci]
@@ -242,7 +244,9 @@ def make_params(beta, lambda_, lle_weight, mu, max_iter=30, tol=1e-4, include_ll
 class Context:
     """Owns one tdlo_ctx (one GPU, one HIP stream)."""
 
-    def __init__(self, device=0, max_frames=1, max_points=65536, max_nodes=64, estep_blocks=0):
+    def __init__(self, device=0, max_frames=1, max_points=65536, max_nodes=64, estep_blocks=0, timing=True):
+        """timing: record the stream events behind loop_ms / total_ms of the results (tdlo_set_timing; the C API's default is off,
+        the measurement scripts want the figures; bench.py times its loop with timing off)."""
         self.lib = load_library()
         cfg = Config(device, max_frames, max_points, max_nodes, estep_blocks)
         err = C.c_int(0)
@@ -250,6 +254,10 @@ class Context:
         if not self.h:
             raise TdloError(err.value, "tdlo_create failed (no usable gfx950 device? there is no CPU fallback)")
         self.max_frames = max_frames
+        self.set_timing(timing)
+
+    def set_timing(self, on):
+        return bool(self.lib.tdlo_set_timing(self.h, 1 if on else 0))
 
     def close(self):
         if getattr(self, "h", None):

@@ -86,6 +86,7 @@ struct tdlo_ctx {
     size_t pin_doubles = 0;
     std::string err;
     int last_F = 0;
+    bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     // split-mode scratch
     int split_active = 0;
     double *xch_dmin = nullptr;      // caller-owned device memory of the device-resident N-split exchange (tdlo_split_bind_exchange)
@@ -336,12 +337,13 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         }
     }
     hipStream_t s = c->stream;
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    const bool timing = c->timing;
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (merged) HIPCHK(c, hipMemcpyAsync(c->xfer, c->pin, (size_t)F * up * sizeof(double), hipMemcpyHostToDevice, s));
     else HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
     HIPCHK(c, launch_prune_and_setup(c->fd, c->fh.data(), F, s));
-    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // A batch runs as up to kBatchStreams groups of frames on as many streams, each group one E-step behind the previous
     // one: a batch's M-step is one workgroup per frame (F of the 256 CUs busy for 17 us), and meanwhile the other groups'
     // E-steps have the rest of the GPU.  The groups are independent registrations: the results do not depend on the split
@@ -427,17 +429,16 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         }
     }
     HIPCHK(c, join());
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
     const size_t rstride = merged ? nc.readback : nc.upload;
     if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
     else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     HIPCHK(c, hipStreamSynchronize(s));
     c->last_F = F;
     float loop_ms = 0, total_ms = 0;
-    hipEventElapsedTime(&loop_ms, c->ev[1], c->ev[2]);
-    hipEventElapsedTime(&total_ms, c->ev[0], c->ev[3]);
+    if (timing) { hipEventElapsedTime(&loop_ms, c->ev[1], c->ev[2]); hipEventElapsedTime(&total_ms, c->ev[0], c->ev[3]); }
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     int worst = 0;
     for (int i = 0; i < F; ++i) {
@@ -906,7 +907,8 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
         b_init = c->split_buf; b_dmin = b_init + 2; b_sums = b_dmin + ((M + 1) & ~1);
         f.sums = b_sums;                                 // the export-only M-step writes, and the M-step from sums reads, this buffer
     }
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    const bool timing = c->timing;
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p) * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev), hipMemcpyHostToDevice, s));
     HIPCHK(c, launch_split_setup(c->fd, c->fh.data(), s));
@@ -921,7 +923,7 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
         if ((rc = nccl(R->AllReduce(b_init, b_init, 2, kNcclFloat64, kNcclSum, nccl_comm, s), "ncclAllReduce(init)"))) return rc;
         HIPCHK(c, launch_split_set_global_dev(c->fd, b_init, s));
     }
-    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     const bool visb = f.vis_branch != 0;
     auto iteration = [&]() -> int {
         if (oneshot) {
@@ -958,9 +960,9 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
         }
     }
     (void)have_state;
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[0].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     HIPCHK(c, hipStreamSynchronize(s));
     std::memcpy(&is, c->pin + (nc.st - nc.Yout), sizeof is);
     c->last_F = 1;
@@ -970,8 +972,7 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
         std::memset(stats, 0, sizeof *stats);
         fill_stats(stats, is);
         if (p->max_iter == 0) stats->converged = 1;
-        hipEventElapsedTime(&stats->loop_ms, c->ev[1], c->ev[2]);
-        hipEventElapsedTime(&stats->total_ms, c->ev[0], c->ev[3]);
+        if (timing) { hipEventElapsedTime(&stats->loop_ms, c->ev[1], c->ev[2]); hipEventElapsedTime(&stats->total_ms, c->ev[0], c->ev[3]); }
         stats->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
     }
     if (is.status == TDLO_E_EMPTY) return fail(c, is.status, "every point of every shard was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
@@ -1294,6 +1295,13 @@ int tdlo_debug_read_cloud(tdlo_ctx *c, int slot, double *out, int max_points, do
 }
 
 int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
+
+int tdlo_set_timing(tdlo_ctx *c, int on) {
+    if (!c) return TDLO_E_INVALID;
+    const int prev = c->timing ? 1 : 0;
+    c->timing = on != 0;
+    return prev;
+}
 
 int tdlo_debug_stamps(tdlo_ctx *c, int slot, unsigned long long *out, int n) {
     if (!c || slot < 0 || slot >= (int)c->slots.size() || !out || n < 1 || n > 64 || c->fh.empty()) return TDLO_E_INVALID;

@@ -85,6 +85,12 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     // counting sort by nearest node: hist[block][node] -> start offset of that (node, block) run.
     // 256 threads = 64 nodes x 4 chunks of blocks; per node an exclusive scan over the blocks in block order.
     const int nb = f.nprune_blocks;
+    __shared__ double sY[3 * kMaxNodes];
+    __shared__ double sc[kMaxNodes];
+    {   // the node block, requested first: it arrives while the counts are scanned (the barriers of the scan cover it)
+        const auto Yg = TDLO_AS_GLOBAL(double, f.Yin);
+        for (int i = t; i < 3 * M; i += kBlock) sY[i] = Yg[i];
+    }
     __shared__ int stot[kMaxNodes];               // kept points per node -> first index of the node's run
     __shared__ int csum[kMaxNodes / 64][4][64];   // kept points per (node, quarter of the prune blocks)
     const int ml = t & 63, ch = t >> 6;
@@ -147,13 +153,6 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     }
     // centring offset, chain coordinate: the node block is staged in LDS first -- the serial sums below (same
     // left-to-right order as the reference) would otherwise pay a global-memory round trip per term
-    __shared__ double sY[3 * kMaxNodes];
-    __shared__ double sc[kMaxNodes];
-    {
-        const auto Yg = TDLO_AS_GLOBAL(double, f.Yin);
-        for (int i = t; i < 3 * M; i += kBlock) sY[i] = Yg[i];
-    }
-    __syncthreads();
     if (t < 3) {
         double a = 0;
         for (int m = 0; m < M; ++m) a += sY[t * M + m];
