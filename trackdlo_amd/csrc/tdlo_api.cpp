@@ -47,13 +47,14 @@ struct NodeCarve {
     // offsets in doubles into Slot::nodeblk for a given M; the first `upload` doubles are the
     // host-supplied block [Yin | aJ | aYd | H] uploaded with one copy, and [Yout | IterState] is read
     // back with one copy.
-    size_t Yin, aJ, aYd, H, upload;
+    size_t fdev, Yin, aJ, aYd, H, upload;      // fdev: the frame's descriptor travels at the head of the upload block (one frame per call)
     size_t Yout, st, readback;
     size_t ctr, Y, Y0, nodes, coord, G, chain, HG, HY0, dmin, sums, dbg, Ascr, acc, total;
     explicit NodeCarve(int M) {
         const size_t m = (size_t)M, mm = m * m;
         size_t o = 0;
         auto take = [&](size_t n) { size_t r = o; o += (n + 1) & ~(size_t)1; return r; };   // keep 16-byte alignment
+        fdev = take((sizeof(FrameDev) + 7) / 8);
         Yin = take(3 * m); aJ = take(m); aYd = take(3 * m); H = take(mm); upload = o;
         Yout = take(3 * m); st = take((sizeof(IterState) + 7) / 8); readback = o - Yout;
         ctr = take(4); Y = take(3 * m); Y0 = take(3 * m); nodes = take(4 * m); coord = take(m);
@@ -315,9 +316,12 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     // node blocks (the kernels only see pointers).
     const bool merged = F > 1;
     const size_t ustride = merged ? up : nc.upload;
-    rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2) + 2 * (size_t)F * std::max(nc.readback, (sizeof(IterState) + 7) / 8) + 4);
+    // the frame descriptors ride in the same host-to-device copy: one frame -> at the head of its upload block, a batch -> as an array
+    // behind the F upload blocks (every separate small copy is a blit kernel plus a dependent-dispatch gap, ~4 us)
+    const size_t fdd = ((size_t)F * sizeof(FrameDev) + 15) / 16 * 2;      // doubles of the descriptor array of a batch
+    rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2) + fdd + 2 * (size_t)F * std::max(nc.readback, (sizeof(IterState) + 7) / 8) + 4);
     if (rc) return rc;
-    if (merged) { rc = ensure_xfer(c, (size_t)F * (up + nc.readback)); if (rc) return rc; }
+    if (merged) { rc = ensure_xfer(c, (size_t)F * (up + nc.readback) + fdd); if (rc) return rc; }
     c->fh.assign(F, FrameDev{});
     for (int i = 0; i < F; ++i) {
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
@@ -330,7 +334,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             // to LDS) and epilogue (wave sums, atomics) are paid half as often (32 frames: 879 k -> 991 k it/s in the loop).  The sums do
             // not depend on how batches are dealt out (integer accumulation), so the results are those of the single call, bit for bit.
             if (c->cfg.estep_blocks <= 0 && f.nblkE >= 64) f.nblkE = (f.nblkE + 1) / 2;
-            double *bu = c->xfer + (size_t)i * up, *br = c->xfer + (size_t)F * up + (size_t)i * nc.readback;
+            double *bu = c->xfer + (size_t)i * up, *br = c->xfer + (size_t)F * up + fdd + (size_t)i * nc.readback;
             f.Yin = bu + nc.Yin; f.aJ = bu + nc.aJ; f.aYd = bu + nc.aYd;
             if (p->include_lle) f.H = bu + nc.H;
             f.Yout = br; f.st = (IterState *)(br + (nc.st - nc.Yout));
@@ -339,10 +343,17 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     hipStream_t s = c->stream;
     const bool timing = c->timing;
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (merged) HIPCHK(c, hipMemcpyAsync(c->xfer, c->pin, (size_t)F * up * sizeof(double), hipMemcpyHostToDevice, s));
-    else HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev) * F, hipMemcpyHostToDevice, s));
-    HIPCHK(c, launch_prune_and_setup(c->fd, c->fh.data(), F, s));
+    const FrameDev *fdp;          // this call's descriptors on the device
+    if (merged) {
+        std::memcpy(c->pin + (size_t)F * up, c->fh.data(), sizeof(FrameDev) * F);
+        HIPCHK(c, hipMemcpyAsync(c->xfer, c->pin, ((size_t)F * up + fdd) * sizeof(double), hipMemcpyHostToDevice, s));
+        fdp = (const FrameDev *)(c->xfer + (size_t)F * up);
+    } else {
+        std::memcpy(c->pin + nc.fdev, c->fh.data(), sizeof(FrameDev));
+        HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
+        fdp = (const FrameDev *)(c->slots[slots[0]].nodeblk + nc.fdev);
+    }
+    HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // A batch runs as up to kBatchStreams groups of frames on as many streams, each group one E-step behind the previous
     // one: a batch's M-step is one workgroup per frame (F of the 256 CUs busy for 17 us), and meanwhile the other groups'
@@ -363,7 +374,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     auto iterate = [&](int n) -> hipError_t {
         for (int it = 0; it < n; ++it) {
             for (int g = 0; g < NS; ++g) {
-                const FrameDev *fdg = c->fd + goff[g], *fhg = c->fh.data() + goff[g];
+                const FrameDev *fdg = fdp + goff[g], *fhg = c->fh.data() + goff[g];
                 const int Fg = goff[g + 1] - goff[g];
                 if (NS > 1 && !forked && g + 1 < NS) {
                     // first iteration, kernel by kernel (same kernels, same order as launch_iteration), so that the next group
@@ -396,8 +407,8 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         // early exit (trackdlo.cpp:424-428) is decided on the device; kernels of finished frames are
         // no-ops.  To avoid enqueueing up to max_iter of them, iterations go out in chunks and the
         // `done` flags of chunk i are inspected while chunk i+1 is already running (the GPU never idles).
-        IterState *flags = (IterState *)(c->pin + (size_t)F * nc.upload);     // pinned, 2 x F entries (one frame) ...
-        double *fl_rb = c->pin + (size_t)F * nc.upload;                        // ... or 2 x F read-back blocks (batches)
+        IterState *flags = (IterState *)(c->pin + (size_t)F * nc.upload + fdd);     // pinned, 2 x F entries (one frame) ...
+        double *fl_rb = c->pin + (size_t)F * nc.upload + fdd;                        // ... or 2 x F read-back blocks (batches)
         int launched = 0, chunk = 0;
         bool stop = false;
         while (launched < p->max_iter && !stop) {
@@ -407,7 +418,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             const int slotp = chunk & 1;
             if (merged) {           // the whole read-back area (Yout + IterState per frame) in one copy, after the groups have joined
                 HIPCHK(c, join());
-                HIPCHK(c, hipMemcpyAsync(fl_rb + (size_t)slotp * F * nc.readback, c->xfer + (size_t)F * up, (size_t)F * nc.readback * sizeof(double),
+                HIPCHK(c, hipMemcpyAsync(fl_rb + (size_t)slotp * F * nc.readback, c->xfer + (size_t)F * up + fdd, (size_t)F * nc.readback * sizeof(double),
                                          hipMemcpyDeviceToHost, s));
             } else {
                 HIPCHK(c, hipMemcpyAsync(&flags[slotp * F], c->fh[0].st, sizeof(IterState), hipMemcpyDeviceToHost, s));
@@ -432,7 +443,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
     const size_t rstride = merged ? nc.readback : nc.upload;
-    if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up + fdd, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
     else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     HIPCHK(c, hipStreamSynchronize(s));
