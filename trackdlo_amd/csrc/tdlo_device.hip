@@ -484,6 +484,26 @@ __device__ __forceinline__ T geo_arg_adj(int m, int lo, T cm, T c_lo, T d_lo, T 
     return t * t;
 }
 
+// wave-wide sum of a 64-bit integer without the LDS crossbar: v_permlane32_swap / v_permlane16_swap put the two halves (row pairs) of the
+// value side by side, four DPP rotations finish inside the rows; every lane returns the total (integer addition: any order)
+template <int CTRL> __device__ __forceinline__ long long dpp_i64(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xf, 0xf, false);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)((unsigned long long)v >> 32);
+    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    long long z = (long long)(((unsigned long long)h32[0] << 32) | l32[0]) + (long long)(((unsigned long long)h32[1] << 32) | l32[1]);       // lanes l and l ^ 32
+    const unsigned zl = (unsigned)z, zh = (unsigned)((unsigned long long)z >> 32);
+    const auto l16 = __builtin_amdgcn_permlane16_swap(zl, zl, false, false), h16 = __builtin_amdgcn_permlane16_swap(zh, zh, false, false);
+    z = (long long)(((unsigned long long)h16[0] << 32) | l16[0]) + (long long)(((unsigned long long)h16[1] << 32) | l16[1]);                 // rows r and r ^ 1
+    z += dpp_i64<0x128>(z);      // row_ror:8
+    z += dpp_i64<0x124>(z);      // row_ror:4
+    z += dpp_i64<0x122>(z);      // row_ror:2
+    z += dpp_i64<0x121>(z);      // row_ror:1
+    return z;
+}
+
 // the value of the lane 8 away in the same row of 16 (DPP row_ror:8)
 __device__ __forceinline__ float row_ror8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true)); }
 __device__ __forceinline__ double row_ror8(double v) {
@@ -845,9 +865,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     //      workgroup % kAccRows (integer atomics: neither the order of the waves nor that of the workgroups matters)
     long long *iscr = (long long *)scratch;
     {
-        long long qw = accQ;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) qw += __shfl_xor(qw, o);
+        const long long qw = wave_sum_i64(accQ);
         if (lane == 0) iscr[wave] = qw;
     }
     __syncthreads();
