@@ -89,10 +89,25 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
     return v;
 }
 
+// wave-wide sum, the total in every lane.  The same pairs in the same order as an xor-32, 16, 8, 4, 2, 1 shuffle tree (identical bits), but
+// without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) lay the two halves / the rows 16 apart of the value side by
+// side, DPP rotations inside the rows do the rest (a rotation by 8, 4, 2, 1 of a value that already has that period pairs lane l with l ^ 8, ...).
+template <int CTRL> __device__ __forceinline__ double dpp_rot_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    double z = __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+    const unsigned zl = (unsigned)__double2loint(z), zh = (unsigned)__double2hiint(z);
+    const auto l16 = __builtin_amdgcn_permlane16_swap(zl, zl, false, false), h16 = __builtin_amdgcn_permlane16_swap(zh, zh, false, false);
+    z = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);
+    z += dpp_rot_f64<0x128>(z);      // row_ror:8
+    z += dpp_rot_f64<0x124>(z);      // row_ror:4
+    z += dpp_rot_f64<0x122>(z);      // row_ror:2
+    z += dpp_rot_f64<0x121>(z);      // row_ror:1
+    return z;
 }
 
 // block-wide sum for kBlock threads; scratch holds >= 4 doubles; result valid in every thread

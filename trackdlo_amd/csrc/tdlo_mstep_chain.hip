@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         const double sg = hf ? 1.0 : -1.0;
         double J00 = fma(F00, WF00, F10 * WF10) + aJ0.x, J01 = sg * (fma(F00, WF01, F10 * WF11) + aJ0.y), J11 = fma(F01, WF01, F11 * WF11) + aJ1.y;
         double e0 = fma(F00, v0, F10 * v1) + aE.x, e1 = sg * (fma(F01, v0, F11 * v1) + aE.y);
-        J00 += __shfl_xor(J00, 32); J01 += __shfl_xor(J01, 32); J11 += __shfl_xor(J11, 32); e0 += __shfl_xor(e0, 32); e1 += __shfl_xor(e1, 32);
+        J00 = swap_add32(J00, J00); J01 = swap_add32(J01, J01); J11 = swap_add32(J11, J11); e0 = swap_add32(e0, e0); e1 = swap_add32(e1, e1);      // both halves: left + right
         J00 += cp0; J11 += cp1;
         const double rJ = fast_rcp(fma(J00, J11, -(J01 * J01)));
         const double x0 = (J11 * e0 - J01 * e1) * rJ, x1 = (J00 * e1 - J01 * e0) * rJ;      // state at j2, frame of the process
