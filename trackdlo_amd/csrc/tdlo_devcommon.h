@@ -78,16 +78,30 @@ template <bool MAX> __device__ __forceinline__ unsigned wave_minmax_u32(unsigned
 }
 __device__ __forceinline__ float wave_min_nonneg(float v) { return __uint_as_float(wave_minmax_u32<false>(__float_as_uint(v))); }
 __device__ __forceinline__ float wave_max_nonneg(float v) { return __uint_as_float(wave_minmax_u32<true>(__float_as_uint(v))); }
-__device__ __forceinline__ double wave_min_nonneg(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = tmin(v, __shfl_xor(v, o));
-    return v;
+// fp64: the same butterfly as wave_sum below (v_permlane32_swap / v_permlane16_swap, then DPP rotations inside the rows), result in every
+// lane; min / max are exact, so the order does not matter (the former __shfl_xor tree cost the fp64 E-step 24 LDS round trips per batch)
+template <bool MAX, int CTRL> __device__ __forceinline__ double dpp_minmax_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    const double o = __hiloint2double(hi, lo);
+    return MAX ? (v > o ? v : o) : (v < o ? v : o);
 }
-__device__ __forceinline__ double wave_max_nonneg(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = -tmin(-v, -__shfl_xor(v, o));
-    return v;
+template <bool MAX> __device__ __forceinline__ double wave_minmax_f64(double v) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double a = __hiloint2double((int)h32[0], (int)l32[0]), b = __hiloint2double((int)h32[1], (int)l32[1]);
+    double z = MAX ? (a > b ? a : b) : (a < b ? a : b);
+    const unsigned zl = (unsigned)__double2loint(z), zh = (unsigned)__double2hiint(z);
+    const auto l16 = __builtin_amdgcn_permlane16_swap(zl, zl, false, false), h16 = __builtin_amdgcn_permlane16_swap(zh, zh, false, false);
+    const double c = __hiloint2double((int)h16[0], (int)l16[0]), d = __hiloint2double((int)h16[1], (int)l16[1]);
+    z = MAX ? (c > d ? c : d) : (c < d ? c : d);
+    z = dpp_minmax_f64<MAX, 0x128>(z);      // row_ror:8
+    z = dpp_minmax_f64<MAX, 0x124>(z);      // row_ror:4
+    z = dpp_minmax_f64<MAX, 0x122>(z);      // row_ror:2
+    z = dpp_minmax_f64<MAX, 0x121>(z);      // row_ror:1
+    return z;
 }
+__device__ __forceinline__ double wave_min_nonneg(double v) { return wave_minmax_f64<false>(v); }
+__device__ __forceinline__ double wave_max_nonneg(double v) { return wave_minmax_f64<true>(v); }
 
 // wave-wide sum, the total in every lane.  The same pairs in the same order as an xor-32, 16, 8, 4, 2, 1 shuffle tree (identical bits), but
 // without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) lay the two halves / the rows 16 apart of the value side by
