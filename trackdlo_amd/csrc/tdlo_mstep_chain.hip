@@ -111,12 +111,13 @@ template <int L> __device__ __forceinline__ double row_bcast_f64(double v) {
 constexpr int kSlot = 34;             // (272 bytes: consecutive slots start 4 banks apart, so a 128-bit access of 16 lanes -- thread = slot -- covers the
                                       //  64 banks exactly once; a stride of 256 bytes would put every lane on the same four banks)
 constexpr int kAhead = 6;             // slots behind the last one that the software-pipelined loops may read
-constexpr int kBehind = 9;            // slots in front of the first one that the anchor walk may read (values unused)
+constexpr int kBehind = 9;            // slots in front of the first one that the backward walks may read (values unused)
 constexpr int kDump = 32;              // doubles of the dump area (lanes that have nothing to store write there; never read for a result)
 constexpr int kRed = 112;              // [0..15] wave sums, [24] exchange flag, [26, 27] zeros, [28] progress counter,
                                        // [32..71] likelihood sums of the four directions (5 columns x 2), [72..77] junction state x2,
                                        // [80..93], [96..109] junction matrices of the left / right half
 constexpr int kND = 4;                 // directions
+constexpr int kDirectMax = 21;         // up to this many steps per direction the backward pass is walked step by step (below)
 
 // Four directions, nQ steps each (leading dummy steps -- identity link, nothing observed -- make all four end in their last step):
 //   0: nodes 0 .. j1 of the process, from the stationary prior             2: nodes j2 .. j3 of the process, from the state AT j2
@@ -515,7 +516,56 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     }
     __syncthreads();
     CSTAMP(5);
-    // ---- 5. backward pass in strides of four.  thread = step slot: the slot's step composed with the steps between it and the next
+    // ---- 5. backward pass.  Short directions: one wave walks every direction step by step, x_k = e_k (+ E_k x) + C_k x_{k+1} (lane =
+    //         (direction, coordinate); a step is ~10 instructions with two dependent FMAs, the records are requested two steps ahead) --
+    //         cheaper than the strided form below while a direction has fewer than ~25 steps (its two parallel phases and two barriers cost
+    //         ~2000 clocks before the first anchor moves).
+    const bool direct = nQ <= kDirectMax;
+    if (direct) {
+        if (wv == 0) {
+            const int dir = lane >> 4, hl = lane & 15;
+            const bool wr = hl < 3, inner = dir == 1 || dir == 2;
+            char *const sb = (char *)slots, *const db = (char *)dump;
+            const char *ra = sb + (size_t)SB * (dir * nQ + nQ - 1);             // the direction's last slot
+            char *la = wr ? (char *)ra + 16 * hl : db;
+            const int lstep = wr ? SB : 0;
+            dbl2 xs = dbl2{0.0, 0.0};                                           // the inner directions' start state, own frame
+            if (inner && wr) { xs = *(const dbl2 *)(red + 72 + 2 * hl); if (dir == 1) xs.y = -xs.y; }
+            const dbl2 xj = *(const dbl2 *)(la + 112);
+            double x0 = xj.x, x1 = xj.y;
+            struct BRec { dbl2 e, C0, C1, E0, E1; };
+            // (four steps per trip on four register sets, as in the forward pass: every record is requested two steps before its use, nothing
+            //  is copied; i = 1 .. 6: the slot i steps below the current one.  Slots in front of a direction's first one are readable)
+            auto bfetch = [&](int i) __attribute__((always_inline)) {
+                BRec r;
+                const char *sp = ra - SB * i;
+                r.e = *(const dbl2 *)(la - lstep * i + 112); r.C0 = *(const dbl2 *)(sp + 192); r.C1 = *(const dbl2 *)(sp + 208);
+                r.E0 = *(const dbl2 *)(sp + 224); r.E1 = *(const dbl2 *)(sp + 240);
+                return r;
+            };
+            auto bstep = [&](const BRec &r, int i) __attribute__((always_inline)) {
+                const double e0 = fma(r.E0.x, xs.x, fma(r.E1.x, xs.y, r.e.x)), e1 = fma(r.E0.y, xs.x, fma(r.E1.y, xs.y, r.e.y));
+                const double y0 = fma(r.C0.x, x0, fma(r.C0.y, x1, e0)), y1 = fma(r.C1.x, x0, fma(r.C1.y, x1, e1));
+                x0 = y0; x1 = y1;
+                *(dbl2 *)(la - lstep * i + 112) = dbl2{x0, x1};
+            };
+            int k = 1;
+            BRec rA = bfetch(1), rB = bfetch(2);
+            for (; k + 3 < nQ; k += 4) {
+                const BRec rC = bfetch(3), rD = bfetch(4);
+                bstep(rA, 1); bstep(rB, 2);
+                rA = bfetch(5); rB = bfetch(6);
+                bstep(rC, 3); bstep(rD, 4);
+                ra -= 4 * SB; la -= 4 * lstep;
+            }
+            const int rem = nQ - k;                     // 0 .. 3 steps left
+            if (rem >= 1) bstep(rA, 1);
+            if (rem >= 2) bstep(rB, 2);
+            if (rem >= 3) { const BRec r = bfetch(3); bstep(r, 3); }
+        }
+        __syncthreads();
+    } else {
+    // ---- backward pass in strides of four.  thread = step slot: the slot's step composed with the steps between it and the next
     //         ANCHOR above it (the slots a multiple of four below the junction): x_k = eh + Ch x_anchor.  The composites go where the
     //         records and right-hand sides were (dead by now): Ch -> [0..3], eh -> [8..13].
     for (int sl = t; sl < nSl; sl += MB) {
@@ -593,6 +643,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         if (i < na) astep(rA, 1);
     }
     __syncthreads();
+    }
     CSTAMP(6);
 
     // ---- 5. T = Y0 + V, sigma2 (residual form of :418-422) and the convergence criterion (:424); publish Y and the nodes.  thread = step slot
@@ -607,7 +658,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         // smoothed state: junction and anchors hold it; every other slot is one composite step below its anchor
         const int ks = sl - slot_dir(sl) * nQ, r4 = (nQ - 1 - ks) & 3;
         double Vd[3];
-        if (r4 == 0) {
+        if (direct || r4 == 0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) Vd[d] = o[14 + 2 * d];
         } else {
