@@ -22,8 +22,11 @@ Extra objects on the JSON line:
                     (E-step: algorithmic bytes 3 * s * N per launch against 8 TB/s HBM, plus its VALU fraction; M-step:
                     (2/3) M^3 + 14 M^2 flops per launch against the fp64 matrix peak).  Durations are measured live: HIP
                     start/stop events bound to every E-step and M-step dispatch of real iterations on the context's stream
-                    (tdlo_profile_iteration).  `traffic` is never measured by this script (PMC counters need rocprofv3):
-                    it is copied from the newest committed profiles/*_pmc_hbm.json and labelled with `traffic_source`.
+                    (tdlo_profile_iteration).  `traffic` = HBM bytes per launch from the PMC counters, collected by
+                    THIS run at N = 1: two child passes of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+                    (separate passes, no trace flags; FETCH_SIZE calibrated on k_prune_pass1's known read volume, the gfx950
+                    correction of MI355X_MICROARCH.md) -- `traffic_source` says so.  Without rocprofv3 (or with --pmc off) the
+                    figure of the newest committed profiles/*_pmc_hbm.json is used instead and labelled with that file.
   cpu_baseline      the CPU oracle (a plain-C port of the reference loop; the reference's own Eigen build cannot be produced
                     here) timed on this box's host on a bounded sample of the same workload, single thread like the reference
 """
@@ -40,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 EM_ITERS = 50
+PMC_CHILD_STEPS = 3             # cpd_lle calls (besides one warm-up call) of a PMC child pass
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_VECTOR_TFLOPS = 157.3      # same guide: peak FP32 (vector)
 FP64_TFLOPS = 78.6              # MI355X public specification: fp64 vector = fp64 matrix = half the fp32 vector rate (not in the guide's table)
@@ -90,6 +94,88 @@ def _traffic_from_profiles(F):
         return None, None
 
 
+def _pmc_pass(counter, args, tmp):
+    """One child run of this script under `rocprofv3 --pmc <counter>` (nothing else: no trace flags).  The child (--pmc child) makes 1 + PMC_CHILD_STEPS
+    cpd_lle calls of the workload and nothing else, so every dispatch it records belongs to a call of exactly EM_ITERS iterations."""
+    import csv
+    import shutil
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    out = os.path.join(tmp, counter)
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--config", args.config,
+           "--steps", str(PMC_CHILD_STEPS), "--warmup", "1", "--no-cpu-baseline", "--pmc", "child"]
+    if args.frames is not None:
+        cmd += ["--frames", str(args.frames)]
+    env = dict(os.environ, TMPDIR=tmp)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=300, check=True)
+    acc = defaultdict(lambda: [0.0, 0])
+    for root, _, files in os.walk(out):
+        for fn in files:
+            if fn.endswith("counter_collection.csv"):
+                with open(os.path.join(root, fn)) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter:
+                            a = acc[row["Kernel_Name"]]
+                            a[0] += float(row["Counter_Value"])
+                            a[1] += 1
+    return {k: (v[0], v[1]) for k, v in acc.items()}       # (sum of KB over the dispatches, dispatches)
+
+
+def _pmc_traffic_live(args, cfg, mstep_name):
+    """HBM bytes per launch of the two per-iteration kernels, measured now: FETCH_SIZE and WRITE_SIZE (KB per dispatch) in two separate
+    rocprofv3 passes over a short child run of the same workload.  FETCH_SIZE tallies a wide coalesced read at half its bytes on gfx950
+    (MI355X_MICROARCH.md, HBM section): the factor is calibrated in the same pass on k_prune_pass1, which reads the raw cloud exactly once
+    (3 x 8 B x N0 per frame).  Returns None when the counters cannot be collected (no rocprofv3, already under a profiler, pass failed)."""
+    import shutil
+    import tempfile
+    if args.pmc != "auto" or os.environ.get("TDLO_BENCH_STUB") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None
+    tmp = tempfile.mkdtemp(prefix="tdlo_pmc_", dir="/tmp")
+    try:
+        F = _pmc_pass("FETCH_SIZE", args, tmp)
+        W = _pmc_pass("WRITE_SIZE", args, tmp)
+        prune = [k for k in F if "k_prune_pass1" in k]
+        if not prune:
+            return None
+        frames = args.frames if args.frames is not None else cfg["frames"]
+        calls = 1 + PMC_CHILD_STEPS
+        cal = (3 * 8 * cfg["N"] * frames * calls / 1024.0) / F[prune[0]][0]
+        tname = "float" if cfg["prec"] == "f32" else "double"
+
+        def pick(prefix):
+            ks = [k for k in F if prefix in k and k in W]
+            return max(ks, key=lambda k: F[k][1]) if ks else None
+
+        res = dict(fetch_calibration_factor=round(cal, 4),
+                   source=f"this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two separate child passes of {calls} cpd_lle calls each; bytes of all "
+                          f"dispatches of the kernel / ({calls} calls x {EM_ITERS} iterations); FETCH_SIZE x {cal:.3f} (calibrated on k_prune_pass1's known "
+                          "read volume in the same pass)")
+        its = calls * EM_ITERS
+        for key, prefix in (("estep", f"k_estep<{tname}"), ("mstep", f"{mstep_name}<{tname}")):
+            k = pick(prefix)
+            if k is not None:
+                res[key] = dict(kernel=k, bytes=round((F[k][0] * cal + W[k][0]) * 1024.0 / its), fetch_KB_raw=round(F[k][0] / its, 2),
+                                write_KB=round(W[k][0] / its, 2), dispatches_per_iteration=round(F[k][1] / its, 2))
+        return res if "estep" in res else None
+    except Exception as e:      # the bench line must not depend on the profiler
+        print(f"[bench] live PMC pass failed ({type(e).__name__}: {e}); traffic falls back to the committed profile", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _apply_live_traffic(live, roof, roof_all):
+    if live is None:
+        return
+    for o in [roof] + roof_all:
+        m = live.get("estep" if o["kernel"].startswith("k_estep") else "mstep")
+        if m is not None:
+            o["traffic"], o["traffic_source"] = m["bytes"], live["source"]
+            o["traffic_detail"] = dict(kernel=m["kernel"], fetch_KB_raw=m["fetch_KB_raw"], write_KB=m["write_KB"], dispatches_per_iteration=m["dispatches_per_iteration"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +185,8 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="override the frames registered concurrently per rank (c2: 1, c3: 32)")
     ap.add_argument("--mode", choices=["frames", "nsplit"], default=None, help="deprecated alias: nsplit == --config c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", choices=["auto", "off", "child"], default="auto",
+                    help="auto: at N = 1 collect roofline.traffic in two rocprofv3 --pmc child passes; child: the pass itself (the calls only, no output)")
     args = ap.parse_args()
     if args.mode == "nsplit":
         args.config = "c4"
@@ -290,6 +378,9 @@ def bench_frames(args, cfg, env):
         step()
     barrier()
     dt = _max_over_ranks(env, time.perf_counter() - t0)
+    if args.pmc == "child":     # a PMC pass of _pmc_traffic_live: the calls above are all it is for
+        ctx.close()
+        return
     n_ranks, ranks = _rank_table(env)
     value = cfg["steps"] * F * EM_ITERS * n_ranks / dt
     # outside the timed region: the same calls with the timing events on, for the stream time of the loop alone
@@ -311,6 +402,8 @@ def bench_frames(args, cfg, env):
         # timed loop takes is the stream time between the loop's own events
         roof["iteration_us_profiled"] = roof.pop("iteration_us")
         roof["iteration_us"] = round(loop_ms * 1e3 / (loop_steps * EM_ITERS), 3)
+        live = _pmc_traffic_live(args, cfg, mname) if n_ranks == 1 else None
+        _apply_live_traffic(live, roof, roof_all)
         out = dict(metric=cfg["metric"], value=round(value, 2), unit="EM iterations/s", n_gpus=n_ranks, ranks=ranks,
                    steps=cfg["steps"], warmup=cfg["warmup"], ms_per_step=round(dt * 1e3 / cfg["steps"], 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=cfg["prec"], data="synthetic",
@@ -413,11 +506,17 @@ def bench_nsplit(args, cfg, env):
         out = step()
     barrier()
     dt = _max_over_ranks(env, time.perf_counter() - t0)
+    if args.pmc == "child":     # a PMC pass of _pmc_traffic_live: the calls above are all it is for
+        ctx.close()
+        return
     n_ranks, ranks = _rank_table(env)
     if rank == 0:
         est_us = ctx.profile_kernel(0, 50)
         mst_us = ctx.profile_kernel(2, 50)
-        roof, roof_all = _roofline_objects(hi - lo, M, 1, 4, est_us, mst_us, dt * 1e6 / (cfg["steps"] * EM_ITERS), ctx.profile_iteration(1)[3])
+        mname = ctx.profile_iteration(1)[3]
+        roof, roof_all = _roofline_objects(hi - lo, M, 1, 4, est_us, mst_us, dt * 1e6 / (cfg["steps"] * EM_ITERS), mname)
+        live = _pmc_traffic_live(args, dict(cfg, N=hi - lo, frames=1), mname) if n_ranks == 1 else None
+        _apply_live_traffic(live, roof, roof_all)
         roof["note_durations"] = "back-to-back launches on the shard's state (in the split loop the M-step kernel also waits for the peers' sums, so its in-situ duration is not a kernel cost)"
         line = dict(metric=cfg["metric"], value=round(cfg["steps"] * EM_ITERS / dt, 2), unit="EM iterations/s", n_gpus=n_ranks, ranks=ranks,
                     steps=cfg["steps"], warmup=cfg["warmup"], ms_per_step=round(dt * 1e3 / cfg["steps"], 4),

@@ -13,7 +13,7 @@ for c in c3 c4 c5; do timeout 600 python bench.py --config $c --no-cpu-baseline 
 # 2. kernel-trace stats of the same commands
 cd /tmp
 for c in c2 c3 c4 c5; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t_$c -- python $R/bench.py --config $c --no-cpu-baseline > $O/trace_$c.log 2>&1 </dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t_$c -- python $R/bench.py --config $c --no-cpu-baseline --pmc off > $O/trace_$c.log 2>&1 </dev/null
   f=$(find $O/t_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_$c.csv
   rm -rf $O/t_$c
 done
