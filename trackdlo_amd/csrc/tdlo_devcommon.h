@@ -34,7 +34,26 @@ template <> struct Num<float> {
 };
 template <> struct Num<double> {
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
-    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
+    // 2^x in 17 instructions: n = rint(x), f = x - n in [-1/2, 1/2] (exact), 2^f by the Taylor polynomial of degree 13 in f (coefficients
+    // ln2^k / k!, truncation 4e-18, 0.8 ulp with the rounding of the Horner steps), scaled by v_ldexp_f64 (which also delivers the denormals and the
+    // exact zero below 2^-1075 that the E-step's node window relies on).  The library's exp2 is the same scheme, but its Horner steps are
+    // v_fmac_f64 INTO the coefficient registers, so every evaluation re-creates its nine coefficients (v_mov_b64 each) and ends in two range
+    // compares and three selects: 32 instructions -- two thirds of a (point, node) pair of the fp64 E-step.  Here the steps are the
+    // three-address v_fma_f64 (inline asm; the coefficients stay in registers across the loop) and the range handling is the ldexp's own.
+    static __device__ __forceinline__ double exp2(double x) {
+        const double n = __builtin_rint(x), f = x - n;
+        double p;
+        // (one asm statement: between separate ones the compiler pads every dependent pair with an s_nop, not knowing what the first one wrote)
+        asm("v_fma_f64 %0, %1, %2, %3\n\tv_fma_f64 %0, %1, %0, %4\n\tv_fma_f64 %0, %1, %0, %5\n\tv_fma_f64 %0, %1, %0, %6\n\t"
+            "v_fma_f64 %0, %1, %0, %7\n\tv_fma_f64 %0, %1, %0, %8\n\tv_fma_f64 %0, %1, %0, %9\n\tv_fma_f64 %0, %1, %0, %10\n\t"
+            "v_fma_f64 %0, %1, %0, %11\n\tv_fma_f64 %0, %1, %0, %12\n\tv_fma_f64 %0, %1, %0, %13\n\tv_fma_f64 %0, %1, %0, %14"
+            : "=&v"(p)
+            : "v"(f), "v"(0x1.816193166d0f9p-40), "v"(0x1.c3bd650fc2986p-36), "v"(0x1.e8cac7351bb25p-32), "v"(0x1.e4cf5158b8ecap-28),
+              "v"(0x1.b5253d395e7c4p-24), "v"(0x1.62c0223a5c824p-20), "v"(0x1.ffcbfc588b0c7p-17), "v"(0x1.430912f86c787p-13),
+              "v"(0x1.5d87fe78a6731p-10), "v"(0x1.3b2ab6fba4e77p-7), "v"(0x1.c6b08d704a0c0p-5), "v"(0x1.ebfbdff82c58fp-3), "v"(0x1.62e42fefa39efp-1));
+        p = __builtin_fma(f, p, 1.0);
+        return __builtin_ldexp(p, (int)n);
+    }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double sqrt_fast(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
