@@ -289,9 +289,9 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     // workgroup).  A larger cloud is VALU-bound instead: it takes the 24-row tile of the batch path (more workgroups per CU hide the
     // LDS / scalar-load latencies: 47 -> 36 us at N = 2 000 000).  Batches (run_frames, F > 1) always use the small tile.
     f.wide_tile = (M > kChunk || nbatch < 4096) ? 1 : 0;
-    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : (f.wide_tile ? ((M > kChunk && p->precision == TDLO_PREC_F64) ? 256 : 512) : 1024);
-    // (more than 64 nodes in fp64: 256 -- C5 28 vs 32 us per E-step, the fp64 pairs are bound by VALU throughput either way; the same chain in
-    //  fp32 is bound by latency: N = 200 000, M = 300: 512 workgroups 12.1 us per E-step / 42.8 us per iteration against 17.1 / 53.4 with 256)
+    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : (f.wide_tile ? 512 : 1024);
+    // (more than 64 nodes: the 24-row tile lets two fp64 workgroups share a CU -- C5: 512 workgroups 21.4 us per converged E-step and 69.7 us per
+    //  iteration over a whole call, against 28.4 / 86.3 with 256 workgroups of the former 64-row tile, which filled a CU's LDS alone)
     { static const int cap_env = getenv("TDLO_ESTEP_BLOCKS") ? atoi(getenv("TDLO_ESTEP_BLOCKS")) : 0; if (cap_env > 0) cap = cap_env; }
     cap = std::min(cap, kMaxEstepBlocks);
     f.nblkE = std::max(1, std::min(nblk, cap));

@@ -543,9 +543,11 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const int M = f.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // tile rows: one frame (SINGLE) cannot fill the GPU anyway, so it keeps the whole window in the tile; batches use the
-    // small tile (two workgroups per CU) and recompute the memberships of the later chunks of a wide window
-    constexpr int RT = (NCH == 1 && !SINGLE) ? kTileRows : kChunk;
+    // tile rows: one frame (SINGLE) of up to 64 nodes cannot fill the GPU anyway, so it keeps the whole window in the tile; batches use the
+    // small tile (two workgroups per CU) and recompute the memberships of the later chunks of a wide window.  Chains beyond 64 nodes use the
+    // small tile as well: their windows are far wider than any tile (most chunks are recomputed either way), and the 64-row tile of an
+    // fp64 workgroup is 133 KB -- one workgroup per CU, one wave per SIMD, every dependent instruction a stall
+    constexpr int RT = (NCH == 1 && SINGLE) ? kChunk : kTileRows;
     constexpr int RS = (RT / kTileRows) * kTileRows;       // stored rows: whole chunks only (48 of 64, 24 of 24)
     const int rows = M < RT ? M : RT;
     // LDS carve (every offset a multiple of 16 bytes)
@@ -1472,7 +1474,7 @@ template <typename K> static hipError_t set_lds(K kernel, size_t bytes) {
 #define TDLO_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 template <typename T, int EB> static size_t estep_lds_bytes(int M, bool single) {
-    const int rt = (M <= kChunk && !single) ? kTileRows : kChunk;
+    const int rt = (M <= kChunk && single) ? kChunk : kTileRows;
     const int rows = M < rt ? M : rt;
     constexpr int NWE = EB / 64;
     const size_t tile = sizeof(T) * (((size_t)NWE * rows * kPStride + 7) & ~(size_t)3);
