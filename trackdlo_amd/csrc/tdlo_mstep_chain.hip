@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 
     // slot -> (node, link into the step, does the step observe its node); li == 0: identity (a direction's first step from the prior or
     // at j2, dummy steps).  A junction node is observed (and written back) by one direction only.
-    auto slot_dir = [&](int sl) __attribute__((always_inline)) { return (sl >= 2 * nQ) ? (sl >= 3 * nQ ? 3 : 2) : (sl >= nQ ? 1 : 0); };
+    auto slot_dir = [&](int sl) __attribute__((always_inline)) { return (int)(sl >= nQ) + (int)(sl >= 2 * nQ) + (int)(sl >= 3 * nQ); };     // (no branches)
     auto slot_info = [&](int sl, int &node, int &li, bool &obs) __attribute__((always_inline)) {
         const int dir = slot_dir(sl), k = sl - dir * nQ;
         const int kk = k - ((padbits >> (4 * dir)) & 15);
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         const int lc = q.li > 0 ? q.li : 1, mc = q.node;
 #pragma unroll
         for (int i = 0; i < 4; ++i) q.l[i] = chg[4 * (size_t)lc + i];
-        if (q.li == 0) { q.l[0] = dbl2{1.0, 0.0}; q.l[1] = dbl2{0.0, 1.0}; q.l[2] = dbl2{0.0, 0.0}; q.l[3] = dbl2{0.0, 0.0}; }     // identity link
+        // (li == 0, the identity link, is substituted where the record is written: a conditional overwrite here is a branch that waits
+        //  for every load in flight -- the sums included -- before the node's loads below are requested)
         q.y[0] = (double)ndg[mc].x; q.y[1] = (double)ndg[mc].y; q.y[2] = (double)ndg[mc].z; q.w = (double)ndg[mc].w;
 #pragma unroll
         for (int d = 0; d < 3; ++d) { q.y0[d] = Y0g[d * M + mc]; q.yp[d] = Yg[d * M + mc]; q.ay[d] = pri ? aYg[d * M + mc] : 0.0; }
@@ -208,9 +209,19 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     // runs while these are in flight.
     const int itn = stg->it;
     double sq[9];
+    // (the first element without a branch -- index clamped, the accumulators exist in every mode: inside a conditional block the compiler sums the
+    //  16 rows on the spot, i.e. waits for them BEFORE it requests the slot below: two memory round trips in a row instead of one)
+    sq[0] = acc_read_both(f, t < nS ? t : nS - 1, itn);
 #pragma unroll
-    for (int u = 0; u < 9; ++u) { const int i = t + u * MB; sq[u] = (from_sums != 1 && i < nS) ? acc_read_both(f, i, itn) : 0.0; }
-    const SlotQ q0 = load_slot(t);
+    for (int u = 1; u < 9; ++u) sq[u] = 0.0;
+    SlotQ q0;
+    if (nS <= MB) {             // up to 63 nodes: the slot's loads follow the sums' in the same basic block (nothing is waited for in between)
+        q0 = load_slot(t);
+    } else {                    // longer chains: the further elements first -- with the slot's forty registers live the compiler requests their
+#pragma unroll                  // rows one by one, a round trip each
+        for (int u = 1; u < 9; ++u) { const int i = t + u * MB; if (from_sums != 1 && i < nS) sq[u] = acc_read_both(f, i, itn); }
+        q0 = load_slot(t);
+    }
     const double pinf0 = chg[0].x, pinf1 = chg[0].y;  // sf2, s^2 sf2
     const double c2 = f.lambda * sigma2, rc2 = fast_rcp(c2);
     const double cp0 = c2 * chg[1].x, cp1 = c2 * chg[1].y;  // Pinf^-1 in the units of the filter (P = covariance / c); reciprocals from k_setup
@@ -272,8 +283,10 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         dbl2 *o = (dbl2 *)(slots + (size_t)kSlot * sl);
         const SlotQ q = r == 0 ? q0 : load_slot(sl);
         const double p1 = q.obs ? S[q.node] : 0.0;
-        o[0] = q.l[0]; o[1] = q.l[1]; o[2] = q.l[2] * rc2;
-        o[3] = dbl2{q.l[3].x * rc2, q.obs ? p1 + q.aj : 0.0};
+        const bool idl = q.li == 0;     // identity link: a direction's first step, dummy steps
+        o[0] = dbl2{idl ? 1.0 : q.l[0].x, idl ? 0.0 : q.l[0].y}; o[1] = dbl2{idl ? 0.0 : q.l[1].x, idl ? 1.0 : q.l[1].y};
+        o[2] = dbl2{idl ? 0.0 : q.l[2].x * rc2, idl ? 0.0 : q.l[2].y * rc2};
+        o[3] = dbl2{idl ? 0.0 : q.l[3].x * rc2, q.obs ? p1 + q.aj : 0.0};
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[4 + d] = dbl2{q.obs ? S[(1 + d) * M + q.node] + (p1 * (q.y[d] - q.y0[d]) + q.ay[d]) : 0.0, 0.0};
     }
