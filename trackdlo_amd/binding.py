@@ -101,7 +101,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("TDLO_LIBRARY") or LIB_PATH       # TDLO_LIBRARY: an instrumented / experimental build (scripts/build_variant.sh)
     if not os.path.exists(p):
         raise FileNotFoundError(f"{p} not built: run `make -C trackdlo_amd/csrc` (needs hipcc); there is no CPU fallback")
     _pin_hip_runtime()
