@@ -29,7 +29,7 @@ cd $R
 bash scripts/gpu_estep_pmc.sh $tag 2000000 50 0 2>&1 | grep -v amdgpu.ids > $O/estep_sq_counters_c4.txt
 # 5. measured numbers quoted in DESIGN.md
 {
-  echo "== stamps (C2 M-step phases, shader clocks)"; timeout 200 python scripts/gpu_stamps.py
+  echo "== stamps (C2 M-step phases, shader clocks; instrumented build)"; [ -f scripts/tmp/libtrackdlo_stamps.so ] || bash scripts/build_variant.sh stamps -DTDLO_ESTEP_STAMPS -DTDLO_CHAIN_STAMPS > /dev/null 2>&1; timeout 200 python scripts/gpu_stamps.py
   echo "== c5_5it";  ITERS=5 timeout 200 python scripts/gpu_c5.py
   echo "== c5_30it"; ITERS=30 timeout 200 python scripts/gpu_c5.py
   echo "== dense comparators (TDLO_MSTEP=dense)"; TDLO_MSTEP=dense ITERS=5 timeout 200 python scripts/gpu_c5.py

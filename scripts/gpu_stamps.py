@@ -2,6 +2,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trackdlo_amd import binding as B, synth
+# the phase stamps exist only in an instrumented build: bash scripts/build_variant.sh stamps -DTDLO_ESTEP_STAMPS -DTDLO_CHAIN_STAMPS
+_v = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tmp", "libtrackdlo_stamps.so")
+if not os.environ.get("TDLO_LIBRARY") and os.path.exists(_v):
+    B._lib = B.load_library(_v)
 P = synth.LAUNCH_PARAMS
 ctx = B.Context(max_points=1 << 16)
 X, Y0, _ = synth.scene(50000, 50, config=2)

@@ -985,7 +985,11 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
     double *Gs = aux + 7 * 64;                        // M x M (column-major, ld = M)
     double *Ut = Gs + (((size_t)M * M + 1) & ~(size_t)1);    // (M + 3) x 64: the eliminated tableau for the back substitution (pivoted variant only)
 
+#ifdef TDLO_CHAIN_STAMPS      // phase stamps only in an instrumented build (scripts/build_variant.sh): an s_memtime behind a full lgkmcnt wait + a store each
 #define TDLO_STAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TDLO_STAMP(i) do { } while (0)
+#endif
     TDLO_STAMP(0);
 #ifdef TDLO_ESTEP_STAMPS
     if (t == 0) { f.dbg[34] = f.dbg[32]; f.dbg[35] = f.dbg[33]; f.dbg[36] = f.dbg[38]; f.dbg[37] = __builtin_amdgcn_s_memrealtime(); f.dbg[32] = ~0ull; f.dbg[33] = 0ull; }
@@ -1024,7 +1028,9 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         if (t < nS) sq0 = acc_read_both(f, t, itn);
         if (t + MB < nS) sq1 = acc_read_both(f, t + MB, itn);
     }
+#ifdef TDLO_CHAIN_STAMPS
     if (slot < 4) f.dbg[8 + slot] = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int u = 0; u < GQ; ++u) { const int i = t + u * MB; if (i < M * M) Gs[i] = gq[u]; }
     if (done) return;

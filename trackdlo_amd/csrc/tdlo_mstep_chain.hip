@@ -160,7 +160,13 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *S = (double *)smem + cv.S, *red = (double *)smem + cv.red, *dump = (double *)smem + cv.dump, *slots = (double *)smem + cv.slots;
 
+    // phase stamps (scripts/gpu_stamps.py, tdlo_debug_stamps) only in a -DTDLO_CHAIN_STAMPS build (scripts/build_variant.sh stamps ...): each one is an
+    // s_memtime behind a full lgkmcnt wait plus a store behind an exec branch, eight of them per launch
+#ifdef TDLO_CHAIN_STAMPS
 #define CSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
     CSTAMP(0);
     const auto stg = TDLO_AS_GLOBAL(IterState, st);
     const int done = stg->done;
