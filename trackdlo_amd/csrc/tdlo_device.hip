@@ -517,7 +517,7 @@ template <typename T, int NCH, bool VIS, int EB, bool SINGLE>
 __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frames, const FrameDev f0) {
     constexpr int NWE = EB / 64;
     const FrameDev &f = SINGLE ? f0 : frames[blockIdx.y];
-    if ((int)blockIdx.x >= f.nblkE) return;
+    if (!SINGLE && (int)blockIdx.x >= f.nblkE) return;      // (one frame: the grid IS nblkE -- no scalar round trip in front of the other kernarg loads)
 #ifdef TDLO_ESTEP_STAMPS
     if (threadIdx.x == 0) atomicMin(&f.dbg[32], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
