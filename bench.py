@@ -166,6 +166,22 @@ def _pmc_traffic_live(args, cfg, mstep_name):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
+def _emit(obj):
+    """The JSON line, as the LAST thing on stdout: RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would
+    otherwise come out at process exit, behind the line."""
+    _flush_c_stdio()
+    print(json.dumps(obj), flush=True)
+
+
 def _apply_live_traffic(live, roof, roof_all):
     if live is None:
         return
@@ -226,13 +242,15 @@ def main():
         else:
             dist.init_process_group(backend)
     env = dict(rank=rank, world=world, dev_index=dev_index, dist=dist, torch=torch, backend=backend)
-    if args.config == "c4":
-        bench_nsplit(args, cfg, env)
-    else:
-        bench_frames(args, cfg, env)
+    res = bench_nsplit(args, cfg, env) if args.config == "c4" else bench_frames(args, cfg, env)
     if dist is not None:
+        _flush_c_stdio()            # every rank: whatever RCCL has printed so far leaves the buffers before rank 0's line
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0:
+            time.sleep(0.5)         # the other ranks' exit-time output, if any, first
+    if res is not None:
+        _emit(res)
 
 
 def _rank_table(env):
@@ -435,8 +453,8 @@ def bench_frames(args, cfg, env):
             cpu = _cpu_baseline(cfg, X0, Y00, kw, g)
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
     ctx.close()
+    return out if rank == 0 else None
 
 
 def bench_nsplit(args, cfg, env):
@@ -562,8 +580,8 @@ def bench_nsplit(args, cfg, env):
                 cpu = _cpu_baseline(cfg, X, Y0, kw, None)
                 line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
     ctx.close()
+    return line if rank == 0 else None
 
 
 if __name__ == "__main__":
