@@ -53,6 +53,7 @@
 //
 // The dense kernels stay in the tree: with the LLE term (include_lle, the pre-processing registration of tracking_step) the
 // system is not of this form, and TDLO_MSTEP=dense selects them as comparators for the tests.
+#include <type_traits>
 #include "tdlo_devcommon.h"
 #include <atomic>
 #include <cstdlib>
@@ -223,9 +224,41 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     SlotQ q0;
     if (nS <= MB) {             // up to 63 nodes: the slot's loads follow the sums' in the same basic block (nothing is waited for in between)
         q0 = load_slot(t);
-    } else {                    // longer chains: the further elements first -- with the slot's forty registers live the compiler requests their
-#pragma unroll                  // rows one by one, a round trip each
-        for (int u = 1; u < 9; ++u) { const int i = t + u * MB; if (from_sums != 1 && i < nS) sq[u] = acc_read_both(f, i, itn); }
+    } else {                    // longer chains: the further elements first (with the slot's forty registers live the compiler requests their
+        // rows one by one, a round trip each).  Straight-line code per element count -- indices clamped instead of branched, this iteration's
+        // parity only: inside `if (i < nS)` blocks every element's eight rows were waited for before the next element's were requested
+        // (fetch at M = 300: 10 500 clocks, 7 000 of them these serial round trips).
+        if (from_sums != 1) {
+            const auto rows = TDLO_AS_GLOBAL(long long, f.acc) + (size_t)(itn & 1) * kAccRows * acc_stride(M);
+            const int stride = acc_stride(M);
+            auto more = [&](auto U0c, auto U1c) __attribute__((always_inline)) {        // elements U0 .. U1 - 1, all rows requested before any is summed
+                constexpr int U0 = decltype(U0c)::value, U1 = decltype(U1c)::value;
+                long long sa[U1 - U0];
+                int ix[U1 - U0];
+#pragma unroll
+                for (int u = U0; u < U1; ++u) {
+                    const int i = t + u * MB;
+                    ix[u - U0] = i < nS ? i : nS - 1;
+                    long long a = 0;
+#pragma unroll
+                    for (int r = 0; r < kAccRows; ++r) a += rows[(size_t)r * stride + ix[u - U0]];
+                    sa[u - U0] = a;
+                }
+#pragma unroll
+                for (int u = U0; u < U1; ++u) sq[u] = ::ldexp((double)sa[u - U0], -acc_shift(f, ix[u - U0]));
+            };
+            using std::integral_constant;
+            switch ((nS + MB - 1) / MB) {       // (two elements, 64 .. 127 nodes: both parities without waiting for the counter, as before; at most four
+                case 2: if (t + MB < nS) sq[1] = acc_read_both(f, t + MB, itn); break;                          //  elements at a time)
+                case 3: more(integral_constant<int, 1>(), integral_constant<int, 3>()); break;
+                case 4: more(integral_constant<int, 1>(), integral_constant<int, 4>()); break;
+                case 5: more(integral_constant<int, 1>(), integral_constant<int, 5>()); break;
+                default:        // more than 319 nodes: element by element as before (two groups of four in flight measured slower: 32 000 against 16 500 clocks at M = 512)
+#pragma unroll
+                    for (int u = 1; u < 9; ++u) { const int i = t + u * MB; if (i < nS) sq[u] = acc_read_both(f, i, itn); }
+                    break;
+            }
+        }
         q0 = load_slot(t);
     }
     const double pinf0 = chg[0].x, pinf1 = chg[0].y;  // sf2, s^2 sf2
