@@ -81,10 +81,11 @@ def _params(kw, prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [4, 5, 6, 7, 8, 9, 10, 11, 13, 31, 50, 51, 52, 53, 64, 65, 127, 128, 129, 254, 255, 256, 300, 511, 512])
+@pytest.mark.parametrize("M", [4, 5, 6, 7, 8, 9, 10, 11, 13, 31, 50, 51, 52, 53, 64, 65, 127, 128, 129, 191, 192, 254, 255, 256, 300, 319, 320, 511, 512])
 def test_chain_mstep_against_oracle_over_chain_lengths(oracle, M):
     """fp64 mode at the stated tolerance (1e-9 m, 1e-7 in sigma2; equal iteration counts): even / odd chains (a dummy first step in
-    one direction or not), one or several step slots per thread (M + 1 > 256), partial rows fetched in one or several trips."""
+    one direction or not), one or several step slots per thread (M + 1 > 256), partial rows fetched in one or several trips (elements of the sums per thread: 1 up to 63 nodes, 2 up to 127, 3 up to 191,
+    4 up to 255, 5 up to 319 -- fetched in straight-line code -- and the element-by-element form beyond)."""
     from trackdlo_amd import binding as B, synth
     assert B.mstep_dense(False) is False
     N = 3000 if M <= 128 else 6000
