@@ -319,6 +319,9 @@ int tdlo_profile_iteration(tdlo_ctx *ctx, int reps, float *estep_us, float *mste
 /* Development aid: copies the first n (<= 64) shader-clock stamps that the M-step kernel of the last
  * launch wrote at its phase boundaries (reduce / assemble / eliminate / update / publish). */
 int tdlo_debug_stamps(tdlo_ctx *ctx, int slot, unsigned long long *out, int n);
+/* Test aid: y[i] = 2^x[i] as the fp64 E-step computes it (its own 17-instruction form, csrc/tdlo_devcommon.h: Num<double>::exp2, not the
+ * library's); host arrays of n doubles. */
+int tdlo_debug_exp2(tdlo_ctx *ctx, const double *x, double *y, int n);
 /* Test aid: which M-step serves registrations WITHOUT the LLE term from now on, process-wide.  0 (default): the chain smoother
  * (csrc/tdlo_mstep_chain.hip: the system of trackdlo.cpp:405-413 solved in O(M) through the state-space form of the kernel G);
  * 1: the dense eliminations of the same system (k_mstep_fast / k_mstep_mcu), kept as comparators.  Returns the previous

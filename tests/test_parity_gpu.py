@@ -1255,3 +1255,25 @@ def test_results_do_not_depend_on_the_estep_launch_geometry(prec):
                 ref = g
             else:
                 assert np.array_equal(g["Y"], ref["Y"]) and g["sigma2"] == ref["sigma2"], (N, M, blocks)
+
+
+@pytest.mark.gpu
+def test_fp64_exp2_of_the_estep(hip_ctx):
+    """The fp64 E-step's own 2^x (tdlo_devcommon.h: Num<double>::exp2 -- rint, Taylor polynomial of degree 13 as three-address FMAs on
+    register-resident coefficients, v_ldexp_f64 for the range) against numpy's: within 1 ulp over the arguments the memberships
+    produce (exponents <= 0 down to the denormals), exact powers of two at the integers, exact zero below 2^-1075 (what the
+    node window's skipping of far nodes relies on)."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([-rng.random(200000) * 1000.0, -rng.random(50000) * 2.0, -1022.0 - rng.random(20000) * 52.0,
+                        -np.arange(0.0, 1075.0), np.array([0.0, -0.5, -1e-300, -1074.0, -1074.9, -1075.5, -1080.0, -1100.0, -5000.0])])
+    y = hip_ctx.debug_exp2(x)
+    with np.errstate(under="ignore"):
+        ref = np.exp2(x.astype(np.longdouble))
+    normal = x > -1021.5
+    rel = np.abs((y[normal].astype(np.longdouble) - ref[normal]) / ref[normal]).astype(np.float64)
+    assert rel.max() <= 2.3e-16, rel.max()                                  # 1 ulp of a number just above a power of two is 2.2e-16
+    sub = ~normal
+    assert np.all(np.abs(y[sub].astype(np.longdouble) - ref[sub]) <= 5e-324 * 1.5)          # denormals: within one unit of the last (denormal) place
+    ints = -np.arange(0.0, 1075.0)
+    assert np.array_equal(hip_ctx.debug_exp2(ints), np.ldexp(1.0, ints.astype(int)))
+    assert np.all(hip_ctx.debug_exp2(np.array([-1075.5, -1080.0, -1100.0, -5000.0])) == 0.0)

@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_mstep_dense", "tdlo_set_timing", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_set_timing", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -166,6 +166,7 @@ def load_library(path: str | None = None):
     lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
     lib.tdlo_profile_iteration.argtypes = [vp, ci, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_char_p, ci]
     lib.tdlo_debug_stamps.argtypes = [vp, ci, vp, ci]
+    lib.tdlo_debug_exp2.argtypes = [vp, vp, vp, ci]
     lib.tdlo_debug_mstep_dense.argtypes = [ci]
     lib.tdlo_debug_mstep_dense.restype = ci
     lib.tdlo_set_timing.argtypes = [vp, ci]
@@ -411,6 +412,13 @@ class Context:
         if n < 0:
             raise TdloError(n, "tdlo_debug_read_cloud")
         return out.reshape(-1)[:3 * n].reshape(3, n).T.copy(), ctr
+
+    def debug_exp2(self, x):
+        """2^x as the fp64 E-step computes it (test aid)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._chk(self.lib.tdlo_debug_exp2(self.h, _ptr(x), _ptr(y), int(x.size)))
+        return y
 
     def debug_stamps(self, n=16, slot=0):
         out = np.zeros(n, dtype=np.uint64)

@@ -1400,6 +1400,20 @@ int tdlo_debug_stamps(tdlo_ctx *c, int slot, unsigned long long *out, int n) {
     return TDLO_OK;
 }
 
+int tdlo_debug_exp2(tdlo_ctx *c, const double *x, double *y, int n) {
+    if (!c || !x || !y || n < 1) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    double *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, 2 * (size_t)n * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_debug_exp2(d, d + n, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(y, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    HIPCHK(c, e);
+    return TDLO_OK;
+}
+
 // ---- host helpers --------------------------------------------------------------------------------
 int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L) {
     if (!Y || !L || M < 1 || k < 2 || k > 13) return TDLO_E_INVALID;

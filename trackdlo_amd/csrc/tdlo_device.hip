@@ -1710,4 +1710,14 @@ int check_device_image() {
     return e == hipSuccess ? 0 : -1;
 }
 
+// test aid (tdlo_debug_exp2): the fp64 E-step's 2^x on an array
+__global__ void k_debug_exp2(const double *__restrict__ x, double *__restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = Num<double>::exp2(x[i]);
+}
+hipError_t launch_debug_exp2(const double *x, double *y, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_debug_exp2, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
+    return hipGetLastError();
+}
+
 }  // namespace tdlo

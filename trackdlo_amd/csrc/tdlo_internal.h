@@ -107,6 +107,7 @@ hipError_t launch_split_init_pack(const FrameDev *frames_dev, double *init2, hip
 hipError_t launch_split_set_global_dev(const FrameDev *frames_dev, const double *init2, hipStream_t s);   // ... and back, reduced
 hipError_t launch_xch_init(const FrameDev *frames_dev, hipStream_t s);                             // one-shot exchange of the same two numbers
 hipError_t launch_split_dmin_xch(const FrameDev *frames_dev, const FrameDev *frames_host, double *xch, int import, hipStream_t s);
+hipError_t launch_debug_exp2(const double *x, double *y, int n, hipStream_t s);       // test aid: Num<double>::exp2 on an array
 hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s);
 size_t mstep_lds_bytes(int M);
 // tdlo_mstep_big.hip: M-step for 60 < M <= kMaxNodes without LLE (blocked Gauss-Jordan, tableau in global memory)
