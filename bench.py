@@ -109,7 +109,7 @@ def _pmc_pass(counter, args, tmp):
     env = dict(os.environ, TMPDIR=tmp)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=300, check=True)
+    subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=150, check=True)
     acc = defaultdict(lambda: [0.0, 0])
     for root, _, files in os.walk(out):
         for fn in files:
