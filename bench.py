@@ -109,7 +109,16 @@ def _pmc_pass(counter, args, tmp):
     env = dict(os.environ, TMPDIR=tmp)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=150, check=True)
+    proc = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, start_new_session=True)
+    try:
+        rc = proc.wait(timeout=150)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)         # the profiler AND the bench.py under it (its own process group: nothing else is touched)
+        proc.wait()
+        raise
+    if rc != 0:
+        raise RuntimeError(f"rocprofv3 --pmc {counter} pass exited with {rc}")
     acc = defaultdict(lambda: [0.0, 0])
     for root, _, files in os.walk(out):
         for fn in files:
