@@ -14,3 +14,4 @@ g = ctx.cpd_lle_resident(0, Y0, 0.0, pr)
 st = ctx.debug_stamps(64).astype(np.int64)
 print('loop_ms', g['loop_ms'])
 print('estep block 0 wave 0 stamps (clocks): start, loads+barrier, pass1, second node+window, pass2, column sums, block barrier, end', (st[40:48] - st[40]).tolist())
+print('   of pass1: candidate range known after', int(st[48] - st[41]), 'clocks, candidates loop', int(st[42] - st[48]))

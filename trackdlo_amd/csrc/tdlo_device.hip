@@ -652,6 +652,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             if (last >= 0) { plo = first; phi = last; }
             plo = __builtin_amdgcn_readfirstlane(plo); phi = __builtin_amdgcn_readfirstlane(phi);
         }
+        ESTAMP(8);      // (instrumented builds: the candidate range is known; the rest of the phase is the candidates' loop)
         T best = Num<T>::inf();
         int a = plo;
         // candidates in groups of 4: the group's scalar loads are issued together (index clamped to phi), the evaluations
