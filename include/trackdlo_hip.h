@@ -327,6 +327,13 @@ int tdlo_debug_exp2(tdlo_ctx *ctx, const double *x, double *y, int n);
  * 1: the dense eliminations of the same system (k_mstep_fast / k_mstep_mcu), kept as comparators.  Returns the previous
  * setting.  The initial setting is 1 when the environment holds TDLO_MSTEP=dense. */
 int tdlo_debug_mstep_dense(int on);
+/* Test aid: which M-step serves registrations WITH the LLE term (include_lle: the pre-processing registration of tracking_step,
+ * trackdlo.cpp:925-927) from now on, process-wide.  0 (default): the banded L D L^T of the system of :396-415 in the state (f, f') of
+ * the chain (csrc/tdlo_mstep_band.hip, O(M)), wherever the chain and H allow it -- no two consecutive nodes closer than about a
+ * millimetre, H banded like the reference's own (I - L)^T (I - L); 1: always the dense pivoted eliminations (k_mstep_fast<pivoted> /
+ * k_mstep / k_mstep_pivot_mcu), kept as comparators and for everything the banded form does not take.  Returns the previous setting.
+ * The initial setting is 1 when the environment holds TDLO_MSTEP_LLE=dense. */
+int tdlo_debug_mstep_lle_dense(int on);
 /* Whether the registrations of this context record the four stream events behind tdlo_stats.loop_ms / total_ms.  Off by default: the
  * reference has no such figures, and the markers cost about 15 us per call (2 % of a 50-iteration call at N = 50 000).  Returns the
  * previous setting (or TDLO_E_INVALID). */

@@ -53,7 +53,7 @@ struct NodeCarve {
     // back with one copy.
     size_t fdev, Yin, aJ, aYd, H, upload;      // fdev: the frame's descriptor travels at the head of the upload block (one frame per call)
     size_t Yout, st, readback;
-    size_t ctr, Y, Y0, nodes, coord, G, chain, HG, HY0, dmin, sums, dbg, Ascr, acc, total;
+    size_t ctr, Y, Y0, nodes, coord, G, chain, HG, HY0, dmin, sums, dbg, Ascr, acc, band, total;
     explicit NodeCarve(int M) {
         const size_t m = (size_t)M, mm = m * m;
         size_t o = 0;
@@ -65,6 +65,7 @@ struct NodeCarve {
         G = take(mm); chain = take(8 * (m + 1)); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2); dbg = take(64);
         Ascr = take(std::max((size_t)(M | 1) * (m + 3), mstep_big_scratch_doubles(M)));
         acc = take((size_t)2 * kAccRows * (4 * m + 2));       // the E-step's fixed-point accumulators, two iteration parities
+        band = take(band_record_doubles(M));                  // column records of the banded LLE M-step
         total = o;
     }
 };
@@ -262,7 +263,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         aJ[idx] = p->alpha;
         for (int d = 0; d < 3; ++d) aYd[d * M + idx] = p->alpha * (priors[4 * i + 1 + d] - Y[d * M + idx]);
     }
-    size_t upload = nc.H;            // doubles to upload
+    bool lle_band = false;
     if (p->include_lle) {
         double *H = stage + nc.H;
         if (H_override) std::memcpy(H, H_override, sizeof(double) * (size_t)M * M);
@@ -271,9 +272,29 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
             lle_weights(6, Y, M, L.data());                  // trackdlo.cpp:236
             lle_regulariser(L.data(), M, H);                 // :237
         }
-        upload = nc.upload;
+        // The banded L D L^T in the chain's state (tdlo_mstep_band.hip) serves the registration when (i) H is banded like the
+        // reference's own (I - L)^T (I - L) -- +-6 nodes; an H_override may be anything --, (ii) it is symmetric there (the band is read
+        // from one triangle), (iii) no two consecutive nodes are closer than h_min: the state precision K contains Q^-1 ~ 3 beta^4 / h^3, and
+        // the solve's error grows like eps lambda sigma2 K / P1: at h = 1 mm with the pre-processing parameters (beta 3, lambda 1)
+        // 1e-13 m, at 0.1 mm 1e-11 m, at 0.01 mm 1e-7 m (scripts/band_gap_study.py); the bound scales with cbrt(lambda beta^4).
+        // Everything else (coincident nodes in particular: K is infinite there) keeps the dense pivoted eliminations.
+        if (mstep_band_enabled() && p->lambda > 0 && p->beta > 0) {
+            lle_band = true;
+            const double hmin = 1e-3 * std::cbrt(p->lambda * std::pow(p->beta / 3.0, 4));
+            for (int i = 0; i + 1 < M && lle_band; ++i) {
+                double d2 = 0;
+                for (int d = 0; d < 3; ++d) { const double e = Y[d * M + i + 1] - Y[d * M + i]; d2 += e * e; }
+                if (!(d2 >= hmin * hmin)) lle_band = false;
+            }
+            if (H_override) {
+                for (int j = 0; j < M && lle_band; ++j)
+                    for (int i = 0; i < M; ++i) {
+                        const double v = H[(size_t)j * M + i];
+                        if ((std::abs(i - j) > 6 && v != 0.0) || v != H[(size_t)i * M + j] || !(v == v)) { lle_band = false; break; }
+                    }
+            }
+        }
     }
-    (void)upload;
 
     std::memset(&f, 0, sizeof f);
     f.N0 = s.N0; f.M = M; f.ldx = s.cap_points;
@@ -300,7 +321,10 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.vis_branch = (n_vis != M && n_vis != 0 && p->k_vis != 0) ? 1 : 0;
     (void)vis;
     f.precision = p->precision;
-    f.need_G = (p->include_lle || !mstep_chain_enabled()) ? 1 : 0;
+    // which M-step: decided here, once per frame (the launchers dispatch on the descriptor, not on the process-wide toggles)
+    f.mstep_dense = mstep_chain_enabled() ? 0 : 1;
+    f.lle_band = lle_band ? 1 : 0;
+    f.need_G = ((p->include_lle && !lle_band) || (!p->include_lle && f.mstep_dense)) ? 1 : 0;
     {   // test hook: iteration k of the multi-CU M-steps behaves as if a hand-off had timed out (tests/test_parity_gpu.py)
         static const int force_it = getenv("TDLO_MCU_FORCE_TIMEOUT") ? atoi(getenv("TDLO_MCU_FORCE_TIMEOUT")) : -1;
         f.force_timeout_it = force_it;
@@ -327,6 +351,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.coord = blk + nc.coord; f.G = blk + nc.G; f.chain = blk + nc.chain; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
     f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
     f.acc = (long long *)(blk + nc.acc);
+    f.band = blk + nc.band;
     {   // fixed-point exponents of the accumulators: totals stay below 2^62.  P1_m <= N0.  |R_m| <= sum_n P_mn |x_n - y_m| <= N0 D and
         // Q <= N0 D^2 with D a bound on point-node distances: every kept point is within 0.1 m of a node (:177-195), nodes are within
         // the chain's length of each other; doubled for the motion of the nodes during the registration, rounded up to a power of two
@@ -398,6 +423,11 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             if (p->include_lle) f.H = bu + nc.H;
             f.Yout = br; f.st = (IterState *)(br + (nc.st - nc.Yout));
         }
+    }
+    if (p->include_lle) {          // one M-step kernel serves the whole batch: a frame whose chain the banded solve cannot take
+        bool all_band = true;      // sends all frames to the dense one
+        for (int i = 0; i < F; ++i) all_band = all_band && c->fh[i].lle_band;
+        if (!all_band) for (int i = 0; i < F; ++i) { c->fh[i].lle_band = 0; c->fh[i].need_G = 1; }
     }
     hipStream_t s = c->stream;
     const bool timing = c->timing;
@@ -961,9 +991,6 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     if (oneshot) {
         if (c->xch_nranks < 1) return fail(c, TDLO_E_INVALID, "tdlo_split_run without a communicator needs the one-shot exchange (tdlo_xch_create / tdlo_xch_bind)");
         if (M > c->xch_mcap) return fail(c, TDLO_E_INVALID, "more nodes than the inbox was created for");
-        // the exchange lives in the one-workgroup M-steps: the chain smoother (any chain length, no LLE term) and k_mstep_fast
-        if (!((!p->include_lle && (mstep_chain_enabled() || M <= 60)) || (p->include_lle && M <= 64)))
-            return fail(c, TDLO_E_INVALID, "the one-shot exchange with the LLE term lives in the one-workgroup M-step (up to 64 nodes): pass an RCCL communicator for longer chains");
     } else {
         std::string why;
         R = rccl_api(nullptr, &why);
@@ -977,6 +1004,10 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     rc = prepare_frame(c, 0, Y, M, *sigma2, p, priors, K, vis, n_vis, H_override, c->pin, c->fh[0]);
     if (rc) return rc;
     FrameDev &f = c->fh[0];
+    // the exchange lives in the one-workgroup M-steps: the chain smoother (no LLE term), the banded L D L^T (LLE term) -- any chain
+    // length -- and the dense k_mstep_fast (up to 60 / 64 nodes)
+    if (oneshot && !((!p->include_lle && (!f.mstep_dense || M <= 60)) || (p->include_lle && (f.lle_band || M <= 64))))
+        return fail(c, TDLO_E_INVALID, "the one-shot exchange lives in the one-workgroup M-steps: this registration takes a dense multi-workgroup elimination (LLE term on a chain the banded solve cannot take, beyond 64 nodes): pass an RCCL communicator");
     hipStream_t s = c->stream;
     double *b_init = nullptr, *b_dmin = nullptr, *b_sums = nullptr;
     if (oneshot) {
@@ -1382,6 +1413,7 @@ int tdlo_debug_read_cloud(tdlo_ctx *c, int slot, double *out, int max_points, do
 }
 
 int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
+int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 
 int tdlo_set_timing(tdlo_ctx *c, int on) {
     if (!c) return TDLO_E_INVALID;

@@ -195,7 +195,64 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
             }
     }
     __syncthreads();
-    if (f.include_lle) {
+    if (f.include_lle && f.lle_band) {
+        // Banded LLE M-step (tdlo_mstep_band.hip): one column record per unknown of the state-space system, column n of
+        // lambda K + lle_weight H, rows n - 12 .. n, each at the position of its row's slot (row mod 13).  K: joint precision of the
+        // states (f_i, f'_i) of the chain, block tridiagonal: diagonal block of node b = (b == 0 ? Pinf^-1 : Q_b^-1) + Phi_{b+1}^T Q_{b+1}^-1 Phi_{b+1},
+        // block (node b, node b - 1) = -Q_b^-1 Phi_b (link b between nodes b - 1 and b).  H enters through its 7 diagonals (:236-237: the
+        // rows of I - L reach +-3 nodes).  Unknowns that do not exist (padding to whole chunks of 13 steps, the columns that enter
+        // behind the last pivot) are identity records.  H Y0 from the same diagonals: the dense product's terms outside them are exact zeros.
+        const auto Hg = TDLO_AS_GLOBAL(double, f.H);
+        const int nU = 2 * M, nR = band_records(M);
+        const double lam = f.lambda, gam = f.lle_weight;
+        for (int j = t; j < nR; j += kBlock) {
+            double *o = f.band + 16 * (size_t)j;
+            o[7] = 0.0; o[11] = 0.0; o[15] = 0.0;                            // the right-hand side's positions (the M-step fills them)
+            const int sj = j % kBandSlots;
+            if (j >= nU) {
+                for (int q = 0; q < kBandSlots; ++q) o[band_rec_pos(q)] = q == sj ? 1.0 : 0.0;
+                continue;
+            }
+            const int b = j >> 1, tj = j & 1;
+            double kd0, kd1, kd2, ko[4] = {0.0, 0.0, 0.0, 0.0};            // diagonal block of node b (ff, fp, pp), block (node b rows, node b - 1 columns)
+            if (b == 0) { const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta); kd0 = 1.0 / sf2; kd1 = 0.0; kd2 = 1.0 / (s * s * sf2); }
+            else {
+                double L[8];
+                chain_link(beta, sc[b] - sc[b - 1], L);
+                const double rdet = 1.0 / (L[4] * L[6] - L[5] * L[5]);
+                const double qa = L[6] * rdet, qb = -L[5] * rdet, qd = L[4] * rdet;                  // Q^-1
+                kd0 = qa; kd1 = qb; kd2 = qd;
+                ko[0] = -(qa * L[0] + qb * L[2]); ko[1] = -(qa * L[1] + qb * L[3]);                 // -(Q^-1 Phi): row f
+                ko[2] = -(qb * L[0] + qd * L[2]); ko[3] = -(qb * L[1] + qd * L[3]);                 //              row f'
+            }
+            if (b + 1 < M) {
+                double L[8];
+                chain_link(beta, sc[b + 1] - sc[b], L);
+                const double rdet = 1.0 / (L[4] * L[6] - L[5] * L[5]);
+                const double qa = L[6] * rdet, qb = -L[5] * rdet, qd = L[4] * rdet;
+                const double t11 = qa * L[0] + qb * L[2], t12 = qa * L[1] + qb * L[3], t21 = qb * L[0] + qd * L[2], t22 = qb * L[1] + qd * L[3];
+                kd0 += L[0] * t11 + L[2] * t21; kd1 += L[0] * t12 + L[2] * t22; kd2 += L[1] * t12 + L[3] * t22;      // Phi^T Q^-1 Phi
+            }
+            for (int q = 0; q < kBandSlots; ++q) {
+                const int i = j - (j - q + 2 * kBandSlots) % kBandSlots;      // the row in j - 12 .. j with slot q
+                double v = 0.0;
+                if (i >= 0) {
+                    const int a = i >> 1, ti = i & 1;
+                    if (a == b) v = lam * (ti == tj ? (ti ? kd2 : kd0) : kd1);
+                    else if (a == b - 1) v = lam * (tj ? (ti ? ko[3] : ko[2]) : (ti ? ko[1] : ko[0]));
+                    if (!ti && !tj && b - a <= 6) v += gam * Hg[(size_t)b * M + a];
+                }
+                o[band_rec_pos(q)] = v;
+            }
+        }
+        for (int e = t; e < 3 * M; e += kBlock) {
+            const int i = e % M, d = e / M;
+            const int k0 = i - 6 > 0 ? i - 6 : 0, k1 = i + 6 < M - 1 ? i + 6 : M - 1;
+            double a = 0;
+            for (int k = k0; k <= k1; ++k) a += Hg[(size_t)k * M + i] * sY[d * M + k];
+            f.HY0[e] = a;
+        }
+    } else if (f.include_lle) {
         // H G and H Y0 (:396-401).  Global address space + unrolled k loop: independent loads in flight instead of one
         // flat load per multiply-add (this block was 50 us of a 65 us kernel).
         const auto Hg = TDLO_AS_GLOBAL(double, f.H);
@@ -1494,9 +1551,9 @@ template <typename T, int EB> static size_t estep_lds_bytes(int M, bool single) 
 
 // measurement aid (tdlo_profile_kernel kind 10): when set, the E-step is launched with start/stop events bound to the
 // dispatch itself (hipExtLaunchKernelGGL), i.e. the same begin/end timestamps a kernel trace reports
-static hipEvent_t g_estep_ev[2] = {nullptr, nullptr};
+static thread_local hipEvent_t g_estep_ev[2] = {nullptr, nullptr};      // (per launching thread: another context's launches on another host thread must not pick these up)
 // the same for the M-step dispatch (k_mstep_fast here, k_mstep_mcu in tdlo_mstep_big.hip): tdlo_profile_iteration
-hipEvent_t g_mstep_ev[2] = {nullptr, nullptr};
+thread_local hipEvent_t g_mstep_ev[2] = {nullptr, nullptr};
 
 template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
     const int M = fh[0].M, nch = nch_for(M);
@@ -1573,7 +1630,8 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
     const int M = fh[0].M;
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
-    if (!any_lle && mstep_chain_enabled()) return launch_mstep_chain(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
+    if (!any_lle && !fh[0].mstep_dense) return launch_mstep_chain(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
+    if (any_lle && fh[0].lle_band) return launch_mstep_band(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     if (M <= 60 && !any_lle) return launch_mstep_fast<T, 4, 1, true>(fd, fh, F, from_sums, s);
     // (M = 61..64 without LLE: the 64-column register tableau has no room for the right-hand sides; the tracer-column
     //  variant of the register path is an order of magnitude less accurate at weak regularisation, so these sizes take
@@ -1635,7 +1693,8 @@ const char *mstep_kernel_name(const FrameDev *fh, int F) {
     const int M = fh[0].M;
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
-    if (!any_lle && mstep_chain_enabled()) return "k_mstep_chain";
+    if (!any_lle && !fh[0].mstep_dense) return "k_mstep_chain";
+    if (any_lle && fh[0].lle_band) return "k_mstep_band";
     if (M <= 60 && !any_lle) return "k_mstep_fast<MFMA>";
     if (!any_lle) return "k_mstep_mcu";
     if (M <= 64) return "k_mstep_fast<pivoted>";

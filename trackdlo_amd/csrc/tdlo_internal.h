@@ -69,7 +69,10 @@ struct FrameDev {
     int acc_sh[3];          // binary exponents of the fixed point: value = integer * 2^-sh for P1 / R / Q
     int force_timeout_it;   // test hook (environment TDLO_MCU_FORCE_TIMEOUT=k): iteration k of the multi-CU M-steps behaves as if a hand-off timed out; -1 = off
     int prune_tiles;        // 256-point tiles one prune workgroup handles (1 up to 262 144 points)
-    int need_G;             // the M x M kernel matrix is built at setup (dense M-steps: LLE term, comparators); the chain smoother does not read it
+    int need_G;             // the M x M kernel matrix is built at setup (dense M-steps: dense LLE path, comparators); the chain smoother and the banded LLE M-step do not read it
+    int mstep_dense;        // registrations without the LLE term: 0 the chain smoother, 1 the dense eliminations (comparators) -- decided when the frame is prepared
+    int lle_band;           // registrations with the LLE term: 1 the banded L D L^T in the chain's state (tdlo_mstep_band.hip), 0 the dense pivoted eliminations
+    double *band;           // lle_band: one 16-double column record per unknown of the state-space system (band_record_doubles(M)), written by k_setup
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
@@ -93,6 +96,13 @@ __host__ __device__ inline size_t xch_off_init(int R) { return (5 * (size_t)R + 
 __host__ __device__ inline size_t xch_off_dmin(int R, int Mc) { (void)Mc; return xch_off_init(R) + 2 * (size_t)R; }
 __host__ __device__ inline size_t xch_off_sums(int R, int Mc) { return xch_off_dmin(R, Mc) + 2 * (size_t)R * Mc; }
 __host__ __device__ inline size_t xch_words(int R, int Mc) { return xch_off_sums(R, Mc) + 2 * (size_t)R * (4 * (size_t)Mc + 2); }
+
+// Banded LLE M-step (tdlo_mstep_band.hip): unknowns of the state-space system incl. identity padding to whole chunks of 13 steps, and column
+// records (13 more: the columns that enter behind the last pivot); position of row slot q inside a 16-double column record
+constexpr int kBandSlots = 13;
+__host__ __device__ inline int band_unknowns_padded(int M) { return (2 * M + kBandSlots - 1) / kBandSlots * kBandSlots; }
+__host__ __device__ inline int band_records(int M) { return band_unknowns_padded(M) + kBandSlots; }
+__host__ __device__ inline int band_rec_pos(int q) { return (q & 3) * 4 + (q >> 2); }
 
 // launchers implemented in tdlo_device.hip
 hipError_t launch_prune_and_setup(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
@@ -120,6 +130,12 @@ bool mstep_pivot_mcu_enabled();
 hipError_t launch_mstep_chain(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
 bool mstep_chain_enabled();
 int mstep_set_dense(int on);      // returns the previous setting
+// tdlo_mstep_band.hip: M-step with the LLE term as a banded L D L^T in the chain's state (f, f'), any M
+hipError_t launch_mstep_band(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
+size_t band_record_doubles(int M);
+size_t mstep_band_lds_bytes(int M);
+bool mstep_band_enabled();
+int mstep_set_lle_dense(int on);  // 1: registrations with the LLE term take the dense pivoted eliminations (comparators); returns the previous setting
 // tdlo_reg.hip: plain GMM-EM `reg` (utils.cpp:21-82); ws layout: state (8) | Y (3 M) | block partials
 size_t reg_ws_doubles(int M, int nblk);
 int reg_max_nodes();        // the E-step's per-wave accumulators must fit 160 KB of LDS

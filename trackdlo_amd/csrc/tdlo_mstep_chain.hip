@@ -60,7 +60,7 @@
 #include <hip/hip_ext.h>
 
 namespace tdlo {
-extern hipEvent_t g_mstep_ev[2];       // tdlo_device.hip: start/stop events for the M-step dispatch (tdlo_profile_iteration)
+extern thread_local hipEvent_t g_mstep_ev[2];       // tdlo_device.hip: start/stop events for the M-step dispatch (tdlo_profile_iteration)
 namespace {
 
 constexpr int kCB = 256;               // workgroup size
