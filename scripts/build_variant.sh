@@ -13,6 +13,7 @@ cd $S
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -c tdlo_device.hip -o $B/tdlo_device.o &
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -c tdlo_mstep_big.hip -o $B/tdlo_mstep_big.o &
 /opt/rocm/bin/hipcc $F -c tdlo_mstep_chain.hip -o $B/tdlo_mstep_chain.o &
+/opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -c tdlo_mstep_band.hip -o $B/tdlo_mstep_band.o &
 /opt/rocm/bin/hipcc $F -c tdlo_cloud.hip -o $B/tdlo_cloud.o &
 /opt/rocm/bin/hipcc $F -c tdlo_reg.hip -o $B/tdlo_reg.o &
 /opt/rocm/bin/hipcc $F -x hip -c tdlo_api.cpp -o $B/tdlo_api.o &

@@ -196,25 +196,31 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     }
     __syncthreads();
     if (f.include_lle && f.lle_band) {
-        // Banded LLE M-step (tdlo_mstep_band.hip): one column record per unknown of the state-space system, column n of
-        // lambda K + lle_weight H, rows n - 12 .. n, each at the position of its row's slot (row mod 13).  K: joint precision of the
-        // states (f_i, f'_i) of the chain, block tridiagonal: diagonal block of node b = (b == 0 ? Pinf^-1 : Q_b^-1) + Phi_{b+1}^T Q_{b+1}^-1 Phi_{b+1},
-        // block (node b, node b - 1) = -Q_b^-1 Phi_b (link b between nodes b - 1 and b).  H enters through its 7 diagonals (:236-237: the
-        // rows of I - L reach +-3 nodes).  Unknowns that do not exist (padding to whole chunks of 13 steps, the columns that enter
-        // behind the last pivot) are identity records.  H Y0 from the same diagonals: the dense product's terms outside them are exact zeros.
+        // Banded LLE M-step (tdlo_mstep_band.hip): one column record per step of each direction of the elimination (BandPlan), column j
+        // of lambda K + lle_weight H in the direction's own order of the unknowns, rows j - 12 .. j, each at the position of its row's
+        // slot (row mod 13).  K: joint precision of the states (f_i, f'_i) of the chain, block tridiagonal: diagonal block of node
+        // b = (b == 0 ? Pinf^-1 : Q_b^-1) + Phi_{b+1}^T Q_{b+1}^-1 Phi_{b+1}, block (node b, node b - 1) = -Q_b^-1 Phi_b (link b between
+        // nodes b - 1 and b).  H enters through its 7 diagonals (:236-237: the rows of I - L reach +-3 nodes).  Direction 0 walks the
+        // unknowns u = 0, 1, 2, ...; direction 1 (twisted plan) walks u~ = nUp - 1 - u from the chain's tail and leaves out the block
+        // R x R of the 12 unknowns between the two sides (it belongs to direction 0's records).  Unknowns that do not exist (padding,
+        // the other side's, the columns entering behind the last pivot) are identity records.
         const auto Hg = TDLO_AS_GLOBAL(double, f.H);
-        const int nU = 2 * M, nR = band_records(M);
+        const BandPlan bp(M);
         const double lam = f.lambda, gam = f.lle_weight;
-        for (int j = t; j < nR; j += kBlock) {
-            double *o = f.band + 16 * (size_t)j;
+        for (int jj = t; jj < bp.nRecT + bp.nRecB; jj += kBlock) {
+            const int dir = jj >= bp.nRecT ? 1 : 0, j = dir ? jj - bp.nRecT : jj;
+            double *o = f.band + 16 * (size_t)jj;
             o[7] = 0.0; o[11] = 0.0; o[15] = 0.0;                            // the right-hand side's positions (the M-step fills them)
             const int sj = j % kBandSlots;
-            if (j >= nU) {
+            const bool real = dir ? (j >= bp.D && j < bp.mB + 12) : (j < bp.limT);
+            if (!real) {
                 for (int q = 0; q < kBandSlots; ++q) o[band_rec_pos(q)] = q == sj ? 1.0 : 0.0;
                 continue;
             }
-            const int b = j >> 1, tj = j & 1;
-            double kd0, kd1, kd2, ko[4] = {0.0, 0.0, 0.0, 0.0};            // diagonal block of node b (ff, fp, pp), block (node b rows, node b - 1 columns)
+            const int uj = dir ? bp.nUp - 1 - j : j;                         // the unknown: node b, component tj (0: f, 1: f')
+            const int b = uj >> 1, tj = uj & 1;
+            double kd0, kd1, kd2, ko[4] = {0.0, 0.0, 0.0, 0.0}, kn[4] = {0.0, 0.0, 0.0, 0.0};
+            // diagonal block of node b (ff, fp, pp); ko: block (node b rows, node b - 1 columns); kn: block (node b + 1 rows, node b columns)
             if (b == 0) { const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta); kd0 = 1.0 / sf2; kd1 = 0.0; kd2 = 1.0 / (s * s * sf2); }
             else {
                 double L[8];
@@ -232,15 +238,21 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
                 const double qa = L[6] * rdet, qb = -L[5] * rdet, qd = L[4] * rdet;
                 const double t11 = qa * L[0] + qb * L[2], t12 = qa * L[1] + qb * L[3], t21 = qb * L[0] + qd * L[2], t22 = qb * L[1] + qd * L[3];
                 kd0 += L[0] * t11 + L[2] * t21; kd1 += L[0] * t12 + L[2] * t22; kd2 += L[1] * t12 + L[3] * t22;      // Phi^T Q^-1 Phi
+                kn[0] = -t11; kn[1] = -t12; kn[2] = -t21; kn[3] = -t22;
             }
             for (int q = 0; q < kBandSlots; ++q) {
-                const int i = j - (j - q + 2 * kBandSlots) % kBandSlots;      // the row in j - 12 .. j with slot q
+                const int i = j - (j - q + 2 * kBandSlots) % kBandSlots;      // the row in j - 12 .. j with slot q (direction's own index)
                 double v = 0.0;
-                if (i >= 0) {
-                    const int a = i >> 1, ti = i & 1;
+                const bool rowreal = dir ? (i >= bp.D) : (i >= 0);
+                const bool inRR = dir && i >= bp.mB && j >= bp.mB;            // direction 1 leaves R x R to direction 0
+                if (rowreal && !inRR) {
+                    const int ui = dir ? bp.nUp - 1 - i : i;
+                    const int a = ui >> 1, ti = ui & 1;
                     if (a == b) v = lam * (ti == tj ? (ti ? kd2 : kd0) : kd1);
-                    else if (a == b - 1) v = lam * (tj ? (ti ? ko[3] : ko[2]) : (ti ? ko[1] : ko[0]));
-                    if (!ti && !tj && b - a <= 6) v += gam * Hg[(size_t)b * M + a];
+                    else if (a == b - 1) v = lam * (tj ? (ti ? ko[3] : ko[2]) : (ti ? ko[1] : ko[0]));      // K[2b + tj][2(b-1) + ti]
+                    else if (a == b + 1) v = lam * (ti ? (tj ? kn[3] : kn[2]) : (tj ? kn[1] : kn[0]));      // K[2(b+1) + ti][2b + tj]
+                    const int dab = a > b ? a - b : b - a;
+                    if (!ti && !tj && dab <= 6) v += gam * Hg[(size_t)b * M + a];
                 }
                 o[band_rec_pos(q)] = v;
             }

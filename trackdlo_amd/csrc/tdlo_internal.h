@@ -97,12 +97,40 @@ __host__ __device__ inline size_t xch_off_dmin(int R, int Mc) { (void)Mc; return
 __host__ __device__ inline size_t xch_off_sums(int R, int Mc) { return xch_off_dmin(R, Mc) + 2 * (size_t)R * Mc; }
 __host__ __device__ inline size_t xch_words(int R, int Mc) { return xch_off_sums(R, Mc) + 2 * (size_t)R * (4 * (size_t)Mc + 2); }
 
-// Banded LLE M-step (tdlo_mstep_band.hip): unknowns of the state-space system incl. identity padding to whole chunks of 13 steps, and column
-// records (13 more: the columns that enter behind the last pivot); position of row slot q inside a 16-double column record
+// Banded LLE M-step (tdlo_mstep_band.hip): how the 2M unknowns of the state-space system are dealt out.  One direction (short chains, and
+// chains whose records would not fit the LDS twice): wave 0 eliminates unknowns 0, 1, 2, ... in whole chunks of 13 steps (identity
+// unknowns pad the last chunk).  TWISTED (tw): wave 0 eliminates unknowns 0 .. mT-1 from the chain's head, wave 1 the unknowns from
+// the tail backwards, in its own order u~ = nUp - 1 - u (D identity unknowns in front make its count a whole number of chunks as
+// well); the 12 unknowns R = mT .. mT+11 between them (half-bandwidth 12: they separate the two sides) receive both sides' Schur
+// complements, and BOTH waves finish with them (one more chunk each) -- no hand-over of results, each wave back-substitutes
+// its own side.  A direction's records: one per step (+ 15: the columns entering behind the last pivot, and the requests two steps ahead).
 constexpr int kBandSlots = 13;
-__host__ __device__ inline int band_unknowns_padded(int M) { return (2 * M + kBandSlots - 1) / kBandSlots * kBandSlots; }
-__host__ __device__ inline int band_records(int M) { return band_unknowns_padded(M) + kBandSlots; }
-__host__ __device__ inline int band_rec_pos(int q) { return (q & 3) * 4 + (q >> 2); }
+struct BandPlan {
+    int nU, tw, cT, cB, D, mT, mB, nUp, limT, sT, sB, nRecT, nRecB;
+    __host__ __device__ explicit BandPlan(int M, int allow_twisted = 1) {
+        nU = 2 * M;
+        tw = (allow_twisted && nU >= 38) ? 1 : 0;                    // (below: two directions of 13 + 13 steps are no shorter than one)
+        for (;;) {
+            if (!tw) { cT = (nU + kBandSlots - 1) / kBandSlots; cB = 0; D = 0; }
+            else { const int q = nU - 12, ch = (q + kBandSlots - 1) / kBandSlots; D = kBandSlots * ch - q; cT = (ch + 1) / 2; cB = ch - cT; }
+            mT = kBandSlots * cT; mB = kBandSlots * cB; nUp = nU + D;
+            limT = tw ? mT + 12 : nU;                                   // top's records below limT are real columns, identity from there on
+            sT = kBandSlots * (cT + tw); sB = tw ? kBandSlots * (cB + 1) : 0;
+            nRecT = sT + 15; nRecB = tw ? sB + 15 : 0;
+            if (!tw || lds_doubles(M) * 8 <= 160 * 1024) break;
+            tw = 0;                                                     // both directions' records do not fit the LDS: one direction
+        }
+    }
+    // LDS of k_mstep_band (doubles): sums | scratch | per direction: dump, zeros (28 records, right in front of the records), records | merge tiles
+    __host__ __device__ size_t off_S() const { return 0; }
+    __host__ __device__ size_t lds_doubles(int M) const {
+        size_t o = (size_t)((4 * M + 2 + 1) & ~1) + 32;
+        o += (size_t)(tw ? 2 : 1) * (16 * 28 + 64 + 16 * 28) + (size_t)16 * (nRecT + nRecB);
+        o += tw ? 2 * 256 : 0;
+        return o;
+    }
+};
+__host__ __device__ inline int band_rec_pos(int q) { return (q & 3) * 4 + (q >> 2); }      // position of row slot q inside a 16-double column record
 
 // launchers implemented in tdlo_device.hip
 hipError_t launch_prune_and_setup(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);

@@ -78,28 +78,8 @@ __device__ __forceinline__ double neg_rcp(double d) {
 
 }  // namespace
 
-// LDS layout (doubles).  rec: one 16-double record per unknown (+ 13 identity records behind the padded count): the column
-// record written by k_setup until the unknown has entered the window, the step record `a` after its elimination, x_k in [13..15] after
-// the back substitution.  zero / dump: where lanes that have nothing to read / write go (the loops use immediate offsets of up to 26
-// records on top of the lane's base address, so both areas are that long).
-struct BandCarve {
-    int nU, nP, nR;
-    size_t S, red, zero, dump, rec, total;
-    __host__ __device__ explicit BandCarve(int M) {
-        nU = 2 * M;
-        nP = band_unknowns_padded(M);           // unknowns incl. identity padding: whole chunks of 13 steps
-        nR = band_records(M);                   // records: the columns that enter behind the last pivot are identity as well
-        size_t o = 0;
-        S = o; o += (size_t)((4 * M + 2 + 1) & ~1);
-        red = o; o += 32;
-        zero = o; o += 16 * 28;
-        dump = o; o += 16 * 28 + 64;
-        rec = o; o += (size_t)16 * (nR + 1);      // (+ one: the last step requests the column behind the last record)
-        total = o;
-    }
-};
-size_t band_record_doubles(int M) { return (size_t)16 * BandCarve(M).nR; }
-size_t mstep_band_lds_bytes(int M) { return BandCarve(M).total * sizeof(double); }
+size_t band_record_doubles(int M) { const BandPlan bp(M); return (size_t)16 * (bp.nRecT + bp.nRecB); }
+size_t mstep_band_lds_bytes(int M) { return BandPlan(M).lds_doubles(M) * sizeof(double); }
 
 template <typename T, bool SINGLE, bool XCH>
 __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
@@ -109,10 +89,15 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
     const int M = f.M, t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nS = 4 * M + 1;
-    const BandCarve cv(M);
+    const BandPlan bp(M);
+    const int tw = bp.tw;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *S = (double *)smem + cv.S, *red = (double *)smem + cv.red, *zero = (double *)smem + cv.zero, *dump = (double *)smem + cv.dump,
-           *rec = (double *)smem + cv.rec;
+    // LDS (BandPlan::lds_doubles): sums | scratch | direction 0: dump, zeros, records | direction 1: the same | merge tiles
+    double *S = (double *)smem, *red = S + ((4 * M + 2 + 1) & ~1);
+    constexpr int kDump = 16 * 28 + 64, kZero = 16 * 28;
+    double *dump0 = red + 32, *zero0 = dump0 + kDump, *rec0 = zero0 + kZero;
+    double *dump1 = rec0 + 16 * (size_t)bp.nRecT, *zero1 = dump1 + kDump, *rec1 = zero1 + kZero;
+    double *tiles = tw ? rec1 + 16 * (size_t)bp.nRecB : dump1;
 #ifdef TDLO_CHAIN_STAMPS
 #define BSTAMP(i) do { if (t == 0) f.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -144,13 +129,19 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
         q.aj = pri ? aJg[mc] : 0.0;
         return q;
     };
+    // where unknown 2m (the f component of node m) lives: direction 0 record 2m up to limT, else direction 1 record nUp - 1 - 2m
+    auto rec_of_node = [&](int m) __attribute__((always_inline)) -> double * {
+        const int u = 2 * m;
+        return u < bp.limT ? rec0 + 16 * (size_t)u : rec1 + 16 * (size_t)(bp.nUp - 1 - u);
+    };
+    auto slot_of_node = [&](int m) __attribute__((always_inline)) { const int u = 2 * m; return (u < bp.limT ? u : bp.nUp - 1 - u) % kNS; };
     const int itn = stg->it;
     double sq[9];
     sq[0] = acc_read_both(f, t < nS ? t : nS - 1, itn);
 #pragma unroll
     for (int u = 1; u < 9; ++u) sq[u] = 0.0;
-    constexpr int RQ = 4;                               // column records through registers: 4 x 16 bytes per thread cover 57 nodes
-    const int nR2 = 8 * cv.nR;                          // dbl2 elements of the records
+    constexpr int RQ = 5;                               // column records through registers: 5 x 16 bytes per thread cover 50 nodes
+    const int nT2 = 8 * bp.nRecT, nR2 = 8 * (bp.nRecT + bp.nRecB);      // dbl2 elements of direction 0's records / of all records
     dbl2 rq[RQ];
 #pragma unroll
     for (int u = 0; u < RQ; ++u) { const int i = t + u * MB; rq[u] = bandg[i < nR2 ? i : nR2 - 1]; }
@@ -173,13 +164,13 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
         for (int i = t; i < nS; i += MB) S[i] = sums[i];
     }
     {
-        dbl2 *rl = (dbl2 *)rec;
+        dbl2 *r0 = (dbl2 *)rec0, *r1 = (dbl2 *)rec1;
+        auto put = [&](int i, dbl2 v) __attribute__((always_inline)) { if (i < nT2) r0[i] = v; else if (i < nR2) r1[i - nT2] = v; };
 #pragma unroll
-        for (int u = 0; u < RQ; ++u) { const int i = t + u * MB; if (i < nR2) rl[i] = rq[u]; }
-        for (int i = t + RQ * MB; i < nR2; i += MB) rl[i] = bandg[i];
+        for (int u = 0; u < RQ; ++u) put(t + u * MB, rq[u]);
+        for (int i = t + RQ * MB; i < nR2; i += MB) put(i, bandg[i]);
     }
-    for (int i = t; i < 16 * 28; i += MB) zero[i] = 0.0;
-    if (t < 16) rec[16 * (size_t)cv.nR + t] = 0.0;
+    for (int i = t; i < kZero; i += MB) { zero0[i] = 0.0; if (tw) zero1[i] = 0.0; }
     __syncthreads();
     if (from_sums == 2) {       // split mode, export only
         acc_clear_other<MB>(f, itn, t);
@@ -216,122 +207,164 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
     }
     BSTAMP(2);
 
-    // ---- 2. thread = node: D_a / sigma2 onto the diagonal of record 2a, the right-hand side
+    // ---- 2. thread = node: D_a / sigma2 onto the diagonal of the node's f record, the right-hand side
     //         B / sigma2 = (R + P1 (y - Y0) + alpha (Y_ext - Y0)) / sigma2 - lle_weight H Y0   into its spare positions
     //         (the E-step delivers R = PX - P1 y, y = the nodes as it saw them)
     for (int m = t, r = 0; m < M; m += MB, ++r) {
         const NodeQ q = r == 0 ? q0 : load_node(m);
         const double p1 = S[m];
-        double *o = rec + 32 * (size_t)m;
-        const int sl = (2 * m) % kNS;
-        o[band_rec_pos(sl)] += (p1 + q.aj) * rs;
+        double *o = rec_of_node(m);
+        o[band_rec_pos(slot_of_node(m))] += (p1 + q.aj) * rs;
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[4 * d + 7] = fma(S[(1 + d) * M + m] + (p1 * (q.y[d] - q.y0[d]) + q.ay[d]), rs, -(gam * q.hy[d]));
     }
     __syncthreads();
     BSTAMP(3);
 
-    // ---- 3. elimination and back substitution on wave 0; the other waves clear the other parity's accumulator rows for the next E-step
+    // ---- 3. elimination and back substitution: wave 0 from the chain's head, wave 1 (twisted plan) from its tail -- the same code on
+    //         their own records; the other waves clear the other parity's accumulator rows for the next E-step
     int bad_pivot = 0;
-    if (wv != 0) {
-        if (from_sums != 1) acc_clear_other<MB - 64>(f, itn, t - 64);
-    } else {
-        const int c = lane & 15, gl = lane >> 4;
-        const unsigned recB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)rec;
-        const unsigned zeroB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)zero;
-        const unsigned dumpB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)dump + 8u * (unsigned)lane;
-        auto lds_d2 = [](unsigned addr) __attribute__((always_inline)) { return *(const dbl2 *)(__attribute__((address_space(3))) const void *)(uintptr_t)addr; };
-        auto lds_d1 = [](unsigned addr) __attribute__((always_inline)) { return *(const double *)(__attribute__((address_space(3))) const void *)(uintptr_t)addr; };
-        auto lds_w1 = [](unsigned addr, double v) __attribute__((always_inline)) { *(double *)(__attribute__((address_space(3))) void *)(uintptr_t)addr = v; };
-        mfma_d4 C = {0.0, 0.0, 0.0, 0.0};
-        // column j of the window's matrix: the four registers of the lanes that own tile column j % 13 (zeros for every other lane)
-        struct Col { dbl2 lo, hi; };
-        auto load_col = [&](int P, unsigned chunkB, int ahead) __attribute__((always_inline)) {     // record (chunk base) + ahead
-            const unsigned a = (c == P ? chunkB + 32u * (unsigned)gl : zeroB) + 128u * (unsigned)ahead;
-            Col r; r.lo = lds_d2(a); r.hi = lds_d2(a + 16);
-            return r;
-        };
-        auto set_col = [&](int P, const Col &n) __attribute__((always_inline)) {
-            const double keep = c == P ? 0.0 : 1.0;
-            C[0] = fma(C[0], keep, n.lo.x); C[1] = fma(C[1], keep, n.lo.y); C[2] = fma(C[2], keep, n.hi.x); C[3] = fma(C[3], keep, n.hi.y);
-        };
-        // the first window: columns 0 .. 12 and the right-hand sides of rows 0 .. 12 (lane c >= 13 of group gl, register r: row slot 4 r + gl)
-#pragma unroll
-        for (int j = 0; j < kNS; ++j) set_col(j, load_col(j, recB, j));
+    const bool worker = wv == 0 || (tw && wv == 1);
+    if (!worker && from_sums != 1) { if (tw) { if (wv >= 2) acc_clear_other<MB - 128>(f, itn, t - 128); } else acc_clear_other<MB - 64>(f, itn, t - 64); }
+    const int c = lane & 15, gl = lane >> 4;
+    double *const recD = wv == 1 ? rec1 : rec0;
+    const unsigned recB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)recD;
+    const unsigned zeroB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(wv == 1 ? zero1 : zero0);
+    const unsigned dumpB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(wv == 1 ? dump1 : dump0) + 8u * (unsigned)lane;
+    auto lds_d2 = [](unsigned addr) __attribute__((always_inline)) { return *(const dbl2 *)(__attribute__((address_space(3))) const void *)(uintptr_t)addr; };
+    auto lds_d1 = [](unsigned addr) __attribute__((always_inline)) { return *(const double *)(__attribute__((address_space(3))) const void *)(uintptr_t)addr; };
+    auto lds_w1 = [](unsigned addr, double v) __attribute__((always_inline)) { *(double *)(__attribute__((address_space(3))) void *)(uintptr_t)addr = v; };
+    mfma_d4 C = {0.0, 0.0, 0.0, 0.0};
+    // column j of the window's matrix: the four registers of the lanes that own tile column j % 13 (zeros for every other lane)
+    struct Col { dbl2 lo, hi; };
+    auto load_col = [&](int P, unsigned chunkB, int ahead) __attribute__((always_inline)) {     // record (chunk base) + ahead
+        const unsigned a = (c == P ? chunkB + 32u * (unsigned)gl : zeroB) + 128u * (unsigned)ahead;
+        Col r; r.lo = lds_d2(a); r.hi = lds_d2(a + 16);
+        return r;
+    };
+    auto set_col = [&](int P, const Col &n) __attribute__((always_inline)) {
+        const double keep = c == P ? 0.0 : 1.0;
+        C[0] = fma(C[0], keep, n.lo.x); C[1] = fma(C[1], keep, n.lo.y); C[2] = fma(C[2], keep, n.hi.x); C[3] = fma(C[3], keep, n.hi.y);
+    };
+    // Steps come in chunks of 13 with static slots.  Carried from step to step: C = the result of the last MFMA, `ncp` = the column that
+    // enters the slot it freed (k + 12 into slot Pm; still to be SET), `rb` = the right-hand side of the same unknown (enters through
+    // the k-slot gs = g ^ 2 of this step's MFMA, onto what the elimination left in that slot's row: a rounding-level multiple of
+    // the eliminated row's y -- a perturbation of b of relative size 1e-16, as every solver commits).  The pivot row is extracted
+    // from the raw MFMA result with the pending column folded in (one FMA: t = C[r] m + add, m = 0/1 mask of the pivot's lane group
+    // without the pending column, add = that column's entry + the entering b).  A lone wave cannot issue anything while its
+    // v_mfma_f64_16x16x4 runs (scripts/ubench/mfma64.hip: 65 clocks, and eight independent VALU instructions behind it add their full
+    // 46), so a step costs the MFMA plus every other instruction: the step is written for instruction count -- the reciprocal of the
+    // pivot (v_rcp_f64 + a third-order correction, wave-uniform) sits on the chain; predicting it a step ahead costs more
+    // instructions than it hides.
+    unsigned chunkB = recB;                                           // record kb
+    Col ncp, ncq;
+    double rb = 0.0, rbq = 0.0;
+    auto step = [&](auto PC) __attribute__((always_inline)) {
+        constexpr int P = decltype(PC)::value, g = P & 3, r = P >> 2, Pm = (P + kNS - 1) % kNS, gs = g ^ 2;
+        constexpr int P1 = (P + 1) % kNS, P2 = (P + 2) % kNS, gs2 = (P2 & 3) ^ 2;
+        const double ncr = r == 0 ? ncp.lo.x : (r == 1 ? ncp.lo.y : (r == 2 ? ncp.hi.x : ncp.hi.y));
+        const double add2 = fma(ncr, gl == g ? 1.0 : 0.0, rb);
+        const double tt = fma(C[r], (gl == g && c != Pm) ? 1.0 : 0.0, add2);
+        const double d = rl_f64(tt, P + 16 * g);
+        bad_pivot |= __double2hiint(d);                               // a negative pivot (the matrix is not positive definite in floating point); zero
+                                                                      // and non-finite pivots end in a non-finite sigma2
+        const double nr = neg_rcp(d);
+        const double a = fma(tt, nr, (lane == Pm + 16 * gs) ? 1.0 : 0.0);
+        set_col(Pm, ncp);
+        C = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt, C, 0, 0, 0);
+        // the step's record; the requests for step k + 2: column k + 14 (enters slot P1), right-hand side of row k + 14
+        lds_w1((gl == g ? chunkB + 8u * (unsigned)c : dumpB) + 128u * (unsigned)P, a);
+        ncp = ncq; rb = rbq;
+        ncq = load_col(P1, chunkB, P + kNS + 1);
+        rbq = lds_d1(((c >= 13 && gl == gs2) ? chunkB + 8u * (unsigned)(4 * (c - 13) + 7) : zeroB) + 128u * (unsigned)(P + kNS + 1));
+    };
+    auto chunk = [&]() __attribute__((always_inline)) {
+        step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
+        step(std::integral_constant<int, 3>()); step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
+        step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>()); step(std::integral_constant<int, 8>());
+        step(std::integral_constant<int, 9>()); step(std::integral_constant<int, 10>()); step(std::integral_constant<int, 11>());
+        step(std::integral_constant<int, 12>());
+        chunkB += 128u * kNS;
+    };
+    const int nchA = wv == 1 ? bp.cB : bp.cT;                             // chunks before the two sides meet (one direction: all of them)
+    if (worker) {
+        // the first window: lane (c, gl) of column c < 13 reads its four registers straight from record c (32 consecutive bytes: the rows
+        // at or above the diagonal; a record's positions for rows below are zeros); the right-hand sides of rows 0 .. 12 go to the
+        // lanes c >= 13 (register r of group gl: row slot 4 r + gl)
         {
+            const unsigned a0 = c < kNS ? recB + 128u * (unsigned)c + 32u * (unsigned)gl : zeroB;
+            const dbl2 lo = lds_d2(a0), hi = lds_d2(a0 + 16);
             const int d = c - 13;
+            double v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = 4 * r + gl;
-                const double v = lds_d1((c >= 13 && q < kNS) ? recB + 128u * (unsigned)q + 8u * (unsigned)(4 * d + 7) : zeroB);
-                C[r] = (c >= 13 && q < kNS) ? v : C[r];
+                v[r] = lds_d1((c >= 13 && q < kNS) ? recB + 128u * (unsigned)q + 8u * (unsigned)(4 * d + 7) : zeroB);
             }
+            C[0] = lo.x + v[0]; C[1] = lo.y + v[1]; C[2] = hi.x + v[2]; C[3] = hi.y + v[3];
         }
-        // steps: chunks of 13 with static slots.  At the top of step k (slot P): C holds the window with column k + 12 entered; `nc` =
-        // column k + 13, `rb` = the right-hand side of row k + 12 (enters through the k-slot gs = g ^ 2 of this step's MFMA, onto what
-        // the elimination of row k - 1 left in its slot: a rounding-level multiple of that row's y -- a perturbation of b of relative size
-        // 1e-16, as every solver commits).
-        unsigned chunkB = recB;                                           // record kb
-        Col nc = load_col(0, chunkB, kNS);
-        double rb = 0.0;
-        auto step = [&](auto PC) __attribute__((always_inline)) {
-            constexpr int P = decltype(PC)::value, g = P & 3, r = P >> 2, Pm = (P + kNS - 1) % kNS, gs = g ^ 2;
-            constexpr int P1 = (P + 1) % kNS, gs1 = (P1 & 3) ^ 2;
-            // requests for the next step: column k + 14 (slot P1), right-hand side of row k + 13
-            const Col nc2 = load_col(P1, chunkB, P + kNS + 1);
-            const double rb2 = lds_d1(((c >= 13 && gl == gs1) ? chunkB + 8u * (unsigned)(4 * (c - 13) + 7) : zeroB) + 128u * (unsigned)(P + kNS));
-            const double tt = fma(C[r], gl == g ? 1.0 : 0.0, rb);
-            const double d = rl_f64(tt, P + 16 * g);
-            bad_pivot |= __double2hiint(d);                               // a negative pivot (the matrix is not positive definite in floating point); zero
-                                                                          // and non-finite pivots end in a non-finite sigma2
-            const double nr = neg_rcp(d);
-            const double a = fma(tt, nr, (lane == Pm + 16 * gs) ? 1.0 : 0.0);
-            lds_w1((gl == g ? chunkB + 8u * (unsigned)c : dumpB) + 128u * (unsigned)P, a);
-            C = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tt, C, 0, 0, 0);
-            set_col(P, nc);
-            nc = nc2; rb = rb2;
-        };
-        for (int kb = 0; kb < cv.nP; kb += kNS) {
-            step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>());
-            step(std::integral_constant<int, 3>()); step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>());
-            step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>()); step(std::integral_constant<int, 8>());
-            step(std::integral_constant<int, 9>()); step(std::integral_constant<int, 10>()); step(std::integral_constant<int, 11>());
-            step(std::integral_constant<int, 12>());
-            chunkB += 128u * kNS;
-        }
-        BSTAMP(4);
-        // back substitution L^T x = D^-1 y from the last unknown; lane = (slot c, right-hand side gl).  acc[c] collects -sum_i l_ik x_i of
-        // the row in slot c over the unknowns already final; x_k = z_k + acc, broadcast inside the row of 16 lanes, and every row
-        // k - 12 .. k - 1 takes its l_ki x_k (record of row i, position of slot k); slot k's lane restarts at zero for row k - 13.
-        // Chunks of 13 steps: the l_ki and z_k of a chunk are requested one chunk ahead (26 LDS reads whose addresses do not depend
-        // on the walk), the x_k of a chunk are written with one store at its end -- inside a chunk the chain is
-        // subtract -> broadcast (DPP) -> multiply-add per step and nothing waits for memory.
-        wave_lds_sync();
-        struct BQ { double L[kNS], Z[kNS]; };
-        auto bload = [&](unsigned cb, int kbv) __attribute__((always_inline)) {
-            BQ q;
+        BSTAMP(8);
+        ncp = load_col(kNS - 1, recB, kNS - 1);                           // (column 12 once more: setting it twice changes nothing)
+        ncq = load_col(0, recB, kNS);                                     // column 13: pending at step 1
+        rbq = lds_d1((c >= 13 && gl == ((1 & 3) ^ 2)) ? recB + 128u * kNS + 8u * (unsigned)(4 * (c - 13) + 7) : zeroB);     // b of row 13: enters at step 1
+        for (int kb = 0; kb < nchA; ++kb) chunk();
+    }
+    if (tw) {
+        // The two sides meet: each wave's window holds, in its own order, the 12 unknowns R between them -- direction 0 with R's own
+        // matrix entries and right-hand sides minus its updates, direction 1 with minus its updates only (k_setup left R x R out of its
+        // records).  Slot s of one direction is slot 11 - s of the other (mT and mB are whole chunks; the 13th slot is an identity
+        // unknown on both sides).  A window keeps only the entries at or right of the diagonal IN ITS OWN ORDER valid, and the other
+        // side's order is the reverse: element (row q, column c) of this window pairs with the other's element (row 11 - c, column
+        // 11 - q) -- the transposed position, which is the valid one there (right-hand sides: row 11 - q, the same column).  Both
+        // waves add the other's tile and finish R themselves (one more chunk).
+        if (worker) {
+            double *mine = tiles + 256 * wv;
 #pragma unroll
-            for (int P = 0; P < kNS; ++P) {
-                // rows of the window at step kb + P: slot c < P -> unknown kb + c, slot c > P -> kb - 13 + c (none for slot P, none in front of the first chunk)
-                const unsigned la = (c < kNS && c != P && (c < P || kbv >= kNS)) ? cb + 128u * (unsigned)c - (c > P ? 128u * kNS : 0u) + 8u * (unsigned)P : zeroB;
-                q.L[P] = kbv >= 0 ? lds_d1(la) : 0.0;
-                q.Z[P] = kbv >= 0 ? lds_d1((c == P && gl < 3) ? cb + 128u * (unsigned)P + 8u * (unsigned)(13 + gl) : zeroB) : 0.0;
+            for (int r = 0; r < 4; ++r) mine[64 * r + lane] = C[r];
+        }
+        __syncthreads();
+        if (worker) {
+            const double *other = tiles + 256 * (1 - wv);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int q = 4 * r + gl;                                 // my row slot (0 .. 11)
+                const int orow = c < 12 ? 11 - c : 11 - q, ocol = c < 12 ? 11 - q : c;
+                const double v = other[64 * (orow >> 2) + ocol + 16 * (orow & 3)];
+                C[r] += c != 12 ? v : 0.0;
             }
+            chunk();
+        }
+    }
+    BSTAMP(4);
+    if (worker) {
+        // back substitution L^T x = D^-1 y from the last unknown; lane = (slot c, right-hand side gl).  acc[c] = z_i - sum_k l_ki x_k of the
+        // row i in slot c over the unknowns k > i already final.  Step k (slot P): x_k = acc[P], broadcast inside the row of 16 lanes
+        // (DPP), every waiting row takes acc -= l_ki x_k (l_ki from the record of step i, position of slot k) -- and lane P, whose
+        // "l" is the record's own pivot position a_P = -d_k / d_k = -1 up to rounding, falls back to ~0 for the row k - 13 that
+        // takes the slot over (what stays is a rounding-level multiple of x_k).  Chunks of 13 steps: a chunk's 13 l-vectors and the
+        // z of the rows that take its slots over are requested one chunk ahead (addresses do not depend on the walk), the z are
+        // added and the x written once per chunk: inside a chunk the chain is  broadcast -> multiply-add  per step.
+        wave_lds_sync();
+        struct BQ { double L[kNS], zn; };
+        auto bload = [&](unsigned cb) __attribute__((always_inline)) {      // chunk whose first record is cb (the 28 records in front of record 0 are zeros)
+            BQ q;
+            const unsigned b0 = cb + 128u * (unsigned)c, b1 = b0 - 128u * kNS;
+#pragma unroll
+            for (int P = 0; P < kNS; ++P) q.L[P] = lds_d1((c > P ? b1 : b0) + 8u * (unsigned)P);       // slot c < P: unknown kb + c, slot c > P: kb - 13 + c
+            q.zn = lds_d1((c < kNS && gl < 3) ? b0 + 8u * (unsigned)(13 + gl) : zeroB);                // -z of unknown kb + c
             return q;
         };
-        double acc = 0.0;
-        unsigned cb = chunkB - 128u * kNS;                                // record of the chunk's first unknown
-        int kbv = cv.nP - kNS;
-        BQ cur = bload(cb, kbv);
-        for (; kbv >= 0; kbv -= kNS) {
-            const BQ nxt = bload(cb - 128u * kNS, kbv - kNS);
+        unsigned cb = chunkB - 128u * kNS;                                // record of the last chunk's first unknown
+        BQ cur = bload(cb);
+        double acc = -cur.zn;
+        for (int kb = nchA + tw - 1; kb >= 0; --kb) {
+            const BQ nxt = bload(cb - 128u * kNS);
             double xs = 0.0;
             auto bstep = [&](auto PC) __attribute__((always_inline)) {
                 constexpr int P = decltype(PC)::value;
-                const double xk = acc - cur.Z[P];
-                const double xb = row_bcast<P>(xk);
-                acc = fma(cur.L[P], xb, acc * (c == P ? 0.0 : 1.0));
-                xs = fma(xk, c == P ? 1.0 : 0.0, xs);
+                const double xb = row_bcast<P>(acc);
+                xs = fma(acc, c == P ? 1.0 : 0.0, xs);
+                acc = fma(cur.L[P], xb, acc);
             };
             bstep(std::integral_constant<int, 12>()); bstep(std::integral_constant<int, 11>()); bstep(std::integral_constant<int, 10>());
             bstep(std::integral_constant<int, 9>()); bstep(std::integral_constant<int, 8>()); bstep(std::integral_constant<int, 7>());
@@ -339,9 +372,11 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
             bstep(std::integral_constant<int, 3>()); bstep(std::integral_constant<int, 2>()); bstep(std::integral_constant<int, 1>());
             bstep(std::integral_constant<int, 0>());
             lds_w1((c < kNS && gl < 3) ? cb + 128u * (unsigned)c + 8u * (unsigned)(13 + gl) : dumpB, xs);
+            acc -= nxt.zn;
             cur = nxt;
             cb -= 128u * kNS;
         }
+        BSTAMP(5);
     }
     bad_pivot = __syncthreads_or(bad_pivot < 0 ? 1 : 0);
     BSTAMP(6);
@@ -351,7 +386,7 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
     double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
     for (int m = t, r = 0; m < M; m += MB, ++r) {
         const NodeQ q = r == 0 ? q0 : load_node(m);
-        const double *o = rec + 32 * (size_t)m + 13;
+        const double *o = rec_of_node(m) + 13;
         const double p1 = S[m];
         double Td[3], cr2 = 0, dr = 0, pd2 = 0;
 #pragma unroll
