@@ -17,9 +17,20 @@ cloud that is already resident in HBM.    value = steps * frames * 50 * ranks / 
 driver's launch) it must agree with --gpus.  Frames are independent (c2 / c3 / c5): no data-path collective, "weak" scaling;
 RCCL carries only the closing barrier and the max-over-ranks of the time.
 
+The default run (--gpus 1, config c2) also carries, after the headline measurement (none of it inside the timed region):
+  configs           short legs of the other BASELINE configurations on this GPU: c3 (32-frame batch), c4 (N = 2 000 000 on one rank through the
+                    split driver), c5 (M = 300, fp64) -- each {value, ms_per_step, roofline, roofline_kernels, cpu_baseline}
+  sustained         >= 3 s of back-to-back C2 calls (sustained_iters_per_s): the same quantity as `value` over a span a GPU-activity sampler sees
+  preproc           the pre-processing registration of tracking_step (include_lle: trackdlo.cpp:925-927) at production size (N = 5 000, M = 45):
+                    its per-iteration kernels (the banded LLE M-step k_mstep_band among them) and tracking_step's ms per frame
+(--no-legs switches them off.)
+
 Extra objects on the JSON line:
   roofline          the per-iteration kernel with the LARGER share of GPU time in this run; roofline_kernels holds both
-                    (E-step: algorithmic bytes 3 * s * N per launch against 8 TB/s HBM, plus its VALU fraction; M-step:
+                    (E-step: algorithmic bytes 3 * s * N per launch against 8 TB/s HBM; `algorithmic_valu_ratio` = SURVEY.md 8(d)'s flop
+                    count / time / vector peak -- NOT an achieved fraction: the kernel skips the exactly-zero memberships outside a wave's node
+                    window; `valu_issue_frac` = VALU instructions actually issued (SQ_INSTS_VALU, a third PMC child pass) x 64 lanes / time /
+                    the lane-issue peak; M-step:
                     (2/3) M^3 + 14 M^2 flops per launch against the fp64 matrix peak).  Durations are measured live: HIP
                     start/stop events bound to every E-step and M-step dispatch of real iterations on the context's stream
                     (tdlo_profile_iteration).  `traffic` = HBM bytes per launch from the PMC counters, collected by
@@ -58,6 +69,16 @@ CONFIGS = {
     "c4": dict(N=2000000, M=50, frames=1, prec="f32", steps=200, warmup=5, cpu_iters=6, cpu_repeats=1,
                metric="EM iterations/sec at N=2M cloud pts, M=50 nodes, cloud split over the ranks"),
 }
+
+
+# the short legs of the default run (the headline stays c2): step counts for about a second of GPU time each, a CPU baseline of a few iterations
+LEGS = {
+    "c3": dict(steps=60, warmup=4, cpu_iters=10, cpu_repeats=1),
+    "c4": dict(steps=16, warmup=3, cpu_iters=3, cpu_repeats=1),
+    "c5": dict(steps=40, warmup=3, cpu_iters=3, cpu_repeats=1),
+}
+SUSTAINED_SECONDS = 3.0
+LANE_ISSUE_PEAK = FP32_VECTOR_TFLOPS * 1e12 / 2.0      # lane-instructions per second: one FMA per lane and cycle is two of the peak's flops
 
 
 def _self_launch(args):
@@ -145,6 +166,10 @@ def _pmc_traffic_live(args, cfg, mstep_name):
     try:
         F = _pmc_pass("FETCH_SIZE", args, tmp)
         W = _pmc_pass("WRITE_SIZE", args, tmp)
+        try:
+            V = _pmc_pass("SQ_INSTS_VALU", args, tmp)       # instructions issued by the vector ALUs, summed over the waves of a dispatch
+        except Exception:
+            V = {}
         prune = [k for k in F if "k_prune_pass1" in k]
         if not prune:
             return None
@@ -166,7 +191,8 @@ def _pmc_traffic_live(args, cfg, mstep_name):
             k = pick(prefix)
             if k is not None:
                 res[key] = dict(kernel=k, bytes=round((F[k][0] * cal + W[k][0]) * 1024.0 / its), fetch_KB_raw=round(F[k][0] / its, 2),
-                                write_KB=round(W[k][0] / its, 2), dispatches_per_iteration=round(F[k][1] / its, 2))
+                                write_KB=round(W[k][0] / its, 2), dispatches_per_iteration=round(F[k][1] / its, 2),
+                                valu_insts=(round(V[k][0] / its) if k in V else None))
         return res if "estep" in res else None
     except Exception as e:      # the bench line must not depend on the profiler
         print(f"[bench] live PMC pass failed ({type(e).__name__}: {e}); traffic falls back to the committed profile", file=sys.stderr)
@@ -199,6 +225,11 @@ def _apply_live_traffic(live, roof, roof_all):
         if m is not None:
             o["traffic"], o["traffic_source"] = m["bytes"], live["source"]
             o["traffic_detail"] = dict(kernel=m["kernel"], fetch_KB_raw=m["fetch_KB_raw"], write_KB=m["write_KB"], dispatches_per_iteration=m["dispatches_per_iteration"])
+            if m.get("valu_insts"):
+                # VALU instructions the kernel really issued per launch (all its waves) x 64 lanes / its duration / the lane-issue peak
+                o["valu_insts_per_launch"] = m["valu_insts"]
+                o["valu_issue_frac"] = round(m["valu_insts"] * 64.0 / (o["avg_launch_us"] * 1e-6) / LANE_ISSUE_PEAK, 5)
+                o["valu_issue_frac_source"] = "this run: rocprofv3 --pmc SQ_INSTS_VALU (a third child pass), instructions x 64 lanes / avg_launch_us / (fp32 vector peak / 2)"
 
 
 def main():
@@ -210,6 +241,7 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="override the frames registered concurrently per rank (c2: 1, c3: 32)")
     ap.add_argument("--mode", choices=["frames", "nsplit"], default=None, help="deprecated alias: nsplit == --config c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="default run (1 GPU, c2): skip the c3 / c4 / c5 legs, the sustained leg and the pre-processing leg")
     ap.add_argument("--pmc", choices=["auto", "off", "child"], default="auto",
                     help="auto: at N = 1 collect roofline.traffic in two rocprofv3 --pmc child passes; child: the pass itself (the calls only, no output)")
     args = ap.parse_args()
@@ -252,6 +284,22 @@ def main():
             dist.init_process_group(backend)
     env = dict(rank=rank, world=world, dev_index=dev_index, dist=dist, torch=torch, backend=backend)
     res = bench_nsplit(args, cfg, env) if args.config == "c4" else bench_frames(args, cfg, env)
+    if res is not None and world == 1 and args.config == "c2" and not args.frames and not args.no_legs and args.pmc != "child":
+        # the other BASELINE configurations, short: the headline above stays what the driver parses
+        import copy
+        res["configs"] = {}
+        for name in ("c3", "c4", "c5"):
+            a = copy.copy(args)
+            a.config, a.frames = name, None
+            lcfg = dict(CONFIGS[name], leg=True, **LEGS[name])
+            try:
+                t0 = time.perf_counter()
+                r = bench_nsplit(a, lcfg, env) if name == "c4" else bench_frames(a, lcfg, env)
+                res["configs"][name] = dict({k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "scaling", "config",
+                                                                 "roofline", "roofline_kernels", "cpu_baseline", "gpu_over_cpu") if k in r},
+                                            leg_seconds=round(time.perf_counter() - t0, 1))
+            except Exception as e:          # a leg must not take the headline down
+                res["configs"][name] = dict(error=f"{type(e).__name__}: {e}")
     if dist is not None:
         _flush_c_stdio()            # every rank: whatever RCCL has printed so far leaves the buffers before rank 0's line
         dist.barrier()
@@ -293,9 +341,12 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
     est = dict(bound="hbm", kernel=f"k_estep<{'float' if esize == 4 else 'double'}>", achieved=round(bw, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                frac=round(bw / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc, avg_launch_us=round(est_us, 3),
                algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=e_flops,
-               valu_tflops=round(e_flops / (est_us * 1e-6) / 1e12, 3), valu_peak_tflops=vpeak, valu_frac=round(e_flops / (est_us * 1e-6) / 1e12 / vpeak, 5),
-               note="VALU / latency-bound (about 100 flop per byte at M = 50 against a ridge of 20): the HBM fraction is reported as the metric requires; "
-                    "valu_frac counts every (node, point) pair although the kernel skips the exactly-zero memberships outside the wave's node window")
+               algorithmic_valu_tflops=round(e_flops / (est_us * 1e-6) / 1e12, 3), valu_peak_tflops=vpeak,
+               algorithmic_valu_ratio=round(e_flops / (est_us * 1e-6) / 1e12 / vpeak, 5),
+               note="VALU / latency-bound (about 100 flop per byte at M = 50 against a ridge of 20): the HBM fraction is reported as the metric requires.  "
+                    "algorithmic_valu_ratio is SURVEY.md 8(d)'s 24 M N flops / time / vector peak: NOT an achieved fraction -- the kernel skips the "
+                    "exactly-zero memberships outside a wave's node window (about 80 % of the pairs once sigma is millimetres); what the vector ALUs "
+                    "really issue is valu_issue_frac (SQ_INSTS_VALU), present when the PMC child passes ran")
     if est_b2b_us is not None:
         est["avg_launch_us_back_to_back"] = round(est_b2b_us, 3)
     objs = [est]
@@ -311,6 +362,15 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
                          note="one workgroup per frame; the solve is a Kalman filter / RTS smoother along the chain (M/4 dependent 2 x 2 steps from four ends "
                               "on one wave, ~8 cycles per instruction), preceded by one memory round trip for the sums: latency-bound, "
                               "neither bytes nor flops are near a roofline"))
+    elif mst_us is not None and mstep_name == "k_mstep_band":
+        # the banded L D L^T of the LLE system in the chain's state: 2M unknowns, one v_mfma_f64_16x16x4 (2048 flop issued, 13 x 16 of them
+        # algorithmic) per unknown on one wave per direction -- a dependent chain like the chain smoother
+        b_flops = 2.0 * (2 * M) * 13 * 16 * 2 * F
+        tf = b_flops / (mst_us * 1e-6) / 1e12
+        objs.append(dict(bound="mfma", kernel=mstep_name, achieved=round(tf, 6), peak=FP64_TFLOPS, unit="TFLOP/s", frac=round(tf / FP64_TFLOPS, 7), traffic=None,
+                         avg_launch_us=round(mst_us, 3), algorithmic_flops_per_launch=b_flops,
+                         note="one workgroup per frame; two waves eliminate the 2M-unknown banded system from both ends of the chain (one fp64 MFMA per unknown, "
+                              "65 clocks each and nothing of the same wave overlaps it), then back-substitute: latency-bound, neither bytes nor flops near a roofline"))
     elif mst_us is not None:
         tf = m_flops / (mst_us * 1e-6) / 1e12
         objs.append(dict(bound="mfma", kernel=mstep_name, achieved=round(tf, 6), peak=FP64_TFLOPS, unit="TFLOP/s", frac=round(tf / FP64_TFLOPS, 7), traffic=None,
@@ -358,6 +418,59 @@ def _cpu_baseline(cfg, X0, Y00, kw, g_single):
     except Exception as e:      # the baseline proper is the single-thread figure above
         cpu["all_cores"] = dict(error=str(e))
     return cpu
+
+
+def _sustained(ctx, step):
+    """>= SUSTAINED_SECONDS of back-to-back calls of the headline workload (cloud resident, one host sync at the end of every block of 200 calls)."""
+    ctx.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(200):
+            step()
+        n += 200
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= SUSTAINED_SECONDS:
+            break
+    return dict(sustained_iters_per_s=round(n * EM_ITERS / dt, 2), calls=n, seconds=round(dt, 3),
+                note="the headline workload, call after call: the same quantity as `value` over a span long enough for a GPU-activity sampler")
+
+
+def _preproc_leg(ctx, B, synth):
+    """The pre-processing registration of tracking_step (trackdlo.cpp:925-927: include_lle, beta_pre_proc, lambda_pre_proc) at production size, and
+    tracking_step itself: N = 5 000 points, M = 45 nodes (launch/trackdlo.launch), all nodes visible."""
+    P = synth.LAUNCH_PARAMS
+    N, M = 5000, 45
+    X, Y0, _ = synth.scene(N, M, config=2)
+    pp = B.make_params(P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=True,
+                       alpha=0.0, k_vis=0.0, visibility_threshold=0.01, precision=B.PREC_F32)
+    ctx.set_cloud(0, X)
+    for _ in range(3):
+        ctx.cpd_lle_resident(0, Y0, 1e-4, pp)
+    ctx.synchronize(); t0 = time.perf_counter()
+    n = 100
+    for _ in range(n):
+        ctx.cpd_lle_resident(0, Y0, 1e-4, pp)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    est_us, mst_us, iter_us, mname = ctx.profile_iteration(200)
+    _, kernels = _roofline_objects(N, M, 1, 4, est_us, mst_us, iter_us, mname)
+    out = dict(workload=f"cpd_lle with the LLE term (beta={P['beta_pre_proc']}, lambda={P['lambda_pre_proc']}, lle_weight={P['lle_weight']}), N={N}, M={M}, "
+                        f"{EM_ITERS} iterations per call, tol=0, fp32 E-step",
+               em_iters_per_s=round(n * EM_ITERS / dt, 2), ms_per_call=round(dt * 1e3 / n, 4), iteration_us_profiled=round(iter_us, 3), roofline_kernels=kernels)
+    coord = synth.geodesic_coord(Y0)
+    trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 50, P["tol"], P["beta_pre_proc"],
+                     P["lambda_pre_proc"], P["lle_weight"], ctx=ctx)
+    trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+    vis = np.arange(M)
+    for _ in range(5):
+        trk.tracking_step(X, vis, vis)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        trk.tracking_step(X, vis, vis)
+    out["tracking_step_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3 / 200, 4)
+    out["tracking_step_note"] = "host buffers in, results out, production tolerance (tol = 2e-4: a steady-state frame converges in a few iterations)"
+    return out
 
 
 def bench_frames(args, cfg, env):
@@ -440,7 +553,7 @@ def bench_frames(args, cfg, env):
                    timed_region_s=round(dt, 3), frames_per_s=round(cfg["steps"] * F * n_ranks / dt, 2),
                    em_loop_only_iters_per_s=round(loop_steps * F * EM_ITERS / (loop_ms * 1e-3), 2),
                    roofline=roof, roofline_kernels=roof_all)
-        if args.config == "c2" and F == 1:
+        if args.config == "c2" and F == 1 and not cfg.get("leg"):
             # the reference's arithmetic is fp64 throughout: the same workload with TDLO_PREC_F64 (not the headline: BASELINE C2 names fp32)
             p64 = mk_params(B.PREC_F64)
             for _ in range(5):
@@ -462,6 +575,12 @@ def bench_frames(args, cfg, env):
             cpu = _cpu_baseline(cfg, X0, Y00, kw, g)
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         out["cpu_baseline"] = cpu
+        if args.config == "c2" and F == 1 and not cfg.get("leg") and n_ranks == 1 and not args.no_legs and args.pmc != "child":
+            out["sustained"] = _sustained(ctx, step)
+            try:
+                out["preproc"] = _preproc_leg(ctx, B, synth)
+            except Exception as e:
+                out["preproc"] = dict(error=f"{type(e).__name__}: {e}")
     ctx.close()
     return out if rank == 0 else None
 
@@ -553,7 +672,12 @@ def bench_nsplit(args, cfg, env):
                     timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"],
                     roofline=roof, roofline_kernels=roof_all)
         cpu = None
-        if n_ranks == 1:
+        if n_ranks == 1 and cfg.get("leg") and not args.no_cpu_baseline:
+            kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
+                      include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+            cpu = _cpu_baseline(cfg, X, Y0, kw, None)
+            line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
+        elif n_ranks == 1:
             # what the split costs on one rank: the plain (unsplit) call on the same cloud, the RCCL form of the same call, and one
             # 250 000-point shard (a rank's share on 8 GPUs) with visibility weighting on, i.e. with the MIN exchange as well
             def rate(fn, n):

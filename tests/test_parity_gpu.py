@@ -211,6 +211,84 @@ def test_error_paths(hip_ctx):
     assert g["rc"] == 0 and g["iters"] == 5
 
 
+def _oracle_or_clean_error(g, o, prec):
+    """The result is the oracle's at the stated tolerance, or the call says TDLO_E_NUMERIC -- never finite garbage with rc = 0."""
+    from trackdlo_amd import binding as B
+    if g["rc"] == B.TDLO_E_NUMERIC:
+        return "error"
+    assert g["rc"] == 0 and g["iters"] == o["iters"] and g["n_kept"] == o["n_kept"]
+    ty, ts = (1e-5, 1e-3) if prec == 0 else (1e-9, 1e-7)
+    assert np.abs(g["Y"] - o["Y"]).max() <= ty and abs(g["sigma2"] - o["sigma2"]) <= ts * o["sigma2"]
+    return "ok"
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_sums_beyond_the_assumed_extent_are_right_or_refused(oracle, prec):
+    """The E-step's 64-bit fixed-point sums are scaled from an ASSUMED extent of the scene (twice the chain's length); nothing in the reference
+    bounds the nodes by it (trackdlo.cpp:240-260: a correspondence prior pulls a node wherever it says; :386-389 have no range at all).  (i) a prior
+    2 m off the rope with alpha = 3, (ii) a registration started 9 cm beside the cloud with lambda = 1 (nodes free to fly), (iii) mu = 0 far from the
+    cloud (c = 0: a point whose memberships all underflow divides 0 by 0): the oracle's result, or TDLO_E_NUMERIC -- the range check of every
+    converted value (FrameDev::acc_lim) is what stands between a wrapped-around integer and a result that merely looks fine."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M, N = 30, 4000
+    X, Y0, _ = synth.scene(N, M, config=810)
+    base = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=12, tol=0.0, include_lle=False,
+                alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+    outcomes = []
+    ctx = B.Context(device=0, max_points=N, max_nodes=M)
+    try:
+        # (i)
+        kw = dict(base, alpha=3.0)
+        pri = np.array([[7, Y0[7, 0], Y0[7, 1] + 2.0, Y0[7, 2]], [20, Y0[20, 0] - 1.5, Y0[20, 1], Y0[20, 2] + 1.0]])
+        g = ctx.cpd_lle(X, Y0, 0.0, _params(kw, prec), priors=pri, check=False)
+        outcomes.append(_oracle_or_clean_error(g, oracle.cpd_lle(X, Y0, 0.0, priors=pri, **kw), prec))
+        # (ii)
+        kw = dict(base, lambda_=1.0, beta=0.1)
+        Yoff = np.asfortranarray(Y0 + np.array([0.0, 0.09, 0.0]))
+        g = ctx.cpd_lle(X, Yoff, 0.0, _params(kw, prec), check=False)
+        outcomes.append(_oracle_or_clean_error(g, oracle.cpd_lle(X, Yoff, 0.0, **kw), prec))
+        # (iii)
+        kw = dict(base, mu=0.0)
+        g = ctx.cpd_lle(X, Yoff, 1e-6, _params(kw, prec), check=False)
+        o = oracle.cpd_lle(X, Yoff, 1e-6, **kw)
+        if np.isfinite(o["Y"]).all() and np.isfinite(o["sigma2"]):
+            outcomes.append(_oracle_or_clean_error(g, o, prec))
+        else:                                   # the reference itself produces NaN here (0 / 0 at :301): an error is the only right answer
+            assert g["rc"] == B.TDLO_E_NUMERIC
+            outcomes.append("error")
+        # the context stays usable
+        g = ctx.cpd_lle(X, Y0, 0.0, _params(base, prec))
+        assert g["rc"] == 0 and g["iters"] == 12
+    finally:
+        ctx.close()
+    print("outcomes:", outcomes)
+
+
+def test_a_contribution_beyond_the_fixed_point_range_is_refused():
+    """Forces the range check itself: a cloud of a few points and a prior a kilometre away -- after the first M-step the node sits ~1 km
+    from its points, far beyond anything the accumulators' exponents were chosen for (R ~ 1e3 m against an assumed extent of ~1 m is still
+    representable; 1e9 m is not).  The call must not return rc = 0 with a finite-looking result that differs from the oracle's."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M, N = 12, 600
+    X, Y0, _ = synth.scene(N, M, config=811)
+    kw = dict(beta=P["beta"], lambda_=1.0, lle_weight=P["lle_weight"], mu=P["mu"], max_iter=6, tol=0.0, include_lle=False,
+              alpha=1e12, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+    pri = np.array([[5, Y0[5, 0] + 3e4, Y0[5, 1], Y0[5, 2]]])
+    ctx = B.Context(device=0, max_points=N, max_nodes=M)
+    try:
+        g = ctx.cpd_lle(X, Y0, 0.0, _params(kw, 1), priors=pri, check=False)
+    finally:
+        ctx.close()
+    if g["rc"] == 0:        # then it must be right
+        import oracle.ref_cpu as ref
+        o = ref.cpd_lle(X, Y0, 0.0, priors=pri, **kw)
+        assert np.abs(g["Y"] - o["Y"]).max() <= 1e-6 * max(1.0, np.abs(o["Y"]).max())
+    else:
+        assert g["rc"] == B.TDLO_E_NUMERIC
+
+
 def test_batch_with_an_empty_frame():
     """A batch (stream groups, merged copies) in which one frame loses every point to the prune: the call reports
     TDLO_E_EMPTY, the other frames are registered as if alone, and the context stays usable."""
@@ -1166,6 +1244,7 @@ def test_multi_cu_mstep_redoes_an_iteration_after_a_timed_out_hand_off(tmp_path,
         env = dict(os.environ)
         env.pop("TDLO_MCU_FORCE_TIMEOUT", None)
         env["TDLO_MSTEP"] = "dense"              # the multi-CU dense elimination (comparator since round 2)
+        env["TDLO_MSTEP_LLE"] = "dense"          # ... and the dense pivoted one for the LLE term (round 3: the banded L D L^T is the product path)
         if mode == "forced": env["TDLO_MCU_FORCE_TIMEOUT"] = "1"          # the second iteration
         out = tmp_path / f"{mode}.npz"
         r = subprocess.run([sys.executable, "-c", _RETRY_SCRIPT, root, str(out), repr(cases)], env=env, capture_output=True, text=True, timeout=900)

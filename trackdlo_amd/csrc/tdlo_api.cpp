@@ -362,6 +362,11 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         // ... and one wave's share of one 64-point batch below 2^51 (acc_fix): P1 <= 64, |R| <= 64 D, a point's share of Q <= D^2
         const int shP = std::min(60 - ln, 44);
         f.acc_sh[0] = shP; f.acc_sh[1] = shP - ld; f.acc_sh[2] = shP - 2 * ld;
+        // D is a heuristic (nodes can be pulled anywhere by a prior, a diverging registration leaves it): the E-step CHECKS every value it
+        // converts against these limits -- the conversion stays exact below 2^51, the sum of all batches' shares (P1, R: one per 64-point
+        // batch and node; Q: one per point) below 2^62 -- and ends the registration with TDLO_E_NUMERIC beyond them, as it does for NaN
+        const int lshare = std::min(51, 67 - std::max(ln, 6)), lpoint = std::min(51, 61 - ln);
+        f.acc_lim[0] = std::ldexp(1.0, lshare - f.acc_sh[0]); f.acc_lim[1] = std::ldexp(1.0, lshare - f.acc_sh[1]); f.acc_lim[2] = std::ldexp(1.0, lpoint - f.acc_sh[2]);
     }
     f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
     f.sync = s.sync;

@@ -670,6 +670,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     for (int c = 0; c < NCH; ++c) { accP[c] = 0; accX[c] = 0; accY[c] = 0; accZ[c] = 0; }
     long long accQ = 0;
     const double scP = acc_scale(f.acc_sh[0]), scR = acc_scale(f.acc_sh[1]), scQ = acc_scale(f.acc_sh[2]);
+    // every converted value is checked against its limit (FrameDev::acc_lim: exact conversion, no wrap-around of the totals; a NaN fails
+    // the comparison too): one compare per conversion into a lane mask, looked at once per wave at the end
+    const double limP = f.acc_lim[0], limR = f.acc_lim[1], limQ = f.acc_lim[2];
+    bool acc_ok = true;
     // NCH == 1 (M <= 64): windowed variant.  The cloud is sorted by nearest node, so the 64 points of a
     // wave sit on a short piece of the chain, and every membership whose exponent is below -151 (fp32;
     // -1080 in fp64) is EXACTLY zero: only the nodes inside an arc-length window around the wave's
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         ESTAMP(4);
         EPHASE(4);
         const T inv = valid ? Num<T>::rcp_fast(sum + cn) : T(0);
-        accQ += acc_fix((double)(inv * qs), scQ);
+        { const double qv = (double)(inv * qs); acc_ok &= __builtin_fabs(qv) < limQ; accQ += acc_fix(qv, scQ); }
         // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
         // wave's points within centimetres) and leave as the residual R_m = sum_n P_mn (x_n - y_m):
         // small numbers, so fp32 tile sums lose nothing that matters (everything after a tile's sums is 64-bit fixed point)
@@ -896,11 +900,13 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                     long long *ac = accL + (size_t)(wlo_c + lane) * 4;
                     const V4<T> ym = nodesL[wlo_c + lane];
                     const double w0 = (double)s0;
+                    const double r1 = (double)sx + ((double)ox - (double)ym.x) * w0, r2 = (double)sy + ((double)oy - (double)ym.y) * w0, r3 = (double)sz + ((double)oz - (double)ym.z) * w0;
+                    acc_ok &= (__builtin_fabs(w0) < limP) & (__builtin_fabs(r1) < limR) & (__builtin_fabs(r2) < limR) & (__builtin_fabs(r3) < limR);
                     // (ds_add_u64 without return: one LDS instruction per value instead of read, 64-bit add, write)
                     __hip_atomic_fetch_add(ac + 0, acc_fix(w0, scP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(ac + 1, acc_fix((double)sx + ((double)ox - (double)ym.x) * w0, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(ac + 2, acc_fix((double)sy + ((double)oy - (double)ym.y) * w0, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(ac + 3, acc_fix((double)sz + ((double)oz - (double)ym.z) * w0, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ac + 1, acc_fix(r1, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ac + 2, acc_fix(r2, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ac + 3, acc_fix(r3, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 wave_lds_sync();
             } else {
@@ -910,10 +916,12 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 if (lane < Wn) {
                     const V4<T> ym = nodesL[wlo_c + lane];
                     const double w0 = (double)s0;
+                    const double r1 = (double)sx + ((double)ox - (double)ym.x) * w0, r2 = (double)sy + ((double)oy - (double)ym.y) * w0, r3 = (double)sz + ((double)oz - (double)ym.z) * w0;
+                    acc_ok &= (__builtin_fabs(w0) < limP) & (__builtin_fabs(r1) < limR) & (__builtin_fabs(r2) < limR) & (__builtin_fabs(r3) < limR);
                     v0 = acc_fix(w0, scP);
-                    v1 = acc_fix((double)sx + ((double)ox - (double)ym.x) * w0, scR);
-                    v2 = acc_fix((double)sy + ((double)oy - (double)ym.y) * w0, scR);
-                    v3 = acc_fix((double)sz + ((double)oz - (double)ym.z) * w0, scR);
+                    v1 = acc_fix(r1, scR);
+                    v2 = acc_fix(r2, scR);
+                    v3 = acc_fix(r3, scR);
                 }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -939,6 +947,12 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     {
         const long long qw = wave_sum_i64(accQ);
         if (lane == 0) iscr[wave] = qw;
+    }
+    if (__ballot(!acc_ok) != 0ull && lane == 0) {
+        // a contribution beyond the fixed point's range, or not a number: the sums of this iteration are void.  The registration ends here with
+        // an error (the M-step that follows finds done = 1 and leaves Y as it is) instead of continuing on wrapped-around integers.
+        IterState *sw = f.st;
+        sw->status = TDLO_E_NUMERIC; sw->converged = 0; sw->done = 1;
     }
     __syncthreads();
     ESTAMP(6);

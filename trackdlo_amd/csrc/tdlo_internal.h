@@ -67,6 +67,8 @@ struct FrameDev {
     long long *acc;         // [2 (iteration parity)][kAccRows][4M+2]: the E-step's sums [P1 | Rx | Ry | Rz | Q] in 64-bit fixed point, added with
                             // integer atomics (order-independent, i.e. reproducible); the M-step of iteration `it` reads parity it & 1 and zeroes the other
     int acc_sh[3];          // binary exponents of the fixed point: value = integer * 2^-sh for P1 / R / Q
+    double acc_lim[3];      // largest |value| one conversion may take for P1 / R / Q: keeps the conversion exact (|v 2^sh| < 2^51) and the totals
+                            // of all batches below 2^62; a contribution beyond it (or NaN) ends the registration with TDLO_E_NUMERIC
     int force_timeout_it;   // test hook (environment TDLO_MCU_FORCE_TIMEOUT=k): iteration k of the multi-CU M-steps behaves as if a hand-off timed out; -1 = off
     int prune_tiles;        // 256-point tiles one prune workgroup handles (1 up to 262 144 points)
     int need_G;             // the M x M kernel matrix is built at setup (dense M-steps: dense LLE path, comparators); the chain smoother and the banded LLE M-step do not read it
