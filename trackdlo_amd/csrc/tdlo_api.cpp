@@ -40,6 +40,11 @@ struct Slot {
     int *hist = nullptr;
     size_t hist_ints = 0;
     double *blksum = nullptr;
+    // what the sorted cloud Xs was last made for (prune + counting sort by nearest node depend on the cloud and on the nodes only): a
+    // registration of the SAME nodes on the same cloud in the same precision reuses it (FrameDev::reuse_sorted)
+    std::vector<double> sorted_Y;
+    int sorted_prec = -1;
+    bool sorted_valid = false;
     // node-sized (one allocation, carved)
     int cap_nodes = 0;
     double *nodeblk = nullptr;
@@ -210,8 +215,9 @@ int ensure_points(tdlo_ctx *c, Slot &s, int n) {
     HIPCHK(c, hipMalloc((void **)&s.Xraw, 3 * cap * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&s.Xs, 3 * cap * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&s.bucket, cap * sizeof(unsigned short)));
-    HIPCHK(c, hipMalloc((void **)&s.blksum, nb * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&s.blksum, (nb + 2) * sizeof(double)));      // (+ 2: FrameDev::keep)
     s.cap_points = (int)cap;
+    s.sorted_valid = false;
     return 0;
 }
 
@@ -347,6 +353,10 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         }
     }
     f.Xraw = s.Xraw; f.Xs = s.Xs; f.bucket = s.bucket; f.hist = s.hist; f.blksum = s.blksum;
+    f.keep = s.blksum + (size_t)s.cap_points / kBlock + 1;
+    static const bool reuse_on = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);
+    f.reuse_sorted = (reuse_on && s.sorted_valid && s.sorted_prec == p->precision && s.sorted_Y.size() == 3 * (size_t)M &&
+                      std::memcmp(s.sorted_Y.data(), Y, sizeof(double) * 3 * M) == 0) ? 1 : 0;
     f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
     f.coord = blk + nc.coord; f.G = blk + nc.G; f.chain = blk + nc.chain; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
     f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
@@ -448,6 +458,10 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         fdp = (const FrameDev *)(c->slots[slots[0]].nodeblk + nc.fdev);
     }
     HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
+    for (int i = 0; i < F; ++i) {           // the slots' sorted clouds now belong to these nodes
+        Slot &sl = c->slots[slots[i]];
+        if (!c->fh[i].reuse_sorted) { sl.sorted_Y.assign(Y + (size_t)i * 3 * M, Y + (size_t)(i + 1) * 3 * M); sl.sorted_prec = p->precision; sl.sorted_valid = true; }
+    }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // A batch runs as up to kBatchStreams groups of frames on as many streams, each group one E-step behind the previous
     // one: a batch's M-step is one workgroup per frame (F of the 256 CUs busy for 17 us), and meanwhile the other groups'
@@ -683,7 +697,7 @@ int tdlo_set_cloud(tdlo_ctx *c, int slot, const double *X, int N) {
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(s.Xraw, X, 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));      // caller may free X on return (by-value semantics)
-    s.N0 = N;
+    s.N0 = N; s.sorted_valid = false;
     return TDLO_OK;
 }
 
@@ -729,6 +743,7 @@ int tdlo_split_begin(tdlo_ctx *c, const double *Y, int M, double sigma2, const t
     c->fh.assign(1, FrameDev{});
     rc = prepare_frame(c, 0, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, c->pin, c->fh[0]);
     if (rc) return rc;
+    c->fh[0].reuse_sorted = 0; c->slots[0].sorted_valid = false;      // a shard is pruned and sorted by the split's own setup
     if (c->xch_sums) c->fh[0].sums = c->xch_sums;       // the reduced sums are exported to / consumed from the caller's buffer
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p) * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1008,6 +1023,7 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     c->fh.assign(1, FrameDev{});
     rc = prepare_frame(c, 0, Y, M, *sigma2, p, priors, K, vis, n_vis, H_override, c->pin, c->fh[0]);
     if (rc) return rc;
+    c->fh[0].reuse_sorted = 0; c->slots[0].sorted_valid = false;      // a shard is pruned and sorted by the split's own setup
     FrameDev &f = c->fh[0];
     // the exchange lives in the one-workgroup M-steps: the chain smoother (no LLE term), the banded L D L^T (LLE term) -- any chain
     // length -- and the dense k_mstep_fast (up to 60 / 64 nodes)
@@ -1185,7 +1201,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     const int nraw = (int)hb[6];
     if (n_raw_out) *n_raw_out = nraw;
     if (n_out) *n_out = 0;
-    s.N0 = 0;
+    s.N0 = 0; s.sorted_valid = false;
     if (nraw == 0) return TDLO_OK;
     auto decode = [](unsigned o) { const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; std::memcpy(&f, &u, 4); return f; };
     float mn[3], mx[3];
@@ -1211,7 +1227,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     HIPCHK(c, hipStreamSynchronize(st));
     const int n = (int)hb[0];
     if (n < 0 || n > s.cap_points) return fail(c, TDLO_E_HIP, "voxel grid produced an impossible point count");
-    s.N0 = n;
+    s.N0 = n; s.sorted_valid = false;
     if (n_out) *n_out = n;
     if (X_out) {
         if (n > x_capacity) return fail(c, TDLO_E_INVALID, "X_out too small for the down-sampled cloud");

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     __shared__ int csum[kMaxNodes / 64][4][64];   // kept points per (node, quarter of the prune blocks)
     const int ml = t & 63, ch = t >> 6;
     const int cb0 = (int)((long long)nb * ch / 4), cb1 = (int)((long long)nb * (ch + 1) / 4);
+    const bool reuse = f.reuse_sorted != 0 && !split_mode;      // the sorted cloud of the previous registration serves: no counts to scan
+    if (!reuse) {
     {
         const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);       // (global address space and 16 independent loads per trip:
         for (int mg = 0; mg < M; mg += 64) {                  //  a load-add chain over ~50 blocks costs a memory latency each)
@@ -119,20 +121,22 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         for (int b = b0; b < b1; ++b) s += f.blksum[b];
         sd[t] = s;
     }
+    }
     __syncthreads();
     // the two serial sums on two waves: first index of every node's run (thread 0), the sigma2 initialisation sum in its fixed order (thread 64)
-    if (t == 0) {
+    if (t == 0 && !reuse) {
         int run = 0;
         for (int m = 0; m < M; ++m) { const int g = m >> 6, l = m & 63; const int v = (csum[g][0][l] + csum[g][1][l]) + (csum[g][2][l] + csum[g][3][l]); stot[m] = run; run += v; }
         sN = run;
     }
-    if (t == 64) {
+    if (t == 64 && !reuse) {
         double tot = 0;
         for (int i = 0; i < kBlock; ++i) tot += sd[i];
         sS = tot;
     }
+    if (t == 0 && reuse) { sN = (int)f.keep[0]; sS = f.keep[1]; }
     __syncthreads();
-    {
+    if (!reuse) {
         // second pass over the counts: (node, block) count -> where that run starts = node's first index + the earlier quarters + the
         // earlier blocks of this quarter, written in place (one pass instead of a scan within the node plus a pass adding the node's base)
         const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     }
     if (t == 0) {
         const int N = sN;
+        if (!reuse && !split_mode) { f.keep[0] = (double)N; f.keep[1] = sS; }
         st->N = N; st->sum_d2 = sS;
         st->it = 0; st->converged = 1; st->crit = 0; st->Np = 0;
         st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0;
@@ -1688,11 +1693,15 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     int gx = 0;
     for (int i = 0; i < F; ++i) gx = fh[i].nprune_blocks > gx ? fh[i].nprune_blocks : gx;
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
-    hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
+    bool reuse = true;                      // every frame's sorted cloud serves as it is: neither prune nor scatter
+    for (int i = 0; i < F; ++i) reuse = reuse && fh[i].reuse_sorted;
+    if (!reuse) hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(F), dim3(kBlock), 0, s, fd, 0);
     else hipLaunchKernelGGL((k_setup<float>), dim3(F), dim3(kBlock), 0, s, fd, 0);
-    if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
-    else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
+    if (!reuse) {
+        if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
+        else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
+    }
     return hipGetLastError();
 }
 

@@ -71,6 +71,9 @@ struct FrameDev {
                             // of all batches below 2^62; a contribution beyond it (or NaN) ends the registration with TDLO_E_NUMERIC
     int force_timeout_it;   // test hook (environment TDLO_MCU_FORCE_TIMEOUT=k): iteration k of the multi-CU M-steps behaves as if a hand-off timed out; -1 = off
     int prune_tiles;        // 256-point tiles one prune workgroup handles (1 up to 262 144 points)
+    int reuse_sorted;       // 1: the slot's pruned, centred, node-sorted cloud was made for exactly these nodes by the previous registration (the two
+                            // registrations of one tracking_step when every node is visible, trackdlo.cpp:913-927 / :998): prune and sort are skipped
+    double *keep;           // 2 doubles that outlive a registration: kept points and sum of d2 of the slot's sorted cloud (for reuse_sorted)
     int need_G;             // the M x M kernel matrix is built at setup (dense M-steps: dense LLE path, comparators); the chain smoother and the banded LLE M-step do not read it
     int mstep_dense;        // registrations without the LLE term: 0 the chain smoother, 1 the dense eliminations (comparators) -- decided when the frame is prepared
     int lle_band;           // registrations with the LLE term: 1 the banded L D L^T in the chain's state (tdlo_mstep_band.hip), 0 the dense pivoted eliminations
