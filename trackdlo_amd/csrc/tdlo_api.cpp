@@ -181,6 +181,22 @@ int fail(tdlo_ctx *c, int code, const std::string &msg) {
             return fail((c), TDLO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+// Waits for the stream like hipStreamSynchronize, but polls hipStreamQuery for the first few hundred microseconds: the blocking wait wakes
+// the host thread through an interrupt, 20 - 40 us after the work has finished -- as long as the whole GPU side of a production-size
+// registration (N = 5 000, M = 45: prune + setup + one or two iterations).  Longer calls fall back on the blocking wait.  TDLO_SPIN_US=0 disables.
+hipError_t wait_stream(hipStream_t s) {
+    static const int spin_us = getenv("TDLO_SPIN_US") ? atoi(getenv("TDLO_SPIN_US")) : 400;
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return e;
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(s);
+}
+
 int ensure_pin(tdlo_ctx *c, size_t doubles) {
     if (doubles <= c->pin_doubles) return 0;
     if (c->pin) hipHostFree(c->pin);
@@ -509,6 +525,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         return hipSuccess;
     };
     static const bool pool_on = !(getenv("TDLO_BATCH_THREADS") && atoi(getenv("TDLO_BATCH_THREADS")) == 0);
+    bool have_readback = false;            // the results are already in pinned memory (early exit after the first iteration)
     if (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) {
         // fixed iteration count: enqueue everything, no host involvement.  Several stream groups and enough iterations: the first
         // iteration (which releases the groups one after the other) from this thread, the rest of every group from a thread of its own.
@@ -533,8 +550,27 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         // `done` flags of chunk i are inspected while chunk i+1 is already running (the GPU never idles).
         IterState *flags = (IterState *)(c->pin + (size_t)F * nc.upload + fdd);     // pinned, 2 x F entries (one frame) ...
         double *fl_rb = c->pin + (size_t)F * nc.upload + fdd;                        // ... or 2 x F read-back blocks (batches)
-        int launched = 0, chunk = 0;
-        bool stop = false;
+        // A tracker in steady state converges in its first iteration (launch tolerance 2e-4): the first iteration is followed by the
+        // read-back block itself (results + state) and a host sync; if every frame is done the call is over -- no second chunk of
+        // no-op kernels, no separate flag copies (two no-op kernels and two 4 us copies per registration: 20 us of a 90 us call).
+        HIPCHK(c, iterate(1));
+        HIPCHK(c, join());
+        if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
+        if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up + fdd, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+        else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
+        HIPCHK(c, wait_stream(s));
+        {
+            bool all = true;
+            for (int i = 0; i < F; ++i) {
+                IterState is;
+                std::memcpy(&is, c->pin + (size_t)i * (merged ? nc.readback : nc.upload) + (nc.st - nc.Yout), sizeof is);
+                all = all && is.done != 0;
+            }
+            have_readback = all;
+        }
+        int launched = 1, chunk = 0;
+        bool stop = have_readback;
         while (launched < p->max_iter && !stop) {
             const int n = std::min(chunk < 2 ? 1 : (chunk == 2 ? 2 : kChunkIters), p->max_iter - launched);      // 1, 1, 2, 4, 4, ...
             HIPCHK(c, iterate(n));
@@ -563,14 +599,16 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             ++chunk;
         }
     }
-    HIPCHK(c, join());
-    if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
     const size_t rstride = merged ? nc.readback : nc.upload;
-    if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up + fdd, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
-    else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (!have_readback) {
+        HIPCHK(c, join());
+        if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
+        // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
+        if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up + fdd, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+        else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
+        HIPCHK(c, wait_stream(s));
+    }
     c->last_F = F;
     float loop_ms = 0, total_ms = 0;
     if (timing) { hipEventElapsedTime(&loop_ms, c->ev[1], c->ev[2]); hipEventElapsedTime(&total_ms, c->ev[0], c->ev[3]); }
@@ -687,7 +725,9 @@ int tdlo_synchronize(tdlo_ctx *c) {
     return TDLO_OK;
 }
 
-int tdlo_set_cloud(tdlo_ctx *c, int slot, const double *X, int N) {
+// sync == false: the copy is only enqueued -- for callers that keep X alive until their next synchronisation with the stream
+// (tracking_step: the first registration's read-back waits for everything before it)
+static int set_cloud_impl(tdlo_ctx *c, int slot, const double *X, int N, bool sync) {
     if (!c) return TDLO_E_INVALID;
     if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
     if (!X || N <= 0) return fail(c, TDLO_E_INVALID, "empty cloud");
@@ -696,10 +736,12 @@ int tdlo_set_cloud(tdlo_ctx *c, int slot, const double *X, int N) {
     int rc = ensure_points(c, s, N);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(s.Xraw, X, 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // caller may free X on return (by-value semantics)
+    if (sync) HIPCHK(c, wait_stream(c->stream));      // caller may free X on return (by-value semantics)
     s.N0 = N; s.sorted_valid = false;
     return TDLO_OK;
 }
+
+int tdlo_set_cloud(tdlo_ctx *c, int slot, const double *X, int N) { return set_cloud_impl(c, slot, X, N, true); }
 
 int tdlo_cpd_lle_resident(tdlo_ctx *c, int slot, double *Y, int M, double *sigma2, const tdlo_params *p,
                           const double *priors, int K, const int *vis, int n_vis, const double *H_override,
@@ -1611,7 +1653,8 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     for (int i = 0; i < n_vis; ++i) if (vis[i] < 0 || vis[i] >= M) return fail(c, TDLO_E_INVALID, "visible_nodes index out of range");
     t->priors.clear();                                                   // :908
     int rc = TDLO_OK;
-    if (X) rc = tdlo_set_cloud(c, t->slot, X, N);                        // X_orig by value: one upload for both registrations
+    if (X) rc = set_cloud_impl(c, t->slot, X, N, false);                 // X_orig by value: one upload for both registrations (X stays the caller's
+                                                                         // until this function returns; the first registration's read-back waits for the copy)
     else if (c->slots[t->slot].N0 <= 0) rc = fail(c, TDLO_E_INVALID, "X is NULL and no cloud is resident in the tracker's slot");
     if (rc) return rc;
 
@@ -1631,7 +1674,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     tdlo_stats st_pre{}, st_main{};
     rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
     if (stats) stats[0] = st_pre;
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
 
     std::vector<int> ve(vis_ext, vis_ext + n_ext);
     std::vector<double> p1, p2;

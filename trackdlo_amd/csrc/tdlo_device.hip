@@ -244,28 +244,43 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
                 kd0 += L[0] * t11 + L[2] * t21; kd1 += L[0] * t12 + L[2] * t22; kd2 += L[1] * t12 + L[3] * t22;      // Phi^T Q^-1 Phi
                 kn[0] = -t11; kn[1] = -t12; kn[2] = -t21; kn[3] = -t22;
             }
-            for (int q = 0; q < kBandSlots; ++q) {
-                const int i = j - (j - q + 2 * kBandSlots) % kBandSlots;      // the row in j - 12 .. j with slot q (direction's own index)
-                double v = 0.0;
-                const bool rowreal = dir ? (i >= bp.D) : (i >= 0);
-                const bool inRR = dir && i >= bp.mB && j >= bp.mB;            // direction 1 leaves R x R to direction 0
-                if (rowreal && !inRR) {
-                    const int ui = dir ? bp.nUp - 1 - i : i;
-                    const int a = ui >> 1, ti = ui & 1;
-                    if (a == b) v = lam * (ti == tj ? (ti ? kd2 : kd0) : kd1);
-                    else if (a == b - 1) v = lam * (tj ? (ti ? ko[3] : ko[2]) : (ti ? ko[1] : ko[0]));      // K[2b + tj][2(b-1) + ti]
-                    else if (a == b + 1) v = lam * (ti ? (tj ? kn[3] : kn[2]) : (tj ? kn[1] : kn[0]));      // K[2(b+1) + ti][2b + tj]
-                    const int dab = a > b ? a - b : b - a;
-                    if (!ti && !tj && dab <= 6) v += gam * Hg[(size_t)b * M + a];
-                }
-                o[band_rec_pos(q)] = v;
+            // The column has at most 11 non-zero entries: node b's own two unknowns, the two of the neighbour node on the side of the rows
+            // already in the window (K), and the f unknowns of the 6 nodes beyond (H).  All of H's values are requested before any is used
+            // (one memory latency instead of one per entry), and the entries are written straight to their positions: no loop over the 13 slots.
+            const int sgn = dir ? 1 : -1;                                     // rows at or above the diagonal in the direction's order: nodes b, b + sgn, ...
+            double h[7];
+#pragma unroll
+            for (int d = 0; d < 7; ++d) { const int a = b + sgn * d; h[d] = (!tj && a >= 0 && a < M) ? Hg[(size_t)b * M + a] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < kBandSlots; ++q) o[band_rec_pos(q)] = 0.0;
+            auto put = [&](int ui, double v) __attribute__((always_inline)) {    // entry (row unknown ui, this column)
+                if (ui < 0 || ui >= 2 * M) return;
+                const int i = dir ? bp.nUp - 1 - ui : ui;                       // the row's index in the direction's order
+                if (i > j || i < j - (kBandSlots - 1)) return;
+                if (dir && i >= bp.mB && j >= bp.mB) return;                    // direction 1 leaves R x R to direction 0
+                o[band_rec_pos(i % kBandSlots)] = v;
+            };
+            // (put() drops the rows behind the diagonal in the direction's order, e.g. f'_b for column f_b in direction 0)
+            const int an = b + sgn;                                            // the neighbour node on the window's side
+            // its coupling with this column: K[2b + tj][2(b-1) + ti] = ko[2 tj + ti],  K[2(b+1) + ti][2b + tj] = kn[2 ti + tj]
+            const double Kf = dir ? (tj ? kn[1] : kn[0]) : (tj ? ko[2] : ko[0]), Kp = dir ? (tj ? kn[3] : kn[2]) : (tj ? ko[3] : ko[1]);
+            put(2 * b, tj ? lam * kd1 : fma(gam, h[0], lam * kd0));
+            put(2 * b + 1, lam * (tj ? kd2 : kd1));
+            put(2 * an, tj ? lam * Kf : fma(gam, h[1], lam * Kf));
+            put(2 * an + 1, lam * Kp);
+            if (!tj) {
+#pragma unroll
+                for (int d = 2; d < 7; ++d) put(2 * (b + sgn * d), gam * h[d]);
             }
         }
-        for (int e = t; e < 3 * M; e += kBlock) {
+        for (int e = t; e < 3 * M; e += kBlock) {          // (13 loads requested at once, indices clamped; same ascending order of the terms as the dense product)
             const int i = e % M, d = e / M;
-            const int k0 = i - 6 > 0 ? i - 6 : 0, k1 = i + 6 < M - 1 ? i + 6 : M - 1;
+            double hv[13];
+#pragma unroll
+            for (int u = 0; u < 13; ++u) { const int k = i - 6 + u, kc = k < 0 ? 0 : (k > M - 1 ? M - 1 : k); hv[u] = Hg[(size_t)kc * M + i]; }
             double a = 0;
-            for (int k = k0; k <= k1; ++k) a += Hg[(size_t)k * M + i] * sY[d * M + k];
+#pragma unroll
+            for (int u = 0; u < 13; ++u) { const int k = i - 6 + u; if (k >= 0 && k < M) a += hv[u] * sY[d * M + k]; }
             f.HY0[e] = a;
         }
     } else if (f.include_lle) {
