@@ -597,8 +597,8 @@ def bench_nsplit(args, cfg, env):
     P = synth.LAUNCH_PARAMS
     rank, world, dev_index, dist, torch, backend = env["rank"], env["world"], env["dev_index"], env["dist"], env["torch"], env["backend"]
     NT, M = cfg["N"], cfg["M"]
-    X, Y0, _ = synth.scene(NT, M, config=4)
     lo, hi = rank * NT // world, (rank + 1) * NT // world
+    Xs, Y0 = synth.scene_range(NT, M, 4, lo, hi)      # this rank's shard only (the cloud is defined chunk by chunk: every split sees the same points)
     ctx = Context(device=dev_index, max_points=hi - lo, max_nodes=M)
     ctx.set_timing(False)       # no stream markers for tdlo_stats.loop_ms in the timed region
 
@@ -606,32 +606,52 @@ def bench_nsplit(args, cfg, env):
         return B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False, alpha=0.0,
                              k_vis=P["k_vis"] if vis_on else 0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32)
     params = mk(False)
-    ctx.set_cloud(0, X[lo:hi])                      # the shard, resident before the timed region
+    ctx.set_cloud(0, Xs)                            # the shard, resident before the timed region
 
-    # ---- exchange set-up: inboxes shared as IPC handles (one process per GPU), else RCCL made by the library
-    form, comm = "one-shot exchange (peer-written inboxes, reduced inside the M-step kernel)", None
+    # ---- exchange set-up: inboxes shared as IPC handles (one process per GPU), else RCCL made by the library.  Every step that can fail for
+    #      reasons of the node (no peer mapping between two GPUs, no fine-grained memory) is probed; the ranks then agree on ONE form:
+    #      MIN over the ranks of "my side is set up" -- a single rank that cannot takes everybody to RCCL, nobody waits for a flag that never comes
+    form, comm, why = "one-shot exchange (peer-written inboxes, reduced inside the M-step kernel)", None, None
+    devices = [dev_index]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, dev_index)
     try:
+        if os.environ.get("TDLO_BENCH_FORCE_RCCL"):
+            raise RuntimeError("TDLO_BENCH_FORCE_RCCL is set")
+        for r, d in enumerate(devices):
+            if r != rank and not ctx.xch_can_access(d):
+                raise RuntimeError(f"GPU {dev_index} cannot map memory of GPU {d} (rank {r})")
         own = ctx.xch_create(world, 64)
-        if world == 1:
-            ctx.xch_bind(0, [own])
-        else:
-            handles = [None] * world
-            dist.all_gather_object(handles, ctx.xch_export())
-            ctx.xch_bind(rank, [own if r == rank else ctx.xch_open(handles[r]) for r in range(world)])
         ok = 1
-    except Exception as e:            # pragma: no cover  (needs a node whose GPUs cannot map each other's memory)
-        print(f"bench.py: rank {rank}: one-shot exchange unavailable ({e})", file=sys.stderr)
+    except Exception as e:
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    handles = [None] * world
+    if world > 1:           # (every rank takes part in the gather, whatever its own outcome: a collective must not depend on a local failure)
+        dist.all_gather_object(handles, ctx.xch_export() if ok else None)
+    if ok and all(h is not None for h in handles[:rank] + handles[rank + 1:]):
+        try:
+            ctx.xch_bind(rank, [own if r == rank else ctx.xch_open(handles[r]) for r in range(world)])
+        except Exception as e:
+            ok, why = 0, f"{type(e).__name__}: {e}"
+    elif world > 1:
         ok = 0
     if world > 1:
         t = torch.tensor([ok], dtype=torch.int64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if why and not int(t.item()):
+            print(f"bench.py: rank {rank}: one-shot exchange unavailable ({why})", file=sys.stderr)
         ok = int(t.item())
+    rccl_size = None
     if not ok:
-        ctx.lib.tdlo_xch_bind(ctx.h, 0, 0, None)
-        ids = [B.rccl_unique_id() if rank == 0 else None]
+        if why:
+            print(f"bench.py: rank {rank}: falling back on the RCCL form ({why})", file=sys.stderr)
+        ctx.xch_unbind()
+        ids = [ctx.rccl_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
         comm = ctx.rccl_comm_init(world, rank, ids[0])
+        rccl_size = ctx.rccl_comm_count(comm)[0]
         form = "RCCL all-reduce MIN / SUM issued by the library on its stream (tdlo_split_run with a communicator)"
 
     def step(p=params, vis=None):
@@ -656,6 +676,13 @@ def bench_nsplit(args, cfg, env):
         ctx.close()
         return
     n_ranks, ranks = _rank_table(env)
+    if world > 1:           # what RCCL itself says about the group each rank is in (ncclCommCount of the library's communicator; null: no RCCL in the data path)
+        sizes = [None] * world
+        dist.all_gather_object(sizes, rccl_size)
+        for r, e in enumerate(ranks):
+            e["rccl_size"] = sizes[r]
+    else:
+        ranks[0]["rccl_size"] = rccl_size
     if rank == 0:
         est_us = ctx.profile_kernel(0, 50)
         mst_us = ctx.profile_kernel(2, 50)
@@ -675,7 +702,7 @@ def bench_nsplit(args, cfg, env):
         if n_ranks == 1 and cfg.get("leg") and not args.no_cpu_baseline:
             kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                       include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
-            cpu = _cpu_baseline(cfg, X, Y0, kw, None)
+            cpu = _cpu_baseline(cfg, Xs, Y0, kw, None)
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         elif n_ranks == 1:
             # what the split costs on one rank: the plain (unsplit) call on the same cloud, the RCCL form of the same call, and one
@@ -698,7 +725,7 @@ def bench_nsplit(args, cfg, env):
                 line["rccl_form_iters_per_s"] = None; line["rccl_form_error"] = str(e)
             _, _, vis = synth.scene(1000, M, config=4, occlude=(0.4, 0.46))
             vext = synth.extend_visible(vis, M, synth.geodesic_coord(Y0))
-            ctx.set_cloud(0, X[:NT // 8])
+            ctx.set_cloud(0, Xs[:NT // 8])
             pv = mk(True)
             shard = dict(points=NT // 8)
             shard["one_shot_vis_us_per_iteration"] = round(1e6 / rate(lambda: step(pv, vext), 60), 2)
@@ -710,7 +737,7 @@ def bench_nsplit(args, cfg, env):
             if not args.no_cpu_baseline:
                 kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                           include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
-                cpu = _cpu_baseline(cfg, X, Y0, kw, None)
+                cpu = _cpu_baseline(cfg, Xs, Y0, kw, None)
                 line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         line["cpu_baseline"] = cpu
     ctx.close()

@@ -185,7 +185,11 @@ int tdlo_split_poll(tdlo_ctx *ctx, int *done, int *iters);   /* synchronises the
  *       sums straight into every peer's inbox (peer stores: xGMI on a multi-GPU node) and raises a flag; the last workgroup of
  *       the min-distance kernel and the one-workgroup M-step wait for the R flags in their own inbox and reduce the R
  *       contributions in rank order.  One EM iteration is the three kernels of the unsplit loop, no launch in between.
- *       Any chain length without the LLE term (the chain smoother carries the exchange), up to 64 nodes with it; up to 8 ranks.
+ *       Any chain length (the one-workgroup M-steps carry the exchange: the chain smoother, and with the LLE term the banded
+ *       L D L^T; a registration whose LLE system takes the dense eliminations -- coincident nodes, an H_override that is not banded --
+ *       only up to 64 nodes); up to 8 ranks.  A rank that is more than 2 s behind its peers (or gone) makes the waiting kernels give up:
+ *       TDLO_E_EXCHANGE on the ranks that waited.  Arguments are validated before anything is exchanged; a shard that loses every point
+ *       to the prune still takes part (it contributes zeros).
  * The stopping rule is evaluated on the device and read after iterations 1, 2, 4, 8, 12, ... (tol > 0). */
 int tdlo_split_run(tdlo_ctx *ctx, void *nccl_comm, double *Y, int M, double *sigma2, const tdlo_params *params,
                    const double *priors, int K, const int *visible_nodes, int n_vis, const double *H_override, tdlo_stats *stats);
@@ -199,12 +203,20 @@ int tdlo_xch_create(tdlo_ctx *ctx, int nranks, int max_nodes, void **inbox);
 int tdlo_xch_ipc_export(tdlo_ctx *ctx, void *handle64);
 int tdlo_xch_ipc_open(tdlo_ctx *ctx, const void *handle64, void **peer_inbox);
 int tdlo_xch_bind(tdlo_ctx *ctx, int rank, int nranks, void *const *inboxes);
+/* Whether this context's GPU can map memory of `peer_device` (hipDeviceCanAccessPeer; 1 for its own device): what a rank asks before it
+ * opens a peer's inbox.  Failures of the exchange's set-up that are properties of the node, not errors of the caller -- no fine-grained
+ * device memory for the inbox (tdlo_xch_create with more than one rank), an inbox that cannot be mapped (tdlo_xch_ipc_open,
+ * tdlo_xch_bind) -- come back as TDLO_E_EXCHANGE: the ranks then agree (e.g. a MIN all-reduce of "set up") to use the RCCL form. */
+int tdlo_xch_can_access(tdlo_ctx *ctx, int peer_device, int *can);
 /* RCCL bootstrap for hosts that have no communicator of their own: rank 0 makes the 128-byte ncclUniqueId and hands it to
  * the other ranks; every rank then creates its communicator (owned by the context, destroyed with it).  tdlo_rccl_load
  * names the librccl to bind (NULL: search as described above); returns 0 when RCCL is usable. */
 int tdlo_rccl_load(const char *path);
 int tdlo_rccl_unique_id(void *id128);
 int tdlo_rccl_comm_init(tdlo_ctx *ctx, int nranks, int rank, const void *id128, void **comm_out);
+/* ncclCommCount / ncclCommUserRank of a communicator (any ncclComm_t of the RCCL this library is bound to): what a rank reports
+ * about the group it really is in. */
+int tdlo_rccl_comm_count(void *comm, int *nranks, int *rank);
 
 /* ---- tracker object: class trackdlo (trackdlo/include/trackdlo.h:53-130) ---------------------- */
 typedef struct tdlo_tracker tdlo_tracker;

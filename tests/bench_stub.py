@@ -37,3 +37,50 @@ class StubContext:
 
     def profile_kernel(self, kind, reps=200, slot=0):
         return 6.0
+
+    # ---- the N-split (bench.py --config c4): the exchange's set-up steps, each of which can be made to fail on one rank
+    #      (TDLO_STUB_FAIL="<step>:<rank>", step in can_access / create / open), and the split registration itself
+    def _fail(self, step):
+        import os
+        spec = os.environ.get("TDLO_STUB_FAIL", "")
+        return spec == f"{step}:{os.environ.get('RANK', '0')}"
+
+    def xch_can_access(self, peer_device):
+        return not self._fail("can_access")
+
+    def xch_create(self, nranks, max_nodes):
+        if self._fail("create"):
+            raise RuntimeError("stub: no fine-grained memory")
+        return 0x1000 + self.device
+
+    def xch_export(self):
+        return bytes([self.device]) * 64
+
+    def xch_open(self, handle):
+        if self._fail("open"):
+            raise RuntimeError("stub: peer inbox cannot be mapped")
+        return 0x2000 + handle[0]
+
+    def xch_bind(self, rank, inboxes):
+        self.bound = (rank, list(inboxes))
+
+    def xch_unbind(self):
+        self.bound = None
+
+    @staticmethod
+    def rccl_unique_id():
+        return b"stub-unique-id".ljust(128, b"\0")
+
+    def rccl_comm_init(self, nranks, rank, unique_id):
+        assert unique_id.startswith(b"stub-unique-id")
+        self.comm = (nranks, rank)
+        return 0x3000 + rank
+
+    def rccl_comm_count(self, comm):
+        return self.comm
+
+    def split_run(self, Y, sigma2, params, comm=None, visible_nodes=None, **_):
+        import numpy as np
+        time.sleep(0.001)
+        assert (comm is None) == (getattr(self, "bound", None) is not None)      # exactly one form is in use
+        return dict(Y=np.asarray(Y), sigma2=1e-5, iters=params.max_iter, n_kept=0, converged=False, rc=0, status=0, loop_ms=1.0, total_ms=1.0, host_ms=1.0)

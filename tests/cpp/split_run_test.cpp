@@ -4,8 +4,9 @@
 //   2. tdlo_split_run with an RCCL communicator made by tdlo_rccl_unique_id / tdlo_rccl_comm_init (one rank: this box has one GPU;
 //      the library binds librccl at run time and issues ncclAllReduce itself)                  -> must equal 1 bit for bit
 //   3. tdlo_split_run with the one-shot exchange, two ranks = two contexts on two host threads, each with half of the cloud
-//      (peer-written inboxes; the pointers are plain device pointers because the ranks share the GPU) -> both ranks the same bits,
-//      and the plain call's result to the stated fp32-mode tolerance (the halves are pruned / sorted separately).
+//      (peer-written inboxes as plain device pointers).  On a box with two or more GPUs the ranks take devices 0 and 1 -- the peer
+//      stores then cross xGMI, tdlo_xch_bind enables the peer mapping --, on a one-GPU box they share device 0
+//      -> both ranks the same bits, and the plain call's result to the stated fp32-mode tolerance (the halves are pruned / sorted separately).
 // build: __graft_entry__.build();  run: tests/test_split_native_gpu.py::test_cpp_driver (GPU box).
 #include <cmath>
 #include <cstdio>
@@ -67,7 +68,9 @@ int main() {
         tdlo_ctx *c[R] = {nullptr, nullptr};
         void *inbox[R] = {nullptr, nullptr};
         tdlo_config cr = cfg; cr.max_points = N / R + 64;
-        for (int r = 0; r < R; ++r) { c[r] = tdlo_create(&cr, &err); if (!c[r]) { std::printf("FAIL tdlo_create -> %d\n", err); return 1; } CHECK(tdlo_xch_create(c[r], R, 64, &inbox[r])); }
+        const bool two_gpus = tdlo_device_count() >= 2;
+        std::printf("one-shot exchange on %s\n", two_gpus ? "devices 0 and 1 (peer stores over xGMI)" : "device 0 (both ranks: this box has one GPU)");
+        for (int r = 0; r < R; ++r) { cr.device = two_gpus ? r : 0; c[r] = tdlo_create(&cr, &err); if (!c[r]) { std::printf("FAIL tdlo_create -> %d\n", err); return 1; } CHECK(tdlo_xch_create(c[r], R, 64, &inbox[r])); }
         std::vector<double> Yr[R] = {Y0, Y0}; double s2r[R] = {0, 0}; tdlo_stats str[R] = {}; int rcs[R] = {0, 0};
         auto work = [&](int r) {
             const int n0 = r * (N / R), n1 = (r + 1) * (N / R), n = n1 - n0;

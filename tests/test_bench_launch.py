@@ -65,3 +65,22 @@ def test_single_rank_line_schema():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in line["roofline"]
     assert "em_iters_per_s_f64" in line
+
+
+@pytest.mark.parametrize("fail", ["", "can_access:1", "create:0", "open:1"])
+def test_c4_exchange_negotiation_and_rccl_fallback(fail):
+    """bench.py --config c4 --gpus 2: the ranks set the one-shot exchange up step by step -- peer-access probe, inbox, IPC handles
+    gathered by EVERY rank, peer inboxes opened -- and agree by a MIN all-reduce; one rank that cannot takes both to the RCCL form (the library's
+    own communicator), and the line says which form ran and what RCCL reports as the group size."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c4", "--no-cpu-baseline"],
+                       env=_env(TDLO_BENCH_PORT="29641", TDLO_STUB_FAIL=fail), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and [e["rank"] for e in line["ranks"]] == [0, 1]
+    par = line["config"]["parallelism"]
+    if fail:
+        assert "RCCL all-reduce" in par and [e["rccl_size"] for e in line["ranks"]] == [2, 2]
+        assert "falling back on the RCCL form" in r.stderr or "one-shot exchange unavailable" in r.stderr
+    else:
+        assert "one-shot exchange" in par and [e["rccl_size"] for e in line["ranks"]] == [None, None]
+    assert "2000000 points split over 2 rank(s) (1000000 per rank)" in line["config"]["workload"]

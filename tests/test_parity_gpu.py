@@ -12,6 +12,7 @@ import pytest
 
 # TDLO_SWEEP_SCALE=k multiplies the number of seeds of the randomised sweeps (bug hunting; the committed default is 1)
 _SWEEP = int(__import__("os").environ.get("TDLO_SWEEP_SCALE", "1"))
+_SEQ_EXITS = {"compared": 0, "oracle_undecided": 0, "f32_iteration_count": 0}      # how the frames of the random sequences ended (see the summary test)
 
 from conftest import case_kwargs, load_cases
 
@@ -906,6 +907,7 @@ def test_randomised_tracking_sequences(hip_ctx, oracle, seed):
                a.get_correspondence_pairs().shape != ref.get_correspondence_pairs().shape for a in alts):
             # the last bit of H moves a stopping decision of the ORACLE: this frame pins nothing; carry on from the oracle's state
             assert np.all(np.isfinite(trk.get_tracking_result())) and np.isfinite(trk.get_sigma2())
+            _SEQ_EXITS["oracle_undecided"] += 1
             break
         unc_y = max(np.abs(a.get_tracking_result() - ref.get_tracking_result()).max() for a in alts)
         unc_g = max(max(np.abs(a.get_guide_nodes() - ref.get_guide_nodes()).max(), np.abs(a.get_correspondence_pairs() - ref.get_correspondence_pairs()).max()) for a in alts)
@@ -922,7 +924,9 @@ def test_randomised_tracking_sequences(hip_ctx, oracle, seed):
             np.testing.assert_allclose(t64.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=max(1e-9, 8 * unc_y))
             assert trk.last_stats[0]["converged"] and trk.last_stats[1]["converged"]
             trk.copy_state_from(t64); trk.set_precision(B.PREC_F32)
+            _SEQ_EXITS["f32_iteration_count"] += 1
             continue
+        _SEQ_EXITS["compared"] += 1
         kp, kr = trk.get_correspondence_pairs(), ref.get_correspondence_pairs()
         assert kp.shape == kr.shape
         tol_pre = max(1e-5, 8 * unc_g)                    # outputs of the pre-processing registration: guide nodes, priors
@@ -930,6 +934,21 @@ def test_randomised_tracking_sequences(hip_ctx, oracle, seed):
         np.testing.assert_allclose(trk.get_guide_nodes(), ref.get_guide_nodes(), rtol=0, atol=tol_pre)
         np.testing.assert_allclose(trk.get_tracking_result(), ref.get_tracking_result(), rtol=0, atol=max(1e-5, 8 * unc_y))
         assert abs(trk.get_sigma2() - ref.get_sigma2()) <= max(1e-3, 8 * unc_s) * ref.get_sigma2()
+
+
+@pytest.mark.gpu
+def test_random_sequences_rarely_leave_through_the_escape_hatches():
+    """the two exits of the random-sequence test that compare nothing at the fp32 gates -- a frame on which the last bit of H
+    moves the ORACLE's own stopping decision, and a frame whose fp32-mode iteration count differs from the oracle's by one (then re-run and
+    gated in fp64) -- must stay rare: a regression that pushes many frames through them would otherwise go unseen.  Counted over the
+    sequences of this session (16 sequences x up to 4 frames in the default sweep)."""
+    total = sum(_SEQ_EXITS.values())
+    if total == 0:
+        pytest.skip("the random sequences did not run in this session")
+    print("random-sequence frames:", dict(_SEQ_EXITS))
+    assert _SEQ_EXITS["oracle_undecided"] <= max(2, total // 10), dict(_SEQ_EXITS)
+    assert _SEQ_EXITS["f32_iteration_count"] <= max(2, total // 10), dict(_SEQ_EXITS)
+    assert _SEQ_EXITS["compared"] >= (3 * total) // 4, dict(_SEQ_EXITS)
 
 
 @pytest.mark.gpu

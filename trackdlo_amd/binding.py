@@ -49,7 +49,7 @@ SYMBOLS = [
     "tdlo_abi_version", "tdlo_device_count", "tdlo_default_config", "tdlo_create", "tdlo_destroy", "tdlo_last_error",
     "tdlo_stream", "tdlo_synchronize", "tdlo_set_cloud", "tdlo_cpd_lle_resident", "tdlo_cpd_lle", "tdlo_cpd_lle_batch",
     "tdlo_split_begin", "tdlo_split_set_global", "tdlo_split_dmin", "tdlo_split_estep", "tdlo_split_mstep", "tdlo_split_end", "tdlo_split_abort",
-    "tdlo_split_run", "tdlo_xch_bytes", "tdlo_xch_create", "tdlo_xch_ipc_export", "tdlo_xch_ipc_open", "tdlo_xch_bind",
+    "tdlo_split_run", "tdlo_xch_bytes", "tdlo_xch_create", "tdlo_xch_ipc_export", "tdlo_xch_ipc_open", "tdlo_xch_bind", "tdlo_xch_can_access", "tdlo_rccl_comm_count",
     "tdlo_rccl_load", "tdlo_rccl_unique_id", "tdlo_rccl_comm_init",
     "tdlo_split_bind_exchange", "tdlo_split_dmin_enqueue", "tdlo_split_estep_enqueue", "tdlo_split_mstep_enqueue", "tdlo_split_poll",
     "tdlo_tracker_create", "tdlo_tracker_create_default", "tdlo_tracker_destroy", "tdlo_tracker_set_precision",
@@ -136,6 +136,9 @@ def load_library(path: str | None = None):
     lib.tdlo_xch_ipc_export.argtypes = [vp, vp]
     lib.tdlo_xch_ipc_open.argtypes = [vp, vp, C.POINTER(vp)]
     lib.tdlo_xch_bind.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    lib.tdlo_xch_can_access.argtypes = [vp, ci, C.POINTER(ci)]
+    lib.tdlo_xch_can_access.restype = ci
+    lib.tdlo_rccl_comm_count.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.tdlo_rccl_load.argtypes = [C.c_char_p]
     lib.tdlo_rccl_unique_id.argtypes = [vp]
     lib.tdlo_rccl_comm_init.argtypes = [vp, ci, ci, vp, C.POINTER(vp)]
@@ -230,6 +233,8 @@ class _StatsView:
         return len(self._st)
 
     def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [s.as_dict() for s in self._st[i]]
         return self._st[i].as_dict()
 
     def __iter__(self):
@@ -363,6 +368,12 @@ class Context:
         self._chk(self.lib.tdlo_xch_ipc_export(self.h, buf))
         return bytes(buf.raw)
 
+    def xch_can_access(self, peer_device: int) -> bool:
+        """Whether this context's GPU can map memory of `peer_device` (asked before a peer's inbox is opened)."""
+        can = C.c_int(0)
+        self._chk(self.lib.tdlo_xch_can_access(self.h, int(peer_device), C.byref(can)))
+        return bool(can.value)
+
     def xch_open(self, handle: bytes):
         p = C.c_void_p(0)
         buf = C.create_string_buffer(handle, 64)
@@ -373,6 +384,13 @@ class Context:
         arr = (C.c_void_p * len(inboxes))(*[C.c_void_p(int(p)) for p in inboxes])
         self._chk(self.lib.tdlo_xch_bind(self.h, int(rank), len(inboxes), arr))
 
+    def xch_unbind(self):
+        self._chk(self.lib.tdlo_xch_bind(self.h, 0, 0, None))
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        return rccl_unique_id()
+
     def rccl_comm_init(self, nranks, rank, unique_id: bytes):
         """An RCCL communicator over `nranks` ranks, owned by the context; returns the ncclComm_t as an integer."""
         rccl_load()
@@ -380,6 +398,12 @@ class Context:
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self.lib.tdlo_rccl_comm_init(self.h, int(nranks), int(rank), buf, C.byref(comm)))
         return int(comm.value)
+
+    def rccl_comm_count(self, comm):
+        """(ranks, own rank) of an RCCL communicator as RCCL itself reports them."""
+        n = C.c_int(0); me = C.c_int(0)
+        self._chk(self.lib.tdlo_rccl_comm_count(C.c_void_p(comm), C.byref(n), C.byref(me)))
+        return n.value, me.value
 
     def visibility_prepass(self, slot, Y, visibility_threshold, d_vis, geodesic_coord):
         """trackdlo_node.cpp:257-277 + :345-360 (distance test and gap fill; no painter test)."""

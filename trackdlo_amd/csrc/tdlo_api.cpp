@@ -261,6 +261,10 @@ int check_params(tdlo_ctx *c, int M, const tdlo_params *p) {
     if (M > kMaxNodes) return fail(c, TDLO_E_INVALID, "M > 512 is not supported by the E-step tiling");
     if (p->max_iter < 0) return fail(c, TDLO_E_INVALID, "max_iter < 0");
     if (p->precision != TDLO_PREC_F32 && p->precision != TDLO_PREC_F64) return fail(c, TDLO_E_INVALID, "bad precision");
+    // the kernel G of trackdlo.cpp:233 divides by beta; a negative lambda makes the M-step's system indefinite (the reference's launch files use
+    // 0.35 / 3.0 and 50 000 / 1).  lambda == 0 is legal there (A = D G, least-squares solve): it takes the dense eliminations (prepare_frame).
+    if (!(p->beta > 0.0)) return fail(c, TDLO_E_INVALID, "beta must be positive (kernel G of trackdlo.cpp:233)");
+    if (!(p->lambda >= 0.0)) return fail(c, TDLO_E_INVALID, "lambda must not be negative");
     return 0;
 }
 
@@ -344,7 +348,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     (void)vis;
     f.precision = p->precision;
     // which M-step: decided here, once per frame (the launchers dispatch on the descriptor, not on the process-wide toggles)
-    f.mstep_dense = mstep_chain_enabled() ? 0 : 1;
+    f.mstep_dense = (mstep_chain_enabled() && p->lambda > 0.0) ? 0 : 1;      // (the chain smoother works in units of 1 / (lambda sigma2))
     f.lle_band = lle_band ? 1 : 0;
     f.need_G = ((p->include_lle && !lle_band) || (!p->include_lle && f.mstep_dense)) ? 1 : 0;
     {   // test hook: iteration k of the multi-CU M-steps behaves as if a hand-off had timed out (tests/test_parity_gpu.py)
@@ -977,6 +981,17 @@ int tdlo_rccl_comm_init(tdlo_ctx *c, int nranks, int rank, const void *id128, vo
     return TDLO_OK;
 }
 
+int tdlo_rccl_comm_count(void *comm, int *nranks, int *rank) {
+    std::string why;
+    const RcclApi *r = rccl_api(nullptr, &why);
+    if (!r || !comm || !r->CommCount || !r->CommUserRank) return TDLO_E_EXCHANGE;
+    int n = 0, me = 0;
+    if (r->CommCount(comm, &n) != 0 || r->CommUserRank(comm, &me) != 0) return TDLO_E_EXCHANGE;
+    if (nranks) *nranks = n;
+    if (rank) *rank = me;
+    return TDLO_OK;
+}
+
 size_t tdlo_xch_bytes(int nranks, int max_nodes) {
     if (nranks < 1 || nranks > kMaxXchRanks || max_nodes < 4) return 0;
     return xch_words(nranks, max_nodes) * sizeof(unsigned long long);
@@ -991,11 +1006,14 @@ int tdlo_xch_create(tdlo_ctx *c, int nranks, int max_nodes, void **inbox) {
     if (c->xch_own) { hipFree(c->xch_own); c->xch_own = nullptr; }
     c->xch_nranks = 0;
     const size_t words = xch_words(nranks, max_nodes);
-    // peers write this buffer over xGMI while this GPU polls it: uncached (fine-grained) device memory where the runtime offers
-    // it; the accesses are system-scope atomics either way
+    // peers write this buffer over xGMI while this GPU polls it: it must be uncached (fine-grained) device memory -- a peer's stores to
+    // coarse-grained memory are not guaranteed to become visible to a kernel that polls through its local L2, and every wait would then
+    // run into its time limit.  Where the runtime does not offer it the exchange is refused (TDLO_E_EXCHANGE) so that callers take the
+    // RCCL form instead; a single rank has no peers and may use any memory.
     void *p = nullptr;
     if (hipExtMallocWithFlags(&p, words * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
+        if (nranks > 1) return fail(c, TDLO_E_EXCHANGE, "tdlo_xch_create: no fine-grained (uncached) device memory for the inbox: use tdlo_split_run with an RCCL communicator");
         HIPCHK(c, hipMalloc(&p, words * sizeof(unsigned long long)));
     }
     HIPCHK(c, hipMemset(p, 0, words * sizeof(unsigned long long)));
@@ -1022,9 +1040,25 @@ int tdlo_xch_ipc_open(tdlo_ctx *c, const void *handle64, void **peer_inbox) {
     hipIpcMemHandle_t h;
     std::memcpy(&h, handle64, sizeof h);
     void *p = nullptr;
-    HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    {   // a GPU that cannot map the peer's memory is not a HIP failure of this library but a property of the node: TDLO_E_EXCHANGE, so that
+        // every rank can fall back on the RCCL form together (bench.py: MIN over the ranks of "the exchange is set up")
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, TDLO_E_EXCHANGE, std::string("tdlo_xch_ipc_open: the peer's inbox cannot be mapped on this GPU (") + hipGetErrorString(e) + ")"); }
+    }
     c->xch_opened.push_back(p);
     *peer_inbox = p;
+    return TDLO_OK;
+}
+
+int tdlo_xch_can_access(tdlo_ctx *c, int peer_device, int *can) {
+    if (!c || !can) return TDLO_E_INVALID;
+    *can = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || peer_device < 0 || peer_device >= n) return fail(c, TDLO_E_INVALID, "tdlo_xch_can_access: no such device");
+    if (peer_device == c->device) { *can = 1; return TDLO_OK; }
+    int ok = 0;
+    HIPCHK(c, hipDeviceCanAccessPeer(&ok, c->device, peer_device));
+    *can = ok;
     return TDLO_OK;
 }
 
@@ -1035,6 +1069,20 @@ int tdlo_xch_bind(tdlo_ctx *c, int rank, int nranks, void *const *inboxes) {
     if (!c->xch_own || !inboxes || nranks != c->xch_cap_ranks || rank < 0 || rank >= nranks) return fail(c, TDLO_E_INVALID, "tdlo_xch_bind: create the inbox for this many ranks first");
     for (int r = 0; r < nranks; ++r) if (!inboxes[r]) return fail(c, TDLO_E_INVALID, "tdlo_xch_bind: null peer inbox");
     if (inboxes[rank] != (void *)c->xch_own) return fail(c, TDLO_E_INVALID, "tdlo_xch_bind: inboxes[rank] is not this context's own inbox");
+    // inboxes of contexts of THIS process on other devices (one thread per GPU): plain device pointers -- this GPU must be able to map them
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) continue;
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, inboxes[r]) != hipSuccess) { (void)hipGetLastError(); continue; }      // (an IPC mapping: opened for this device already)
+        if (at.device == c->device) continue;
+        int ok = 0;
+        HIPCHK(c, hipDeviceCanAccessPeer(&ok, c->device, at.device));
+        if (!ok) return fail(c, TDLO_E_EXCHANGE, "tdlo_xch_bind: this GPU cannot access a peer's inbox (no peer mapping between the devices): use the RCCL form");
+        const hipError_t e = hipDeviceEnablePeerAccess(at.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(c, TDLO_E_EXCHANGE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
     for (int r = 0; r < kMaxXchRanks; ++r) c->xch_peer[r] = r < nranks ? (unsigned long long *)inboxes[r] : nullptr;
     c->xch_rank = rank; c->xch_nranks = nranks;
     return TDLO_OK;
@@ -1127,25 +1175,38 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
         return 0;
     };
     IterState is{};
-    bool have_state = false;
+    int common_status = 0;              // RCCL form: the MIN over the ranks of their status
     for (int it = 1; it <= p->max_iter; ++it) {
         if ((rc = iteration())) return rc;
         // the stopping rule lives on the device (the same flag on every rank: they solve the same system); it is read after
-        // iterations 1, 2, 4, 8, 12, ... -- a tracker in steady state converges within a couple of iterations
+        // iterations 1, 2, 4, 8, 12, ... -- a tracker in steady state converges within a couple of iterations.  With a communicator the
+        // decision is taken TOGETHER (MIN all-reduce of [done without error, status]): a rank that stopped on an error of its own -- a
+        // shard whose sums leave the fixed point's range -- must not leave its peers inside the next all-reduce
         const bool poll = p->tol > 0.0 && it < p->max_iter && (it == 1 || it == 2 || it == 4 || (it >= 8 && it % 4 == 0));
-        if (poll) {
+        if (poll && oneshot) {
             HIPCHK(c, hipMemcpyAsync(c->pin, f.st, sizeof(IterState), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, wait_stream(s));
             std::memcpy(&is, c->pin, sizeof is);
-            if (is.done) { have_state = true; break; }
+            if (is.done) break;
+        } else if (poll) {
+            HIPCHK(c, launch_split_poll_pack(c->fd, b_init, s));
+            if ((rc = nccl(R->AllReduce(b_init, b_init, 2, kNcclFloat64, kNcclMin, nccl_comm, s), "ncclAllReduce(poll)"))) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->pin, b_init, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, wait_stream(s));
+            if (c->pin[0] != 0.0 || c->pin[1] < 0.0) { common_status = (int)c->pin[1]; break; }
         }
     }
-    (void)have_state;
+    if (!oneshot) {                     // every rank leaves with the same verdict
+        HIPCHK(c, launch_split_poll_pack(c->fd, b_init, s));
+        if ((rc = nccl(R->AllReduce(b_init, b_init, 2, kNcclFloat64, kNcclMin, nccl_comm, s), "ncclAllReduce(status)"))) return rc;
+    }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[0].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
     if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (!oneshot) HIPCHK(c, hipMemcpyAsync(c->pin + nc.readback, b_init, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, wait_stream(s));
     std::memcpy(&is, c->pin + (nc.st - nc.Yout), sizeof is);
+    if (!oneshot) { common_status = (int)c->pin[nc.readback + 1]; if (common_status < 0 && is.status == 0) is.status = common_status; }
     c->last_F = 1;
     if ((is.status == 0 || is.status == TDLO_E_NUMERIC) && is.it > 0) { std::memcpy(Y, c->pin, sizeof(double) * 3 * M); }
     if (is.status == 0 || is.status == TDLO_E_NUMERIC) *sigma2 = is.sigma2;

@@ -383,6 +383,13 @@ __global__ void k_split_init_pack(const FrameDev *__restrict__ frames, double *_
     const IterState *st = frames[0].st;
     if (threadIdx.x == 0) { init2[0] = (double)st->N; init2[1] = st->sum_d2; }
 }
+// [all done without an error ? 1 : 0, status (0 or negative)] of this rank, for the MIN all-reduce that makes the decision to stop -- and an
+// error of ONE rank (a shard whose sums leave the fixed point's range, say) -- common to all ranks: a rank-local decision would leave the
+// others inside a collective
+__global__ void k_split_poll_pack(const FrameDev *__restrict__ frames, double *__restrict__ out2) {
+    const IterState *st = frames[0].st;
+    if (threadIdx.x == 0) { out2[0] = (st->done && st->status == 0) ? 1.0 : 0.0; out2[1] = (double)st->status; }
+}
 __global__ void k_split_set_global_dev(const FrameDev *__restrict__ frames, const double *__restrict__ init2) {
     const FrameDev &f = frames[0];
     IterState *st = f.st;
@@ -1797,6 +1804,10 @@ hipError_t launch_split_dmin_xch(const FrameDev *fd, const FrameDev *fh, double 
 
 hipError_t launch_split_init_pack(const FrameDev *fd, double *init2, hipStream_t s) {
     hipLaunchKernelGGL(k_split_init_pack, dim3(1), dim3(64), 0, s, fd, init2);
+    return hipGetLastError();
+}
+hipError_t launch_split_poll_pack(const FrameDev *fd, double *out2, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_poll_pack, dim3(1), dim3(64), 0, s, fd, out2);
     return hipGetLastError();
 }
 hipError_t launch_split_set_global_dev(const FrameDev *fd, const double *init2, hipStream_t s) {

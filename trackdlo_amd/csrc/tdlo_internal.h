@@ -148,6 +148,7 @@ hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
 hipError_t launch_split_init_pack(const FrameDev *frames_dev, double *init2, hipStream_t s);        // [kept points, sum d2] of the shard -> device buffer (for the all-reduce)
 hipError_t launch_split_set_global_dev(const FrameDev *frames_dev, const double *init2, hipStream_t s);   // ... and back, reduced
+hipError_t launch_split_poll_pack(const FrameDev *frames_dev, double *out2, hipStream_t s);             // [done without error, status] of the shard (for a MIN all-reduce)
 hipError_t launch_xch_init(const FrameDev *frames_dev, hipStream_t s);                             // one-shot exchange of the same two numbers
 hipError_t launch_split_dmin_xch(const FrameDev *frames_dev, const FrameDev *frames_host, double *xch, int import, hipStream_t s);
 hipError_t launch_debug_exp2(const double *x, double *y, int n, hipStream_t s);       // test aid: Num<double>::exp2 on an array

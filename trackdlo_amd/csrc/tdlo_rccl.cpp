@@ -4,12 +4,17 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <mutex>
-#include <rccl/rccl.h>          // compile-time check of the constants and signatures only; nothing links against it
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>          // compile-time check of the constants and signatures only; nothing links against it.  Without the RCCL
+#define TDLO_HAVE_RCCL_H 1      // development headers the library still builds: RCCL is optional at run time, so it is at build time
+#endif
 
 namespace tdlo {
 
+#ifdef TDLO_HAVE_RCCL_H
 static_assert(kNcclFloat64 == (int)ncclFloat64 && kNcclSum == (int)ncclSum && kNcclMin == (int)ncclMin, "rccl.h enum values");
 static_assert(sizeof(RcclApi::UniqueId) == sizeof(ncclUniqueId), "ncclUniqueId");
+#endif
 
 const RcclApi *rccl_api(const char *path_hint, std::string *why) {
     static RcclApi api;

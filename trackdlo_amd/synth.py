@@ -65,6 +65,19 @@ def scene(N: int, M: int, config: int = 0, frame: int = 0, *, noise: float = 0.0
     return np.asfortranarray(X), Y0, vis
 
 
+def scene_range(N: int, M: int, config: int, lo: int, hi: int, chunk: int = 250000, **kw):
+    """Points [lo, hi) of a large cloud that is DEFINED as consecutive chunks of `chunk` points, chunk k = scene(chunk, M, config, frame=k):
+    a rank of the N-split builds only the chunks its shard overlaps (BASELINE configs[3]: 2 000 000 points, 250 000 per rank on 8 GPUs),
+    and every split of the same cloud sees the same points.  Returns (X[lo:hi], Y0)."""
+    parts, Y0 = [], nodes(M)
+    for k in range(lo // chunk, (max(hi, lo + 1) - 1) // chunk + 1):
+        c0 = k * chunk
+        n = min(chunk, N - c0)
+        Xk, _, _ = scene(n, M, config=config, frame=k, **kw)
+        parts.append(Xk[max(lo, c0) - c0: min(hi, c0 + n) - c0])
+    return np.asfortranarray(np.concatenate(parts, axis=0)), Y0
+
+
 def extend_visible(vis: np.ndarray, M: int, coord: np.ndarray, d_vis: float = 0.06) -> np.ndarray:
     """visible_nodes_extended gap fill of the ROS node (trackdlo_node.cpp:350-360): an occluded
     run between two visible nodes is marked visible when its arc length is below d_vis."""
