@@ -900,6 +900,68 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 }
             }
             wave_lds_sync();
+#ifdef TDLO_ESTEP_MFMA_COLSUMS       // (round 3 experiment, measured SLOWER and therefore off: scripts/build_variant.sh mfmacs -DTDLO_ESTEP_MFMA_COLSUMS, scripts/gpu_estep_ab.py)
+            if constexpr (sizeof(T) == 4 && NCH == 1) {
+                // Column sums on the matrix pipe: [P1 | S] (nodes x 4) = P (nodes x 64 points) [inv | inv (x - o)] (64 x 4) is a GEMM whose
+                // reduction dimension is the points -- v_mfma_f32_16x16x4_f32, 16 nodes per tile, K = 4 points per instruction, 16 instructions
+                // per 64-point batch (fp32 products and sums like the vector form; fp32-input MFMA runs at the vector rate, but beside the VALU).
+                // The operands come straight from the tiles already in LDS: A[i][k] = p(node i, point 16 k + q) for instruction q -- lane i + 16 k
+                // reads row i, column 16 k + q of the membership tile (row stride 65: the 64 lanes fall on 64 different banks); B[k][j] = component j
+                // of point 16 k + q (lanes j < 4; zero beyond).  Any assignment of the points to (instruction, k) gives the same sums up to the
+                // order of the fp32 additions; this one is fixed, so a batch's share is the same bits wherever it is computed.  The accumulator is
+                // cleared per batch and converted to fixed point at the grain of one wave x one batch, as before.
+                // RESULT (MI355X, N = 2 000 000, M = 50): E-step 34.6 us against 26.9 us for the vector form below; C2 5.05 against 4.6 us; 32-frame batch
+                // 32.0 against 25.7 us.  Why: fp32-input MFMA has the VECTOR rate on gfx950 (256 flop / clk / CU either way), a 16 x 16 x 4 tile does
+                // 1024 multiply-adds where 8 window nodes x 4 sums x 4 points = 128 are wanted (12 of 16 columns and half the rows are padding), and a wave
+                // issues nothing else while its MFMA runs (scripts/ubench/mfma64.hip) -- 16 x 32 clocks per batch against ~250 for the 32 v_pk_fma of the
+                // vector form.  MFMA pays where the tile is full; here K is the only large dimension.
+                typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+                const int ci = lane & 15, ck = lane >> 4;
+                const T *prow0 = pb + (size_t)rbase * kPStride + 16 * ck;
+                const T *bsrc = (const T *)(pts + wave * kPtsStride + 17 * ck) + (ci < 4 ? ci : 0);
+                const float bmask = ci < 4 ? 1.f : 0.f;
+                for (int s0n = 0; s0n < Wn; s0n += 16) {                     // 16 nodes of the chunk at a time (a converged window: one tile)
+                    // (tile rows behind the chunk's last node belong to nobody: those lanes re-read the last row; their output rows are not looked at)
+                    const T *prow = prow0 + (size_t)((s0n + ci) < Wn ? (s0n + ci) : (Wn - 1)) * kPStride;
+                    // all 32 operand values are requested before the first MFMA (one LDS latency, not sixteen), two accumulators halve the
+                    // chain of dependent MFMAs
+                    float av[16], bv[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { av[q] = (float)prow[q]; bv[q] = (float)bsrc[4 * q]; }
+                    mfma_f4 acc4 = {0.f, 0.f, 0.f, 0.f}, acc4b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q] * bmask, acc4, 0, 0, 0);      // (lanes j >= 4 loaded component 0: the mask zeroes them)
+                        acc4b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q + 1], bv[q + 1] * bmask, acc4b, 0, 0, 0);
+                    }
+                    acc4 += acc4b;
+                    // C[row 4 g + r][column j] in lane j + 16 g, register r: lanes j < 4 hold (w0, sx, sy, sz) of nodes 4 g .. 4 g + 3.
+                    // The four nodes' coordinates are requested together, the four values formed, then the four integer adds.
+                    {
+                        const int i0 = s0n + 4 * ck;                         // first of this lane's four nodes of the chunk
+                        T ymj[4]; float w0f[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int nd = wlo_c + ((i0 + r) < Wn ? (i0 + r) : (Wn - 1));
+                            ymj[r] = ((const T *)(nodesL + nd))[(ci > 0 && ci < 4) ? ci - 1 : 0];
+                            w0f[r] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc4[r]), 0x00, 0xf, 0xf, false));   // quad_perm [0,0,0,0]: column 0 of the row
+                        }
+                        const T oj = ci == 1 ? ox : (ci == 2 ? oy : oz);
+                        const double lim = ci == 0 ? limP : limR, sc = ci == 0 ? scP : scR;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double w0 = (double)w0f[r];
+                            const double v = ci == 0 ? w0 : (double)acc4[r] + ((double)oj - (double)ymj[r]) * w0;
+                            const bool on = ci < 4 && (i0 + r) < Wn;
+                            acc_ok &= !on || __builtin_fabs(v) < lim;
+                            if (on) __hip_atomic_fetch_add(accL + (size_t)(wlo_c + i0 + r) * 4 + ci, acc_fix(v, sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                }
+                wave_lds_sync();
+                continue;
+            }
+#endif
             // (a converged window is 5 to 8 nodes: with 8 lanes per slice a lane sums 8 points instead of 16, and the extra
             // level of the slice reduction is one DPP add per sum)
             const int shift = Wn <= 8 ? 3 : (Wn <= 16 ? 4 : 5);          // wave-uniform
