@@ -215,3 +215,54 @@ def tile_solve(rec, dobs, B, sigma2, n_unknowns):
             acc[p] += lrec[k, i % NS] * x[i]
         x[k] = acc[p]
     return x
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The twisted plan (BandPlan in csrc/tdlo_internal.h): two directions of elimination that meet at a 12-unknown separator.
+def band_plan(M, lds_limit=160 * 1024):
+    """(tw, cT, cB, D, mT, mB, nUp, limT, sT, sB, nRecT, nRecB) exactly as the kernels compute them."""
+    nU = 2 * M
+    tw = 1 if nU >= 38 else 0
+    while True:
+        if not tw:
+            cT, cB, D = (nU + NS - 1) // NS, 0, 0
+        else:
+            q = nU - 12; ch = (q + NS - 1) // NS
+            D = NS * ch - q; cT = (ch + 1) // 2; cB = ch - cT
+        mT, mB, nUp = NS * cT, NS * cB, nU + D
+        limT = mT + 12 if tw else nU
+        sT = NS * (cT + tw); sB = NS * (cB + 1) if tw else 0
+        nRecT = sT + 15; nRecB = sB + 15 if tw else 0
+        lds = (((4 * M + 2 + 1) & ~1) + 32 + (2 if tw else 1) * (16 * 28 + 64 + 16 * 28) + 16 * (nRecT + nRecB) + (512 if tw else 0)) * 8
+        if not tw or lds <= lds_limit:
+            break
+        tw = 0
+    return dict(tw=tw, cT=cT, cB=cB, D=D, mT=mT, mB=mB, nUp=nUp, limT=limT, sT=sT, sB=sB, nRecT=nRecT, nRecB=nRecB, lds_bytes=lds)
+
+
+def twisted_solve(A, R, mT):
+    """L D L^T of the banded SPD system from both ends: unknowns 0 .. mT-1 are eliminated forwards, unknowns n-1 .. mT+12 backwards; both
+    leave their Schur complements on the 12 unknowns in between (half-bandwidth 12: nothing else couples the two sides), those are
+    solved, and each side is back-substituted on its own -- the arithmetic of the two waves of k_mstep_band."""
+    A = A.copy(); Y = R.copy()
+    n = len(A)
+    sep = list(range(mT, mT + HB))
+    top = list(range(0, mT)); bot = list(range(n - 1, mT + HB - 1, -1))
+    rec = {}
+    for order in (top, bot):
+        step = 1 if order is top else -1
+        for k in order:
+            r = 1.0 / A[k, k]
+            nb = [k + step * j for j in range(1, WIN) if 0 <= k + step * j < n]
+            nb = [i for i in nb if (i > k if step > 0 else i < k)]
+            l = A[k, nb] * r
+            rec[k] = (nb, l.copy(), r)
+            A[np.ix_(nb, nb)] -= np.outer(l, A[k, nb])
+            Y[nb] -= np.outer(l, Y[k])
+    X = np.zeros_like(Y)
+    X[sep] = np.linalg.solve(A[np.ix_(sep, sep)], Y[sep])
+    for order in (top[::-1], bot[::-1]):
+        for k in order:
+            nb, l, r = rec[k]
+            X[k] = Y[k] * r - l @ X[nb]
+    return X

@@ -72,6 +72,30 @@ def test_tile_data_flow_is_the_band_elimination(oracle, M):
     assert np.abs(x[0::2] - V).max() <= 1e-15
 
 
+@pytest.mark.parametrize("M", [19, 20, 30, 45, 50, 128, 300, 448, 512])
+def test_twisted_plan_and_its_arithmetic(oracle, M):
+    """BandPlan (csrc/tdlo_internal.h), restated: both directions eliminate whole chunks of 13 unknowns, the 12 unknowns between them are
+    exactly the separator, the dummy unknowns of the tail direction number fewer than 13, the records fit the LDS (else one direction) -- and
+    eliminating from both ends with the Schur complements merged on the separator IS the banded solve."""
+    bp = bn.band_plan(M)
+    nU = 2 * M
+    if bp["tw"]:
+        assert bp["mT"] % 13 == 0 and bp["mB"] % 13 == 0 and 0 <= bp["D"] < 13
+        assert bp["mT"] + 12 + bp["mB"] == nU + bp["D"] == bp["nUp"] and abs(bp["cT"] - bp["cB"]) <= 1
+        assert bp["lds_bytes"] <= 160 * 1024
+    else:
+        assert bp["cB"] == 0 and bp["limT"] == nU and bp["sT"] >= nU
+    assert (M >= 19) == bool(bp["tw"]) or M > 448          # two directions from 19 nodes on, one again where the records would not fit twice
+    if M > 128:
+        return
+    sigma2 = 1e-5
+    coord, H, p, B, c, g = _system(oracle, M, sigma2, 9, 0.002)
+    A, R = bn.assemble(coord, 3.0, c, p, g, bn.lle_band(H, M), B)
+    X1, _ = bn.band_ldlt_solve(A, R)
+    X2 = bn.twisted_solve(A, R, bp["mT"] if bp["tw"] else 2 * M - 12)
+    assert np.abs(X1[0::2] - X2[0::2]).max() <= 1e-14
+
+
 def test_short_gaps_bound_of_prepare_frame(oracle):
     """K contains Q^-1 ~ 1 / h^3: the banded form degrades as two nodes approach each other.  At the bound prepare_frame applies
     (1 mm with beta 3, lambda 1) it is still at 1e-12 m; one decade below it is not better than the dense solve any more."""
