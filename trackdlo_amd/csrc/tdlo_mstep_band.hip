@@ -48,6 +48,7 @@
 #include <type_traits>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 namespace tdlo {
 extern thread_local hipEvent_t g_mstep_ev[2];       // tdlo_device.hip: start/stop events for the M-step dispatch (tdlo_profile_iteration)
@@ -458,7 +459,7 @@ hipError_t launch_mstep_band(const FrameDev *fd, const FrameDev *fh, int F, int 
 // Which M-step serves registrations WITH the LLE term: 0 the banded L D L^T (default, where prepare_frame finds the chain and H
 // suitable), 1 the dense pivoted eliminations, kept as comparators.  Read when a frame is prepared (FrameDev::lle_band); initial
 // value from TDLO_MSTEP_LLE=dense.
-static std::atomic<int> g_lle_dense{[] { const char *e = getenv("TDLO_MSTEP_LLE"); return (e && e[0] == 'd') ? 1 : 0; }()};
+static std::atomic<int> g_lle_dense{[] { const char *e = getenv("TDLO_MSTEP_LLE"); return (e && (strstr(e, "dense") || strstr(e, "1wg"))) ? 1 : 0; }()};    // ("1wg": the one-workgroup dense kernel, a comparator of the multi-workgroup one)
 bool mstep_band_enabled() { return g_lle_dense.load(std::memory_order_relaxed) == 0; }
 int mstep_set_lle_dense(int on) { return g_lle_dense.exchange(on ? 1 : 0); }
 

@@ -29,6 +29,7 @@
 #include "tdlo_mstep_generic.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_ext.h>
 
 namespace tdlo {
@@ -1046,7 +1047,7 @@ static bool mcu_enabled() {
 // M-step with the LLE term beyond kLdsSolveMaxM nodes: rows over the CUs, pivot search across the workgroups.
 // TDLO_MSTEP_LLE=1wg keeps the one-workgroup kernel k_mstep (comparator).
 bool mstep_pivot_mcu_enabled() {
-    static const int on = [] { const char *e = getenv("TDLO_MSTEP_LLE"); return (e && e[0] == '1') ? 0 : 1; }();
+    static const int on = [] { const char *e = getenv("TDLO_MSTEP_LLE"); return (e && strstr(e, "1wg")) ? 0 : 1; }();
     return on != 0;
 }
 
