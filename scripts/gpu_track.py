@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trackdlo_amd import binding as B, synth
 P = synth.LAUNCH_PARAMS
-ctx = B.Context(max_points=1 << 16)
+ctx = B.Context(max_points=1 << 16, timing=os.environ.get('TIMING', '1') != '0')      # TIMING=0: without the stream markers behind loop_ms / total_ms (the C API's default)
 N, M = 5000, 45
 X, Y0, _ = synth.scene(N, M, config=2)
 coord = synth.geodesic_coord(Y0)

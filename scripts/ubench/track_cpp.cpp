@@ -1,0 +1,33 @@
+// tracking_step at production size (N = 5000, M = 45) from plain C++ through the C ABI: ms per frame without a Python caller,
+// and a host-side breakdown (set TDLO_TRACK_PROFILE=1 in the library for its own stage timers).
+// build: g++ -O2 -std=c++17 scripts/ubench/track_cpp.cpp -o scripts/ubench/track_cpp -Ltrackdlo_amd -ltrackdlo_hip -Wl,-rpath,$PWD/trackdlo_amd
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "../../include/trackdlo_hip.h"
+static unsigned long long rs = 88172645463325252ull;
+static double ur() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (rs >> 11) * (1.0 / 9007199254740992.0); }
+static double nr() { return std::sqrt(-2 * std::log(ur() + 1e-300)) * std::cos(6.283185307179586 * ur()); }
+int main() {
+    const int M = 45, N = 5000;
+    std::vector<double> Y0(3 * M), X(3 * (size_t)N), coord(M);
+    for (int m = 0; m < M; ++m) { const double s = m / (double)(M - 1); Y0[m] = 0.88 * (s - 0.5); Y0[M + m] = 0.08 * std::sin(6.283185307179586 * s); Y0[2 * M + m] = 0.6 + 0.03 * std::cos(9.42477796076938 * s); }
+    coord[0] = 0; for (int i = 1; i < M; ++i) { double d2 = 0; for (int d = 0; d < 3; ++d) { const double e = Y0[d * M + i] - Y0[d * M + i - 1]; d2 += e * e; } coord[i] = coord[i - 1] + std::sqrt(d2); }
+    for (int n = 0; n < N; ++n) { const int i = (int)(ur() * (M - 1)); const double t = ur(); for (int d = 0; d < 3; ++d) X[(size_t)d * N + n] = (double)(float)((1 - t) * Y0[d * M + i] + t * Y0[d * M + i + 1] + 0.002 * nr() + (d == 1 ? 0.005 : 0.0)); }
+    tdlo_config cfg{}; tdlo_default_config(&cfg); cfg.max_points = 1 << 16; cfg.max_nodes = 64;
+    int err = 0; tdlo_ctx *ctx = tdlo_create(&cfg, &err);
+    if (!ctx) { std::printf("tdlo_create -> %d\n", err); return 1; }
+    tdlo_tracker *t = tdlo_tracker_create(ctx, 0, M, 0.008, 0.35, 50000, 3, 50, 0.1, 50, 0.0002, 3.0, 1.0, 10.0);
+    tdlo_tracker_initialize_nodes(t, Y0.data()); tdlo_tracker_initialize_geodesic_coord(t, coord.data(), M);
+    std::vector<int> vis(M); for (int i = 0; i < M; ++i) vis[i] = i;
+    tdlo_stats st[2];
+    for (int r = 0; r < 20; ++r) if (tdlo_tracker_tracking_step(t, X.data(), N, vis.data(), M, vis.data(), M, nullptr, st)) { std::printf("FAIL %s\n", tdlo_last_error(ctx)); return 1; }
+    const int R = 2000;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < R; ++r) tdlo_tracker_tracking_step(t, X.data(), N, vis.data(), M, vis.data(), M, nullptr, st);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / R;
+    std::printf("C++ caller: tracking_step N=%d M=%d: %.4f ms/frame (pre %d it host %.3f ms, main %d it host %.3f ms)\n", N, M, ms, st[0].iters, st[0].host_ms, st[1].iters, st[1].host_ms);
+    tdlo_tracker_destroy(t); tdlo_destroy(ctx);
+    return 0;
+}

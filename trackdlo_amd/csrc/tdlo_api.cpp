@@ -181,11 +181,12 @@ int fail(tdlo_ctx *c, int code, const std::string &msg) {
             return fail((c), TDLO_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
-// Waits for the stream like hipStreamSynchronize, but polls hipStreamQuery for the first few hundred microseconds: the blocking wait wakes
-// the host thread through an interrupt, 20 - 40 us after the work has finished -- as long as the whole GPU side of a production-size
-// registration (N = 5 000, M = 45: prune + setup + one or two iterations).  Longer calls fall back on the blocking wait.  TDLO_SPIN_US=0 disables.
+// Waits for the stream.  TDLO_SPIN_US=n polls hipStreamQuery for the first n microseconds before it blocks.  Measured on the production-size
+// tracking_step (N = 5 000, M = 45; scripts/ubench/track_cpp.cpp, scripts/gpu_track.py): with the stream markers of tdlo_set_timing on, the
+// blocking wait wakes up late and polling helps (0.189 -> 0.178 ms per frame); WITHOUT them -- the C API's default -- hipStreamSynchronize is the
+// faster one (C++ caller 0.129 against 0.143 ms per frame: the runtime spins by itself, and hipStreamQuery is the more expensive call).  Default: off.
 hipError_t wait_stream(hipStream_t s) {
-    static const int spin_us = getenv("TDLO_SPIN_US") ? atoi(getenv("TDLO_SPIN_US")) : 400;
+    static const int spin_us = getenv("TDLO_SPIN_US") ? atoi(getenv("TDLO_SPIN_US")) : 0;
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
