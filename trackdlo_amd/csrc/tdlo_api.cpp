@@ -369,11 +369,11 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (s.hist) hipFree(s.hist);
             s.hist = nullptr; s.hist_ints = 0;
-            HIPCHK(c, hipMalloc((void **)&s.hist, need * sizeof(int)));
+            HIPCHK(c, hipMalloc((void **)&s.hist, 2 * need * sizeof(int)));       // counts | start offsets
             s.hist_ints = need;
         }
     }
-    f.Xraw = s.Xraw; f.Xs = s.Xs; f.bucket = s.bucket; f.hist = s.hist; f.blksum = s.blksum;
+    f.Xraw = s.Xraw; f.Xs = s.Xs; f.bucket = s.bucket; f.hist = s.hist; f.hist_off = s.hist + (size_t)f.nprune_blocks * M; f.blksum = s.blksum;
     f.keep = s.blksum + (size_t)s.cap_points / kBlock + 1;
     static const bool reuse_on = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);
     f.reuse_sorted = (reuse_on && s.sorted_valid && s.sorted_prec == p->precision && s.sorted_Y.size() == 3 * (size_t)M &&

@@ -158,13 +158,17 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 // which is associative: the totals depend neither on the order in which workgroups arrive nor on how the batches are dealt out to waves
 // and workgroups.  Batches, repetitions and any launch geometry give the same bits; and the M-step fetches kAccRows short rows instead
 // of one row per workgroup (98 rows = 80 KB through one CU took 3 us at N = 50 000; 512 rows needed a reduction kernel of their own).
-// Resolution 2^-sh: sh is chosen per quantity from the cloud size and the extent of the scene so that totals stay below 2^62 and a
-// batch's share below 2^51 (prepare_frame); at N = 50 000 that is 6e-14 on P1 ~ 1000 -- finer than the fp32 rows it replaces by
-// seven decimal digits, and at the level of fp64 rounding.
+// Resolution 2^-sh: sh is chosen per quantity from the cloud size and an ASSUMED extent D of the scene so that totals stay below 2^62 and a
+// batch's share below 2^51 (prepare_frame): shP = min(60 - ceil(log2 N), 44) for P1, shP - ld for R, shP - 2 ld for Q, 2^ld >= D.  At
+// N = 50 000 that is 6e-14 on P1 ~ 1000 -- finer than the fp32 rows it replaces by seven decimal digits.  It is NOT uniformly "fp64 level":
+// at N = 2 000 000 shP falls to 39 and Q, with 2 ld bits less, resolves ~2^-35 m^2 -- about fp32-level relative accuracy once sigma2 is
+// small.  That is ample for what Q feeds (sigma2, gated at 1e-3 relative in fp32 mode, 1e-7 in fp64 mode at the sizes the gates are tested
+// on); a caller who needs more at multi-million-point clouds splits the cloud (the shards' exponents follow their own N).
+// The extent is a heuristic: every converted value is therefore CHECKED against FrameDev::acc_lim in the E-step (exact conversion below 2^51,
+// totals below 2^62, NaN fails the comparison) and a violation ends the registration with TDLO_E_NUMERIC -- never a wrapped-around integer.
 __host__ __device__ inline int acc_stride(int M) { return 4 * M + 2; }
 __device__ __forceinline__ int acc_shift(const FrameDev &f, int i) { const int M = f.M; return i < M ? f.acc_sh[0] : (i < 4 * M ? f.acc_sh[1] : f.acc_sh[2]); }
-// double -> fixed point, round to nearest, |v * 2^sh| < 2^51 (guaranteed for one wave's share of one 64-point batch by the exponents
-// prepare_frame chooses): the sum v * 2^sh + 1.5 * 2^52 has unit spacing, so its low mantissa bits ARE the integer -- one FMA and
+// double -> fixed point, round to nearest, |v * 2^sh| < 2^51 (checked by the caller against FrameDev::acc_lim): the sum v * 2^sh + 1.5 * 2^52 has unit spacing, so its low mantissa bits ARE the integer -- one FMA and
 // one 64-bit subtraction instead of the ~12 instructions of a double -> int64 conversion
 __device__ __forceinline__ double acc_scale(int sh) { return __hiloint2double((1023 + sh) << 20, 0); }
 __device__ __forceinline__ long long acc_fix(double v, double scale) {

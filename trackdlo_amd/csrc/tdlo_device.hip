@@ -82,6 +82,12 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     __shared__ int sN;
     __shared__ double sS;
     const int t = threadIdx.x, M = f.M;
+#ifdef TDLO_CHAIN_STAMPS      // phase stamps of the setup kernel (instrumented build only): f.dbg[16 ..]
+#define SSTAMP(i) do { if (t == 0) f.dbg[16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+    SSTAMP(0);
     // counting sort by nearest node: hist[block][node] -> start offset of that (node, block) run.
     // 256 threads = 64 nodes x 4 chunks of blocks; per node an exclusive scan over the blocks in block order.
     const int nb = f.nprune_blocks;
@@ -98,22 +104,36 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     const bool reuse = f.reuse_sorted != 0 && !split_mode;      // the sorted cloud of the previous registration serves: no counts to scan
     if (!reuse) {
     {
-        const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);       // (global address space and 16 independent loads per trip:
-        for (int mg = 0; mg < M; mg += 64) {                  //  a load-add chain over ~50 blocks costs a memory latency each)
-            const int m = mg + ml;
-            const int mc = m < M ? m : M - 1;
-            int run = 0;
-            for (int b = cb0; b < cb1; b += 16) {
-                int v[16];
+        // (global address space and 16 independent loads per trip: a load-add chain over ~50 blocks costs a memory latency each.  Chains beyond
+        //  64 nodes: the loads of ALL node groups of a block chunk are requested together -- 782 blocks x 300 nodes at C5 took 5 groups x 13
+        //  dependent trips per pass)
+        const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);
+        auto pass1 = [&](auto NGc, auto Uc) __attribute__((always_inline)) {
+            constexpr int NG = decltype(NGc)::value, U = decltype(Uc)::value;
+            int run[NG];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + mc];
+            for (int g = 0; g < NG; ++g) run[g] = 0;
+            for (int b = cb0; b < cb1; b += U) {
+                int v[NG][U];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) if (b + u < cb1) run += v[u];
+                for (int g = 0; g < NG; ++g) {
+                    const int m = 64 * g + ml, mc = m < M ? m : M - 1;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v[g][u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + mc];
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) if (b + u < cb1) run[g] += v[g][u];
             }
-            if (cb1 <= cb0 || m >= M) run = 0;
-            csum[mg >> 6][ch][ml] = run;
-        }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) if (64 * g < M) csum[g][ch][ml] = (cb1 <= cb0 || 64 * g + ml >= M) ? 0 : run[g];
+        };
+        if (M <= 64) pass1(std::integral_constant<int, 1>(), std::integral_constant<int, 16>());
+        else if (M <= 256) pass1(std::integral_constant<int, 4>(), std::integral_constant<int, 8>());
+        else pass1(std::integral_constant<int, 8>(), std::integral_constant<int, 8>());
     }
+    SSTAMP(1);
     {
         const int per = (nb + kBlock - 1) / kBlock;
         const int b0 = min(nb, t * per), b1 = min(nb, b0 + per);
@@ -123,44 +143,77 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     }
     }
     __syncthreads();
-    // the two serial sums on two waves: first index of every node's run (thread 0), the sigma2 initialisation sum in its fixed order (thread 64)
-    if (t == 0 && !reuse) {
-        int run = 0;
-        for (int m = 0; m < M; ++m) { const int g = m >> 6, l = m & 63; const int v = (csum[g][0][l] + csum[g][1][l]) + (csum[g][2][l] + csum[g][3][l]); stot[m] = run; run += v; }
-        sN = run;
-    }
-    if (t == 64 && !reuse) {
-        double tot = 0;
-        for (int i = 0; i < kBlock; ++i) tot += sd[i];
-        sS = tot;
+    // first index of every node's run: exclusive prefix sum of the per-node totals (integers: any order of the additions gives the same
+    // result) -- two nodes per thread, a shuffle scan inside the waves, the waves' totals through LDS; and the sigma2 initialisation sum in a
+    // FIXED order: every wave's 64 partial sums by the butterfly of wave_sum, the four waves' sums left to right.  (Round 2 had thread 0 walk the
+    // M nodes and thread 64 add 256 numbers one after the other: 6000 clocks = 2.5 us of every call.)
+    if (!reuse) {
+        const int m0 = 2 * t, m1 = 2 * t + 1;
+        auto tot_of = [&](int m) __attribute__((always_inline)) { const int g = m >> 6, l = m & 63; return m < M ? (csum[g][0][l] + csum[g][1][l]) + (csum[g][2][l] + csum[g][3][l]) : 0; };
+        const int v0 = tot_of(m0), v1 = tot_of(m1);
+        int incl = v0 + v1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((t & 63) >= d) incl += o; }
+        __shared__ int wtot[4];
+        if ((t & 63) == 63) wtot[t >> 6] = incl;
+        const double ssum = wave_sum(sd[t]);
+        __shared__ double wsd[4];
+        if ((t & 63) == 0) wsd[t >> 6] = ssum;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (t >> 6); ++w) base += wtot[w];
+        const int excl = base + incl - (v0 + v1);
+        if (m0 < M) stot[m0] = excl;
+        if (m1 < M) stot[m1] = excl + v0;
+        if (t == 0) { sN = wtot[0] + wtot[1] + wtot[2] + wtot[3]; sS = ((wsd[0] + wsd[1]) + wsd[2]) + wsd[3]; }
     }
     if (t == 0 && reuse) { sN = (int)f.keep[0]; sS = f.keep[1]; }
     __syncthreads();
+    SSTAMP(2);
     if (!reuse) {
         // second pass over the counts: (node, block) count -> where that run starts = node's first index + the earlier quarters + the
-        // earlier blocks of this quarter, written in place (one pass instead of a scan within the node plus a pass adding the node's base)
-        const auto hg = TDLO_AS_GLOBAL_RW(int, f.hist);
-        for (int mg = 0; mg < M; mg += 64) {
-            const int m = mg + ml;
-            if (m < M) {
-                int r2 = stot[m];
-                for (int c2 = 0; c2 < ch; ++c2) r2 += csum[mg >> 6][c2][ml];
-                for (int b = cb0; b < cb1; b += 16) {
-                    int v[16];
+        // earlier blocks of this quarter, written to hist_off (NOT in place: behind stores into the array it reads, every trip's loads
+        // waited for the previous trip's stores -- 1.7 us per trip against 0.7 us in the first pass)
+        const auto hg = TDLO_AS_GLOBAL(int, f.hist);
+        const auto ho = TDLO_AS_GLOBAL_RW(int, f.hist_off);
+        auto pass2 = [&](auto NGc, auto Uc) __attribute__((always_inline)) {
+            constexpr int NG = decltype(NGc)::value, U = decltype(Uc)::value;
+            int r2[NG];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + m];
+            for (int g = 0; g < NG; ++g) {
+                const int m = 64 * g + ml;
+                r2[g] = m < M ? stot[m] : 0;
+                for (int c2 = 0; c2 < ch; ++c2) r2[g] += (64 * g < M) ? csum[g][c2][ml] : 0;
+            }
+            for (int b = cb0; b < cb1; b += U) {
+                int v[NG][U];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) if (b + u < cb1) { hg[(size_t)(b + u) * M + m] = r2; r2 += v[u]; }
+                for (int g = 0; g < NG; ++g) {
+                    const int m = 64 * g + ml, mc = m < M ? m : M - 1;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v[g][u] = hg[(size_t)(b + u < cb1 ? b + u : cb1 - 1) * M + mc];
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int m = 64 * g + ml;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) if (b + u < cb1 && m < M) { ho[(size_t)(b + u) * M + m] = r2[g]; r2[g] += v[g][u]; }
                 }
             }
-        }
+        };
+        if (M <= 64) pass2(std::integral_constant<int, 1>(), std::integral_constant<int, 16>());
+        else if (M <= 256) pass2(std::integral_constant<int, 4>(), std::integral_constant<int, 8>());
+        else pass2(std::integral_constant<int, 8>(), std::integral_constant<int, 8>());
     }
+    SSTAMP(3);
     // centring offset, chain coordinate: the node block is staged in LDS first -- the serial sums below (same
     // left-to-right order as the reference) would otherwise pay a global-memory round trip per term
-    if (t < 3) {
+    if (t < 192) {          // centring offset = centroid of the nodes: wave w sums coordinate w (lane l the nodes l, l + 64, ...; then the butterfly of wave_sum: a fixed order)
+        const int d = t >> 6, l = t & 63;
         double a = 0;
-        for (int m = 0; m < M; ++m) a += sY[t * M + m];
-        sctr[t] = a / M; f.ctr[t] = a / M;
+        for (int m = l; m < M; m += 64) a += sY[d * M + m];
+        a = wave_sum(a);
+        if (l == 0) { sctr[d] = a / M; f.ctr[d] = a / M; }
     }
     for (int i = t; i < M - 1; i += kBlock) {
         const double dx = sY[i + 1] - sY[i], dy = sY[M + i + 1] - sY[M + i], dz = sY[2 * M + i + 1] - sY[2 * M + i];
@@ -171,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         double cur = 0; sc[0] = 0;
         for (int i = 0; i < M - 1; ++i) { cur += sc[i + 1]; sc[i + 1] = cur; }
     }
+    SSTAMP(4);
     for (int i = t; i < 3 * M; i += kBlock) { const double v = sY[i] - sctr[i / M]; f.Y[i] = v; f.Y0[i] = v; f.Yout[i] = sY[i]; }
     __syncthreads();
     V4<T> *nodes = (V4<T> *)f.nodes;
@@ -190,6 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
 #pragma unroll
         for (int q = 0; q < 8; ++q) f.chain[8 * (size_t)i + q] = o[q];
     }
+    SSTAMP(5);
     if (f.need_G) {         // the dense M-steps only (LLE term, comparators): the chain smoother works from the links above
         const auto Gw = TDLO_AS_GLOBAL_RW(double, f.G);
         for (int j = t >> 6; j < M; j += kBlock / 64)
@@ -209,6 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         // R x R of the 12 unknowns between the two sides (it belongs to direction 0's records).  Unknowns that do not exist (padding,
         // the other side's, the columns entering behind the last pivot) are identity records.
         const auto Hg = TDLO_AS_GLOBAL(double, f.H);
+        const auto lk = TDLO_AS_GLOBAL(double, f.chain);
         const BandPlan bp(M);
         const double lam = f.lambda, gam = f.lle_weight;
         for (int jj = t; jj < bp.nRecT + bp.nRecB; jj += kBlock) {
@@ -228,7 +284,8 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
             if (b == 0) { const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta); kd0 = 1.0 / sf2; kd1 = 0.0; kd2 = 1.0 / (s * s * sf2); }
             else {
                 double L[8];
-                chain_link(beta, sc[b] - sc[b - 1], L);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) L[q] = lk[8 * (size_t)b + q];          // link b, formed a phase ago by thread b (behind the barrier above)
                 const double rdet = 1.0 / (L[4] * L[6] - L[5] * L[5]);
                 const double qa = L[6] * rdet, qb = -L[5] * rdet, qd = L[4] * rdet;                  // Q^-1
                 kd0 = qa; kd1 = qb; kd2 = qd;
@@ -237,7 +294,8 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
             }
             if (b + 1 < M) {
                 double L[8];
-                chain_link(beta, sc[b + 1] - sc[b], L);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) L[q] = lk[8 * (size_t)(b + 1) + q];
                 const double rdet = 1.0 / (L[4] * L[6] - L[5] * L[5]);
                 const double qa = L[6] * rdet, qb = -L[5] * rdet, qd = L[4] * rdet;
                 const double t11 = qa * L[0] + qb * L[2], t12 = qa * L[1] + qb * L[3], t21 = qb * L[0] + qd * L[2], t22 = qb * L[1] + qd * L[3];
@@ -303,6 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
             f.HY0[e] = a;
         }
     }
+    SSTAMP(6);
     if (t == 0) {
         const int N = sN;
         if (!reuse && !split_mode) { f.keep[0] = (double)N; f.keep[1] = sS; }
@@ -329,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_prune_scatter(const FrameDev *__rest
     const int M = f.M;
     int *base = wcnt + 4 * M;                         // M: where this workgroup's next point of a node goes
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int m = threadIdx.x; m < M; m += kBlock) base[m] = f.hist[(size_t)blockIdx.x * M + m];
+    for (int m = threadIdx.x; m < M; m += kBlock) base[m] = f.hist_off[(size_t)blockIdx.x * M + m];
     for (int tt = 0; tt < f.prune_tiles; ++tt) {          // the workgroup's tiles in order: the sort stays stable
         const int n = (blockIdx.x * f.prune_tiles + tt) * kBlock + threadIdx.x;
         for (int i = threadIdx.x; i < 4 * M; i += kBlock) wcnt[i] = 0;

@@ -47,7 +47,9 @@ struct FrameDev {
     const double *Xraw;     // N0 x 3 column-major as uploaded
     void *Xs;               // pruned, centred SoA in compute precision: x[ldx] y[ldx] z[ldx]
     unsigned short *bucket; // N0: nearest node of a kept point, 0xffff = pruned
-    int *hist;              // nprune_blocks x M: kept points per (block, nearest node) -> start offsets after setup
+    int *hist;              // nprune_blocks x M: kept points per (block, nearest node), written by k_prune_pass1
+    int *hist_off;          // nprune_blocks x M: where each (block, node) run starts in the sorted cloud, written by k_setup (a separate array: the
+                            // scan's loads need not wait for its own stores), read by k_prune_scatter
     double *blksum;         // per prune block sum of d2 over kept points
     // nodes
     const double *Yin;      // M x 3 as given by the caller
