@@ -25,7 +25,7 @@ namespace {
 
 #define TDLO_RET(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-constexpr int kMaxEstepBlocks = 1024;
+constexpr int kMaxEstepBlocks = 4096;      // (upper bound of TDLO_ESTEP_BLOCKS / tdlo_config.estep_blocks; the defaults are 512 and 1024)
 constexpr int kBatchStreams = 4;       // streams a batch of frames is spread over (run_frames); more than 4 lose (measured: 6 or 8 fall below one stream)
 constexpr int kChunkIters = 4;          // EM iterations per early-exit polling chunk; the first chunks are shorter (1, 1, 2):
                                         // a tracker in steady state converges in one or two iterations
@@ -337,7 +337,8 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     // workgroup).  A larger cloud is VALU-bound instead: it takes the 24-row tile of the batch path (more workgroups per CU hide the
     // LDS / scalar-load latencies: 47 -> 36 us at N = 2 000 000).  Batches (run_frames, F > 1) always use the small tile.
     f.wide_tile = (M > kChunk || nbatch < 4096) ? 1 : 0;
-    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : (f.wide_tile ? 512 : 1024);
+    // (fp32, chains up to 64 nodes, a cloud that fills the GPU: 2048 workgroups of the 16-row tile -- 26.5 against 27.9 us per E-step at N = 2 000 000)
+    int cap = c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : (f.wide_tile ? 512 : ((M <= kChunk && p->precision == TDLO_PREC_F32) ? 2048 : 1024));
     // (more than 64 nodes: the 24-row tile lets two fp64 workgroups share a CU -- C5: 512 workgroups 21.4 us per converged E-step and 69.7 us per
     //  iteration over a whole call, against 28.4 / 86.3 with 256 workgroups of the former 64-row tile, which filled a CU's LDS alone)
     { static const int cap_env = getenv("TDLO_ESTEP_BLOCKS") ? atoi(getenv("TDLO_ESTEP_BLOCKS")) : 0; if (cap_env > 0) cap = cap_env; }

@@ -702,8 +702,9 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     // small tile (two workgroups per CU) and recompute the memberships of the later chunks of a wide window.  Chains beyond 64 nodes use the
     // small tile as well: their windows are far wider than any tile (most chunks are recomputed either way), and the 64-row tile of an
     // fp64 workgroup is 133 KB -- one workgroup per CU, one wave per SIMD, every dependent instruction a stall
-    constexpr int RT = (NCH == 1 && SINGLE) ? kChunk : kTileRows;
-    constexpr int RS = (RT / kTileRows) * kTileRows;       // stored rows: whole chunks only (48 of 64, 24 of 24)
+    constexpr int TR = tile_rows<T>(NCH);
+    constexpr int RT = (NCH == 1 && SINGLE) ? kChunk : TR;
+    constexpr int RS = (RT / TR) * TR;                     // stored rows: whole chunks only
     const int rows = M < RT ? M : RT;
     // LDS carve (every offset a multiple of 16 bytes)
     V4<T> *nodesL = (V4<T> *)smem;                                    // M
@@ -944,8 +945,8 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             // take several.  With the small batch tile the memberships of the later chunks are recomputed (same
             // expression, same bits) instead of being kept in a 64-row tile.
             const int Wtot = whi - wlo + 1;
-            for (int c0 = 0; c0 < Wtot; c0 += kTileRows) {
-            const int Wn = (Wtot - c0) < kTileRows ? (Wtot - c0) : kTileRows;
+            for (int c0 = 0; c0 < Wtot; c0 += TR) {
+            const int Wn = (Wtot - c0) < TR ? (Wtot - c0) : TR;
             const int wlo_c = wlo + c0;
             const bool rec = c0 >= RS;                                   // chunk beyond the stored part of the window
             const int rbase = rec ? 0 : c0;                              // first tile row of this chunk
@@ -1712,7 +1713,7 @@ template <typename K> static hipError_t set_lds(K kernel, size_t bytes) {
 #define TDLO_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 template <typename T, int EB> static size_t estep_lds_bytes(int M, bool single) {
-    const int rt = (M <= kChunk && single) ? kChunk : kTileRows;
+    const int rt = (M <= kChunk && single) ? kChunk : tile_rows<T>(M <= kChunk ? 1 : 2);
     const int rows = M < rt ? M : rt;
     constexpr int NWE = EB / 64;
     const size_t tile = sizeof(T) * (((size_t)NWE * rows * kPStride + 7) & ~(size_t)3);
