@@ -30,7 +30,8 @@ Extra objects on the JSON line:
                     (E-step: algorithmic bytes 3 * s * N per launch against 8 TB/s HBM; `algorithmic_valu_ratio` = SURVEY.md 8(d)'s flop
                     count / time / vector peak -- NOT an achieved fraction: the kernel skips the exactly-zero memberships outside a wave's node
                     window; `valu_issue_frac` = VALU instructions actually issued (SQ_INSTS_VALU, a third PMC child pass) x 64 lanes / time /
-                    the lane-issue peak; M-step:
+                    the lane-issue peak (`valu_issue_frac_of_sustained_fma_rate`: against the 53 T lane-instructions/s a full GPU sustains on
+                    v_fma_f32, profiles/r03_valu_rate.txt); M-step:
                     (2/3) M^3 + 14 M^2 flops per launch against the fp64 matrix peak).  Durations are measured live: HIP
                     start/stop events bound to every E-step and M-step dispatch of real iterations on the context's stream
                     (tdlo_profile_iteration).  `traffic` = HBM bytes per launch from the PMC counters, collected by
@@ -79,6 +80,10 @@ LEGS = {
 }
 SUSTAINED_SECONDS = 3.0
 LANE_ISSUE_PEAK = FP32_VECTOR_TFLOPS * 1e12 / 2.0      # lane-instructions per second: one FMA per lane and cycle is two of the peak's flops
+# what a full GPU really issues (scripts/ubench/valu_rate.hip, profiles/r03_valu_rate.txt: 8 waves per SIMD, eight independent chains per
+# wave): v_fma_f32 53 T lane-instructions/s -- the clock falls from 2.4 to ~1.87 GHz under that load --, compares / selects / conversions /
+# DPP / min / max 35-37 T, v_exp / v_rcp / v_sqrt 19 T, and a scalar instruction between two vector ones of a wave costs as much as a vector one
+LANE_ISSUE_SUSTAINED = 53.0e12
 
 
 def _self_launch(args):
@@ -230,6 +235,7 @@ def _apply_live_traffic(live, roof, roof_all):
                 o["valu_insts_per_launch"] = m["valu_insts"]
                 o["valu_issue_frac"] = round(m["valu_insts"] * 64.0 / (o["avg_launch_us"] * 1e-6) / LANE_ISSUE_PEAK, 5)
                 o["valu_issue_frac_source"] = "this run: rocprofv3 --pmc SQ_INSTS_VALU (a third child pass), instructions x 64 lanes / avg_launch_us / (fp32 vector peak / 2)"
+                o["valu_issue_frac_of_sustained_fma_rate"] = round(m["valu_insts"] * 64.0 / (o["avg_launch_us"] * 1e-6) / LANE_ISSUE_SUSTAINED, 5)
 
 
 def main():

@@ -346,6 +346,10 @@ int tdlo_debug_mstep_dense(int on);
  * k_mstep / k_mstep_pivot_mcu), kept as comparators and for everything the banded form does not take.  Returns the previous setting.
  * The initial setting is 1 when the environment holds TDLO_MSTEP_LLE=dense. */
 int tdlo_debug_mstep_lle_dense(int on);
+/* How many calls of this context were repeated on the dense pivoted kernels because the banded L D L^T (which takes no pivots) met a
+ * non-positive pivot or produced a non-finite sigma2: an indefinite H_override, or a chain at the edge of the gap test.  The reference's
+ * solver is a general one (trackdlo.cpp:415); the caller sees the dense kernels' result.  -1 for a null context. */
+long long tdlo_debug_band_retries(tdlo_ctx *ctx);
 /* Whether the registrations of this context record the four stream events behind tdlo_stats.loop_ms / total_ms.  Off by default: the
  * reference has no such figures, and the markers cost about 15 us per call (2 % of a 50-iteration call at N = 50 000).  Returns the
  * previous setting (or TDLO_E_INVALID). */

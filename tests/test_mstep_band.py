@@ -245,3 +245,44 @@ def test_band_mstep_batch_equals_single(oracle):
             assert np.array_equal(np.asarray(out["Y"][fr]), single[fr]["Y"]) and out["stats"][fr]["sigma2"] == single[fr]["sigma2"]
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_band_mstep_hands_an_indefinite_system_to_the_dense_kernels(oracle):
+    """The banded L D L^T takes no pivots.  An H_override that is banded and symmetric but NOT positive semi-definite (here
+    (I - L)^T (I - L) - I with lle_weight 1e7: eigenvalues down to -110, condition number ~100) makes the M-step system indefinite: the reference's general solver
+    (trackdlo.cpp:415) still solves it, so the call is repeated once on the dense pivoted kernels and the caller gets their result --
+    the oracle's, not an error."""
+    from trackdlo_amd import binding as B, synth
+    assert B.mstep_lle_dense(False) is False
+    M, N = 30, 3000
+    X, Y0, _ = synth.scene(N, M, config=480, noise=0.003)
+    L = np.zeros((M, M))
+    for i in range(M):
+        nb = [j for j in range(i - 3, i + 4) if j != i and 0 <= j < M]
+        L[i, nb] = 1.0 / len(nb)
+    IL = np.eye(M) - L
+    kw = _kw(1, lle_weight=1e7)
+    ctx = B.Context(device=0, max_points=N, max_nodes=M)
+    try:
+        # positive semi-definite: the banded solve serves it, no retry
+        H = IL.T @ IL
+        g = ctx.cpd_lle(X, Y0, 2e-5, _params(kw, 1), H=H)
+        o = oracle.cpd_lle(X, Y0, 2e-5, H=H, **kw)
+        assert g["rc"] == 0 and ctx.band_retries() == 0
+        assert np.abs(g["Y"] - o["Y"]).max() <= 1e-9
+        # indefinite: one retry, the dense kernels' result
+        H = IL.T @ IL - np.eye(M)
+        g = ctx.cpd_lle(X, Y0, 2e-5, _params(kw, 1), H=H)
+        o = oracle.cpd_lle(X, Y0, 2e-5, H=H, **kw)
+        assert ctx.band_retries() == 1
+        assert g["rc"] == 0 and g["iters"] == o["iters"] == 1
+        move = np.abs(o["Y"] - Y0).max()
+        assert move > 0.01                                   # (the indefinite system throws the nodes far: that is the reference's behaviour too)
+        assert np.abs(g["Y"] - o["Y"]).max() <= 1e-8 and abs(g["sigma2"] - o["sigma2"]) <= 1e-6 * o["sigma2"]
+        # and the context goes back to the banded solve afterwards
+        H = IL.T @ IL
+        g = ctx.cpd_lle(X, Y0, 2e-5, _params(kw, 1), H=H)
+        assert g["rc"] == 0 and ctx.band_retries() == 1 and ctx.profile_iteration(1)[3] == "k_mstep_band"
+    finally:
+        ctx.close()

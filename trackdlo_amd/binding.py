@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_set_timing", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_set_timing", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -174,6 +174,8 @@ def load_library(path: str | None = None):
     lib.tdlo_debug_mstep_dense.restype = ci
     lib.tdlo_debug_mstep_lle_dense.argtypes = [ci]
     lib.tdlo_debug_mstep_lle_dense.restype = ci
+    lib.tdlo_debug_band_retries.argtypes = [vp]
+    lib.tdlo_debug_band_retries.restype = C.c_longlong
     lib.tdlo_set_timing.argtypes = [vp, ci]
     lib.tdlo_set_timing.restype = ci
     lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
@@ -404,6 +406,10 @@ class Context:
         n = C.c_int(0); me = C.c_int(0)
         self._chk(self.lib.tdlo_rccl_comm_count(C.c_void_p(comm), C.byref(n), C.byref(me)))
         return n.value, me.value
+
+    def band_retries(self):
+        """Calls of this context that were repeated on the dense pivoted kernels after the banded LLE solve gave up (tdlo_debug_band_retries)."""
+        return int(self.lib.tdlo_debug_band_retries(self.h))
 
     def visibility_prepass(self, slot, Y, visibility_threshold, d_vis, geodesic_coord):
         """trackdlo_node.cpp:257-277 + :345-360 (distance test and gap fill; no painter test)."""

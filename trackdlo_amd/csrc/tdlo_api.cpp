@@ -149,6 +149,8 @@ struct tdlo_ctx {
     size_t pin_doubles = 0;
     std::string err;
     int last_F = 0;
+    bool lle_dense_once = false;          // run_frames' retry: the banded LLE solve reported a numeric failure, this call repeats with the dense pivoted kernels
+    long long band_retries = 0;           // how often that happened (tdlo_debug_band_retries)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
     // split-mode scratch
@@ -305,7 +307,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         // the solve's error grows like eps lambda sigma2 K / P1: at h = 1 mm with the pre-processing parameters (beta 3, lambda 1)
         // 1e-13 m, at 0.1 mm 1e-11 m, at 0.01 mm 1e-7 m (scripts/band_gap_study.py); the bound scales with cbrt(lambda beta^4).
         // Everything else (coincident nodes in particular: K is infinite there) keeps the dense pivoted eliminations.
-        if (mstep_band_enabled() && p->lambda > 0 && p->beta > 0) {
+        if (mstep_band_enabled() && !c->lle_dense_once && p->lambda > 0 && p->beta > 0) {
             lle_band = true;
             const double hmin = 1e-3 * std::cbrt(p->lambda * std::pow(p->beta / 3.0, 4));
             for (int i = 0; i + 1 < M && lle_band; ++i) {
@@ -616,6 +618,25 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         HIPCHK(c, wait_stream(s));
     }
     c->last_F = F;
+    // The banded L D L^T takes no pivots: a system that is not positive definite in floating point (an indefinite H_override; a chain the gap
+    // test let through and rounding did not) ends its registration with TDLO_E_NUMERIC.  The reference's solver is a general one
+    // (trackdlo.cpp:415), so the call is repeated once on the dense pivoted kernels -- inputs, Y and sigma2 are untouched so far -- and only
+    // their verdict is reported.
+    if (p->include_lle && c->fh[0].lle_band && !c->lle_dense_once) {
+        bool numeric = false;
+        for (int i = 0; i < F; ++i) {
+            IterState is;
+            std::memcpy(&is, c->pin + (size_t)i * rstride + (nc.st - nc.Yout), sizeof is);
+            numeric = numeric || is.status == TDLO_E_NUMERIC;
+        }
+        if (numeric) {
+            c->lle_dense_once = true;
+            ++c->band_retries;
+            const int rr = run_frames(c, F, slots, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+            c->lle_dense_once = false;
+            return rr;
+        }
+    }
     float loop_ms = 0, total_ms = 0;
     if (timing) { hipEventElapsedTime(&loop_ms, c->ev[1], c->ev[2]); hipEventElapsedTime(&total_ms, c->ev[0], c->ev[3]); }
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
@@ -1540,6 +1561,7 @@ int tdlo_debug_read_cloud(tdlo_ctx *c, int slot, double *out, int max_points, do
 
 int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
+long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
 int tdlo_set_timing(tdlo_ctx *c, int on) {
     if (!c) return TDLO_E_INVALID;
