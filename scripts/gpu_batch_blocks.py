@@ -7,7 +7,7 @@ P = synth.LAUNCH_PARAMS
 F, N, M = 32, 50000, 50
 pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], 50, 0.0, False)
 scenes = [synth.scene(N, M, config=2, frame=f) for f in range(F)]
-for blocks in (0, 80, 66, 49, 40, 33, 25):
+for blocks in (0, 196, 131, 98, 66, 49, 0):
     ctx = B.Context(max_frames=F, max_points=N, max_nodes=M, estep_blocks=blocks)
     for f in range(F): ctx.set_cloud(f, scenes[f][0])
     Ys = [s[1] for s in scenes]

@@ -1186,14 +1186,17 @@ def _hand_offs_under_uneven_load():
             ctx.close()
 
 
+@pytest.mark.parametrize("dense", [True, False], ids=["dense", "band"])
 @pytest.mark.parametrize("M,F", [(129, 3), (200, 9), (300, 5)])
-def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F):
+def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F, dense):
     """k_mstep_pivot_mcu (LLE term, more than 128 nodes: 16 rows per workgroup, pivot search across the workgroups, one
     hand-off per column; back substitution by the finishing workgroup): against the oracle at the stated fp64 tolerance
     (1e-9 m / 1e-7; the oracle's own error on these systems is 1e-11 m, tests/test_solver_error.py) -- and frames registered
-    concurrently / repeatedly must reproduce the single call bit for bit."""
+    concurrently / repeatedly must reproduce the single call bit for bit.  Since round 3 a banded H like this one goes to
+    k_mstep_band by default: the dense kernels are forced for one half of the cases, the banded solve takes the other (same assertions)."""
     from trackdlo_amd import binding as B, synth
     rng = np.random.default_rng(9500 + M)
+    prev_dense = B.mstep_lle_dense(dense)
     ctx = B.Context(device=0, max_frames=F, max_points=1 << 14, max_nodes=M)
     try:
         kw = dict(beta=3.0, lambda_=1.0, lle_weight=10.0, mu=0.1, max_iter=3, tol=0.0, include_lle=True, alpha=0.0, k_vis=0.0, visibility_threshold=0.008)
@@ -1207,6 +1210,7 @@ def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F):
             g = ctx.cpd_lle_resident(f, Y0, 2e-5, pr, H=H)
             single.append(g)
             if f == 0:
+                assert (ctx.profile_iteration(1)[3] == "k_mstep_band") != dense
                 o = oracle.cpd_lle(X, Y0, 2e-5, H=H, **kw)
                 assert g["status"] == 0 and g["iters"] == o["iters"] and g["n_kept"] == o["n_kept"]
                 assert np.abs(g["Y"] - o["Y"]).max() <= TOL[1][0] and abs(g["sigma2"] - o["sigma2"]) <= TOL[1][1] * o["sigma2"]
@@ -1217,6 +1221,7 @@ def test_multi_cu_pivoted_mstep_with_lle(oracle, M, F):
                 assert np.array_equal(out["Y"][f], single[f]["Y"]) and out["sigma2"][f] == single[f]["sigma2"]
     finally:
         ctx.close()
+        B.mstep_lle_dense(prev_dense)
 
 
 _RETRY_SCRIPT = r"""
