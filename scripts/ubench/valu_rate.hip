@@ -44,6 +44,10 @@ constexpr int kIters = 2048;
 #define I_RDL(i)   "v_readlane_b32 s14, %" #i ", 3\n"
 #define I_LOG(i)   "v_log_f32 %" #i ", %" #i "\n"
 #define I_RSQ(i)   "v_rsq_f32 %" #i ", %" #i "\n"
+#define I_ADDS(i)  "v_add_f32 %" #i ", s12, %" #i "\n"
+#define I_CMPS(i)  "v_cmp_lt_f32 vcc, s12, %" #i "\n"
+#define I_MULS(i)  "v_mul_f32 %" #i ", s12, %" #i "\n"
+#define I_FMACS(i) "v_fmac_f32 %" #i ", s12, %8\n"
 
 template <int K> __global__ __launch_bounds__(256) void k32(float* out, float b, float c) {
   float a[8];
@@ -82,6 +86,10 @@ template <int K> __global__ __launch_bounds__(256) void k32(float* out, float b,
     if (K == 30) BODY8(I_RDL);
     if (K == 31) BODY8(I_LOG);
     if (K == 32) BODY8(I_RSQ);
+    if (K == 33) BODY8(I_ADDS);
+    if (K == 34) BODY8(I_CMPS);
+    if (K == 35) BODY8(I_MULS);
+    if (K == 36) BODY8(I_FMACS);
   }
   float s = 0; for (int i = 0; i < 8; ++i) s += a[i];
   if (s == 123.456f) out[0] = s;
@@ -93,6 +101,7 @@ template <int K> __global__ __launch_bounds__(256) void k32(float* out, float b,
 #define D_FMA(i)  "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
 #define D_MUL(i)  "v_mul_f64 %" #i ", %" #i ", %8\n"
 #define D_ADD(i)  "v_add_f64 %" #i ", %" #i ", %8\n"
+#define P_ADDS(i) "v_pk_add_f32 %" #i ", %" #i ", s[12:13]\n"
 template <int K> __global__ __launch_bounds__(256) void k64(double* out, double b, double c) {
   double a[8];
   for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 1e-3 + i;
@@ -103,6 +112,7 @@ template <int K> __global__ __launch_bounds__(256) void k64(double* out, double 
     if (K == 3) BODY8(D_FMA);
     if (K == 4) BODY8(D_MUL);
     if (K == 5) BODY8(D_ADD);
+    if (K == 6) BODY8(P_ADDS);
   }
   double s = 0; for (int i = 0; i < 8; ++i) s += a[i];
   if (s == 123.456) out[0] = s;
@@ -189,8 +199,10 @@ int main(int argc, char** argv) {
   R32(15, "v_mov_b32"); R32(16, "v_and_b32"); R32(17, "v_min_f32"); R32(18, "v_max_u32"); R32(19, "v_add_f32"); R32(20, "v_fmac_f32 (VOP2)");
   R32(21, "v_lshlrev_b32"); R32(22, "v_cvt_f32_u32"); R32(23, "v_mad_u32_u24"); R32(24, "v_mul_f32 with a literal"); R32(25, "v_med3_f32"); R32(26, "v_max3_f32");
   R32(27, "v_bfe_u32"); R32(28, "v_permlane32_swap"); R32(29, "v_mov_b32 DPP quad_perm"); R32(30, "v_readlane_b32"); R32(31, "v_log_f32"); R32(32, "v_rsq_f32");
+  R32(33, "v_add_f32 (VOP2) with an SGPR operand"); R32(35, "v_mul_f32 (VOP2) with an SGPR operand"); R32(36, "v_fmac_f32 (VOP2) with an SGPR operand"); R32(34, "v_cmp_lt_f32 with an SGPR operand");
   R32(3, "v_exp_f32"); R32(4, "v_rcp_f32"); R32(5, "v_sqrt_f32");
   R64(0, "v_pk_fma_f32 (2 fp32 per lane)"); R64(1, "v_pk_mul_f32"); R64(2, "v_pk_add_f32");
+  R64(6, "v_pk_add_f32 with an SGPR pair");
   R64(3, "v_fma_f64"); R64(4, "v_mul_f64"); R64(5, "v_add_f64");
   rep("v_fma_f32 + s_add_u32 alternating", time_ms([&] { hipLaunchKernelGGL(kmix_salu, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 1e-9f); }), 8);
   rep("8 v_fma_f32 + 2 ds_read_b32 (VALU)", time_ms([&] { hipLaunchKernelGGL(kmix_lds, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 1e-9f); }), 10);
