@@ -219,7 +219,7 @@ def tile_solve(rec, dobs, B, sigma2, n_unknowns):
 
 # ------------------------------------------------------------------------------------------------------------------------------
 # The twisted plan (BandPlan in csrc/tdlo_internal.h): two directions of elimination that meet at a 12-unknown separator.
-def band_plan(M, lds_limit=160 * 1024):
+def band_plan(M, lds_limit=160 * 1024 - 1024):
     """(tw, cT, cB, D, mT, mB, nUp, limT, sT, sB, nRecT, nRecB) exactly as the kernels compute them."""
     nU = 2 * M
     tw = 1 if nU >= 38 else 0

@@ -125,7 +125,7 @@ def _params(kw, prec):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [4, 5, 6, 7, 8, 12, 13, 14, 19, 20, 26, 45, 50, 64, 65, 100, 128, 129, 200, 256, 257, 300, 511, 512])
+@pytest.mark.parametrize("M", [4, 5, 6, 7, 8, 12, 13, 14, 19, 20, 26, 45, 50, 64, 65, 100, 128, 129, 200, 256, 257, 300, 448, 470, 477, 481, 482, 511, 512])
 def test_band_mstep_against_oracle_over_chain_lengths(oracle, M):
     """fp64 mode at the stated tolerance (1e-9 m, 1e-7 in sigma2; equal iteration counts), the oracle's own H of :236-237 injected on both
     sides (the LLE weights themselves are not reproducible to the last digits: rank-3 Gram matrices): 2M unknowns in whole and partial chunks

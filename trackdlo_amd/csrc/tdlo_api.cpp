@@ -173,6 +173,9 @@ namespace {
 
 int fail(tdlo_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
+    // a refused launch or attribute leaves HIP's per-thread "last error" set; the launchers of the NEXT call read it after their own
+    // (successful) launches and would report this call's failure a second time
+    if (code == TDLO_E_HIP) (void)hipGetLastError();
     return code;
 }
 

@@ -114,6 +114,9 @@ __host__ __device__ inline size_t xch_words(int R, int Mc) { return xch_off_sums
 // complements, and BOTH waves finish with them (one more chunk each) -- no hand-over of results, each wave back-substitutes
 // its own side.  A direction's records: one per step (+ 15: the columns entering behind the last pivot, and the requests two steps ahead).
 constexpr int kBandSlots = 13;
+// dynamic LDS k_mstep_band may ask for: the CU's 160 KB less 1 KB for the kernel's own static allocations (256 bytes today: a plan that
+// used the last kilobyte -- chains of 477 .. 481 nodes -- was refused at launch with hipErrorInvalidValue)
+constexpr size_t kBandLdsLimit = 160 * 1024 - 1024;
 struct BandPlan {
     int nU, tw, cT, cB, D, mT, mB, nUp, limT, sT, sB, nRecT, nRecB;
     __host__ __device__ explicit BandPlan(int M, int allow_twisted = 1) {
@@ -126,7 +129,7 @@ struct BandPlan {
             limT = tw ? mT + 12 : nU;                                   // top's records below limT are real columns, identity from there on
             sT = kBandSlots * (cT + tw); sB = tw ? kBandSlots * (cB + 1) : 0;
             nRecT = sT + 15; nRecB = tw ? sB + 15 : 0;
-            if (!tw || lds_doubles(M) * 8 <= 160 * 1024) break;
+            if (!tw || lds_doubles(M) * 8 <= kBandLdsLimit) break;
             tw = 0;                                                     // both directions' records do not fit the LDS: one direction
         }
     }
