@@ -91,14 +91,23 @@ sys.path.insert(0, sys.argv[1])
 from trackdlo_amd import binding as B, synth
 P = synth.LAUNCH_PARAMS
 res = {}
-for ci, (R, N, M, cfg, vis_on, tol, prec, max_iter, empty_first) in enumerate(eval(sys.argv[3])):
+for ci, case in enumerate(eval(sys.argv[3])):
+    R, N, M, cfg, vis_on, tol, prec, max_iter, empty_first = case[:9]
+    lle = len(case) > 9 and case[9]                            # the pre-processing registration's parameters and the library's own H
     X, Y0, v = synth.scene(N, M, config=cfg, occlude=(0.4, 0.6) if vis_on else None, outliers=9)
     vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0)) if vis_on else None
     n = X.shape[0]                                             # (the occlusion removes points)
     if empty_first:
         X = X.copy(); X[:n // R] += np.array([0.0, 0.0, 5.0])      # the first shard loses every point to the prune
-    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter, tol, False, 0.0, P["k_vis"] if vis_on else 0.0,
-                       P["visibility_threshold"], precision=prec)
+    pr = B.make_params(P["beta_pre_proc"] if lle else P["beta"], P["lambda_pre_proc"] if lle else P["lambda_"], P["lle_weight"], P["mu"], max_iter, tol, bool(lle), 0.0,
+                       P["k_vis"] if vis_on else 0.0, P["visibility_threshold"], precision=prec)
+    s2in = 2e-5 if lle else 0.0
+    if lle:                                                    # the unsplit registration on one context: what the shards must reproduce
+        c1 = B.Context(device=0, max_frames=1, max_points=n, max_nodes=max(64, M))
+        g = c1.cpd_lle(X, Y0, s2in, pr, visible_nodes=vext, check=False)
+        res[f"c{ci}_plain_Y"] = g["Y"]; res[f"c{ci}_plain_s"] = np.array([g["sigma2"], g["iters"], g["n_kept"], g["rc"], int(g["converged"])])
+        res[f"c{ci}_plain_band"] = np.array([c1.profile_iteration(1)[3] == "k_mstep_band"])
+        c1.close()
     ctxs = [B.Context(device=0, max_frames=1, max_points=max(1024, n // R + 1), max_nodes=max(64, M)) for _ in range(R)]
     inboxes = [c.xch_create(R, max(64, M)) for c in ctxs]
     out = queue.Queue()
@@ -106,7 +115,7 @@ for ci, (R, N, M, cfg, vis_on, tol, prec, max_iter, empty_first) in enumerate(ev
         try:
             ctxs[r].xch_bind(r, inboxes)
             ctxs[r].set_cloud(0, X[r * n // R:(r + 1) * n // R])
-            out.put((r, ctxs[r].split_run(Y0, 0.0, pr, visible_nodes=vext, check=False)))
+            out.put((r, ctxs[r].split_run(Y0, s2in, pr, visible_nodes=vext, check=False)))
         except Exception as e:
             out.put((r, dict(rc=-99, err=repr(e))))
     th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
@@ -174,6 +183,31 @@ def test_one_shot_exchange_R_shards_against_the_oracle(tmp_path, oracle):
         assert kept == o["n_kept"]
         if case[8]:
             assert z[f"c{ci}_r0_s"][2] == 0
+
+
+def test_one_shot_exchange_R_shards_with_the_lle_term(tmp_path):
+    """The pre-processing registration (include_lle, the library's own H, the banded L D L^T with the exchange inside k_mstep_band) split over
+    R shards: every rank ends with the same bits, and they are the unsplit registration's up to the order in which the shards' sums are added
+    (fp64 mode 1e-11 m; fp32 mode at its stated tolerance), with the same iteration count, also with the stopping rule on."""
+    #        R   N      M   cfg vis    tol   prec iters empty  lle
+    cases = [(2, 12000, 45, 24, False, 0.0, 1, 6, False, True), (3, 12000, 45, 24, False, 2e-4, 1, 30, False, True), (4, 20000, 30, 25, False, 0.0, 0, 6, False, True),
+             (8, 16000, 64, 26, False, 0.0, 1, 4, False, True), (2, 30000, 150, 27, False, 0.0, 1, 4, False, True), (3, 9000, 18, 28, False, 0.0, 1, 5, False, True)]
+    z = _run_shard_cases(tmp_path, cases)
+    for ci, case in enumerate(cases):
+        R, prec = case[0], case[6]
+        Yp = z[f"c{ci}_plain_Y"]; sp, itp, nkp, rcp, convp = z[f"c{ci}_plain_s"]
+        assert rcp == 0 and bool(z[f"c{ci}_plain_band"][0]), case
+        kept = 0
+        for r in range(R):
+            Y = z[f"c{ci}_r{r}_Y"]; s2, it, nk, rc, conv, _ = z[f"c{ci}_r{r}_s"]
+            assert rc == 0, (case, r, rc)
+            assert it == itp and conv == convp, (case, r, it, itp)
+            ty, ts = (1e-11, 1e-9) if prec == 1 else TOL[0]
+            assert np.abs(Y - Yp).max() <= ty and abs(s2 - sp) <= ts * sp, (case, r, np.abs(Y - Yp).max())
+            np.testing.assert_array_equal(Y, z[f"c{ci}_r0_Y"])
+            assert s2 == z[f"c{ci}_r0_s"][0]
+            kept += int(nk)
+        assert kept == nkp
 
 
 def test_rccl_form_single_rank_communicator(hip_ctx):
