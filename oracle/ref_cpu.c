@@ -16,7 +16,10 @@
  * -- MatrixXd::inverse()/determinant() (PartialPivLU) and
  * completeOrthogonalDecomposition().solve().  Restated here as partial-pivot LU and
  * Householder QR with column pivoting; for the full-rank systems of this path all agree to
- * cond(A)*eps.
+ * cond(A)*eps.  Array exp() (:298, :354) is the C library's exp here: denormals down to e^-745, zero below
+ * (an all-zero Euclidean column sends the point to node 0, :310).  Eigen's SSE2 packet exp for doubles
+ * clamps its argument and returns zero somewhat earlier (about e^-708.7); builds without a double packet exp
+ * call std::exp.  The band between the two is not reproducible across builds of the reference itself.
  *
  * Deliberately NOT reproduced (they do not change results): per-call heap allocations of
  * pt2pt_dis by-value MatrixXd arguments, the dead P_stored copy (:299) and diff_yy (:205-212).

@@ -178,6 +178,35 @@ def test_large_cloud_grouped_partials(hip_ctx, oracle, prec):
         ctx.close()
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_points_whose_every_membership_underflows_go_to_node_zero(hip_ctx, oracle, prec):
+    """trackdlo.cpp:298-310 takes the nearest node as the argmax of exp(-d2 / (2 sigma2)): for a kept point further than 38.6 sigma from
+    every node (here 6 .. 9 cm off the chain with sigma = 1 mm) the whole column is exactly zero in fp64 and the argmax is the FIRST index,
+    node 0 -- and with node 2 nearer than node 1 the end-node rule of :313-321 then hands node 1 a membership of exp(0) = 1 for a point
+    at the other end of the rope.  The reference's behaviour, reproduced: same nodes as the oracle at the stated tolerances, iteration by
+    iteration, with the rule firing (the oracle counts it) and the nodes really thrown (so a product that took the true nearest node
+    would fail here)."""
+    from trackdlo_amd import synth
+    P = synth.LAUNCH_PARAMS
+    for M, N, far in ((20, 1500, 3), (45, 4000, 1), (100, 3000, 5)):
+        X, Y0, _ = synth.scene(N, M, config=330 + M, noise=0.0008)
+        rng = np.random.default_rng(3300 + M)
+        idx = rng.integers(M // 2, M - 1, size=far)                           # off the far half of the chain: node 2 is nearer than node 1
+        off = np.column_stack([np.zeros(far), rng.uniform(0.06, 0.09, size=far) * rng.choice([-1.0, 1.0], size=far), np.zeros(far)])
+        Xf = np.vstack([X, (Y0[idx] + off).astype(np.float32).astype(np.float64)])
+        kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=1, tol=0.0, include_lle=False,
+                  alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+        plain = oracle.cpd_lle(X, Y0, 1e-6, **kw)
+        for it in (1, 2, 3):
+            kw["max_iter"] = it
+            o = oracle.cpd_lle(Xf, Y0, 1e-6, **kw)
+            g = hip_ctx.cpd_lle(Xf, Y0, 1e-6, _params(kw, prec))
+            _check(g, o, prec)
+            if it == 1:
+                assert o["gap_quirk"] >= far and o["n_kept"] == plain["n_kept"] + far
+                assert np.abs(o["Y"] - plain["Y"]).max() > 1e-3               # the far points did move the nodes (through node 1)
+
+
 def test_early_exit_and_max_iter_flags(hip_ctx, oracle):
     from trackdlo_amd import synth
     P = synth.LAUNCH_PARAMS

@@ -840,6 +840,20 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 }
             }
         }
+        // The reference takes the nearest node as the argmax of exp(-d2 / (2 sigma2)) / (column sum + c) (:298-310).  When even the nearest
+        // node's exponent is below -1075 in base 2 every entry of the column has underflowed to exactly zero in fp64, and the argmax of an
+        // all-zero column is its FIRST index: node 0 (from there the end-node rule of :313-321 can give node 1 a membership of exp(0) = 1 for a
+        // point a metre away -- the reference's behaviour, reproduced).  Reachable once sigma is below d / 38.6 for a kept point d <= 0.1 m
+        // from the chain, i.e. sigma2 < 6.7e-6: rare, so the wave looks at it together.
+        {
+            const bool under = valid && best * k2 < T(-1075);
+            if (__ballot(under) != 0ull) {
+                const V4<T> q0 = nodesL[0];
+                const T dx0 = x - q0.x, dy0 = y - q0.y, dz0 = z - q0.z;
+                const T d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                if (under) { a = 0; best = d0; }
+            }
+        }
         ESTAMP(2);
         EPHASE(2);
         // ---- second node by distance (:313-329)
