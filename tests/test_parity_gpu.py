@@ -207,6 +207,18 @@ def test_points_whose_every_membership_underflows_go_to_node_zero(hip_ctx, oracl
                 assert np.abs(o["Y"] - plain["Y"]).max() > 1e-3               # the far points did move the nodes (through node 1)
 
 
+def test_hostile_inputs_come_back_and_leave_the_context_usable():
+    """NaN / Inf / 1e30 coordinates in the cloud or the nodes, sigma2 negative / NaN / 1e300, NaN or extreme parameters, NaN priors, NaN or 1e300 H,
+    coincident nodes, a single point: 124 calls (both precisions, with and without the LLE term), each of which must return -- a result with
+    finite numbers or a negative TDLO_E_* code, never a hang -- and be followed by a plain registration that reproduces its bits
+    (scripts/gpu_hostile_inputs.py, run in a child process under a time limit)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "gpu_hostile_inputs.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "all calls returned" in r.stdout.splitlines()[-1]
+
+
 def test_early_exit_and_max_iter_flags(hip_ctx, oracle):
     from trackdlo_amd import synth
     P = synth.LAUNCH_PARAMS
