@@ -69,7 +69,7 @@ def test_one_shot_exchange_with_lle_and_error_paths(hip_ctx, oracle):
         a = hip_ctx.cpd_lle(X, Y0, 2e-5, pr, H=H)
         b = hip_ctx.split_run(Y0, 2e-5, pr, H=H)
         np.testing.assert_array_equal(a["Y"], b["Y"])
-        # chains beyond the one-workgroup M-step need the RCCL form
+        # more nodes than the inbox was created for (tdlo_xch_create(1, 64)): refused before anything is exchanged
         X2, Y2, _ = _scene(3000, 100, 8, False)
         hip_ctx.set_cloud(0, X2)
         g = hip_ctx.split_run(Y2, 0.0, _params(P, B, 3, 0.0, False, 0), check=False)
