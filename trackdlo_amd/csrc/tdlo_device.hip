@@ -846,8 +846,8 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         // point a metre away -- the reference's behaviour, reproduced).  Reachable once sigma is below d / 38.6 for a kept point d <= 0.1 m
         // from the chain, i.e. sigma2 < 6.7e-6: rare, so the wave looks at it together.
         {
-            const bool under = valid && best * k2 < T(-1075);
-            if (__ballot(under) != 0ull) {
+            const bool under = best * k2 < T(-1075);          // (lanes without a point: whatever they decide is masked out below, as their nearest node is)
+            if (__builtin_expect(__ballot(under) != 0ull, 0)) {
                 const V4<T> q0 = nodesL[0];
                 const T dx0 = x - q0.x, dy0 = y - q0.y, dz0 = z - q0.z;
                 const T d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
