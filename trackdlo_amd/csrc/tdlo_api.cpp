@@ -496,7 +496,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     // (TDLO_BATCH_STREAMS=1 disables it).
     static const int ns_env = getenv("TDLO_BATCH_STREAMS") ? atoi(getenv("TDLO_BATCH_STREAMS")) : 0;
     // (32 frames: three groups of 11 / 11 / 10 frames -- 1078 workgroups per E-step launch, about what the GPU holds at once -- give 1.155 M it/s against
-    // 1.129 M for four groups of 8, three runs each; 24 frames: four groups 0.93 M against 0.91 M; 48 frames: three groups 1.26 M against 1.18 M)
+    // 1.129 M for four groups of 8, three runs each, on one box and 1.124 M against 1.118 M on another; 24 frames: four groups 0.93 M against 0.91 M; 48 frames: three groups 1.26 M against 1.18 M)
     int NS = ns_env > 0 ? ns_env : (F >= 28 ? 3 : (F >= 16 ? 4 : (F >= 8 ? 2 : 1)));
     NS = std::max(1, std::min(std::min(NS, kBatchStreams), F));
     int goff[kBatchStreams + 1];
