@@ -69,7 +69,8 @@ struct SmallLU {
     }
 };
 
-std::vector<int> chain_neighbours(int half, int M, int idx) {   // trackdlo.cpp:92-117 (truncated at the ends)
+// (no heap: this runs M times on the host in front of every pre-processing registration -- 45 small vectors had cost half of lle_weights' 13 us)
+int chain_neighbours(int half, int M, int idx, int *out, int cap) {   // trackdlo.cpp:92-117 (truncated at the ends); returns the count (may exceed cap)
     int first = idx - half, last = idx + half;
     if (idx - half < 0) first = 0;
     else if (idx + half >= M) last = M - 1;
@@ -77,9 +78,9 @@ std::vector<int> chain_neighbours(int half, int M, int idx) {   // trackdlo.cpp:
     // bounds (undefined behaviour, trackdlo.cpp:96-104).  Here the range is clipped on both sides.
     if (last > M - 1) last = M - 1;
     if (first < 0) first = 0;
-    std::vector<int> out;
-    for (int i = first; i <= last; ++i) if (i != idx) out.push_back(i);
-    return out;
+    int n = 0;
+    for (int i = first; i <= last; ++i) if (i != idx) { if (n < cap) out[n] = i; ++n; }
+    return n;
 }
 
 }  // namespace
@@ -87,8 +88,8 @@ std::vector<int> chain_neighbours(int half, int M, int idx) {   // trackdlo.cpp:
 void lle_weights(int k, const double *Y, int M, double *L) {
     std::fill(L, L + (size_t)M * M, 0.0);
     for (int i = 0; i < M; ++i) {
-        const std::vector<int> nb = chain_neighbours(k / 2, M, i);
-        const int n = (int)nb.size();
+        int nb[6];
+        const int n = chain_neighbours(k / 2, M, i, nb, 6);
         if (n == 0 || n > 6) continue;
         double gram[36];
         for (int r = 0; r < n; ++r)
