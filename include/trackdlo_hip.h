@@ -350,6 +350,10 @@ int tdlo_debug_mstep_lle_dense(int on);
  * non-positive pivot or produced a non-finite sigma2: an indefinite H_override, or a chain at the edge of the gap test.  The reference's
  * solver is a general one (trackdlo.cpp:415); the caller sees the dense kernels' result.  -1 for a null context. */
 long long tdlo_debug_band_retries(tdlo_ctx *ctx);
+/* Test aid: provokes a HIP runtime error inside the library (an invalid copy) and reports it like any other: returns TDLO_E_HIP with the
+ * text in tdlo_last_error.  The calls that follow must be unaffected -- HIP keeps a per-thread "last error" that the launch checks of a later
+ * call would otherwise read (tests/test_parity_gpu.py::test_a_hip_error_does_not_leak_into_the_next_call). */
+int tdlo_debug_fail_hip(tdlo_ctx *ctx);
 /* Whether the registrations of this context record the four stream events behind tdlo_stats.loop_ms / total_ms.  Off by default: the
  * reference has no such figures, and the markers cost about 15 us per call (2 % of a 50-iteration call at N = 50 000).  Returns the
  * previous setting (or TDLO_E_INVALID). */

@@ -207,6 +207,20 @@ def test_points_whose_every_membership_underflows_go_to_node_zero(hip_ctx, oracl
                 assert np.abs(o["Y"] - plain["Y"]).max() > 1e-3               # the far points did move the nodes (through node 1)
 
 
+def test_a_hip_error_does_not_leak_into_the_next_call(hip_ctx):
+    """HIP keeps a per-thread "last error"; the launchers read it after their own launches.  A call that ended with TDLO_E_HIP (round 3: a
+    launch refused for 477-node chains) used to leave it set, and the NEXT, perfectly good call then reported it again."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, _ = synth.scene(3000, 30, config=710)
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 5, 0.0, False)
+    a = hip_ctx.cpd_lle(X, Y0, 0.0, pr)
+    assert hip_ctx.lib.tdlo_debug_fail_hip(hip_ctx.h) == B.TDLO_E_HIP
+    assert "invalid" in hip_ctx.lib.tdlo_last_error(hip_ctx.h).decode().lower()
+    b = hip_ctx.cpd_lle(X, Y0, 0.0, pr)
+    assert b["rc"] == 0 and np.array_equal(a["Y"], b["Y"]) and a["sigma2"] == b["sigma2"]
+
+
 def test_hostile_inputs_come_back_and_leave_the_context_usable():
     """NaN / Inf / 1e30 coordinates in the cloud or the nodes, sigma2 negative / NaN / 1e300, NaN or extreme parameters, NaN priors, NaN or 1e300 H,
     coincident nodes, a single point: 124 calls (both precisions, with and without the LLE term), each of which must return -- a result with

@@ -1567,6 +1567,12 @@ int tdlo_debug_read_cloud(tdlo_ctx *c, int slot, double *out, int max_points, do
 int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
+int tdlo_debug_fail_hip(tdlo_ctx *c) {
+    if (!c) return TDLO_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(nullptr, nullptr, 16, hipMemcpyDeviceToDevice));      // hipErrorInvalidValue
+    return TDLO_OK;
+}
 
 int tdlo_set_timing(tdlo_ctx *c, int on) {
     if (!c) return TDLO_E_INVALID;
