@@ -752,9 +752,6 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     EPHASE(0);
 
     // running sums in 64-bit fixed point (acc_fix at the grain of one wave x one batch; integer from there on: tdlo_devcommon.h)
-    long long accP[NCH], accX[NCH], accY[NCH], accZ[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) { accP[c] = 0; accX[c] = 0; accY[c] = 0; accZ[c] = 0; }
     long long accQ = 0;
     const double scP = acc_scale(f.acc_sh[0]), scR = acc_scale(f.acc_sh[1]), scQ = acc_scale(f.acc_sh[2]);
     // every converted value is checked against its limit (FrameDev::acc_lim: exact conversion, no wrap-around of the totals; a NaN fails
@@ -765,9 +762,15 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     // wave sit on a short piece of the chain, and every membership whose exponent is below -151 (fp32;
     // -1080 in fp64) is EXACTLY zero: only the nodes inside an arc-length window around the wave's
     // nearest-pair range can contribute, the others are skipped -- same sums, bit for bit.
-    long long *accL = (long long *)(scratch + 16) + (size_t)wave * M * 4;    // per-wave [M][4] accumulators (NCH == 1)
+    // [M][4] 64-bit accumulators in LDS (ds_add_u64 without return: integer sums, so neither the order nor who adds matters).  Up to 64 nodes: one set
+    // per wave (no contention, 1.6 KB each at M = 50).  Longer chains: ONE set per workgroup -- per-lane register accumulators (4 x NCH 64-bit values
+    // and a cross-lane gather per chunk) had held the fp64 kernel at 227 VGPRs, and a set per wave would cost the second workgroup of a CU its LDS
+    long long *accL = (long long *)(scratch + 16) + (NCH == 1 ? (size_t)wave * M * 4 : (size_t)0);
     if (NCH == 1) {
         for (int i = lane; i < M * 4; i += 64) accL[i] = 0;
+    } else {
+        for (int i = tid; i < M * 4; i += EB) accL[i] = 0;
+        __syncthreads();
     }
     const T Rwin = (T)(sizeof(T) == 4 ? stg->rwin32 : stg->rwin64);      // 1.01 sqrt(151 / |k2|) (fp32; 1080 in fp64), left by the M-step
 
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
             if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
             if (shift <= 3) { s0 += row_ror8(s0); sx += row_ror8(sx); sy += row_ror8(sy); sz += row_ror8(sz); }
-            if (NCH == 1) {
+            {
                 if (lane < Wn) {
                     long long *ac = accL + (size_t)(wlo_c + lane) * 4;
                     const V4<T> ym = nodesL[wlo_c + lane];
@@ -1066,35 +1069,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                     const double r1 = (double)sx + ((double)ox - (double)ym.x) * w0, r2 = (double)sy + ((double)oy - (double)ym.y) * w0, r3 = (double)sz + ((double)oz - (double)ym.z) * w0;
                     acc_ok &= (__builtin_fabs(w0) < limP) & (__builtin_fabs(r1) < limR) & (__builtin_fabs(r2) < limR) & (__builtin_fabs(r3) < limR);
                     // (ds_add_u64 without return: one LDS instruction per value instead of read, 64-bit add, write)
-                    __hip_atomic_fetch_add(ac + 0, acc_fix(w0, scP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(ac + 1, acc_fix(r1, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(ac + 2, acc_fix(r2, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_fetch_add(ac + 3, acc_fix(r3, scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-                wave_lds_sync();
-            } else {
-                // M > 64: the sums of node wlo_c + lane go to the lane that owns that node in the register accumulators
-                // (lane = node - 64 c) by cross-lane reads; a window touches at most two node chunks
-                long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                if (lane < Wn) {
-                    const V4<T> ym = nodesL[wlo_c + lane];
-                    const double w0 = (double)s0;
-                    const double r1 = (double)sx + ((double)ox - (double)ym.x) * w0, r2 = (double)sy + ((double)oy - (double)ym.y) * w0, r3 = (double)sz + ((double)oz - (double)ym.z) * w0;
-                    acc_ok &= (__builtin_fabs(w0) < limP) & (__builtin_fabs(r1) < limR) & (__builtin_fabs(r2) < limR) & (__builtin_fabs(r3) < limR);
-                    v0 = acc_fix(w0, scP);
-                    v1 = acc_fix(r1, scR);
-                    v2 = acc_fix(r2, scR);
-                    v3 = acc_fix(r3, scR);
-                }
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (c * kChunk + 63 >= wlo_c && c * kChunk < wlo_c + Wn) {       // wave-uniform
-                        const int idx = c * kChunk + lane - wlo_c;
-                        const bool ok = idx >= 0 && idx < Wn;
-                        const int src = ok ? idx : 0;
-                        const long long g0 = __shfl(v0, src), g1 = __shfl(v1, src), g2 = __shfl(v2, src), g3 = __shfl(v3, src);
-                        if (ok) { accP[c] += g0; accX[c] += g1; accY[c] += g2; accZ[c] += g3; }
-                    }
+                    __hip_atomic_fetch_add(ac + 0, acc_fix(w0, scP), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ac + 1, acc_fix(r1, scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ac + 2, acc_fix(r2, scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ac + 3, acc_fix(r3, scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 wave_lds_sync();
             }
@@ -1120,36 +1098,19 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     __syncthreads();
     ESTAMP(6);
     long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (blockIdx.x % kAccRows)) * acc_stride(M);
-    if (NCH == 1) {
+    {
         const long long *accAll = (const long long *)(scratch + 16);
         for (int i = tid; i < 4 * M; i += EB) {
             const int m = i >> 2, k = i & 3;
             long long v = 0;
+            if (NCH == 1) {
 #pragma unroll
-            for (int w = 0; w < NWE; ++w) v += accAll[(size_t)w * M * 4 + i];
+                for (int w = 0; w < NWE; ++w) v += accAll[(size_t)w * M * 4 + i];
+            } else {
+                v = accAll[i];
+            }
             acc_add(arow, k * M + m, v);
         }
-    } else {
-    long long *red = (long long *)pbase;      // reuse the tile area: NWE waves x 64 lanes x 4 values per chunk
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        red[(wave * 64 + lane) * 4 + 0] = accP[c];
-        red[(wave * 64 + lane) * 4 + 1] = accX[c];
-        red[(wave * 64 + lane) * 4 + 2] = accY[c];
-        red[(wave * 64 + lane) * 4 + 3] = accZ[c];
-        __syncthreads();
-        if (tid < 256) {
-            const int l = tid >> 2, k = tid & 3;     // 64 lanes x 4 values
-            const int m = c * kChunk + l;
-            if (m < M) {
-                long long v = 0;
-#pragma unroll
-                for (int w = 0; w < NWE; ++w) v += red[(w * 64 + l) * 4 + k];
-                acc_add(arow, k * M + m, v);
-            }
-        }
-        __syncthreads();
-    }
     }
     if (tid == 0) {
         long long q = 0;
@@ -1734,7 +1695,7 @@ template <typename T, int EB> static size_t estep_lds_bytes(int M, bool single) 
     const size_t red = (size_t)NWE * 64 * 4 * sizeof(double);
     size_t b = sizeof(V4<T>) * (size_t)M + sizeof(V4<T>) * NWE * kPtsStride + sizeof(T) * (size_t)((M + 3) & ~3);
     b += (tile > red ? tile : red) + 16 * sizeof(double) + 64;
-    if (M <= kChunk) b += sizeof(double) * (size_t)NWE * M * 4;     // per-wave accumulators of the windowed variant
+    b += sizeof(double) * (size_t)(M <= kChunk ? NWE : 1) * M * 4;     // [M][4] 64-bit accumulators: per wave up to 64 nodes, per workgroup beyond
     return b;
 }
 

@@ -14,7 +14,10 @@ constexpr int kAccRows = 8;          // replica rows of the E-step's fixed-point
 constexpr int kTileRows = 24;        // rows of the E-step's transposition tile: the node window is processed in chunks of this many nodes ...
 constexpr int kTileRows32 = 16;      // ... fp32 E-step, chains up to 64 nodes: 16 (4 KB of LDS per wave; with twice the workgroups the GPU holds more waves per
                                      // SIMD: 32-frame batch 25.6 -> 23.2 us per E-step, N = 2 000 000 27.9 -> 26.5 us; fp64 / long chains lose 5 % with it)
-template <typename T> __host__ __device__ constexpr int tile_rows(int nch) { return (sizeof(T) == 4 && nch == 1) ? kTileRows32 : kTileRows; }
+#ifndef TDLO_TILE_ROWS_LONG
+#define TDLO_TILE_ROWS_LONG 24         // (chains beyond 64 nodes; -DTDLO_TILE_ROWS_LONG=n builds the variants scripts/gpu_c5.py compares)
+#endif
+template <typename T> __host__ __device__ constexpr int tile_rows(int nch) { return nch == 1 ? (sizeof(T) == 4 ? kTileRows32 : kTileRows) : TDLO_TILE_ROWS_LONG; }
 constexpr int kMaxNodes = 512;       // E-step template covers ceil(M/64) in {1,2,4,8}
 constexpr int kLdsSolveMaxM = 128;   // M-step keeps [A|B] in LDS up to this M
 constexpr int kMaxXchRanks = 8;      // ranks of the one-shot N-split exchange (one node: 8 GPUs)
