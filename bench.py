@@ -11,6 +11,15 @@ Workloads (BASELINE.json configs; launch/trackdlo.launch parameter values, tol =
   c5  ONE frame per GPU, N = 200 000 points, M = 300 nodes, fp64 everywhere
 A "step" is one complete trackdlo::cpd_lle call (trackdlo.cpp:161-441: prune, setup, 50 iterations, read-back of Y / sigma2) on a
 cloud that is already resident in HBM.    value = steps * frames * 50 * ranks / wall time      [EM iterations / s, whole job]
+EVERY timed call pays what a real frame pays: the library's sorted-cloud reuse (a registration of the same nodes on the same cloud skips
+prune + sort, tdlo_set_sort_reuse) is switched OFF for every registration leg, and the single-frame configurations (c2, c5) alternate
+between two resident (cloud, Y0) pairs -- frames f and f+1 of the synthetic scene -- so that no call sees the inputs of the call before
+it.  `prune_dispatches_per_call` on the line is counted from tdlo_stats.sort_reused of the timed calls (1.0 = every call pruned).  Only the
+tracking_step leg keeps the reuse on, where the reference's own data flow makes it legitimate (trackdlo.cpp:913-927 / :998).
+
+OUTPUT: the LAST line of stdout is ONE compact JSON object (< 4 KB: the driver's capture holds 8 KB): the contract's keys, `roofline`,
+`cpu_baseline`, and the other configurations as scalars under `configs`.  Everything else (both per-iteration kernels with notes and
+sources, the full legs, `sustained`, `preproc`) is written to bench_detail.json next to this script (path on the line as `detail`).
 
 --gpus N > 1 without a torch.distributed environment: this script launches itself as N ranks
 (python -m torch.distributed.run --nnodes=1 --nproc-per-node N, one rank per GPU, RCCL).  With WORLD_SIZE already set (the
@@ -180,17 +189,24 @@ def _pmc_traffic_live(args, cfg, mstep_name):
             return None
         frames = args.frames if args.frames is not None else cfg["frames"]
         calls = 1 + PMC_CHILD_STEPS
-        cal = (3 * 8 * cfg["N"] * frames * calls / 1024.0) / F[prune[0]][0]
+        # k_prune_pass1 reads the raw cloud of every frame exactly once PER DISPATCH (3 x 8 B x N0 x frames); the number of dispatches is
+        # taken from the counter file itself (round 3 assumed `calls` of them while the sorted-cloud reuse had skipped all but one: x 3.8)
+        pd = F[prune[0]][1]
+        cal_raw = (3 * 8 * cfg["N"] * frames * pd / 1024.0) / F[prune[0]][0]
+        cal_ok = 1.6 <= cal_raw <= 2.4          # MI355X_MICROARCH.md: wide reads are tallied at half their bytes (x 2)
+        cal = cal_raw if cal_ok else 2.0
         tname = "float" if cfg["prec"] == "f32" else "double"
 
         def pick(prefix):
             ks = [k for k in F if prefix in k and k in W]
             return max(ks, key=lambda k: F[k][1]) if ks else None
 
-        res = dict(fetch_calibration_factor=round(cal, 4),
+        res = dict(fetch_calibration_factor=round(cal, 4), fetch_calibration_measured=round(cal_raw, 4), fetch_calibration_in_range=cal_ok,
+                   prune_dispatches=pd, child_calls=calls,
                    source=f"this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, two separate child passes of {calls} cpd_lle calls each; bytes of all "
-                          f"dispatches of the kernel / ({calls} calls x {EM_ITERS} iterations); FETCH_SIZE x {cal:.3f} (calibrated on k_prune_pass1's known "
-                          "read volume in the same pass)")
+                          f"dispatches of the kernel / ({calls} calls x {EM_ITERS} iterations); FETCH_SIZE x {cal:.3f} ("
+                          + (f"calibrated on the {pd} k_prune_pass1 dispatches of the same pass, each reading the raw cloud once" if cal_ok else
+                             f"the guide's factor: the calibration on k_prune_pass1 gave {cal_raw:.3f}, outside 1.6 .. 2.4") + ")")
         its = calls * EM_ITERS
         for key, prefix in (("estep", f"k_estep<{tname}"), ("mstep", f"{mstep_name}<{tname}")):
             k = pick(prefix)
@@ -215,11 +231,85 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
-def _emit(obj):
-    """The JSON line, as the LAST thing on stdout: RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would
-    otherwise come out at process exit, behind the line."""
+LINE_LIMIT = 4096       # bytes of the final stdout line (the driver keeps 8 KB of stdout; round 3's 25.7 KB line scrolled out of it)
+DETAIL_FILE = "bench_detail.json"
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes_per_launch",
+              "algorithmic_flops_per_launch", "share_of_gpu_time", "iteration_us", "valu_issue_frac", "traffic_over_algorithmic")
+
+
+def _compact_roofline(r):
+    if not r:
+        return r
+    o = {k: r[k] for k in _ROOF_KEYS if k in r}
+    o.setdefault("traffic", None)
+    if r.get("traffic_source"):
+        src = r["traffic_source"]
+        o["traffic_source"] = "live rocprofv3 --pmc passes of this run" if src.startswith("this run") else src[:60]
+    return o
+
+
+def _compact_cpu(c):
+    if not c:
+        return c
+    o = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
+    o["sample"] = c.get("sample_short") or c.get("sample", "")[:160]
+    ac = c.get("all_cores")
+    if isinstance(ac, dict) and "value" in ac:
+        o["all_cores_value"], o["all_cores"] = ac["value"], ac["cores"]
+    return o
+
+
+def _compact(full):
+    """The headline the driver parses: the contract's keys with `roofline` and `cpu_baseline` cut down to their figures, the other
+    configurations as scalars.  Notes, sources, both kernels' full objects and the legs stay in the detail file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    o = {k: full[k] for k in keep if k in full}
+    o["config"] = full.get("config")
+    for k in ("timed_region_s", "frames_per_s", "prune_dispatches_per_call", "em_loop_only_iters_per_s", "em_iters_per_s_f64", "us_per_iteration", "gpu_over_cpu"):
+        if k in full:
+            o[k] = full[k]
+    o["roofline"] = _compact_roofline(full.get("roofline"))
+    if full.get("roofline_kernels"):
+        o["roofline_kernels"] = [{k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_us", "traffic") if k in r} for r in full["roofline_kernels"]]
+    o["cpu_baseline"] = _compact_cpu(full.get("cpu_baseline"))
+    legs = {}
+    for name, r in (full.get("configs") or {}).items():
+        if "error" in r:
+            legs[name] = dict(error=r["error"][:120])
+            continue
+        rf, cb = r.get("roofline") or {}, r.get("cpu_baseline") or {}
+        legs[name] = dict(value=r.get("value"), ms_per_step=r.get("ms_per_step"), dtype=r.get("dtype"), roofline_kernel=rf.get("kernel"), roofline_frac=rf.get("frac"),
+                          avg_launch_us=rf.get("avg_launch_us"), traffic=rf.get("traffic"), cpu_value=cb.get("value"))
+    if legs:
+        o["configs"] = legs
+    if "sustained" in full:
+        o["sustained_iters_per_s"] = full["sustained"].get("sustained_iters_per_s")
+    pre = full.get("preproc") or {}
+    for k in ("tracking_step_ms_per_frame", "em_iters_per_s"):
+        if k in pre:
+            o["preproc_" + k if k == "em_iters_per_s" else k] = pre[k]
+    o["ranks"] = full.get("ranks")
+    o["detail"] = DETAIL_FILE
+    # the line must stay under the limit whatever a future leg adds: optional parts go first
+    for drop in ("roofline_kernels", "ranks", "configs", "em_loop_only_iters_per_s", "frames_per_s"):
+        if len(json.dumps(o)) < LINE_LIMIT:
+            break
+        o.pop(drop, None)
+    return o
+
+
+def _emit(full):
+    """The full object goes to bench_detail.json; the compact JSON line is the LAST thing on stdout: RCCL prints its version banner through
+    C stdio, which is block-buffered on a pipe and would otherwise come out at process exit, behind the line."""
+    try:
+        with open(os.path.join(ROOT, DETAIL_FILE), "w") as fh:
+            json.dump(full, fh, indent=1)
+    except OSError as e:
+        print(f"[bench] could not write {DETAIL_FILE}: {e}", file=sys.stderr)
+    line = json.dumps(_compact(full))
+    assert len(line) < LINE_LIMIT, len(line)
     _flush_c_stdio()
-    print(json.dumps(obj), flush=True)
+    print(line, flush=True)
 
 
 def _apply_live_traffic(live, roof, roof_all):
@@ -229,6 +319,10 @@ def _apply_live_traffic(live, roof, roof_all):
         m = live.get("estep" if o["kernel"].startswith("k_estep") else "mstep")
         if m is not None:
             o["traffic"], o["traffic_source"] = m["bytes"], live["source"]
+            if o.get("algorithmic_bytes_per_launch"):
+                o["traffic_over_algorithmic"] = round(m["bytes"] / o["algorithmic_bytes_per_launch"], 3)
+            o["fetch_calibration"] = dict(factor=live["fetch_calibration_factor"], measured=live["fetch_calibration_measured"], in_range=live["fetch_calibration_in_range"],
+                                          prune_dispatches=live["prune_dispatches"], child_calls=live["child_calls"])
             o["traffic_detail"] = dict(kernel=m["kernel"], fetch_KB_raw=m["fetch_KB_raw"], write_KB=m["write_KB"], dispatches_per_iteration=m["dispatches_per_iteration"])
             if m.get("valu_insts"):
                 # VALU instructions the kernel really issued per launch (all its waves) x 64 lanes / its duration / the lane-issue peak
@@ -402,6 +496,7 @@ def _cpu_baseline(cfg, X0, Y00, kw, g_single):
         rates.append(o["iters"] / o["loop_seconds"])
     cpu = dict(value=round(float(np.median(rates)), 3), unit="EM iterations/s", cores=1, kind="port",
                sample=f"one frame of the workload (N={cfg['N']}, M={cfg['M']}), the first {cfg['cpu_iters']} of its {EM_ITERS} iterations, median of {cfg['cpu_repeats']} run(s) of the loop body",
+               sample_short=f"1 frame N={cfg['N']} M={cfg['M']}, first {cfg['cpu_iters']} of {EM_ITERS} iterations, median of {cfg['cpu_repeats']} run(s) of the oracle's loop body",
                seconds=round(time.perf_counter() - t0, 2),
                note="oracle/ref_cpu.c: plain-C fp64 restatement of trackdlo.cpp:275-438, -O3, single thread like the reference")
     if g_single is not None and cfg["cpu_iters"] == EM_ITERS:
@@ -469,13 +564,23 @@ def _preproc_leg(ctx, B, synth):
                      P["lambda_pre_proc"], P["lle_weight"], ctx=ctx)
     trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
     vis = np.arange(M)
-    for _ in range(5):
-        trk.tracking_step(X, vis, vis)
-    t0 = time.perf_counter()
-    for _ in range(200):
-        trk.tracking_step(X, vis, vis)
-    out["tracking_step_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3 / 200, 4)
-    out["tracking_step_note"] = "host buffers in, results out, production tolerance (tol = 2e-4: a steady-state frame converges in a few iterations)"
+    # tracking_step: the cloud comes from the host in every frame (the prune of the first registration always runs); with every node visible the
+    # second registration starts from the same nodes as the first (trackdlo.cpp:913-927 / :998) and may reuse its sorted cloud -- the library's
+    # default, switched back on for this leg only
+    prev = ctx.set_sort_reuse(True)
+    try:
+        for _ in range(5):
+            trk.tracking_step(X, vis, vis)
+        reused = [int(s_["sort_reused"]) for s_ in trk.last_stats]
+        t0 = time.perf_counter()
+        for _ in range(200):
+            trk.tracking_step(X, vis, vis)
+        out["tracking_step_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3 / 200, 4)
+    finally:
+        ctx.set_sort_reuse(prev)
+    out["tracking_step_sort_reused"] = reused       # [pre-processing registration, main registration] of a frame
+    out["tracking_step_note"] = ("host buffers in, results out, production tolerance (tol = 2e-4: a steady-state frame converges in a few iterations); sorted-cloud "
+                                 "reuse ON (library default): the main registration reuses the pre-processing registration's sort when every node is visible")
     return out
 
 
@@ -488,8 +593,10 @@ def bench_frames(args, cfg, env):
     N, M, F = cfg["N"], cfg["M"], cfg["frames"]
     prec = B.PREC_F32 if cfg["prec"] == "f32" else B.PREC_F64
     cfg_id = {"c2": 2, "c3": 2, "c5": 5}[args.config]
-    ctx = Context(device=dev_index, max_frames=F, max_points=N, max_nodes=M)   # raises without a GPU: no CPU fallback
+    NP = 2 if F == 1 else 1     # single-frame configurations: two resident (cloud, Y0) pairs, registered alternately
+    ctx = Context(device=dev_index, max_frames=max(F, NP), max_points=N, max_nodes=M)   # raises without a GPU: no CPU fallback
     ctx.set_timing(False)       # the product's default: no stream markers for tdlo_stats.loop_ms in the timed region (they cost ~15 us per call)
+    ctx.set_sort_reuse(False)   # every call prunes and sorts like the reference's (trackdlo.cpp:177-195): nothing is carried over from the call before
 
     def mk_params(precision):
         return B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False,
@@ -497,16 +604,19 @@ def bench_frames(args, cfg, env):
 
     params = mk_params(prec)
     Ys = []
-    for f in range(F):
-        X, Y0, _ = synth.scene(N, M, config=cfg_id, frame=rank * F + f)
+    for f in range(max(F, NP)):
+        X, Y0, _ = synth.scene(N, M, config=cfg_id, frame=rank * max(F, NP) + f)
         ctx.set_cloud(f, X)                      # inputs resident in HBM before the timed region
         Ys.append(Y0)
 
-    Ystack, s2zero = np.asarray(Ys, dtype=np.float64), np.zeros(F)      # (host-side packing of the inputs is not part of the path)
+    Ystack, s2zero = np.asarray(Ys[:F], dtype=np.float64), np.zeros(F)      # (host-side packing of the inputs is not part of the path)
+    turn = [0]
 
     def step(p=params):
         if F == 1:
-            return ctx.cpd_lle_resident(0, Ys[0], 0.0, p)
+            k = turn[0] % NP
+            turn[0] += 1
+            return ctx.cpd_lle_resident(k, Ys[k], 0.0, p)
         return ctx.cpd_lle_batch(Ystack, s2zero, p)
 
     def barrier():
@@ -519,14 +629,18 @@ def bench_frames(args, cfg, env):
     for _ in range(cfg["warmup"]):
         step()
     barrier()
+    timed = []
     t0 = time.perf_counter()
     for _ in range(cfg["steps"]):
-        step()
+        timed.append(step())
     barrier()
     dt = _max_over_ranks(env, time.perf_counter() - t0)
     if args.pmc == "child":     # a PMC pass of _pmc_traffic_live: the calls above are all it is for
         ctx.close()
         return
+    # (outside the timed region) how many of the timed calls really pruned: tdlo_stats.sort_reused of each
+    pruned = sum(1 - int((r if F == 1 else r["stats"][0]).get("sort_reused", 0)) for r in timed)
+    del timed
     n_ranks, ranks = _rank_table(env)
     value = cfg["steps"] * F * EM_ITERS * n_ranks / dt
     # outside the timed region: the same calls with the timing events on, for the stream time of the loop alone
@@ -554,9 +668,12 @@ def bench_frames(args, cfg, env):
                    steps=cfg["steps"], warmup=cfg["warmup"], ms_per_step=round(dt * 1e3 / cfg["steps"], 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=cfg["prec"], data="synthetic",
                    config=dict(workload=f"{args.config.upper()}: {F} frame(s) per GPU, N={N} points, M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, "
-                                        f"trackdlo.launch parameters, {'fp32 E-step + fp64 M-step' if cfg['prec'] == 'f32' else 'fp64 everywhere'}",
+                                        f"trackdlo.launch parameters, {'fp32 E-step + fp64 M-step' if cfg['prec'] == 'f32' else 'fp64 everywhere'}; whole calls "
+                                        "(prune + sort + setup + loop + read-back), sorted-cloud reuse OFF"
+                                        + (f", calls alternate between {NP} resident (cloud, Y0) pairs" if F == 1 else ""),
                                frames_per_gpu=F, parallelism=f"frames sharded, {n_ranks} rank(s), no data-path collective"),
                    timed_region_s=round(dt, 3), frames_per_s=round(cfg["steps"] * F * n_ranks / dt, 2),
+                   prune_dispatches_per_call=round(pruned / max(1, cfg["steps"]), 3),
                    em_loop_only_iters_per_s=round(loop_steps * F * EM_ITERS / (loop_ms * 1e-3), 2),
                    roofline=roof, roofline_kernels=roof_all)
         if args.config == "c2" and F == 1 and not cfg.get("leg"):
@@ -607,6 +724,7 @@ def bench_nsplit(args, cfg, env):
     Xs, Y0 = synth.scene_range(NT, M, 4, lo, hi)      # this rank's shard only (the cloud is defined chunk by chunk: every split sees the same points)
     ctx = Context(device=dev_index, max_points=hi - lo, max_nodes=M)
     ctx.set_timing(False)       # no stream markers for tdlo_stats.loop_ms in the timed region
+    ctx.set_sort_reuse(False)   # (tdlo_split_run prunes in every call anyway; this is for the unsplit comparison calls below)
 
     def mk(vis_on):
         return B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=EM_ITERS, tol=0.0, include_lle=False, alpha=0.0,
@@ -700,7 +818,8 @@ def bench_nsplit(args, cfg, env):
         line = dict(metric=cfg["metric"], value=round(cfg["steps"] * EM_ITERS / dt, 2), unit="EM iterations/s", n_gpus=n_ranks, ranks=ranks,
                     steps=cfg["steps"], warmup=cfg["warmup"], ms_per_step=round(dt * 1e3 / cfg["steps"], 4),
                     higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
-                    config=dict(workload=f"C4: one frame, N={NT} points split over {n_ranks} rank(s) ({hi - lo} per rank), M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, fp32 E-step + fp64 M-step",
+                    config=dict(workload=f"C4: one frame, N={NT} points split over {n_ranks} rank(s) ({hi - lo} per rank), M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, fp32 E-step + fp64 M-step; "
+                                         "whole calls (prune + sort + setup + loop + read-back), every call prunes",
                                 parallelism=f"points sharded over {n_ranks} rank(s); per iteration: {form}; identical M-step on every rank"),
                     timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"],
                     roofline=roof, roofline_kernels=roof_all)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TDLO_ABI_VERSION 2
+#define TDLO_ABI_VERSION 3
 
 enum {
     TDLO_OK = 0,
@@ -80,8 +80,12 @@ typedef struct {
     float loop_ms;        /* HIP-event time of the EM loop body on the context's stream (trackdlo.cpp:275-438); 0 unless tdlo_set_timing(ctx, 1) */
     float total_ms;       /* HIP-event time of the whole device-side call (prune + setup + loop + readback); 0 unless tdlo_set_timing(ctx, 1) */
     double host_ms;       /* host wall time of the call including uploads and the final synchronise */
-    int mstep_retries;    /* iterations whose multi-CU elimination (more than 60 nodes) ran into the time limit of an
-                           * inter-workgroup hand-off and were redone by the one-workgroup elimination (normally 0) */
+    int mstep_retries;    /* iterations whose dense multi-workgroup elimination (a comparator / fall-back M-step, see tdlo_cpd_lle_resident) ran into
+                           * the time limit of an inter-workgroup hand-off and were redone by the one-workgroup elimination (normally 0) */
+    int sort_reused;      /* 1: this registration reused the slot's pruned, node-sorted cloud of the previous one (same cloud, same nodes, same
+                           * precision: tdlo_set_sort_reuse) and skipped the prune of trackdlo.cpp:177-195 -- identical results; 0: it pruned */
+    int band_retry;       /* 1: the banded LLE M-step met a non-positive pivot (or a non-finite sigma2) and the call was repeated on the dense
+                           * pivoted eliminations, whose result this is (the reference's solver is a general one, trackdlo.cpp:415) */
 } tdlo_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -110,9 +114,20 @@ int tdlo_set_cloud(tdlo_ctx *ctx, int slot, const double *X, int N);
  *   H_override optional M x M column-major matrix used in place of the LLE regulariser
  *              H = (I-L)^T (I-L) of :236-237 (whose weights are numerically ill-defined).
  * Returns 0 or an error; stats->converged carries the reference's bool result.
- * Chains of more than 60 nodes (without the LLE term) and of more than 128 nodes (with it) solve the M x M system on
- * one CU per 16 rows; environment TDLO_MSTEP_BIG=1wg / TDLO_MSTEP_LLE=1wg (read once per process) keep those
- * eliminations in one workgroup -- the comparators of the tests. */
+ * Which kernel solves the M-step (trackdlo.cpp:392-437), by default, for chains of 4 .. 512 nodes:
+ *   include_lle == 0  the chain smoother (csrc/tdlo_mstep_chain.hip: the same linear system in O(M) through the state-space form of
+ *                     the kernel G, one workgroup per frame);  lambda == 0 or TDLO_MSTEP=dense: the dense eliminations k_mstep_fast
+ *                     (up to 60 nodes) / k_mstep_mcu (one workgroup per 16 rows) -- comparators of the tests;
+ *   include_lle == 1  the banded L D L^T in the chain's state (csrc/tdlo_mstep_band.hip, O(M)) when no two consecutive nodes are closer
+ *                     than about a millimetre and H is banded and symmetric (the library's own always is); otherwise, after a
+ *                     non-positive pivot (stats->band_retry), or with TDLO_MSTEP_LLE=dense: the dense pivoted eliminations
+ *                     k_mstep_fast (up to 64 nodes) / k_mstep (up to 128) / k_mstep_pivot_mcu (beyond; TDLO_MSTEP_LLE=1wg keeps it in
+ *                     one workgroup).  stats->mstep_retries counts time-outs of the multi-workgroup forms only.
+ * Sorted-cloud reuse: the prune (:177-195) and the sort by nearest node depend on the cloud and on the incoming nodes only.  A call
+ * whose Y equals, bit for bit, the Y of the previous registration of the same slot in the same precision, with the slot's cloud
+ * untouched in between (no tdlo_set_cloud / tdlo_depth_to_cloud / N-split on it), reuses that result instead of pruning again
+ * (stats->sort_reused = 1; identical output).  In the reference this happens for the two registrations of a tracking_step whose nodes
+ * are all visible (:913-927 and :998 start from the same Y_).  tdlo_set_sort_reuse(ctx, 0) or TDLO_REUSE_SORT=0 turn it off. */
 int tdlo_cpd_lle_resident(tdlo_ctx *ctx, int slot, double *Y, int M, double *sigma2,
                           const tdlo_params *params, const double *priors, int K,
                           const int *visible_nodes, int n_vis, const double *H_override,
@@ -129,10 +144,11 @@ int tdlo_cpd_lle(tdlo_ctx *ctx, const double *X, int N, double *Y, int M, double
  * concurrently on the GPU.  Arrays are indexed by frame; Y is F consecutive M x 3 blocks; priors/
  * visible_nodes are shared by all frames (pass K = 0 / n_vis = 0 for none).  No reference
  * counterpart: the reference processes one frame per call (BASELINE.json configs[2]).
- * Batches of 8 or more frames are spread over 2 (16 or more: 4) streams owned by the context, staggered by one E-step,
- * so that one group's M-step (one workgroup per frame) overlaps another group's E-step; every frame's result is the
- * same, bit for bit, as from tdlo_cpd_lle_resident (environment TDLO_BATCH_STREAMS=1: one stream).  The call returns
- * after all streams have drained. */
+ * Batches of 8 or more frames run as groups of frames on streams owned by the context (2 groups from 8 frames, 4 from 16, 3 from
+ * 28 -- about what the GPU holds at once per E-step launch), staggered by one E-step, so that one group's M-step (one workgroup per
+ * frame) overlaps another group's E-step; every frame's result is the same, bit for bit, as from tdlo_cpd_lle_resident
+ * (environment TDLO_BATCH_STREAMS=n forces n groups, 1: one stream).  The sorted cloud is reused only when EVERY frame of the batch
+ * can reuse its own.  The call returns after all streams have drained. */
 int tdlo_cpd_lle_batch(tdlo_ctx *ctx, int F, double *Y, int M, double *sigma2,
                        const tdlo_params *params, const double *priors, int K,
                        const int *visible_nodes, int n_vis, const double *H_override,
@@ -188,9 +204,12 @@ int tdlo_split_poll(tdlo_ctx *ctx, int *done, int *iters);   /* synchronises the
  *       Any chain length (the one-workgroup M-steps carry the exchange: the chain smoother, and with the LLE term the banded
  *       L D L^T; a registration whose LLE system takes the dense eliminations -- coincident nodes, an H_override that is not banded --
  *       only up to 64 nodes); up to 8 ranks.  A rank that is more than 2 s behind its peers (or gone) makes the waiting kernels give up:
- *       TDLO_E_EXCHANGE on the ranks that waited.  Arguments are validated before anything is exchanged; a shard that loses every point
+ *       TDLO_E_EXCHANGE on the ranks that waited.  A rank whose own shard fails (TDLO_E_NUMERIC from the E-step's range check) raises its
+ *       flag with an error mark: its peers leave the same iteration with TDLO_E_NUMERIC instead of waiting out the limit.  Arguments are validated before anything is exchanged; a shard that loses every point
  *       to the prune still takes part (it contributes zeros).
- * The stopping rule is evaluated on the device and read after iterations 1, 2, 4, 8, 12, ... (tol > 0). */
+ * The stopping rule is evaluated on the device and read after iterations 1, 2, 4, 8, 12, ... (tol > 0).
+ * With the LLE term, a banded solve that meets a non-positive pivot is repeated on the dense pivoted kernels by all ranks together
+ * (stats->band_retry), as tdlo_cpd_lle_resident does; in the one-shot form only for chains of up to 64 nodes (longer: TDLO_E_NUMERIC). */
 int tdlo_split_run(tdlo_ctx *ctx, void *nccl_comm, double *Y, int M, double *sigma2, const tdlo_params *params,
                    const double *priors, int K, const int *visible_nodes, int n_vis, const double *H_override, tdlo_stats *stats);
 /* One-shot exchange set-up.  tdlo_xch_create allocates this rank's inbox (device memory, zeroed; tdlo_xch_bytes bytes) for
@@ -348,7 +367,8 @@ int tdlo_debug_mstep_dense(int on);
 int tdlo_debug_mstep_lle_dense(int on);
 /* How many calls of this context were repeated on the dense pivoted kernels because the banded L D L^T (which takes no pivots) met a
  * non-positive pivot or produced a non-finite sigma2: an indefinite H_override, or a chain at the edge of the gap test.  The reference's
- * solver is a general one (trackdlo.cpp:415); the caller sees the dense kernels' result.  -1 for a null context. */
+ * solver is a general one (trackdlo.cpp:415); the caller sees the dense kernels' result, and tdlo_stats.band_retry = 1 on that call
+ * (tdlo_cpd_lle*, tdlo_split_run in both forms: the ranks solve the same system and repeat together).  -1 for a null context. */
 long long tdlo_debug_band_retries(tdlo_ctx *ctx);
 /* Test aid: provokes a HIP runtime error inside the library (an invalid copy) and reports it like any other: returns TDLO_E_HIP with the
  * text in tdlo_last_error.  The calls that follow must be unaffected -- HIP keeps a per-thread "last error" that the launch checks of a later
@@ -358,6 +378,11 @@ int tdlo_debug_fail_hip(tdlo_ctx *ctx);
  * reference has no such figures, and the markers cost about 15 us per call (2 % of a 50-iteration call at N = 50 000).  Returns the
  * previous setting (or TDLO_E_INVALID). */
 int tdlo_set_timing(tdlo_ctx *ctx, int on);
+/* Whether registrations of this context may reuse a slot's pruned, node-sorted cloud (see tdlo_cpd_lle_resident).  On by default
+ * (off when the environment holds TDLO_REUSE_SORT=0); the reference prunes in every call (trackdlo.cpp:177-195), and a caller that
+ * wants every call to pay for that -- a benchmark that registers the same frame again and again -- turns it off.  Returns the
+ * previous setting (or TDLO_E_INVALID). */
+int tdlo_set_sort_reuse(tdlo_ctx *ctx, int on);
 /* Development aid: copies the pruned, centred, node-sorted cloud of the last call (N x 3 column-major, widened to
  * double) and the centring offset; returns N. */
 int tdlo_debug_read_cloud(tdlo_ctx *ctx, int slot, double *out, int max_points, double *ctr);

@@ -15,6 +15,10 @@ class StubContext:
     def set_timing(self, on):
         return True
 
+    def set_sort_reuse(self, on):
+        prev, self.sort_reuse = getattr(self, "sort_reuse", True), bool(on)
+        return prev
+
     def synchronize(self):
         pass
 
@@ -26,11 +30,12 @@ class StubContext:
 
     def cpd_lle_resident(self, slot, Y, sigma2, params, **_):
         time.sleep(0.001)
-        return dict(Y=np.asarray(Y), sigma2=1e-5, iters=params.max_iter, loop_ms=1.0, n_kept=0, converged=False, rc=0)
+        return dict(Y=np.asarray(Y), sigma2=1e-5, iters=params.max_iter, loop_ms=1.0, n_kept=0, converged=False, rc=0,
+                    sort_reused=int(getattr(self, "sort_reuse", True)))
 
     def cpd_lle_batch(self, Ys, sigma2s, params, **_):
         time.sleep(0.001)
-        return dict(Y=list(Ys), sigma2=np.asarray(sigma2s), stats=[dict(loop_ms=1.0, iters=params.max_iter) for _ in Ys])
+        return dict(Y=list(Ys), sigma2=np.asarray(sigma2s), stats=[dict(loop_ms=1.0, iters=params.max_iter, sort_reused=int(getattr(self, "sort_reuse", True))) for _ in Ys])
 
     def profile_iteration(self, reps=200):
         return 7.0, 17.0, 28.0, "k_mstep_fast<MFMA>"

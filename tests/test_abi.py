@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.tdlo_abi_version() == 2
+    assert lib.tdlo_abi_version() == 3
 
 
 def test_one_hip_runtime_per_process():

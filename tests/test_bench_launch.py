@@ -21,9 +21,18 @@ def _env(**extra):
 
 
 def _json_line(stdout):
+    """The driver's view: the LAST line of stdout is the JSON object, and it fits well inside the 8 KB the driver keeps (a 25.7 KB
+    line scrolled out of the capture and BENCH_r03.parsed was null)."""
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, stdout[-2000:]
+    assert stdout.rstrip("\n").splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 4096, len(lines[0])
     return json.loads(lines[0])
+
+
+def _detail():
+    with open(os.path.join(ROOT, "bench_detail.json")) as fh:
+        return json.load(fh)
 
 
 @pytest.mark.parametrize("config,frames", [("c2", 1), ("c3", 32)])
@@ -39,6 +48,10 @@ def test_gpus_2_self_launches_two_ranks(config, frames):
     assert line["roofline"]["kernel"] == "k_mstep_fast<MFMA>" and abs(line["roofline"]["share_of_gpu_time"] - 17 / 24) < 1e-3
     assert {o["bound"] for o in line["roofline_kernels"]} == {"hbm", "mfma"}
     assert line["cpu_baseline"] is None and line["vs_baseline"] is None
+    # every timed call pruned (the bench switches the sorted-cloud reuse off), and the line says so
+    assert line["prune_dispatches_per_call"] == 1.0 and "reuse OFF" in line["config"]["workload"]
+    d = _detail()
+    assert d["value"] == line["value"] and "note" in d["roofline"] and len(d["roofline_kernels"]) == 2
 
 
 def test_driver_style_launch_and_world_size_mismatch():
@@ -64,7 +77,23 @@ def test_single_rank_line_schema():
     assert line["metric"] == "EM iterations/sec at N=50k cloud pts, M=50 nodes" and line["n_gpus"] == 1 and line["dtype"] == "f32"
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in line["roofline"]
-    assert "em_iters_per_s_f64" in line
+    assert "em_iters_per_s_f64" in line and line["detail"] == "bench_detail.json"
+    assert "2 resident (cloud, Y0) pairs" in line["config"]["workload"]
+
+
+def test_default_run_with_legs_stays_under_the_line_limit():
+    """The driver's command (no --no-legs): the headline plus the c3 / c4 / c5 legs, `sustained` and `preproc` -- the line carries them as
+    scalars, the full objects are in bench_detail.json."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=_env(TDLO_BENCH_STUB_LEGS="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert set(line["configs"]) == {"c3", "c4", "c5"}
+    for name, leg in line["configs"].items():
+        assert "error" not in leg, (name, leg)
+        assert leg["value"] > 0 and leg["roofline_frac"] is not None
+    d = _detail()
+    assert "roofline_kernels" in d["configs"]["c3"] and d["configs"]["c4"]["scaling"] == "strong"
 
 
 @pytest.mark.parametrize("fail", ["", "can_access:1", "create:0", "open:1"])

@@ -300,3 +300,48 @@ def test_cpp_driver_without_python_or_torch():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout and "bit for bit" in r.stdout
+
+
+_FAIL_SCRIPT = r"""
+import sys, queue, threading, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from trackdlo_amd import binding as B, synth
+P = synth.LAUNCH_PARAMS
+R, N, M, lle = 3, 9000, 40, int(sys.argv[3])
+X, Y0, _ = synth.scene(N, M, config=31)
+pr = B.make_params(P["beta_pre_proc"] if lle else P["beta"], P["lambda_pre_proc"] if lle else P["lambda_"], P["lle_weight"], P["mu"], 6, 0.0, bool(lle))
+ctxs = [B.Context(device=0, max_frames=1, max_points=N // R + 1, max_nodes=64) for _ in range(R)]
+inboxes = [c.xch_create(R, 64) for c in ctxs]
+out = queue.Queue()
+def work(r):
+    ctxs[r].xch_bind(r, inboxes)
+    ctxs[r].set_cloud(0, X[r * N // R:(r + 1) * N // R])
+    ctxs[r].cpd_lle_resident(0, Y0, 2e-5 if lle else 0.0, pr, check=False)      # (code objects loaded, buffers sized: the timing below is the exchange's)
+    t0 = time.perf_counter()
+    g = ctxs[r].split_run(Y0, 2e-5 if lle else 0.0, pr, check=False)
+    out.put((r, g["rc"], time.perf_counter() - t0, g["iters"]))
+th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+[t.start() for t in th]; [t.join() for t in th]
+res = sorted(out.get() for _ in range(R))
+np.save(sys.argv[2], np.array([[rc, dt, it] for _, rc, dt, it in res]))
+for c in ctxs: c.close()
+"""
+
+
+@pytest.mark.parametrize("lle", [0, 1], ids=["chain", "band"])
+def test_one_shot_exchange_a_failing_shard_takes_its_peers_along(tmp_path, lle):
+    """a rank whose own shard fails (the E-step's range check -> TDLO_E_NUMERIC, forced here on rank 1 of 3 by the test hook
+    TDLO_TEST_RANGE_FAIL_RANK) used to leave the M-step before the exchange, and its peers sat out the 2 s limit and reported
+    TDLO_E_EXCHANGE.  It now raises its flag with an error mark: every rank returns TDLO_E_NUMERIC, at once.  With the LLE term the
+    ranks then repeat the call together on the dense kernels (tdlo_split_run's retry), where rank 1 fails again: the same verdict."""
+    import subprocess, sys
+    from trackdlo_amd import binding as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "fail.npy"
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", TDLO_TEST_RANGE_FAIL_RANK="1")
+    r = subprocess.run([sys.executable, "-c", _FAIL_SCRIPT, root, str(out), str(lle)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(out)
+    assert [int(v) for v in z[:, 0]] == [B.TDLO_E_NUMERIC] * 3, z
+    assert z[:, 1].max() < 1.5, z            # nobody waited for the 2 s time limit of the exchange
+    assert [int(v) for v in z[:, 2]] == [0, 0, 0]

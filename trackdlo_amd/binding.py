@@ -38,7 +38,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("iters", C.c_int), ("converged", C.c_int), ("n_kept", C.c_int), ("status", C.c_int),
                 ("sigma2", C.c_double), ("loop_ms", C.c_float), ("total_ms", C.c_float), ("host_ms", C.c_double),
-                ("mstep_retries", C.c_int)]
+                ("mstep_retries", C.c_int), ("sort_reused", C.c_int), ("band_retry", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -180,6 +180,8 @@ def load_library(path: str | None = None):
     lib.tdlo_debug_fail_hip.restype = ci
     lib.tdlo_set_timing.argtypes = [vp, ci]
     lib.tdlo_set_timing.restype = ci
+    lib.tdlo_set_sort_reuse.argtypes = [vp, ci]
+    lib.tdlo_set_sort_reuse.restype = ci
     lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
     lib.tdlo_piecewise_error.restype = cd
     lib.tdlo_piecewise_error.argtypes = [vp, ci, vp, ci]
@@ -277,6 +279,11 @@ class Context:
     def set_timing(self, on):
         return bool(self.lib.tdlo_set_timing(self.h, 1 if on else 0))
 
+    def set_sort_reuse(self, on):
+        """Whether a registration may reuse the slot's pruned, node-sorted cloud of the previous one (tdlo_set_sort_reuse; default on).
+        Returns the previous setting."""
+        return bool(self.lib.tdlo_set_sort_reuse(self.h, 1 if on else 0))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.tdlo_destroy(self.h)
@@ -325,7 +332,8 @@ class Context:
         if check:
             self._chk(rc)
         return dict(Y=Y, sigma2=s2.value, converged=bool(st.converged), iters=st.iters, n_kept=st.n_kept, rc=rc,
-                    status=st.status, loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms, mstep_retries=st.mstep_retries)
+                    status=st.status, loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms, mstep_retries=st.mstep_retries,
+                    sort_reused=st.sort_reused, band_retry=st.band_retry)
 
     def cpd_lle(self, X, Y, sigma2, params: Params, priors=None, visible_nodes=None, H=None, check=True):
         """trackdlo::cpd_lle (trackdlo.cpp:161-441): returns dict(Y, sigma2, converged, ...)."""
@@ -358,7 +366,7 @@ class Context:
         if check:
             self._chk(rc)
         return dict(Y=Y, sigma2=s2.value, converged=bool(st.converged), iters=st.iters, n_kept=st.n_kept, rc=rc, status=st.status,
-                    loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms)
+                    loop_ms=st.loop_ms, total_ms=st.total_ms, host_ms=st.host_ms, band_retry=st.band_retry)
 
     def xch_create(self, nranks, max_nodes):
         """This rank's inbox of the one-shot exchange; returns its device pointer (an integer)."""

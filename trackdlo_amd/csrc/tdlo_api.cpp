@@ -151,6 +151,7 @@ struct tdlo_ctx {
     int last_F = 0;
     bool lle_dense_once = false;          // run_frames' retry: the banded LLE solve reported a numeric failure, this call repeats with the dense pivoted kernels
     long long band_retries = 0;           // how often that happened (tdlo_debug_band_retries)
+    bool sort_reuse = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);   // tdlo_set_sort_reuse: a slot's sorted cloud may serve the next registration of the same nodes
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
     // split-mode scratch
@@ -381,8 +382,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     }
     f.Xraw = s.Xraw; f.Xs = s.Xs; f.bucket = s.bucket; f.hist = s.hist; f.hist_off = s.hist + (size_t)f.nprune_blocks * M; f.blksum = s.blksum;
     f.keep = s.blksum + (size_t)s.cap_points / kBlock + 1;
-    static const bool reuse_on = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);
-    f.reuse_sorted = (reuse_on && s.sorted_valid && s.sorted_prec == p->precision && s.sorted_Y.size() == 3 * (size_t)M &&
+    f.reuse_sorted = (c->sort_reuse && s.sorted_valid && s.sorted_prec == p->precision && s.sorted_Y.size() == 3 * (size_t)M &&
                       std::memcmp(s.sorted_Y.data(), Y, sizeof(double) * 3 * M) == 0) ? 1 : 0;
     f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
     f.coord = blk + nc.coord; f.G = blk + nc.G; f.chain = blk + nc.chain; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
@@ -465,6 +465,12 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             if (p->include_lle) f.H = bu + nc.H;
             f.Yout = br; f.st = (IterState *)(br + (nc.st - nc.Yout));
         }
+    }
+    {   // prune, scan and scatter are skipped per LAUNCH: the sorted clouds are reused only when every frame of the call can reuse its own
+        // (a frame that skipped its scan while the batch's scatter ran would have its cloud re-scattered from stale start offsets)
+        bool all_reuse = true;
+        for (int i = 0; i < F; ++i) all_reuse = all_reuse && c->fh[i].reuse_sorted;
+        if (!all_reuse) for (int i = 0; i < F; ++i) c->fh[i].reuse_sorted = 0;
     }
     if (p->include_lle) {          // one M-step kernel serves the whole batch: a frame whose chain the banded solve cannot take
         bool all_band = true;      // sends all frames to the dense one
@@ -658,6 +664,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (stats) {
             fill_stats(&stats[i], is);
             stats[i].loop_ms = loop_ms; stats[i].total_ms = total_ms; stats[i].host_ms = host_ms;
+            stats[i].sort_reused = c->fh[i].reuse_sorted; stats[i].band_retry = c->lle_dense_once ? 1 : 0;
         }
         if (is.status != 0 && worst == 0) worst = is.status;
     }
@@ -1152,6 +1159,11 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     if (oneshot) {
         for (int r = 0; r < kMaxXchRanks; ++r) f.xch_inbox[r] = c->xch_peer[r];
         f.xch_rank = c->xch_rank; f.xch_nranks = c->xch_nranks; f.xch_mcap = c->xch_mcap; f.xch_epoch = ++c->xch_calls;
+        {   // test hook (tests/test_split_native_gpu.py): rank r's E-step refuses every sum as out of range -- an error of ONE shard, which its
+            // peers must learn about inside the exchange (kXchErrMark) instead of waiting out the time limit
+            static const int fail_rank = getenv("TDLO_TEST_RANGE_FAIL_RANK") ? atoi(getenv("TDLO_TEST_RANGE_FAIL_RANK")) : -1;
+            if (fail_rank >= 0 && fail_rank == c->xch_rank) f.acc_lim[0] = f.acc_lim[1] = f.acc_lim[2] = 0.0;
+        }
     } else {
         const size_t need = 2 + (size_t)M + 4 * (size_t)M + 2 + 2;
         if (need > c->split_buf_doubles) {
@@ -1236,6 +1248,18 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     std::memcpy(&is, c->pin + (nc.st - nc.Yout), sizeof is);
     if (!oneshot) { common_status = (int)c->pin[nc.readback + 1]; if (common_status < 0 && is.status == 0) is.status = common_status; }
     c->last_F = 1;
+    // The banded L D L^T gave up (non-positive pivot, non-finite sigma2): every rank solves the same system from the same sums, so every rank
+    // is here with TDLO_E_NUMERIC (RCCL form: the common status; one-shot form: the same pivots, and a rank whose own shard failed has told
+    // its peers, kXchErrMark) and repeats the call on the dense pivoted kernels, like run_frames -- Y and sigma2 are untouched so far.  The
+    // one-shot exchange lives in one-workgroup kernels only: the dense k_mstep_fast serves up to 64 nodes, longer chains keep the error.
+    if (is.status == TDLO_E_NUMERIC && p->include_lle && f.lle_band && !c->lle_dense_once && (!oneshot || M <= 64)) {
+        c->lle_dense_once = true;
+        ++c->band_retries;
+        const int rr = tdlo_split_run(c, nccl_comm, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+        c->lle_dense_once = false;
+        if (stats) stats->band_retry = 1;
+        return rr;
+    }
     if ((is.status == 0 || is.status == TDLO_E_NUMERIC) && is.it > 0) { std::memcpy(Y, c->pin, sizeof(double) * 3 * M); }
     if (is.status == 0 || is.status == TDLO_E_NUMERIC) *sigma2 = is.sigma2;
     if (stats) {
@@ -1572,6 +1596,13 @@ int tdlo_debug_fail_hip(tdlo_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(nullptr, nullptr, 16, hipMemcpyDeviceToDevice));      // hipErrorInvalidValue
     return TDLO_OK;
+}
+
+int tdlo_set_sort_reuse(tdlo_ctx *c, int on) {
+    if (!c) return TDLO_E_INVALID;
+    const int prev = c->sort_reuse ? 1 : 0;
+    c->sort_reuse = on != 0;
+    return prev;
 }
 
 int tdlo_set_timing(tdlo_ctx *c, int on) {

@@ -265,6 +265,10 @@ __device__ __forceinline__ double xch_load_f64(const xch_word *p) { return __lon
 __device__ __forceinline__ void xch_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
 __device__ __forceinline__ void xch_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
 constexpr unsigned long long kXchSpinTicks = 200000000ull;      // 2 s of the 100 MHz real-time clock: a peer that is this late is gone
+// A rank whose registration ended on an error of its OWN shard (the E-step's range check: TDLO_E_NUMERIC) leaves the M-step before the exchange;
+// it still raises its flag, with this mark in the tag, so that its peers leave with the same status instead of sitting out the time limit
+// (tags proper carry the iteration number + 1 < 2^30 in their low word, the once-per-call exchange 0x80000000)
+constexpr unsigned long long kXchErrMark = 0x40000000ull;
 // waits until *flag == tag; false when the time limit passed
 __device__ __forceinline__ bool xch_wait(const xch_word *flag, unsigned long long tag) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -273,6 +277,24 @@ __device__ __forceinline__ bool xch_wait(const xch_word *flag, unsigned long lon
         if (__builtin_amdgcn_s_memrealtime() - t0 > kXchSpinTicks) return false;
     }
     return true;
+}
+// the same for the per-iteration sums: 1 = arrived, 0 = time limit, -1 = the peer reported an error of its own (kXchErrMark)
+__device__ __forceinline__ int xch_wait_sums(const xch_word *flag, unsigned long long tag) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned long long v = xch_load(flag);
+        if (v == tag) return 1;
+        if (v == (tag | kXchErrMark)) return -1;
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kXchSpinTicks) return 0;
+    }
+}
+// a finished registration's M-step in the one-shot exchange: if it finished on TDLO_E_NUMERIC, tell the peers (lane = peer)
+__device__ __forceinline__ void xch_post_error(const FrameDev &f, const IterState *st, int t) {
+    if (f.xch_nranks < 1 || st->status != TDLO_E_NUMERIC) return;
+    const int R = f.xch_nranks, me = f.xch_rank, it = st->it, par = it & 1;
+    const unsigned long long tag = ((unsigned long long)f.xch_epoch << 32) | (unsigned)(it + 1) | kXchErrMark;
+    if (t < R) xch_store(xch_ptr(f.xch_inbox[t]) + xch_off_flag_sums(R) + par * R + me, tag);
 }
 
 }  // namespace tdlo

@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
 #endif
 #pragma unroll
     for (int u = 0; u < GQ; ++u) { const int i = t + u * MB; if (i < M * M) Gs[i] = gq[u]; }
-    if (done) return;
+    if (done) { if (XCH && from_sums == 3) xch_post_error(f, st, t); return; }
     if (slot == 0) {
         aux[row] = (double)nq.x - y0q[0]; aux[64 + row] = (double)nq.y - y0q[1]; aux[128 + row] = (double)nq.z - y0q[2];
         aux[192 + row] = ayq[0]; aux[256 + row] = ayq[1]; aux[320 + row] = ayq[2]; aux[384 + row] = ajq;
@@ -1278,10 +1278,10 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         const xch_word *own = xch_ptr(f.xch_inbox[me]);
         if (t == 0) red[7] = 1.0;
         __syncthreads();
-        if (t < R && !xch_wait(own + xch_off_flag_sums(R) + par * R + t, tag)) red[7] = 0.0;
+        if (t < R) { const int w_ = xch_wait_sums(own + xch_off_flag_sums(R) + par * R + t, tag); if (w_ != 1) red[7] = w_ == 0 ? 0.0 : -1.0; }      // (-1: that peer's own shard failed, kXchErrMark)
         __syncthreads();
         xch_acquire();
-        if (red[7] == 0.0) { if (t == 0) { st->status = TDLO_E_EXCHANGE; st->done = 1; st->converged = 0; } return; }
+        if (red[7] != 1.0) { if (t == 0) { st->status = red[7] == 0.0 ? TDLO_E_EXCHANGE : TDLO_E_NUMERIC; st->done = 1; st->converged = 0; } return; }
         for (int i = t; i < nS; i += MB) {
             double a = 0;
             for (int r = 0; r < R; ++r) a += xch_load_f64(own + so + ((size_t)par * R + r) * sl + i);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
     const double gam = f.lle_weight;
     const double Nc = stg->Nc;
     const double kc = f.mu / (1.0 - f.mu) * (f.vis_branch ? 1.0 / Nc : (double)M / Nc);
-    if (done) return;
+    if (done) { if (XCH && from_sums == 3) xch_post_error(f, st, t); return; }
     BSTAMP(1);
     if (from_sums != 1) {
 #pragma unroll
@@ -195,10 +195,10 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
         const xch_word *own = xch_ptr(f.xch_inbox[me]);
         if (t == 0) red[24] = 1.0;
         __syncthreads();
-        if (t < R && !xch_wait(own + xch_off_flag_sums(R) + par * R + t, tag)) red[24] = 0.0;
+        if (t < R) { const int w_ = xch_wait_sums(own + xch_off_flag_sums(R) + par * R + t, tag); if (w_ != 1) red[24] = w_ == 0 ? 0.0 : -1.0; }      // (-1: that peer's own shard failed, kXchErrMark)
         __syncthreads();
         xch_acquire();
-        if (red[24] == 0.0) { if (t == 0) { st->status = TDLO_E_EXCHANGE; st->done = 1; st->converged = 0; } return; }
+        if (red[24] != 1.0) { if (t == 0) { st->status = red[24] == 0.0 ? TDLO_E_EXCHANGE : TDLO_E_NUMERIC; st->done = 1; st->converged = 0; } return; }
         for (int i = t; i < nS; i += MB) {
             double a = 0;
             for (int r = 0; r < R; ++r) a += xch_load_f64(own + so + ((size_t)par * R + r) * sl + i);
