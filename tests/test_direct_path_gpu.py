@@ -1,0 +1,142 @@
+"""GPU suite for the one-frame fast path of round 4 (the prologue of a production-size frame).
+
+  * the FUSED PROLOGUE: prune + count scan + setup + scatter of a small cloud in one launch (k_prologue), the host-supplied block read from
+    pinned host memory by the kernel -- against the three-kernel form behind a host-to-device copy (TDLO_DIRECT_UPLOAD=0);
+  * the RESULTS MAILBOX: the finishing M-step writes [Y | state] into pinned host memory and the host waits on that word -- against the
+    read-back copy + stream synchronisation (TDLO_HOST_MAILBOX=0).
+Both are implementation routes for the same arithmetic in the same order (trackdlo.cpp:177-273 and the read-back of :440): every result must
+be the same BITS, including the sorted cloud, for every size class either side of the routes' limits.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(B, classic, **kw):
+    keys = ("TDLO_DIRECT_UPLOAD", "TDLO_HOST_MAILBOX")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            if classic:
+                os.environ[k] = "0"
+            else:
+                os.environ.pop(k, None)
+        return B.Context(device=0, **kw)           # the switches are read when the context is made
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _same(a, b):
+    np.testing.assert_array_equal(a["Y"], b["Y"])
+    for k in ("sigma2", "iters", "converged", "n_kept", "rc", "status"):
+        assert a[k] == b[k], (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+@pytest.mark.parametrize("N,M", [(63, 4), (256, 30), (257, 45), (5000, 45), (5000, 64), (5000, 65), (16384, 50), (16385, 50), (9000, 200), (9000, 256), (9000, 257), (3000, 512)])
+def test_fused_prologue_equals_the_three_kernel_form(N, M, prec):
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, v = synth.scene(N, M, config=71, occlude=(0.4, 0.6), outliers=11)
+    vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0))
+    new = _ctx(B, False, max_points=N, max_nodes=max(64, M))
+    old = _ctx(B, True, max_points=N, max_nodes=max(64, M))
+    try:
+        for c in (new, old):
+            c.set_sort_reuse(False)
+            c.set_cloud(0, X)
+        idx = np.arange(0, M, 3)
+        pri = np.concatenate([idx[:, None].astype(float), Y0[idx] + np.array([0, 0.004, 0.0])], axis=1)
+        runs = [
+            dict(p=B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 5, 0.0, False, precision=prec), s2=0.0),
+            dict(p=B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 50, 2e-4, False, P["alpha"], P["k_vis"], P["visibility_threshold"], precision=prec),
+                 s2=0.0, priors=pri, visible_nodes=vext),
+            dict(p=B.make_params(P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], P["mu"], 4, 0.0, True, precision=prec), s2=3e-5),
+            dict(p=B.make_params(P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], P["mu"], 50, 2e-4, True, precision=prec), s2=3e-5),
+            dict(p=B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 1, 0.0, False, precision=prec), s2=1e-4),
+        ]
+        for r in runs:
+            kw = {k: r[k] for k in ("priors", "visible_nodes") if k in r}
+            a = new.cpd_lle_resident(0, Y0, r["s2"], r["p"], check=False, **kw)
+            b = old.cpd_lle_resident(0, Y0, r["s2"], r["p"], check=False, **kw)
+            _same(a, b)
+            ca, oa = new.debug_read_cloud(N); cb, ob = old.debug_read_cloud(N)
+            np.testing.assert_array_equal(ca, cb); np.testing.assert_array_equal(oa, ob)      # the pruned, centred, node-sorted cloud and its offset
+        # with the reuse on: the second call takes the setup workgroup alone (k_setup reading pinned host memory)
+        new.set_sort_reuse(True); old.set_sort_reuse(True)
+        for _ in range(2):
+            a = new.cpd_lle_resident(0, Y0, 0.0, runs[1]["p"], priors=pri, visible_nodes=vext)
+            b = old.cpd_lle_resident(0, Y0, 0.0, runs[1]["p"], priors=pri, visible_nodes=vext)
+            _same(a, b)
+        assert a["sort_reused"] == 1 and b["sort_reused"] == 1
+    finally:
+        new.close(); old.close()
+
+
+def test_direct_path_error_exits_reach_the_host():
+    """Registrations that end somewhere else than in an M-step that finishes them: every point pruned (setup), the E-step's range check.
+    With the mailbox the M-step that finds the registration done reports it; the codes and the untouched Y are those of the copy route."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M, N = 12, 600
+    X, Y0, _ = synth.scene(N, M, config=811)
+    for classic in (False, True):
+        ctx = _ctx(B, classic, max_points=N, max_nodes=64)
+        try:
+            pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 6, 0.0, False)
+            g = ctx.cpd_lle(X + np.array([0.0, 0.0, 5.0]), Y0, 0.0, pr, check=False)
+            assert g["rc"] == B.TDLO_E_EMPTY and g["iters"] == 0
+            np.testing.assert_array_equal(g["Y"], Y0)
+            kw = B.make_params(P["beta"], 1.0, P["lle_weight"], P["mu"], 6, 0.0, False, 1e12, precision=1)
+            pri = np.array([[5, Y0[5, 0] + 3e4, Y0[5, 1], Y0[5, 2]]])
+            g = ctx.cpd_lle(X, Y0, 0.0, kw, priors=pri, check=False)
+            assert g["rc"] in (0, B.TDLO_E_NUMERIC)
+            if classic:
+                ref = g
+            else:
+                first = g
+            g = ctx.cpd_lle(X, Y0, 0.0, pr)                   # and the context stays usable
+            assert g["rc"] == 0 and g["iters"] == 6
+        finally:
+            ctx.close()
+    assert first["rc"] == ref["rc"] and first["iters"] == ref["iters"]
+    np.testing.assert_array_equal(first["Y"], ref["Y"])
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_tracking_sequences_are_the_same_on_both_routes(prec):
+    """tracking_step over a moving, partly occluded rope: 12 frames on the fast path and on the copy route -- the same nodes, sigma2,
+    iteration counts and priors, bit for bit."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M, N = 45, 5000
+    outs = []
+    for classic in (False, True):
+        ctx = _ctx(B, classic, max_points=N, max_nodes=64)
+        try:
+            _, Y0, _ = synth.scene(N, M, config=72)
+            coord = synth.geodesic_coord(Y0)
+            trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 50, P["tol"], P["beta_pre_proc"],
+                             P["lambda_pre_proc"], P["lle_weight"], ctx=ctx, precision=prec)
+            trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+            rec = []
+            for fr in range(12):
+                occl = None if fr % 3 == 0 else ((0.4, 0.5) if fr % 3 == 1 else (0.0, 0.2))
+                X, _, v = synth.scene(N, M, config=72, frame=fr, occlude=occl)
+                v = np.arange(M, dtype=np.int32) if v is None else v
+                vext = synth.extend_visible(v, M, coord)
+                trk.tracking_step(X, v, vext)
+                rec.append((trk.get_tracking_result(), trk.get_sigma2(), [s["iters"] for s in trk.last_stats], trk.get_correspondence_pairs(), trk.get_guide_nodes()))
+            outs.append(rec)
+        finally:
+            ctx.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])

@@ -50,6 +50,7 @@ struct Slot {
     double *nodeblk = nullptr;
     size_t nodeblk_doubles = 0;
     unsigned *sync = nullptr;        // 256 words, zeroed once: cross-workgroup hand-off state of the multi-CU M-step
+    unsigned fuse_epoch = 0;         // launches of the fused prologue on this slot (its grid barrier's flag carries the number)
 };
 
 struct NodeCarve {
@@ -152,6 +153,13 @@ struct tdlo_ctx {
     bool lle_dense_once = false;          // run_frames' retry: the banded LLE solve reported a numeric failure, this call repeats with the dense pivoted kernels
     long long band_retries = 0;           // how often that happened (tdlo_debug_band_retries)
     bool sort_reuse = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);   // tdlo_set_sort_reuse: a slot's sorted cloud may serve the next registration of the same nodes
+    // results mailbox in pinned host memory (FrameDev::host_out / host_prog): [read-back block | progress word], written by the one-workgroup M-steps
+    double *mbox = nullptr;
+    size_t mbox_doubles = 0;
+    unsigned mbox_epoch = 0;
+    bool direct_in = !(getenv("TDLO_DIRECT_UPLOAD") && atoi(getenv("TDLO_DIRECT_UPLOAD")) == 0);   // one frame per call: the set-up kernels read the host-supplied block from pinned host
+                                                                                                // memory themselves (small clouds: the fused prologue); 0: copy + three launches (comparator)
+    bool mbox_on = !(getenv("TDLO_HOST_MAILBOX") && atoi(getenv("TDLO_HOST_MAILBOX")) == 0);   // TDLO_HOST_MAILBOX=0: the read-back copy + stream wait of rounds 1-3 (comparator)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
     // split-mode scratch
@@ -211,6 +219,49 @@ int ensure_pin(tdlo_ctx *c, size_t doubles) {
     HIPCHK(c, hipHostMalloc((void **)&c->pin, doubles * sizeof(double), hipHostMallocDefault));
     c->pin_doubles = doubles;
     return 0;
+}
+
+int ensure_mbox(tdlo_ctx *c, size_t doubles) {
+    if (doubles <= c->mbox_doubles) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // (kernels of an earlier call may still report their progress into the old one)
+    if (c->mbox) hipHostFree(c->mbox);
+    c->mbox = nullptr; c->mbox_doubles = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->mbox, doubles * sizeof(double), hipHostMallocDefault));
+    std::memset(c->mbox, 0, doubles * sizeof(double));
+    c->mbox_doubles = doubles;
+    return 0;
+}
+
+// Waits until the M-steps of registration `epoch` have reported `min_it` completed iterations, or that the registration is done (need_done:
+// only that).  *word = the progress word seen.  Returns 0; 1 when the stream has drained without that report (the caller falls back on the
+// read-back copy); a negative code for a HIP error on the stream.  The wait spins on pinned host memory -- the M-step's own store is the
+// earliest moment the host can know -- and looks at the stream only every 0.5 ms, so that a faulting kernel cannot hang the caller.
+int mbox_wait(tdlo_ctx *c, unsigned epoch, int min_it, bool need_done, unsigned long long *word) {
+    const unsigned long long *w = (const unsigned long long *)(c->mbox + c->mbox_doubles - 2);
+    auto t_chk = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned long long v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+        if ((unsigned)(v >> 32) == epoch) {
+            const bool done = (v >> 31) & 1u;
+            if (done || (!need_done && (int)(v & 0x7fffffffu) >= min_it)) { *word = v; return 0; }
+        }
+        if ((spins & 255u) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (std::chrono::duration<double, std::micro>(now - t_chk).count() > 500.0) {
+                t_chk = now;
+                const hipError_t e = hipStreamQuery(c->stream);
+                if (e == hipSuccess) {          // drained: whatever was going to be reported has been (the kernel's stores precede its completion)
+                    const unsigned long long v2 = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+                    if ((unsigned)(v2 >> 32) == epoch && (((v2 >> 31) & 1u) || (!need_done && (int)(v2 & 0x7fffffffu) >= min_it))) { *word = v2; return 0; }
+                    return 1;
+                }
+                if (e != hipErrorNotReady) return fail(c, TDLO_E_HIP, std::string("stream: ") + hipGetErrorString(e));
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }
 
 int ensure_xfer(tdlo_ctx *c, size_t doubles) {
@@ -477,6 +528,18 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         for (int i = 0; i < F; ++i) all_band = all_band && c->fh[i].lle_band;
         if (!all_band) for (int i = 0; i < F; ++i) { c->fh[i].lle_band = 0; c->fh[i].need_G = 1; }
     }
+    // One frame per call on a one-workgroup M-step (the chain smoother, the banded LLE solve): the results come back through the pinned
+    // mailbox -- the M-step that finishes the registration writes them there itself -- instead of a copy and a stream synchronisation
+    const bool use_mbox = !merged && c->mbox_on && p->max_iter > 0 &&
+                          ((!p->include_lle && !c->fh[0].mstep_dense) || (p->include_lle && c->fh[0].lle_band));
+    unsigned epoch = 0;
+    if (use_mbox) {
+        rc = ensure_mbox(c, nc.readback + 4);
+        if (rc) return rc;
+        epoch = ++c->mbox_epoch;
+        if (epoch == 0) epoch = ++c->mbox_epoch;
+        c->fh[0].host_out = c->mbox; c->fh[0].host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); c->fh[0].host_epoch = epoch;
+    }
     hipStream_t s = c->stream;
     const bool timing = c->timing;
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -487,10 +550,17 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         fdp = (const FrameDev *)(c->xfer + (size_t)F * up);
     } else {
         std::memcpy(c->pin + nc.fdev, c->fh.data(), sizeof(FrameDev));
-        HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
         fdp = (const FrameDev *)(c->slots[slots[0]].nodeblk + nc.fdev);
     }
-    HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
+    if (!merged && c->direct_in && prologue_direct_ok(c->fh[0])) {
+        // one small frame (or a reused sort): ONE launch reads the block from pinned host memory, puts it in its place and does the whole prologue
+        Slot &sl = c->slots[slots[0]];
+        if (++sl.fuse_epoch == 0) ++sl.fuse_epoch;
+        HIPCHK(c, launch_prologue_direct(c->fh.data(), c->pin, sl.nodeblk, (int)up, (int)nc.Yin, sl.fuse_epoch, s));
+    } else {
+        if (!merged) HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
+    }
     for (int i = 0; i < F; ++i) {           // the slots' sorted clouds now belong to these nodes
         Slot &sl = c->slots[slots[i]];
         if (!c->fh[i].reuse_sorted) { sl.sorted_Y.assign(Y + (size_t)i * 3 * M, Y + (size_t)(i + 1) * 3 * M); sl.sorted_prec = p->precision; sl.sorted_valid = true; }
@@ -544,7 +614,24 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         return hipSuccess;
     };
     static const bool pool_on = !(getenv("TDLO_BATCH_THREADS") && atoi(getenv("TDLO_BATCH_THREADS")) == 0);
-    bool have_readback = false;            // the results are already in pinned memory (early exit after the first iteration)
+    bool have_readback = false;            // the results are already in pinned memory (early exit after the first iteration; the mailbox)
+    auto mbox_done = [&](int min_it, bool need_done, bool *done) -> int {     // 0, or an error code
+        unsigned long long w = 0;
+        const int wr = mbox_wait(c, epoch, min_it, need_done, &w);
+        if (wr < 0) return wr;
+        if (wr == 1) return fail(c, TDLO_E_HIP, "the stream drained, but the M-step did not report the state of the registration");
+        *done = (w >> 31) & 1u;
+        return 0;
+    };
+    auto take_mbox = [&](bool events_recorded) -> int {
+        std::memcpy(c->pin, c->mbox, nc.readback * sizeof(double));
+        have_readback = true;
+        if (timing) {
+            if (!events_recorded) { HIPCHK(c, hipEventRecord(c->ev[2], s)); HIPCHK(c, hipEventRecord(c->ev[3], s)); }
+            HIPCHK(c, hipEventSynchronize(c->ev[3]));
+        }
+        return 0;
+    };
     if (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) {
         // fixed iteration count: enqueue everything, no host involvement.  Several stream groups and enough iterations: the first
         // iteration (which releases the groups one after the other) from this thread, the rest of every group from a thread of its own.
@@ -563,6 +650,31 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         } else {
             HIPCHK(c, iterate(p->max_iter));
         }
+        if (use_mbox) {
+            if (timing) { HIPCHK(c, hipEventRecord(c->ev[2], s)); HIPCHK(c, hipEventRecord(c->ev[3], s)); }      // behind the last iteration, as the read-back path does
+            bool done = false;
+            if ((rc = mbox_done(0, true, &done))) return rc;
+            if ((rc = take_mbox(true))) return rc;
+        }
+    } else if (use_mbox) {
+        // early exit (trackdlo.cpp:424-428), decided on the device and read from the mailbox: the first iteration is checked eagerly (a tracker
+        // in steady state converges in it); after that iterations go out in chunks of 1, 1, 2, 4, 4, ... and the host looks at the progress
+        // word of the chunk BEFORE the one it has just enqueued, so that the GPU never idles (kernels of a finished registration are no-ops)
+        c->fh[0].host_report_it = 1;           // (the frame descriptor travels by value with every launch of the one-frame kernels)
+        HIPCHK(c, iterate(1));
+        bool stop = false;
+        if ((rc = mbox_done(1, false, &stop))) return rc;
+        int launched = 1, chunk = 0;
+        while (launched < p->max_iter && !stop) {
+            const int n = std::min(chunk < 2 ? 1 : (chunk == 2 ? 2 : kChunkIters), p->max_iter - launched);
+            c->fh[0].host_report_it = launched + n;      // the chunk's last M-step reports (a store to host memory costs an M-step ~1 us: not every one)
+            HIPCHK(c, iterate(n));
+            launched += n;
+            if ((rc = mbox_done(launched - n, false, &stop))) return rc;
+            ++chunk;
+        }
+        if (!stop && (rc = mbox_done(0, true, &stop))) return rc;      // the last chunk reaches max_iter, which ends the registration
+        if ((rc = take_mbox(false))) return rc;
     } else {
         // early exit (trackdlo.cpp:424-428) is decided on the device; kernels of finished frames are
         // no-ops.  To avoid enqueueing up to max_iter of them, iterations go out in chunks and the
@@ -742,6 +854,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->cloud_ws) hipFree(c->cloud_ws);
     if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
+    if (c->mbox) hipHostFree(c->mbox);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->xfer) hipFree(c->xfer);
     if (c->split_buf) hipFree(c->split_buf);

@@ -253,6 +253,41 @@ __device__ __forceinline__ void chain_link(double beta, double h, double *o) {
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f64_16x16x4_f64
 
+// ---- results into pinned host memory (FrameDev::host_out / host_prog) -------------------------------------------------------------------
+// Called by the 64 lanes of WAVE 0 of a one-workgroup M-step, after a workgroup barrier behind the stores to f.Yout and after lane 0 has
+// updated *st (fresh == true), or at the kernel's early exit from a registration that is already done (fresh == false: only a registration
+// that ended on an error is reported again -- the E-step's range check, an empty cloud --, a finished one has been reported by the M-step that
+// finished it).  Yout and *st are read back through agent-scope loads (this CU's vector cache may hold lines of *st from the kernel's first
+// loads), stored to the host with plain stores, fenced at system scope, then the progress word goes out.
+static_assert(offsetof(IterState, N) == 72 && offsetof(IterState, it) == 76 && offsetof(IterState, done) == 80 && offsetof(IterState, status) == 88 &&
+              sizeof(IterState) <= 13 * 8, "host_publish reads {N, it}, {done, converged}, {status, retry_pending} as 64-bit words");
+__device__ __forceinline__ void host_publish(const FrameDev &f, IterState *st, int lane, bool fresh) {
+    if (!f.host_prog) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // lane 0's stores to *st have been performed
+    const unsigned long long *sw = (const unsigned long long *)st;
+    int it = 0, done = 0, status = 0;
+    if (lane == 0) {
+        const unsigned long long w_it = __hip_atomic_load(sw + offsetof(IterState, it) / 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // {N, it}
+        const unsigned long long w_dn = __hip_atomic_load(sw + offsetof(IterState, done) / 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // {done, converged}
+        const unsigned long long w_st = __hip_atomic_load(sw + offsetof(IterState, status) / 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // {status, retry_pending}
+        it = (int)(w_it >> 32); done = (int)(unsigned)w_dn; status = (int)(unsigned)w_st;
+    }
+    it = __builtin_amdgcn_readfirstlane(it); done = __builtin_amdgcn_readfirstlane(done); status = __builtin_amdgcn_readfirstlane(status);
+    if (!fresh && status == 0) return;
+    if (done) {
+        const int n = 3 * f.M, so = (int)((const double *)st - f.Yout);
+        const unsigned long long *yo = (const unsigned long long *)f.Yout;
+        unsigned long long *ho = (unsigned long long *)f.host_out;
+        for (int i = lane; i < n; i += 64) ho[i] = __hip_atomic_load(yo + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        constexpr int nst = (int)((sizeof(IterState) + 7) / 8);
+        if (lane < nst) ho[so + lane] = __hip_atomic_load(sw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    }
+    if (lane == 0)
+        __hip_atomic_store(f.host_prog, ((unsigned long long)f.host_epoch << 32) | ((unsigned long long)(done ? 1u : 0u) << 31) | (unsigned)(it & 0x7fffffff),
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- one-shot exchange of the N-split: peer-written inboxes (xGMI peer stores on a multi-GPU node), system scope ---------
 // payload: relaxed system-scope stores -> release fence (system) -> flag store; reader: relaxed poll of the flag ->
 // acquire fence (system) -> relaxed system-scope loads of the payload.

@@ -71,11 +71,37 @@ __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restri
     if (threadIdx.x == 0) f.blksum[blockIdx.x] = ssum;
 }
 
+// ---- the fused prologue's grid barrier (k_prologue: up to 64 point workgroups + one node workgroup, all resident at once) ------------------
+// The point workgroups publish their counts with agent-scope stores, wait for them to be performed (vmcnt) and take a ticket; the last one
+// re-arms the counter and raises the flag to this launch's epoch.  Everybody who needs the counts spins on the flag (agent-scope loads) and
+// reads them with agent-scope loads.  (A release fence per workgroup would be an L2 write-back each: tdlo_device.hip, k_dmin.)
+constexpr int kFuseMaxBlocks = 64;       // point workgroups of the fused prologue: clouds of up to 16 384 points
+constexpr int kFuseMaxNodes = 256;       // thread = node in its offset computation
+__device__ __forceinline__ void fuse_arrive(const FrameDev &f, unsigned nblk, unsigned epoch) {      // all threads of a point workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(f.sync + 100, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nblk - 1u) {
+            __hip_atomic_store(f.sync + 100, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(f.sync + 101, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ void fuse_wait(const FrameDev &f, unsigned epoch) {                        // all threads of a workgroup
+    if (threadIdx.x == 0) while (__hip_atomic_load(f.sync + 101, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+}
+
 // One workgroup per frame: scan of the prune counts, centring, chain coordinate + kernel G
 // (:214-233), H*G / H*Y0 (:396-401), iteration-0 constants.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ frames, int split_mode) {
-    const FrameDev &f = frames[blockIdx.x];
+// host_up != nullptr (one frame per call): the host-supplied block [descriptor | Yin | aJ | aYd | H] is read straight from pinned host memory
+// and copied to its place in the slot's node block (dev_up) by this workgroup -- no host-to-device copy in front of the kernel.
+// FUSED: this is the node workgroup of k_prologue; the counts are scanned by the point workgroups themselves, the kept-point count and the
+// sigma2 initialisation sum are formed at the end from what they published.
+template <typename T, bool FUSED>
+__device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, const double *__restrict__ host_up, double *__restrict__ dev_up, int up_doubles,
+                                           int yin_off, unsigned fuse_epoch) {
     IterState *st = f.st;
     __shared__ double sd[kBlock];
     __shared__ double sctr[3];
@@ -93,7 +119,10 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     const int nb = f.nprune_blocks;
     __shared__ double sY[3 * kMaxNodes];
     __shared__ double sc[kMaxNodes];
-    {   // the node block, requested first: it arrives while the counts are scanned (the barriers of the scan cover it)
+    if (host_up) {      // the nodes from pinned host memory, then the whole upload block to its place in device memory (both in flight together)
+        for (int i = t; i < 3 * M; i += kBlock) sY[i] = host_up[yin_off + i];
+        for (int i = t; i < up_doubles; i += kBlock) dev_up[i] = host_up[i];
+    } else {   // the node block, requested first: it arrives while the counts are scanned (the barriers of the scan cover it)
         const auto Yg = TDLO_AS_GLOBAL(double, f.Yin);
         for (int i = t; i < 3 * M; i += kBlock) sY[i] = Yg[i];
     }
@@ -101,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
     __shared__ int csum[kMaxNodes / 64][4][64];   // kept points per (node, quarter of the prune blocks)
     const int ml = t & 63, ch = t >> 6;
     const int cb0 = (int)((long long)nb * ch / 4), cb1 = (int)((long long)nb * (ch + 1) / 4);
-    const bool reuse = f.reuse_sorted != 0 && !split_mode;      // the sorted cloud of the previous registration serves: no counts to scan
+    const bool reuse = FUSED || (f.reuse_sorted != 0 && !split_mode);      // the sorted cloud of the previous registration serves (or the point workgroups of the fused prologue scan): no counts to scan here
     if (!reuse) {
     {
         // (global address space and 16 independent loads per trip: a load-add chain over ~50 blocks costs a memory latency each.  Chains beyond
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         if (m1 < M) stot[m1] = excl + v0;
         if (t == 0) { sN = wtot[0] + wtot[1] + wtot[2] + wtot[3]; sS = ((wsd[0] + wsd[1]) + wsd[2]) + wsd[3]; }
     }
-    if (t == 0 && reuse) { sN = (int)f.keep[0]; sS = f.keep[1]; }
+    if (t == 0 && reuse && !FUSED) { sN = (int)f.keep[0]; sS = f.keep[1]; }
     __syncthreads();
     SSTAMP(2);
     if (!reuse) {
@@ -362,9 +391,29 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
         }
     }
     SSTAMP(6);
+    if (FUSED) {
+        // the point workgroups have published their counts and their shares of the sigma2 initialisation sum: the kept-point count (integers: any
+        // order) and the sum in the order of the unfused kernel -- thread b holds workgroup b's share, the butterfly of wave_sum, the waves left
+        // to right (up to 64 workgroups: only wave 0 holds anything)
+        fuse_wait(f, fuse_epoch);
+        const int nbp = f.nprune_blocks;
+        int cnt = 0;
+        for (int i = t; i < nbp * M; i += kBlock) cnt += __hip_atomic_load(f.hist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double sh = 0.0;
+        if (t < nbp) sh = __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)f.blksum + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        const double ssum = wave_sum(sh);
+        __shared__ int wcn[4];
+        __shared__ double wsd2[4];
+        if ((t & 63) == 0) { wcn[t >> 6] = cnt; wsd2[t >> 6] = ssum; }
+        __syncthreads();
+        if (t == 0) { sN = wcn[0] + wcn[1] + wcn[2] + wcn[3]; sS = ((wsd2[0] + wsd2[1]) + wsd2[2]) + wsd2[3]; }
+        __syncthreads();
+    }
     if (t == 0) {
         const int N = sN;
-        if (!reuse && !split_mode) { f.keep[0] = (double)N; f.keep[1] = sS; }
+        if ((!reuse || FUSED) && !split_mode) { f.keep[0] = (double)N; f.keep[1] = sS; }
         st->N = N; st->sum_d2 = sS;
         st->it = 0; st->converged = 1; st->crit = 0; st->Np = 0;
         st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0;
@@ -376,6 +425,112 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
                 set_iter_consts(f, st, sigma2, (double)N);
             }
         }
+    }
+}
+
+// SINGLE: the frame descriptor arrives by value in the kernarg segment (with host_up the copy in device memory does not exist yet)
+template <typename T, bool SINGLE>
+__global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ frames, const FrameDev f0, int split_mode, const double *__restrict__ host_up,
+                                                  double *__restrict__ dev_up, int up_doubles, int yin_off) {
+    setup_body<T, false>(SINGLE ? f0 : frames[blockIdx.x], split_mode, SINGLE ? host_up : nullptr, dev_up, up_doubles, yin_off, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole prologue of one small frame in ONE launch (production size: a few thousand points, 45 nodes; the registrations of a steady-state
+// tracker converge in one or two iterations, so prune + scan + setup + scatter -- three launches, two dependent-dispatch gaps and a copy --
+// were more than half of a frame's GPU time).  Workgroups 0 .. nb-1 take 256 points each: prune (:177-195) and nearest node exactly as
+// k_prune_pass1, counts published, grid barrier, then every workgroup forms ITS start offsets itself (thread = node: the node's total over
+// all workgroups, the exclusive scan over the nodes, the counts of the workgroups in front of it -- the numbers k_setup's scan gives), and
+// scatters its points like k_prune_scatter from the registers they are still in.  Workgroup nb is k_setup's node work (setup_body<FUSED>),
+// running beside the others.  All nb + 1 <= 65 workgroups are resident at once (256 CUs), which is what lets them wait for each other.
+// The bits are those of the three-kernel form (same arithmetic, same orders; `test_fused_prologue_equals_the_three_kernel_form`).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const double *__restrict__ host_up, double *__restrict__ dev_up, int up_doubles,
+                                                     int yin_off, unsigned epoch) {
+    const int nb = f.nprune_blocks;
+    if ((int)blockIdx.x == nb) { setup_body<T, true>(f, 0, host_up, dev_up, up_doubles, yin_off, epoch); return; }
+    __shared__ double scratch[4];
+    __shared__ double Yl[3 * kFuseMaxNodes];
+    __shared__ double sctr[3];
+    __shared__ int lh[kFuseMaxNodes], base[kFuseMaxNodes], wcnt[4 * kFuseMaxNodes], wtot[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x;
+    const int N0 = f.N0, M = f.M;
+    for (int m = t; m < M; m += kBlock) lh[m] = 0;
+    for (int i = t; i < 3 * M; i += kBlock) Yl[i] = host_up[yin_off + i];
+    const int n = b * kBlock + t;
+    const bool valid = n < N0;
+    double x = 0, y = 0, z = 0;
+    if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
+    __syncthreads();
+    // ---- prune + nearest node (k_prune_pass1)
+    double best = 1e300, sum = 0;
+    int a0 = 0;
+#pragma unroll 4
+    for (int m = 0; m < M; ++m) {
+        const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < best) { best = d2; a0 = m; }
+        sum += d2;
+    }
+    const bool keep = valid && (::sqrt(best) < 0.1);
+    const int bk = keep ? a0 : 0xffff;
+    if (keep) atomicAdd(&lh[a0], 1);
+    const double ssum = block_sum(keep ? sum : 0.0, scratch);
+    __syncthreads();
+    for (int m = t; m < M; m += kBlock) __hip_atomic_store(f.hist + (size_t)b * M + m, lh[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) __hip_atomic_store((unsigned long long *)f.blksum + b, (unsigned long long)__double_as_longlong(ssum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (beside the wait) the centring offset, in k_setup's order: wave d sums coordinate d -- lane l the nodes l, l + 64, ... -- then the butterfly
+    if (t < 192) {
+        const int d = t >> 6;
+        double a = 0;
+        for (int m = lane; m < M; m += 64) a += Yl[d * M + m];
+        a = wave_sum(a);
+        if (lane == 0) sctr[d] = a / M;
+    }
+    fuse_arrive(f, (unsigned)nb, epoch);
+    fuse_wait(f, epoch);
+    // ---- this workgroup's start offsets: thread = node
+    {
+        int tot = 0, pre = 0;
+        if (t < M) {
+#pragma unroll 8
+            for (int bb = 0; bb < nb; ++bb) {
+                const int v = __hip_atomic_load(f.hist + (size_t)bb * M + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tot += v; pre += bb < b ? v : 0;
+            }
+        }
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        int bs = 0;
+        for (int q = 0; q < w; ++q) bs += wtot[q];
+        if (t < M) base[t] = bs + incl - tot + pre;
+        for (int i = t; i < 4 * M; i += kBlock) wcnt[i] = 0;
+    }
+    __syncthreads();
+    // ---- stable scatter (k_prune_scatter): rank among the earlier points of the wave with the same nearest node, then the earlier waves
+    int rank = 0;
+    unsigned long long remaining = __ballot(keep);
+    while (remaining) {
+        const int leader = (int)__builtin_ctzll(remaining);
+        const int b0 = __builtin_amdgcn_readlane(bk, leader);
+        const unsigned long long mask = __ballot(keep && bk == b0);
+        if (keep && bk == b0) rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == leader) wcnt[w * M + b0] = __popcll(mask);
+        remaining &= ~mask;
+    }
+    __syncthreads();
+    if (keep) {
+        int dst = base[bk] + rank;
+        for (int i = 0; i < w; ++i) dst += wcnt[i * M + bk];
+        T *xs = (T *)f.Xs;
+        const size_t ld = f.ldx;
+        xs[dst] = (T)(x - sctr[0]);
+        xs[ld + dst] = (T)(y - sctr[1]);
+        xs[2 * ld + dst] = (T)(z - sctr[2]);
     }
 }
 
@@ -1815,11 +1970,29 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     bool reuse = true;                      // every frame's sorted cloud serves as it is: neither prune nor scatter
     for (int i = 0; i < F; ++i) reuse = reuse && fh[i].reuse_sorted;
     if (!reuse) hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
-    if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(F), dim3(kBlock), 0, s, fd, 0);
-    else hipLaunchKernelGGL((k_setup<float>), dim3(F), dim3(kBlock), 0, s, fd, 0);
+    if (f64) hipLaunchKernelGGL((k_setup<double, false>), dim3(F), dim3(kBlock), 0, s, fd, fh[0], 0, (const double *)nullptr, (double *)nullptr, 0, 0);
+    else hipLaunchKernelGGL((k_setup<float, false>), dim3(F), dim3(kBlock), 0, s, fd, fh[0], 0, (const double *)nullptr, (double *)nullptr, 0, 0);
     if (!reuse) {
         if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
         else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(gx, F), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
+    }
+    return hipGetLastError();
+}
+
+// One frame, host-supplied block read from pinned host memory by the kernel itself (no copy in front of it): the fused prologue for a cloud of up
+// to kFuseMaxBlocks * 256 points on a chain of up to kFuseMaxNodes nodes, or -- when the slot's sorted cloud is reused -- the setup workgroup alone.
+bool prologue_direct_ok(const FrameDev &f) {
+    return f.reuse_sorted || (f.nprune_blocks <= kFuseMaxBlocks && f.prune_tiles == 1 && f.M <= kFuseMaxNodes);
+}
+hipError_t launch_prologue_direct(const FrameDev *fh, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s) {
+    const bool f64 = fh[0].precision == TDLO_PREC_F64;
+    if (fh[0].reuse_sorted) {
+        if (f64) hipLaunchKernelGGL((k_setup<double, true>), dim3(1), dim3(kBlock), 0, s, (const FrameDev *)nullptr, fh[0], 0, host_up, dev_up, up_doubles, yin_off);
+        else hipLaunchKernelGGL((k_setup<float, true>), dim3(1), dim3(kBlock), 0, s, (const FrameDev *)nullptr, fh[0], 0, host_up, dev_up, up_doubles, yin_off);
+    } else {
+        const dim3 grid(fh[0].nprune_blocks + 1);
+        if (f64) hipLaunchKernelGGL((k_prologue<double>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch);
+        else hipLaunchKernelGGL((k_prologue<float>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch);
     }
     return hipGetLastError();
 }
@@ -1874,8 +2047,8 @@ hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int 
 hipError_t launch_split_setup(const FrameDev *fd, const FrameDev *fh, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
-    if (f64) hipLaunchKernelGGL((k_setup<double>), dim3(1), dim3(kBlock), 0, s, fd, 1);
-    else hipLaunchKernelGGL((k_setup<float>), dim3(1), dim3(kBlock), 0, s, fd, 1);
+    if (f64) hipLaunchKernelGGL((k_setup<double, false>), dim3(1), dim3(kBlock), 0, s, fd, fh[0], 1, (const double *)nullptr, (double *)nullptr, 0, 0);
+    else hipLaunchKernelGGL((k_setup<float, false>), dim3(1), dim3(kBlock), 0, s, fd, fh[0], 1, (const double *)nullptr, (double *)nullptr, 0, 0);
     if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
     else hipLaunchKernelGGL((k_prune_scatter<float>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
     return hipGetLastError();

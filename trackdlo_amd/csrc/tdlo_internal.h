@@ -89,8 +89,18 @@ struct FrameDev {
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result
     unsigned long long *dbg; // 64 shader-clock stamps written by the M-step (tdlo_debug_stamps)
-    unsigned *sync;         // 256 words, zeroed when the slot is created: generation / arrivals / flags of the multi-CU M-steps' hand-offs
+    unsigned *sync;         // 256 words, zeroed when the slot is created: generation / arrivals / flags of the multi-CU M-steps' hand-offs (words 0..47, 128..255),
+                            // k_dmin's ticket (8), the fused prologue's grid barrier (100: arrivals, 101: epoch flag)
     IterState *st;
+    // Results straight into pinned host memory (one frame per call, the one-workgroup M-steps k_mstep_chain / k_mstep_band): the M-step that
+    // finishes the registration copies [Yout | IterState] (the layout of the slot's read-back block) to host_out and then raises host_prog;
+    // every other M-step only reports its progress there.  The host waits on that word instead of a device-to-host copy and a stream
+    // synchronisation (a 4-6 us blit kernel, a dependent-dispatch gap and the wake-up of the blocking wait per registration).
+    //   host_prog = epoch << 32 | done << 31 | iterations completed.     nullptr: off (batches, N-split, the dense M-steps)
+    double *host_out;
+    unsigned long long *host_prog;
+    unsigned host_epoch;
+    int host_report_it;     // an M-step that does not finish the registration reports its progress only when it has completed this iteration (0: never)
     // one-shot exchange of the N-split (tdlo_xch_*, tdlo_split_run without a communicator): every rank's inbox as a device
     // pointer valid on THIS device (own inbox included); xch_nranks == 0: no exchange
     unsigned long long *xch_inbox[kMaxXchRanks];
@@ -149,6 +159,8 @@ __host__ __device__ inline int band_rec_pos(int q) { return (q & 3) * 4 + (q >> 
 
 // launchers implemented in tdlo_device.hip
 hipError_t launch_prune_and_setup(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
+bool prologue_direct_ok(const FrameDev &f);
+hipError_t launch_prologue_direct(const FrameDev *frames_host, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s);
 hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
 hipError_t launch_iteration_timed(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
                                   hipEvent_t m_start, hipEvent_t m_stop);

@@ -271,7 +271,11 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 #ifdef TDLO_TIMELINE      // wall-clock (100 MHz) begin / end of iterations 20..27, scripts/gpu_timeline.py
     if (t == 0 && itn >= 20 && itn < 28) f.dbg[4 * (itn - 20) + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (done) { if (XCH && from_sums == 3) xch_post_error(f, st, t); return; }
+    if (done) {
+        if (XCH && from_sums == 3) xch_post_error(f, st, t);
+        if (!XCH && t < 64 && stg->status != 0) host_publish(f, st, lane, false);      // a registration that ended on an error somewhere else (E-step, setup)
+        return;
+    }
     CSTAMP(1);
     if (from_sums != 1) {
 #pragma unroll
@@ -744,6 +748,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     }
     __syncthreads();
     CSTAMP(7);
+    int pub = 0;        // lane 0: this M-step has something to tell the host (results mailbox, FrameDev::host_prog)
     if (t == 0) {
         const double t_np = ((red[0] + red[4]) + red[8]) + red[12], t_dr = ((red[1] + red[5]) + red[9]) + red[13];
         const double t_pd = ((red[2] + red[6]) + red[10]) + red[14], t_cr = ((red[3] + red[7]) + red[11]) + red[15];
@@ -758,13 +763,15 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             st->k2 = -1.4426950408889634 * 0.5 * fast_rcp(new_sigma2);
             st->c_norm = tp * rtp * kc;
             st->rwin32 = 1.01 * 5.7720 * rtp; st->rwin64 = 1.01 * 15.4366 * rtp;      // the E-step's node window (set_iter_consts)
-        } else { st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; }
-        if (crit < f.tol) st->done = 1;                                   // :424-428
-        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; }  // :433-437
+        } else { st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; pub = 1; }
+        if (crit < f.tol) { st->done = 1; pub = 1; }                                   // :424-428
+        else if (it >= f.max_iter) { st->converged = 0; st->done = 1; pub = 1; }      // :433-437
+        if (it == f.host_report_it) pub = 1;      // the host looks at the progress word after this iteration (the last one of an early-exit polling chunk)
 #ifdef TDLO_TIMELINE
         if (itn >= 20 && itn < 28) f.dbg[4 * (itn - 20) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
+    if (!XCH && t < 64 && __builtin_amdgcn_readfirstlane(pub)) host_publish(f, st, lane, true);      // progress (and, from the M-step that finishes the registration, the results) into pinned host memory
 #undef CSTAMP
 }
 
