@@ -317,6 +317,10 @@ int tdlo_visibility_prepass(tdlo_ctx *ctx, int slot, const double *Y, int M, dou
 /* ---- host helpers on the path (exported so the parity tests can address them directly) -------- */
 /* trackdlo::calc_LLE_weights (trackdlo.cpp:119-159), k as passed at :236 (6). L: M x M col-major out. */
 int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L);
+/* H = (I - L)^T (I - L) of trackdlo.cpp:236-237 (L = calc_LLE_weights with k = 6) as the registrations form it: H (M x M col-major, optional) by
+ * the dense route that the dense LLE M-steps use, Hb (13 M, optional; Hb[13 i + u] = H(i, i - 6 + u)) by the O(M) route of the banded LLE
+ * M-step -- the same values bit for bit (tests/test_abi.py). */
+int tdlo_calc_lle_regulariser(const double *Y, int M, double *H, double *Hb);
 /* line_sphere_intersection (trackdlo/src/utils.cpp:185-241): returns number of points (0..2) */
 int tdlo_line_sphere_intersection(const double A[3], const double B[3], const double C[3],
                                   double radius, double out[6]);

@@ -241,3 +241,27 @@ def test_traverse_euclidean_randomised(oracle):
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
     assert n_ok > 300
+
+
+def test_band_regulariser_is_the_dense_one_bit_for_bit(oracle):
+    """The banded LLE M-step receives H = (I - L)^T (I - L) (trackdlo.cpp:236-237) as its 13 diagonals, formed in O(M) on the host
+    (lle_regulariser_band); the dense M-steps receive the M x M matrix.  Same weights, same products in the same order: equal BITS, for
+    chains shorter than the band as well, and H is what the oracle's L gives."""
+    from trackdlo_amd import binding as B, synth
+    rng = np.random.default_rng(5)
+    for M in (4, 5, 6, 7, 8, 12, 13, 14, 30, 45, 64, 65, 200):
+        Y = synth.nodes(M) + rng.normal(0, 2e-3, (M, 3))
+        H, Hb = B.calc_lle_regulariser(Y)
+        ref = np.zeros((M, 13))
+        for i in range(M):
+            for u in range(13):
+                j = i - 6 + u
+                if 0 <= j < M:
+                    ref[i, u] = H[i, j]
+        assert np.array_equal(Hb, ref), M
+        assert np.array_equal(H, H.T)                       # exactly symmetric: the band is read from one triangle
+        far = np.abs(np.subtract.outer(np.arange(M), np.arange(M))) > 6
+        assert not H[far].any()
+        Lo = oracle.calc_lle_weights(Y, 6)
+        Ho = (np.eye(M) - Lo).T @ (np.eye(M) - Lo)
+        np.testing.assert_allclose(H, Ho, rtol=0, atol=1e-6 * max(1.0, np.abs(Ho).max()))

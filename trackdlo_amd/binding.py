@@ -55,7 +55,7 @@ SYMBOLS = [
     "tdlo_tracker_create", "tdlo_tracker_create_default", "tdlo_tracker_destroy", "tdlo_tracker_set_precision",
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
-    "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights",
+    "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
     "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
@@ -164,6 +164,7 @@ def load_library(path: str | None = None):
     lib.tdlo_tracker_get_correspondence_pairs.argtypes = [vp, vp, ci]
     lib.tdlo_tracker_tracking_step.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp]
     lib.tdlo_calc_lle_weights.argtypes = [ci, vp, ci, vp]
+    lib.tdlo_calc_lle_regulariser.argtypes = [vp, ci, vp, vp]
     lib.tdlo_line_sphere_intersection.argtypes = [vp, vp, vp, cd, vp]
     lib.tdlo_traverse_euclidean.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp]
     lib.tdlo_profile_kernel.argtypes = [vp, ci, ci, ci, C.POINTER(C.c_float)]
@@ -574,6 +575,17 @@ def calc_LLE_weights(k, Y):
     if rc:
         raise TdloError(rc, "tdlo_calc_lle_weights")
     return L
+
+
+def calc_lle_regulariser(Y):
+    """(H dense M x M, Hb = its 13 diagonals [M x 13]) as the dense and the banded LLE M-step receive them (tdlo_calc_lle_regulariser)."""
+    lib = load_library()
+    Y = _f64(Y); M = Y.shape[0]
+    H = np.zeros((M, M), order="F"); Hb = np.zeros((M, 13))
+    rc = lib.tdlo_calc_lle_regulariser(_ptr(Y), M, _ptr(H), _ptr(Hb))
+    if rc:
+        raise TdloError(rc, "tdlo_calc_lle_regulariser")
+    return H, Hb
 
 
 def line_sphere_intersection(point_A, point_B, sphere_center, radius):

@@ -55,9 +55,10 @@ struct Slot {
 
 struct NodeCarve {
     // offsets in doubles into Slot::nodeblk for a given M; the first `upload` doubles are the
-    // host-supplied block [Yin | aJ | aYd | H] uploaded with one copy, and [Yout | IterState] is read
-    // back with one copy.
-    size_t fdev, Yin, aJ, aYd, H, upload;      // fdev: the frame's descriptor travels at the head of the upload block (one frame per call)
+    // host-supplied block [descriptor | Yin | aJ | aYd | Hb | H]: without the LLE term it ends in front of Hb, with the banded LLE M-step in
+    // front of H (Hb = the 13 diagonals of H, 13 M doubles instead of M^2), with the dense LLE M-steps it is the whole block; [Yout | IterState]
+    // comes back.
+    size_t fdev, Yin, aJ, aYd, Hb, H, upload;      // fdev: the frame's descriptor travels at the head of the upload block (one frame per call)
     size_t Yout, st, readback;
     size_t ctr, Y, Y0, nodes, coord, G, chain, HG, HY0, dmin, sums, dbg, Ascr, acc, band, total;
     explicit NodeCarve(int M) {
@@ -65,7 +66,7 @@ struct NodeCarve {
         size_t o = 0;
         auto take = [&](size_t n) { size_t r = o; o += (n + 1) & ~(size_t)1; return r; };   // keep 16-byte alignment
         fdev = take((sizeof(FrameDev) + 7) / 8);
-        Yin = take(3 * m); aJ = take(m); aYd = take(3 * m); H = take(mm); upload = o;
+        Yin = take(3 * m); aJ = take(m); aYd = take(3 * m); Hb = take(13 * m); H = take(mm); upload = o;
         Yout = take(3 * m); st = take((sizeof(IterState) + 7) / 8); readback = o - Yout;
         ctr = take(4); Y = take(3 * m); Y0 = take(3 * m); nodes = take(4 * m); coord = take(m);
         G = take(mm); chain = take(8 * (m + 1)); HG = take(mm); HY0 = take(3 * m); dmin = take(m); sums = take(4 * m + 2); dbg = take(64);
@@ -150,6 +151,7 @@ struct tdlo_ctx {
     size_t pin_doubles = 0;
     std::string err;
     int last_F = 0;
+    bool lle_batch_dense = false;         // run_frames: a frame of this batch cannot take the banded LLE solve, all of them are staged for the dense kernels
     bool lle_dense_once = false;          // run_frames' retry: the banded LLE solve reported a numeric failure, this call repeats with the dense pivoted kernels
     long long band_retries = 0;           // how often that happened (tdlo_debug_band_retries)
     bool sort_reuse = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);   // tdlo_set_sort_reuse: a slot's sorted cloud may serve the next registration of the same nodes
@@ -179,6 +181,34 @@ struct tdlo_ctx {
 };
 
 namespace {
+
+// Development aid (TDLO_TRACK_PROFILE=1): host wall time between marks, accumulated per mark and printed when a tracker is destroyed -- where
+// a tracking_step's host time goes (scripts/ubench/track_cpp.cpp).  Off: one predictable branch per mark.
+struct HostProf {
+    static constexpr int kN = 16;
+    const char *name[kN] = {"set_cloud call", "guide nodes", "prepare_frame #1", "enqueue prologue #1", "enqueue iteration #1", "wait #1", "results #1",
+                            "traverse + priors", "prepare_frame #2", "enqueue prologue #2", "enqueue iteration #2", "wait #2", "results #2", "", "", ""};
+    double us[kN] = {};
+    long n[kN] = {};
+    bool on = getenv("TDLO_TRACK_PROFILE") && atoi(getenv("TDLO_TRACK_PROFILE")) != 0;
+    int base = 0;                        // 0 inside the first registration of a tracking_step, 6 inside the second
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void mark(int id) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        us[id] += std::chrono::duration<double, std::micro>(t1 - t0).count(); ++n[id];
+        t0 = t1;
+    }
+    void report() {
+        if (!on) return;
+        double tot = 0;
+        for (int i = 0; i < kN; ++i) if (n[i]) tot += us[i] / (double)n[i];
+        fprintf(stderr, "trackdlo_hip host profile (us per call of the phase; sum %.1f):\n", tot);
+        for (int i = 0; i < kN; ++i) if (n[i]) fprintf(stderr, "  %-24s %8.2f  x %ld\n", name[i], us[i] / (double)n[i], n[i]);
+    }
+};
+HostProf g_prof;
 
 int fail(tdlo_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
@@ -350,19 +380,13 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     bool lle_band = false;
     if (p->include_lle) {
         double *H = stage + nc.H;
-        if (H_override) std::memcpy(H, H_override, sizeof(double) * (size_t)M * M);
-        else {
-            std::vector<double> L((size_t)M * M);
-            lle_weights(6, Y, M, L.data());                  // trackdlo.cpp:236
-            lle_regulariser(L.data(), M, H);                 // :237
-        }
         // The banded L D L^T in the chain's state (tdlo_mstep_band.hip) serves the registration when (i) H is banded like the
         // reference's own (I - L)^T (I - L) -- +-6 nodes; an H_override may be anything --, (ii) it is symmetric there (the band is read
         // from one triangle), (iii) no two consecutive nodes are closer than h_min: the state precision K contains Q^-1 ~ 3 beta^4 / h^3, and
         // the solve's error grows like eps lambda sigma2 K / P1: at h = 1 mm with the pre-processing parameters (beta 3, lambda 1)
         // 1e-13 m, at 0.1 mm 1e-11 m, at 0.01 mm 1e-7 m (scripts/band_gap_study.py); the bound scales with cbrt(lambda beta^4).
         // Everything else (coincident nodes in particular: K is infinite there) keeps the dense pivoted eliminations.
-        if (mstep_band_enabled() && !c->lle_dense_once && p->lambda > 0 && p->beta > 0) {
+        if (mstep_band_enabled() && !c->lle_dense_once && !c->lle_batch_dense && p->lambda > 0 && p->beta > 0) {
             lle_band = true;
             const double hmin = 1e-3 * std::cbrt(p->lambda * std::pow(p->beta / 3.0, 4));
             for (int i = 0; i + 1 < M && lle_band; ++i) {
@@ -373,10 +397,26 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
             if (H_override) {
                 for (int j = 0; j < M && lle_band; ++j)
                     for (int i = 0; i < M; ++i) {
-                        const double v = H[(size_t)j * M + i];
-                        if ((std::abs(i - j) > 6 && v != 0.0) || v != H[(size_t)i * M + j] || !(v == v)) { lle_band = false; break; }
+                        const double v = H_override[(size_t)j * M + i];
+                        if ((std::abs(i - j) > 6 && v != 0.0) || v != H_override[(size_t)i * M + j] || !(v == v)) { lle_band = false; break; }
                     }
             }
+        }
+        if (lle_band) {
+            // the banded solve reads H through its 13 diagonals only (Hb[13 i + u] = H(i, i - 6 + u)): the M x M matrix is neither formed nor uploaded
+            double *Hb = stage + nc.Hb;
+            if (H_override) {
+                for (int i = 0; i < M; ++i)
+                    for (int u = 0; u < 13; ++u) { const int j = i - 6 + u; Hb[(size_t)13 * i + u] = (j >= 0 && j < M) ? H_override[(size_t)j * M + i] : 0.0; }
+            } else {
+                lle_regulariser_band(Y, M, Hb);              // trackdlo.cpp:236-237, O(M)
+            }
+        } else if (H_override) {
+            std::memcpy(H, H_override, sizeof(double) * (size_t)M * M);
+        } else {
+            std::vector<double> L((size_t)M * M);
+            lle_weights(6, Y, M, L.data());                  // trackdlo.cpp:236
+            lle_regulariser(L.data(), M, H);                 // :237
         }
     }
 
@@ -436,7 +476,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.reuse_sorted = (c->sort_reuse && s.sorted_valid && s.sorted_prec == p->precision && s.sorted_Y.size() == 3 * (size_t)M &&
                       std::memcmp(s.sorted_Y.data(), Y, sizeof(double) * 3 * M) == 0) ? 1 : 0;
     f.Yin = blk + nc.Yin; f.ctr = blk + nc.ctr; f.Y = blk + nc.Y; f.Y0 = blk + nc.Y0; f.nodes = blk + nc.nodes;
-    f.coord = blk + nc.coord; f.G = blk + nc.G; f.chain = blk + nc.chain; f.H = blk + nc.H; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
+    f.coord = blk + nc.coord; f.G = blk + nc.G; f.chain = blk + nc.chain; f.H = blk + nc.H; f.Hb = blk + nc.Hb; f.HG = blk + nc.HG; f.HY0 = blk + nc.HY0;
     f.aJ = blk + nc.aJ; f.aYd = blk + nc.aYd; f.dminbits = (unsigned long long *)(blk + nc.dmin);
     f.acc = (long long *)(blk + nc.acc);
     f.band = blk + nc.band;
@@ -471,7 +511,7 @@ hipError_t zero_accumulators(const std::vector<FrameDev> &fh, int F, hipStream_t
     return hipSuccess;
 }
 
-size_t upload_doubles(const NodeCarve &nc, const tdlo_params *p) { return p->include_lle ? nc.upload : nc.H; }
+size_t upload_doubles(const NodeCarve &nc, const tdlo_params *p, bool band) { return p->include_lle ? (band ? nc.H : nc.upload) : nc.Hb; }
 
 void fill_stats(tdlo_stats *st, const IterState &is) {
     st->iters = is.it; st->converged = is.converged; st->n_kept = is.N; st->status = is.status; st->sigma2 = is.sigma2;
@@ -486,20 +526,25 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (rc) return rc;
     if (F < 1 || F > c->cfg.max_frames) return fail(c, TDLO_E_INVALID, "bad frame count");
     NodeCarve nc(M);
-    const size_t up = upload_doubles(nc, p);
     // Batches move their host-supplied blocks and their results with ONE copy each way: every small copy is a 4-5 us blit
     // kernel on the stream, and 32 frames x (upload + read-back [+ flags per polling chunk]) had grown to 0.3 ms of a 2.3 ms
     // call.  The frames' [Yin | aJ | aYd | H] and [Yout | IterState] then live in one device buffer instead of the slots'
     // node blocks (the kernels only see pointers).
     const bool merged = F > 1;
-    const size_t ustride = merged ? up : nc.upload;
+    // how much of a frame's block travels: without the LLE term up to Hb; with it the 13 diagonals Hb when the banded solve serves the call, else
+    // the dense H as well.  A batch is staged at the stride of the banded form first; a frame the banded solve cannot take sends the whole
+    // batch to the dense kernels (one M-step kernel per launch), and the frames are staged again at the full stride.
+    bool band_batch = p->include_lle && mstep_band_enabled() && !c->lle_dense_once;
+    size_t up = upload_doubles(nc, p, band_batch);
+    size_t ustride = merged ? up : nc.upload;
     // the frame descriptors ride in the same host-to-device copy: one frame -> at the head of its upload block, a batch -> as an array
     // behind the F upload blocks (every separate small copy is a blit kernel plus a dependent-dispatch gap, ~4 us)
     const size_t fdd = ((size_t)F * sizeof(FrameDev) + 15) / 16 * 2;      // doubles of the descriptor array of a batch
     rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2) + fdd + 2 * (size_t)F * std::max(nc.readback, (sizeof(IterState) + 7) / 8) + 4);
     if (rc) return rc;
-    if (merged) { rc = ensure_xfer(c, (size_t)F * (up + nc.readback) + fdd); if (rc) return rc; }
+    if (merged) { rc = ensure_xfer(c, (size_t)F * (upload_doubles(nc, p, false) + nc.readback) + fdd); if (rc) return rc; }
     c->fh.assign(F, FrameDev{});
+    for (int pass = 0; pass < 2; ++pass) {
     for (int i = 0; i < F; ++i) {
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
                            c->pin + (size_t)i * ustride, c->fh[i]);
@@ -513,20 +558,24 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             if (c->cfg.estep_blocks <= 0 && f.nblkE >= 64) f.nblkE = (f.nblkE + 1) / 2;
             double *bu = c->xfer + (size_t)i * up, *br = c->xfer + (size_t)F * up + fdd + (size_t)i * nc.readback;
             f.Yin = bu + nc.Yin; f.aJ = bu + nc.aJ; f.aYd = bu + nc.aYd;
-            if (p->include_lle) f.H = bu + nc.H;
+            if (p->include_lle) { f.Hb = bu + nc.Hb; f.H = bu + nc.H; }
             f.Yout = br; f.st = (IterState *)(br + (nc.st - nc.Yout));
         }
     }
+    if (!p->include_lle) break;
+    bool all_band = true;
+    for (int i = 0; i < F; ++i) all_band = all_band && c->fh[i].lle_band;
+    if (all_band) break;
+    if (!merged) { up = upload_doubles(nc, p, false); break; }      // one frame: its block was staged at the full stride anyway
+    if (pass == 0) { c->lle_batch_dense = true; band_batch = false; up = upload_doubles(nc, p, false); ustride = up; }
+    }
+    c->lle_batch_dense = false;
+    g_prof.mark(g_prof.base + 2);
     {   // prune, scan and scatter are skipped per LAUNCH: the sorted clouds are reused only when every frame of the call can reuse its own
         // (a frame that skipped its scan while the batch's scatter ran would have its cloud re-scattered from stale start offsets)
         bool all_reuse = true;
         for (int i = 0; i < F; ++i) all_reuse = all_reuse && c->fh[i].reuse_sorted;
         if (!all_reuse) for (int i = 0; i < F; ++i) c->fh[i].reuse_sorted = 0;
-    }
-    if (p->include_lle) {          // one M-step kernel serves the whole batch: a frame whose chain the banded solve cannot take
-        bool all_band = true;      // sends all frames to the dense one
-        for (int i = 0; i < F; ++i) all_band = all_band && c->fh[i].lle_band;
-        if (!all_band) for (int i = 0; i < F; ++i) { c->fh[i].lle_band = 0; c->fh[i].need_G = 1; }
     }
     // One frame per call on a one-workgroup M-step (the chain smoother, the banded LLE solve): the results come back through the pinned
     // mailbox -- the M-step that finishes the registration writes them there itself -- instead of a copy and a stream synchronisation
@@ -561,6 +610,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (!merged) HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
         HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
     }
+    g_prof.mark(g_prof.base + 3);
     for (int i = 0; i < F; ++i) {           // the slots' sorted clouds now belong to these nodes
         Slot &sl = c->slots[slots[i]];
         if (!c->fh[i].reuse_sorted) { sl.sorted_Y.assign(Y + (size_t)i * 3 * M, Y + (size_t)(i + 1) * 3 * M); sl.sorted_prec = p->precision; sl.sorted_valid = true; }
@@ -662,8 +712,10 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         // word of the chunk BEFORE the one it has just enqueued, so that the GPU never idles (kernels of a finished registration are no-ops)
         c->fh[0].host_report_it = 1;           // (the frame descriptor travels by value with every launch of the one-frame kernels)
         HIPCHK(c, iterate(1));
+        g_prof.mark(g_prof.base + 4);
         bool stop = false;
         if ((rc = mbox_done(1, false, &stop))) return rc;
+        g_prof.mark(g_prof.base + 5);
         int launched = 1, chunk = 0;
         while (launched < p->max_iter && !stop) {
             const int n = std::min(chunk < 2 ? 1 : (chunk == 2 ? 2 : kChunkIters), p->max_iter - launched);
@@ -780,6 +832,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         }
         if (is.status != 0 && worst == 0) worst = is.status;
     }
+    g_prof.mark(g_prof.base + 6);
     if (worst == TDLO_E_EMPTY) return fail(c, worst, "every point was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
     if (worst == TDLO_E_NUMERIC) return fail(c, worst, "non-finite or non-positive sigma2, or singular M-step system");
     return TDLO_OK;
@@ -940,7 +993,7 @@ int tdlo_split_begin(tdlo_ctx *c, const double *Y, int M, double sigma2, const t
     c->fh[0].reuse_sorted = 0; c->slots[0].sorted_valid = false;      // a shard is pruned and sorted by the split's own setup
     if (c->xch_sums) c->fh[0].sums = c->xch_sums;       // the reduced sums are exported to / consumed from the caller's buffer
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p, c->fh[0].lle_band != 0) * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev), hipMemcpyHostToDevice, s));
     HIPCHK(c, launch_split_setup(c->fd, c->fh.data(), s));
     HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[0].nodeblk + nc.st, sizeof(IterState), hipMemcpyDeviceToHost, s));
@@ -1291,7 +1344,7 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     }
     const bool timing = c->timing;
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->slots[0].nodeblk, c->pin, upload_doubles(nc, p, c->fh[0].lle_band != 0) * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->fd, c->fh.data(), sizeof(FrameDev), hipMemcpyHostToDevice, s));
     HIPCHK(c, launch_split_setup(c->fd, c->fh.data(), s));
     auto nccl = [&](int e, const char *what) -> int {
@@ -1756,6 +1809,17 @@ int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L) {
     return TDLO_OK;
 }
 
+int tdlo_calc_lle_regulariser(const double *Y, int M, double *H, double *Hb) {
+    if (!Y || M < 1 || (!H && !Hb)) return TDLO_E_INVALID;
+    if (H) {
+        std::vector<double> L((size_t)M * M);
+        lle_weights(6, Y, M, L.data());
+        lle_regulariser(L.data(), M, H);
+    }
+    if (Hb) lle_regulariser_band(Y, M, Hb);
+    return TDLO_OK;
+}
+
 int tdlo_line_sphere_intersection(const double A[3], const double B[3], const double C[3], double radius, double out[6]) {
     Vec3 o[2];
     const int n = line_sphere(Vec3{A[0], A[1], A[2]}, Vec3{B[0], B[1], B[2]}, Vec3{C[0], C[1], C[2]}, radius, o);
@@ -1829,7 +1893,7 @@ tdlo_tracker *tdlo_tracker_create_default(tdlo_ctx *ctx, int slot, int M) {
                                /*lambda_pre_proc*/ 1.0, /*lle_weight*/ 1.0);
 }
 
-void tdlo_tracker_destroy(tdlo_tracker *t) { delete t; }
+void tdlo_tracker_destroy(tdlo_tracker *t) { g_prof.report(); delete t; }
 
 int tdlo_tracker_set_precision(tdlo_tracker *t, int precision) {
     if (!t || (precision != TDLO_PREC_F32 && precision != TDLO_PREC_F64)) return TDLO_E_INVALID;
@@ -1893,10 +1957,12 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     for (int i = 0; i < n_vis; ++i) if (vis[i] < 0 || vis[i] >= M) return fail(c, TDLO_E_INVALID, "visible_nodes index out of range");
     t->priors.clear();                                                   // :908
     int rc = TDLO_OK;
+    g_prof.start(); g_prof.base = 0;
     if (X) rc = set_cloud_impl(c, t->slot, X, N, false);                 // X_orig by value: one upload for both registrations (X stays the caller's
                                                                          // until this function returns; the first registration's read-back waits for the copy)
     else if (c->slots[t->slot].N0 <= 0) rc = fail(c, TDLO_E_INVALID, "X is NULL and no cloud is resident in the tracker's slot");
     if (rc) return rc;
+    g_prof.mark(0);
 
     // guide nodes = visible sub-chain (:913-921)
     const int Mg = n_ext;
@@ -1912,6 +1978,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     pp.precision = t->precision;
     double sigma2_pre = t->sigma2;
     tdlo_stats st_pre{}, st_main{};
+    g_prof.mark(1);
     rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
     if (stats) stats[0] = st_pre;
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
@@ -1969,6 +2036,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     mp.tol = t->tol; mp.include_lle = 0; mp.alpha = t->alpha; mp.k_vis = t->k_vis; mp.visibility_threshold = t->visibility_threshold;
     mp.precision = t->precision;
     // prior indices may be fractional after the averaging at :954; the reference truncates (:247)
+    g_prof.mark(7); g_prof.base = 6;
     rc = tdlo_cpd_lle_resident(c, t->slot, t->Y.data(), M, &t->sigma2, &mp, t->priors.data(), (int)(t->priors.size() / 4),
                                vis_ext, n_ext, nullptr, &st_main);
     if (stats) stats[1] = st_main;

@@ -30,6 +30,8 @@
 
 namespace tdlo {
 
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------------------------------------
 // prune, trackdlo.cpp:177-195, fused with the sigma2 initialisation sum of :263-273
 // ------------------------------------------------------------------------------------------------
@@ -119,9 +121,19 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
     const int nb = f.nprune_blocks;
     __shared__ double sY[3 * kMaxNodes];
     __shared__ double sc[kMaxNodes];
-    if (host_up) {      // the nodes from pinned host memory, then the whole upload block to its place in device memory (both in flight together)
+    if (host_up) {      // the nodes from pinned host memory, then the whole upload block to its place in device memory: every load of a trip is
+        // requested before the first store (a load-store loop pays one PCIe round trip, ~2 us, per trip); 16 bytes per load
         for (int i = t; i < 3 * M; i += kBlock) sY[i] = host_up[yin_off + i];
-        for (int i = t; i < up_doubles; i += kBlock) dev_up[i] = host_up[i];
+        const dbl2 *src = (const dbl2 *)host_up;
+        dbl2 *dst = (dbl2 *)dev_up;
+        const int n2 = up_doubles >> 1;                          // (the block's parts are padded to 16 bytes)
+        for (int i0 = 0; i0 < n2; i0 += 8 * kBlock) {
+            dbl2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * kBlock + t; v[u] = src[i < n2 ? i : n2 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * kBlock + t; if (i < n2) dst[i] = v[u]; }
+        }
     } else {   // the node block, requested first: it arrives while the counts are scanned (the barriers of the scan cover it)
         const auto Yg = TDLO_AS_GLOBAL(double, f.Yin);
         for (int i = t; i < 3 * M; i += kBlock) sY[i] = Yg[i];
@@ -292,7 +304,7 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         // unknowns u = 0, 1, 2, ...; direction 1 (twisted plan) walks u~ = nUp - 1 - u from the chain's tail and leaves out the block
         // R x R of the 12 unknowns between the two sides (it belongs to direction 0's records).  Unknowns that do not exist (padding,
         // the other side's, the columns entering behind the last pivot) are identity records.
-        const auto Hg = TDLO_AS_GLOBAL(double, f.H);
+        const auto Hbg = TDLO_AS_GLOBAL(double, f.Hb);        // H through its 13 diagonals: Hb[13 i + u] = H(i, i - 6 + u) (symmetric: checked by the host)
         const auto lk = TDLO_AS_GLOBAL(double, f.chain);
         const BandPlan bp(M);
         const double lam = f.lambda, gam = f.lle_weight;
@@ -337,7 +349,7 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
             const int sgn = dir ? 1 : -1;                                     // rows at or above the diagonal in the direction's order: nodes b, b + sgn, ...
             double h[7];
 #pragma unroll
-            for (int d = 0; d < 7; ++d) { const int a = b + sgn * d; h[d] = (!tj && a >= 0 && a < M) ? Hg[(size_t)b * M + a] : 0.0; }
+            for (int d = 0; d < 7; ++d) { const int a = b + sgn * d; h[d] = (!tj && a >= 0 && a < M) ? Hbg[(size_t)13 * b + (a - b + 6)] : 0.0; }
 #pragma unroll
             for (int q = 0; q < kBandSlots; ++q) o[band_rec_pos(q)] = 0.0;
             auto put = [&](int ui, double v) __attribute__((always_inline)) {    // entry (row unknown ui, this column)
@@ -364,7 +376,7 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
             const int i = e % M, d = e / M;
             double hv[13];
 #pragma unroll
-            for (int u = 0; u < 13; ++u) { const int k = i - 6 + u, kc = k < 0 ? 0 : (k > M - 1 ? M - 1 : k); hv[u] = Hg[(size_t)kc * M + i]; }
+            for (int u = 0; u < 13; ++u) hv[u] = Hbg[(size_t)13 * i + u];      // H(i, k), k = i - 6 + u
             double a = 0;
 #pragma unroll
             for (int u = 0; u < 13; ++u) { const int k = i - 6 + u; if (k >= 0 && k < M) a += hv[u] * sY[d * M + k]; }

@@ -85,32 +85,66 @@ int chain_neighbours(int half, int M, int idx, int *out, int cap) {   // trackdl
 
 }  // namespace
 
+// the weights of node i's chain neighbours (trackdlo.cpp:119-159, one row of L): returns their number n (0: none) with nb[r] / w[r]
+static int lle_node_weights(int k, const double *Y, int M, int i, int *nb, double *w) {
+    const int n = chain_neighbours(k / 2, M, i, nb, 6);
+    if (n == 0 || n > 6) return 0;
+    double gram[36];
+    for (int r = 0; r < n; ++r)
+        for (int s = 0; s < n; ++s) {
+            double acc = 0;
+            for (int d = 0; d < 3; ++d) acc += (Y[d * M + i] - Y[d * M + nb[r]]) * (Y[d * M + i] - Y[d * M + nb[s]]);
+            gram[r * n + s] = acc;
+        }
+    SmallLU lu;
+    lu.factor(gram, n);
+    if (lu.det == 0.0) {                                     // trackdlo.cpp:139-144
+        for (int r = 0; r < n; ++r) gram[r * n + r] += 0.00001;
+        lu.factor(gram, n);
+    }
+    // w = Gi^-1 1 / (1^T Gi^-1 1) (:146-150); Gi^-1 1 is obtained as the solution of Gi w = 1
+    double ones[6] = {1, 1, 1, 1, 1, 1}, v[6];
+    lu.solve(ones, v);
+    double tot = 0;
+    for (int r = 0; r < n; ++r) tot += v[r];
+    for (int r = 0; r < n; ++r) w[r] = v[r] / tot;
+    return n;
+}
+
 void lle_weights(int k, const double *Y, int M, double *L) {
     std::fill(L, L + (size_t)M * M, 0.0);
     for (int i = 0; i < M; ++i) {
         int nb[6];
-        const int n = chain_neighbours(k / 2, M, i, nb, 6);
-        if (n == 0 || n > 6) continue;
-        double gram[36];
-        for (int r = 0; r < n; ++r)
-            for (int s = 0; s < n; ++s) {
-                double acc = 0;
-                for (int d = 0; d < 3; ++d) acc += (Y[d * M + i] - Y[d * M + nb[r]]) * (Y[d * M + i] - Y[d * M + nb[s]]);
-                gram[r * n + s] = acc;
-            }
-        SmallLU lu;
-        lu.factor(gram, n);
-        if (lu.det == 0.0) {                                     // trackdlo.cpp:139-144
-            for (int r = 0; r < n; ++r) gram[r * n + r] += 0.00001;
-            lu.factor(gram, n);
-        }
-        // w = Gi^-1 1 / (1^T Gi^-1 1) (:146-150); Gi^-1 1 is obtained as the solution of Gi w = 1
-        double ones[6] = {1, 1, 1, 1, 1, 1}, w[6];
-        lu.solve(ones, w);
-        double tot = 0;
-        for (int r = 0; r < n; ++r) tot += w[r];
-        for (int r = 0; r < n; ++r) L[(size_t)nb[r] * M + i] = w[r] / tot;
+        double w[6];
+        const int n = lle_node_weights(k, Y, M, i, nb, w);
+        for (int r = 0; r < n; ++r) L[(size_t)nb[r] * M + i] = w[r];
     }
+}
+
+// H = (I - L)^T (I - L) of the weights above (k = 6: +-3 chain neighbours) as its 13 diagonals only: Hb[13 i + u] = H(i, i - 6 + u), zero where
+// that column does not exist.  O(M) instead of the M x M matrices of lle_weights + lle_regulariser (two 16 KB fills and a heap allocation at
+// M = 45 in front of every pre-processing registration); every value is the dense routines' bit for bit -- the same weights, and the same
+// products summed in the same ascending order (the terms left out there are exact zeros).
+void lle_regulariser_band(const double *Y, int M, double *Hb) {
+    // A(k, c) = (I - L)(k, c) for |c - k| <= 3, stored as Ab[7 k + (c - k + 3)]
+    std::vector<double> Ab((size_t)7 * M, 0.0);
+    for (int i = 0; i < M; ++i) {
+        int nb[6];
+        double w[6];
+        const int n = lle_node_weights(6, Y, M, i, nb, w);
+        Ab[(size_t)7 * i + 3] = 1.0;
+        for (int r = 0; r < n; ++r) Ab[(size_t)7 * i + (nb[r] - i + 3)] = 0.0 - w[r];
+    }
+    for (int i = 0; i < M; ++i)
+        for (int u = 0; u < 13; ++u) {
+            const int j = i - 6 + u;
+            double s = 0;
+            if (j >= 0 && j < M) {
+                const int k0 = std::max(0, std::max(i, j) - 3), k1 = std::min(M - 1, std::min(i, j) + 3);
+                for (int k = k0; k <= k1; ++k) s += Ab[(size_t)7 * k + (i - k + 3)] * Ab[(size_t)7 * k + (j - k + 3)];
+            }
+            Hb[(size_t)13 * i + u] = s;
+        }
 }
 
 void lle_regulariser(const double *L, int M, double *H) {        // H = (I-L)^T (I-L), trackdlo.cpp:237

@@ -10,6 +10,8 @@ struct Vec3 { double x, y, z; };
 void lle_weights(int k, const double *Y, int M, double *L);
 // H = (I - L)^T (I - L) (trackdlo.cpp:237)
 void lle_regulariser(const double *L, int M, double *H);
+// the same H for k = 6 as its 13 diagonals, Hb[13 i + u] = H(i, i - 6 + u) (bit for bit the dense routines' values), in O(M)
+void lle_regulariser_band(const double *Y, int M, double *Hb);
 // line_sphere_intersection (utils.cpp:185-241)
 int line_sphere(const Vec3 &A, const Vec3 &B, const Vec3 &C, double radius, Vec3 out[2]);
 // trackdlo::traverse_euclidean (trackdlo.cpp:584-898); out receives rows [idx, x, y, z].

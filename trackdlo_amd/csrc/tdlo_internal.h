@@ -65,7 +65,8 @@ struct FrameDev {
     double *coord;          // M cumulative arc length (:214-223)
     double *G;              // M x M kernel (:233)
     double *chain;          // (M + 1) x 8: state-space form of G for the chain smoother (tdlo_mstep_chain.hip): [0] = {sf2, s^2 sf2}, [i] = link between nodes i-1 and i {Phi (4), Q (3)}
-    const double *H;        // M x M LLE regulariser (host supplied) or nullptr
+    const double *H;        // M x M LLE regulariser (host supplied; the dense LLE M-steps only) or nullptr
+    const double *Hb;       // the banded LLE M-step: H's 13 diagonals, Hb[13 i + u] = H(i, i - 6 + u) (host supplied)
     double *HG;             // M x M  H*G   (include_lle)
     double *HY0;            // M x 3  H*Yin (include_lle)
     const double *aJ;       // M: alpha * J_mm (:240-260, :406)
