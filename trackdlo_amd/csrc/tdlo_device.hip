@@ -123,7 +123,7 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
     __shared__ double sc[kMaxNodes];
     if (host_up) {      // the nodes from pinned host memory, then the whole upload block to its place in device memory: every load of a trip is
         // requested before the first store (a load-store loop pays one PCIe round trip, ~2 us, per trip); 16 bytes per load
-        for (int i = t; i < 3 * M; i += kBlock) sY[i] = host_up[yin_off + i];
+        // (the nodes are part of the block: they go to LDS out of the same registers -- ONE round trip over PCIe, ~1.7 us, not two)
         const dbl2 *src = (const dbl2 *)host_up;
         dbl2 *dst = (dbl2 *)dev_up;
         const int n2 = up_doubles >> 1;                          // (the block's parts are padded to 16 bytes)
@@ -132,7 +132,12 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const int i = i0 + u * kBlock + t; v[u] = src[i < n2 ? i : n2 - 1]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * kBlock + t; if (i < n2) dst[i] = v[u]; }
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * kBlock + t;
+                if (i < n2) dst[i] = v[u];
+                const int e = 2 * i - yin_off;                  // (yin_off is even: the parts start on 16-byte boundaries)
+                if (i < n2 && e >= 0 && e < 3 * M) { sY[e] = v[u].x; if (e + 1 < 3 * M) sY[e + 1] = v[u].y; }
+            }
         }
     } else {   // the node block, requested first: it arrives while the counts are scanned (the barriers of the scan cover it)
         const auto Yg = TDLO_AS_GLOBAL(double, f.Yin);
@@ -321,12 +326,18 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
             const int uj = dir ? bp.nUp - 1 - j : j;                         // the unknown: node b, component tj (0: f, 1: f')
             const int b = uj >> 1, tj = uj & 1;
             double kd0, kd1, kd2, ko[4] = {0.0, 0.0, 0.0, 0.0}, kn[4] = {0.0, 0.0, 0.0, 0.0};
+            // everything this record reads from memory is requested here, indices clamped instead of branched: both links and H's seven values
+            // arrive after ONE round trip (behind the branches below they had been three in a row)
+            const int sgn = dir ? 1 : -1;                                     // rows at or above the diagonal in the direction's order: nodes b, b + sgn, ...
+            double La[8], Lb[8], h[7];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { La[q] = lk[8 * (size_t)(b > 0 ? b : 1) + q]; Lb[q] = lk[8 * (size_t)(b + 1 < M ? b + 1 : M - 1) + q]; }
+#pragma unroll
+            for (int d = 0; d < 7; ++d) { const int a = b + sgn * d, ac = a < 0 ? 0 : (a > M - 1 ? M - 1 : a); const double hv = Hbg[(size_t)13 * b + (ac - b + 6)]; h[d] = (!tj && a >= 0 && a < M) ? hv : 0.0; }
             // diagonal block of node b (ff, fp, pp); ko: block (node b rows, node b - 1 columns); kn: block (node b + 1 rows, node b columns)
             if (b == 0) { const double s = ::sqrt(2.0) / beta, sf2 = 1.0 / (2.0 * ::sqrt(2.0) * beta); kd0 = 1.0 / sf2; kd1 = 0.0; kd2 = 1.0 / (s * s * sf2); }
             else {
-                double L[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) L[q] = lk[8 * (size_t)b + q];          // link b, formed a phase ago by thread b (behind the barrier above)
+                const double *L = La;          // link b, formed a phase ago by thread b (behind the barrier above)
                 const double rdet = 1.0 / (L[4] * L[6] - L[5] * L[5]);
                 const double qa = L[6] * rdet, qb = -L[5] * rdet, qd = L[4] * rdet;                  // Q^-1
                 kd0 = qa; kd1 = qb; kd2 = qd;
@@ -334,9 +345,7 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
                 ko[2] = -(qb * L[0] + qd * L[2]); ko[3] = -(qb * L[1] + qd * L[3]);                 //              row f'
             }
             if (b + 1 < M) {
-                double L[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) L[q] = lk[8 * (size_t)(b + 1) + q];
+                const double *L = Lb;
                 const double rdet = 1.0 / (L[4] * L[6] - L[5] * L[5]);
                 const double qa = L[6] * rdet, qb = -L[5] * rdet, qd = L[4] * rdet;
                 const double t11 = qa * L[0] + qb * L[2], t12 = qa * L[1] + qb * L[3], t21 = qb * L[0] + qd * L[2], t22 = qb * L[1] + qd * L[3];
@@ -346,10 +355,6 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
             // The column has at most 11 non-zero entries: node b's own two unknowns, the two of the neighbour node on the side of the rows
             // already in the window (K), and the f unknowns of the 6 nodes beyond (H).  All of H's values are requested before any is used
             // (one memory latency instead of one per entry), and the entries are written straight to their positions: no loop over the 13 slots.
-            const int sgn = dir ? 1 : -1;                                     // rows at or above the diagonal in the direction's order: nodes b, b + sgn, ...
-            double h[7];
-#pragma unroll
-            for (int d = 0; d < 7; ++d) { const int a = b + sgn * d; h[d] = (!tj && a >= 0 && a < M) ? Hbg[(size_t)13 * b + (a - b + 6)] : 0.0; }
 #pragma unroll
             for (int q = 0; q < kBandSlots; ++q) o[band_rec_pos(q)] = 0.0;
             auto put = [&](int ui, double v) __attribute__((always_inline)) {    // entry (row unknown ui, this column)
@@ -372,7 +377,9 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
                 for (int d = 2; d < 7; ++d) put(2 * (b + sgn * d), gam * h[d]);
             }
         }
-        for (int e = t; e < 3 * M; e += kBlock) {          // (13 loads requested at once, indices clamped; same ascending order of the terms as the dense product)
+        // (13 loads requested at once; same ascending order of the terms as the dense product.  Dealt out from the LAST thread down: at production
+        //  size the column records above occupy waves 0 and 1, these 3 M sums waves 2 and 3 -- side by side instead of one after the other)
+        for (int e = kBlock - 1 - t; e < 3 * M; e += kBlock) {
             const int i = e % M, d = e / M;
             double hv[13];
 #pragma unroll
@@ -422,6 +429,7 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         __syncthreads();
         if (t == 0) { sN = wcn[0] + wcn[1] + wcn[2] + wcn[3]; sS = ((wsd2[0] + wsd2[1]) + wsd2[2]) + wsd2[3]; }
         __syncthreads();
+        SSTAMP(7);
     }
     if (t == 0) {
         const int N = sN;
@@ -465,16 +473,25 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
     __shared__ double scratch[4];
     __shared__ double Yl[3 * kFuseMaxNodes];
     __shared__ double sctr[3];
-    __shared__ int lh[kFuseMaxNodes], base[kFuseMaxNodes], wcnt[4 * kFuseMaxNodes], wtot[4];
+    __shared__ int lh[kFuseMaxNodes], base[kFuseMaxNodes], wtot[4];
+    __shared__ unsigned long long lmask[4 * kFuseMaxNodes];      // per (wave, node): which lanes of the wave keep a point nearest to that node
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x;
     const int N0 = f.N0, M = f.M;
+#ifdef TDLO_CHAIN_STAMPS      // phase stamps of point workgroup 0 (instrumented build only): f.dbg[24 ..]
+#define PSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (t == 0 && b == 0) f.dbg[24 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+    PSTAMP(0);
     for (int m = t; m < M; m += kBlock) lh[m] = 0;
+    for (int i = t; i < 4 * M; i += kBlock) lmask[i] = 0ull;
     for (int i = t; i < 3 * M; i += kBlock) Yl[i] = host_up[yin_off + i];
     const int n = b * kBlock + t;
     const bool valid = n < N0;
     double x = 0, y = 0, z = 0;
     if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
     __syncthreads();
+    PSTAMP(1);
     // ---- prune + nearest node (k_prune_pass1)
     double best = 1e300, sum = 0;
     int a0 = 0;
@@ -490,6 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
     if (keep) atomicAdd(&lh[a0], 1);
     const double ssum = block_sum(keep ? sum : 0.0, scratch);
     __syncthreads();
+    PSTAMP(2);
     for (int m = t; m < M; m += kBlock) __hip_atomic_store(f.hist + (size_t)b * M + m, lh[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == 0) __hip_atomic_store((unsigned long long *)f.blksum + b, (unsigned long long)__double_as_longlong(ssum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (beside the wait) the centring offset, in k_setup's order: wave d sums coordinate d -- lane l the nodes l, l + 64, ... -- then the butterfly
@@ -501,7 +519,9 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
         if (lane == 0) sctr[d] = a / M;
     }
     fuse_arrive(f, (unsigned)nb, epoch);
+    PSTAMP(3);
     fuse_wait(f, epoch);
+    PSTAMP(4);
     // ---- this workgroup's start offsets: thread = node
     {
         int tot = 0, pre = 0;
@@ -520,30 +540,25 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
         int bs = 0;
         for (int q = 0; q < w; ++q) bs += wtot[q];
         if (t < M) base[t] = bs + incl - tot + pre;
-        for (int i = t; i < 4 * M; i += kBlock) wcnt[i] = 0;
     }
     __syncthreads();
-    // ---- stable scatter (k_prune_scatter): rank among the earlier points of the wave with the same nearest node, then the earlier waves
-    int rank = 0;
-    unsigned long long remaining = __ballot(keep);
-    while (remaining) {
-        const int leader = (int)__builtin_ctzll(remaining);
-        const int b0 = __builtin_amdgcn_readlane(bk, leader);
-        const unsigned long long mask = __ballot(keep && bk == b0);
-        if (keep && bk == b0) rank = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == leader) wcnt[w * M + b0] = __popcll(mask);
-        remaining &= ~mask;
-    }
+    PSTAMP(5);
+    // ---- stable scatter (the order k_prune_scatter produces): a point goes behind the points of the earlier waves and of the lower lanes of
+    //      its own wave that share its nearest node.  Every lane sets its bit in the (wave, node) mask with one LDS atomic (the masks were
+    //      cleared before the grid barrier) instead of the wave walking its distinct nodes one ballot at a time (up to 45 trips of ~60 clocks)
+    if (keep) __hip_atomic_fetch_or(lmask + w * M + bk, 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     if (keep) {
-        int dst = base[bk] + rank;
-        for (int i = 0; i < w; ++i) dst += wcnt[i * M + bk];
+        int dst = base[bk] + __popcll(lmask[w * M + bk] & ((1ull << lane) - 1ull));
+        for (int i = 0; i < w; ++i) dst += __popcll(lmask[i * M + bk]);
         T *xs = (T *)f.Xs;
         const size_t ld = f.ldx;
         xs[dst] = (T)(x - sctr[0]);
         xs[ld + dst] = (T)(y - sctr[1]);
         xs[2 * ld + dst] = (T)(z - sctr[2]);
     }
+    PSTAMP(6);
+#undef PSTAMP
 }
 
 template <typename T>
