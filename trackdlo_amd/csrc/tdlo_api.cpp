@@ -459,6 +459,10 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.prune_tiles = 1;
     while ((s.N0 + kBlock * f.prune_tiles - 1) / (kBlock * f.prune_tiles) > 1024) f.prune_tiles *= 2;
     f.nprune_blocks = (s.N0 + kBlock * f.prune_tiles - 1) / (kBlock * f.prune_tiles);
+    {   // the E-step's node window in bits (FrameDev::win_e32): TDLO_WINDOW=exact keeps every membership that is not exactly zero in the arithmetic
+        static const bool exact = getenv("TDLO_WINDOW") && getenv("TDLO_WINDOW")[0] == 'e';
+        f.win_e32 = exact ? 154.0 : 36.0; f.win_e64 = exact ? 1100.0 : 66.0;
+    }
     f.tol = p->tol; f.beta = p->beta; f.lambda = p->lambda; f.lle_weight = p->lle_weight; f.mu = p->mu;
     f.alpha = p->alpha; f.k_vis = p->k_vis; f.vis_thr = p->visibility_threshold; f.sigma2_in = sigma2;
     {   // per (prune block, node) histogram of the counting sort

@@ -213,10 +213,9 @@ __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st
     st->Nc = Nc;
     st->k2 = -1.4426950408889634 / (2.0 * sigma2);
     st->c_norm = c;
-    // the E-step's node window: 2^(k2 t^2) rounds to zero below an exponent of -151 (fp32; -1080 in fp64), i.e. beyond
-    // t = sqrt(151 / |k2|) = sqrt(151 * 2 / (2 pi log2 e)) * sqrt(2 pi sigma2); 1 % of margin, the same square root as above
-    st->rwin32 = 1.01 * 5.7720 * rtp;
-    st->rwin64 = 1.01 * 15.4366 * rtp;
+    // the E-step's node window (FrameDev::win_e32): E / |k2| = E 2 ln2 sigma2
+    st->rwin32 = f.win_e32 * 1.3862943611198906 * sigma2;
+    st->rwin64 = f.win_e64 * 1.3862943611198906 * sigma2;
 }
 
 

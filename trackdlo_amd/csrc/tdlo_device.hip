@@ -912,16 +912,28 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     for (int m = tid; m < M; m += EB) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
     if (done) return;
+    double lv_span = 0;      // VIS: the largest -log2 v_m + log2 v_m' over the nodes -- how far the visibility weights can lower a nearest node's membership against another's
     if (VIS) {
         // P_vis rows, :362-372: v_m = exp(-k_vis * dmin_m) / sum, folded into the exponent as log2 v_m
-        double tot = 0;
+        double tot = 0, dmx = 0, dmn = 1e300;
         for (int m = tid; m < M; m += EB) {
             double d = ::sqrt(Num<T>::from_bits(f.dminbits[m]));
             if (d > 10000.0) d = 10000.0;                        // initial value of :282
             if (d <= f.vis_thr) d = 0;                           // :291-293
             tot += ::exp(-f.k_vis * d);
+            dmx = d > dmx ? d : dmx; dmn = d < dmn ? d : dmn;
         }
         tot = block_sum_n<NWE>(tot, scratch);
+        {   // (max and min of d over the nodes: a wave reduction each, the waves through the same scratch)
+            dmx = wave_max_nonneg(dmx); dmn = wave_min_nonneg(dmn);
+            __syncthreads();
+            if (lane == 0) { scratch[wave] = dmx; scratch[NWE + wave] = dmn; }
+            __syncthreads();
+#pragma unroll
+            for (int w_ = 0; w_ < NWE; ++w_) { dmx = scratch[w_] > dmx ? scratch[w_] : dmx; dmn = scratch[NWE + w_] < dmn ? scratch[NWE + w_] : dmn; }
+            lv_span = f.k_vis * (dmx - dmn) * 1.4426950408889634;
+            if (!(lv_span > 0)) lv_span = 0;
+        }
         for (int m = tid; m < M; m += EB) {
             double d = ::sqrt(Num<T>::from_bits(f.dminbits[m]));
             if (d > 10000.0) d = 10000.0;
@@ -954,7 +966,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         for (int i = tid; i < M * 4; i += EB) accL[i] = 0;
         __syncthreads();
     }
-    const T Rwin = (T)(sizeof(T) == 4 ? stg->rwin32 : stg->rwin64);      // 1.01 sqrt(151 / |k2|) (fp32; 1080 in fp64), left by the M-step
+    // Node window: E / |k2| (a squared arc length, left by the M-step; E bits: FrameDev::win_e32 / win_e64), widened by what the visibility
+    // weights can take from a nearest node's membership.  A wave leaves node m out when (coord distance to the wave's nearest pairs)^2 exceeds
+    // (largest nearest-node distance of the wave)^2 + this: every point's membership of m is then below 2^-E of its largest one
+    const T R2win = (T)((sizeof(T) == 4 ? stg->rwin32 : stg->rwin64) * (1.0 + (VIS ? lv_span / (sizeof(T) == 4 ? f.win_e32 : f.win_e64) : 0.0)));
 
     const int nbatch = (N + 63) >> 6;
     for (int batch = batch0; batch < nbatch; batch += f.nblkE * NWE) {
@@ -1064,6 +1079,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         int wlo = 0, whi = M - 1;
         {
             const T amin = wave_min_nonneg(valid ? c_lo : Num<T>::inf()), amax = wave_max_nonneg(valid ? c_hi : T(0));   // coord >= 0
+            const T Rwin = Num<T>::sqrt_fast(wave_max_nonneg(valid ? best : T(0)) + R2win);
             int first = M, last = -1;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {

@@ -31,7 +31,8 @@ struct IterState {
     double Np;          // last Np (:388)
     double sum_d2;      // sum over kept points and nodes of |Y0_m - x_n|^2 (:263-273)
     double Nc;          // N used in the denominator constant c (global N when the cloud is split)
-    double rwin32, rwin64;  // E-step: arc-length radius beyond which a membership is exactly zero in fp32 / fp64 (with 1 % of margin)
+    double rwin32, rwin64;  // E-step's node window, fp32 / fp64 mode: E / |k2| = E 2 ln2 sigma2 (a squared arc length), E = FrameDev::win_e32 / win_e64 bits --
+                            // a membership is dropped once its exponent lies E below that of the point's nearest node (k_estep)
     int N;              // points kept by the prune (:195)
     int it;             // iterations completed
     int done;           // 1: remaining kernels of the loop are no-ops
@@ -98,6 +99,11 @@ struct FrameDev {
     // every other M-step only reports its progress there.  The host waits on that word instead of a device-to-host copy and a stream
     // synchronisation (a 4-6 us blit kernel, a dependent-dispatch gap and the wake-up of the blocking wait per registration).
     //   host_prog = epoch << 32 | done << 31 | iterations completed.     nullptr: off (batches, N-split, the dense M-steps)
+    // The E-step's node window: node m is left out for a wave's 64 points when its membership is below 2^-E of EVERY point's largest one (that
+    // of its nearest node).  E = 36 bits in fp32 mode, 66 in fp64 mode: 12 bits below the arithmetic's own rounding (24 / 53 mantissa bits), i.e.
+    // what is dropped could not have changed a sum's last bit by more than 2^-12 of an ulp.  TDLO_WINDOW=exact: 154 / 1100 bits -- only memberships
+    // that are exactly zero in the arithmetic (fp32 flushes below 2^-149, fp64 below 2^-1075) are left out, the rule of rounds 1-3 (comparator).
+    double win_e32, win_e64;
     double *host_out;
     unsigned long long *host_prog;
     unsigned host_epoch;

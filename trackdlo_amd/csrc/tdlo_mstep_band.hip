@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
             const double tp = 2.0 * M_PI * new_sigma2, rtp = ::sqrt(tp);
             st->k2 = -1.4426950408889634 * 0.5 * fast_rcp(new_sigma2);
             st->c_norm = tp * rtp * kc;
-            st->rwin32 = 1.01 * 5.7720 * rtp; st->rwin64 = 1.01 * 15.4366 * rtp;      // the E-step's node window (set_iter_consts)
+            st->rwin32 = f.win_e32 * 1.3862943611198906 * new_sigma2; st->rwin64 = f.win_e64 * 1.3862943611198906 * new_sigma2;      // the E-step's node window (set_iter_consts)
         } else { st->status = TDLO_E_NUMERIC; st->done = 1; st->converged = 0; pub = 1; }
         if (crit < f.tol) { st->done = 1; pub = 1; }                                   // :424-428
         else if (it >= f.max_iter) { st->converged = 0; st->done = 1; pub = 1; }      // :433-437
