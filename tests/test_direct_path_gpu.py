@@ -40,7 +40,8 @@ def _same(a, b):
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
-@pytest.mark.parametrize("N,M", [(63, 4), (256, 30), (257, 45), (5000, 45), (5000, 64), (5000, 65), (16384, 50), (16385, 50), (9000, 200), (9000, 256), (9000, 257), (3000, 512)])
+@pytest.mark.parametrize("N,M", [(63, 4), (256, 30), (257, 45), (5000, 45), (5000, 64), (5000, 65), (16384, 50), (16385, 50), (9000, 200), (9000, 256), (9000, 257), (3000, 512),
+                                 (30000, 50), (50000, 50), (65536, 45), (65537, 45), (40000, 200)])      # (beyond 64 point workgroups: the three-kernel form on both sides)
 def test_fused_prologue_equals_the_three_kernel_form(N, M, prec):
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
