@@ -9,7 +9,7 @@ _v = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tmp", "libtrackdl
 if not os.environ.get("TDLO_LIBRARY") and os.path.exists(_v):
     B._lib = B.load_library(_v)
 P = synth.LAUNCH_PARAMS
-for N, M, lle, reuse in ((5000, 45, True, False), (5000, 45, False, False), (5000, 45, False, True), (16000, 45, True, False), (1000, 45, True, False), (50000, 50, False, False), (30000, 50, False, False)):
+for N, M, lle, reuse in ((5000, 45, True, False), (5000, 45, False, False), (5000, 45, False, True), (16000, 45, True, False), (1000, 45, True, False)):
     ctx = B.Context(max_points=N, max_nodes=64)
     X, Y0, _ = synth.scene(N, M, config=5)
     pr = B.make_params(3.0 if lle else P['beta'], 1.0 if lle else P['lambda_'], P['lle_weight'], P['mu'], 1, 0.0, lle)
