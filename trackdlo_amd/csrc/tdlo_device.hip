@@ -1260,17 +1260,26 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
             if (shift <= 3) { s0 += row_ror8(s0); sx += row_ror8(sx); sy += row_ror8(sy); sz += row_ror8(sz); }
             {
-                if (lane < Wn) {
-                    long long *ac = accL + (size_t)(wlo_c + lane) * 4;
-                    const V4<T> ym = nodesL[wlo_c + lane];
-                    const double w0 = (double)s0;
-                    const double r1 = (double)sx + ((double)ox - (double)ym.x) * w0, r2 = (double)sy + ((double)oy - (double)ym.y) * w0, r3 = (double)sz + ((double)oz - (double)ym.z) * w0;
-                    acc_ok &= (__builtin_fabs(w0) < limP) & (__builtin_fabs(r1) < limR) & (__builtin_fabs(r2) < limR) & (__builtin_fabs(r3) < limR);
+                // ---- fixed-point tail: ONE value per lane.  Behind the butterflies every lane of a node's slices holds the node's four sums, so lane
+                //      (node wl, slice sl) converts value k = sl of its node -- P1, Rx, Ry, Rz -- instead of lanes 0 .. Wn-1 converting four each: the
+                //      same 4 Wn conversions (half-rate fp64 instructions: conversions, the residual's FMA, the range check, acc_fix) in a quarter
+                //      of the instructions.  (32-lane slices have two slices: two values per lane.)  R_k = s_k + (o_k - y_k) w0; P1 = 0 + 1 w0.
+                typedef __attribute__((address_space(3))) long long lds_i64;
+                const V4<T> ym = nodesL[wlo_c + (wl < Wn ? wl : 0)];
+                lds_i64 *acn = (lds_i64 *)(accL + (size_t)(wlo_c + wl) * 4);
+                const double w0 = (double)s0;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (r == 1 && shift != 5) break;                 // (wave-uniform: 32-lane slices come in two, every lane converts two values)
+                    const int k = sl + 2 * r;
+                    const bool k0 = k == 0, k1 = k == 1, k2 = k == 2;
+                    const T sk = k1 ? sx : (k2 ? sy : sz), ok = k1 ? ox : (k2 ? oy : oz), yk = k1 ? ym.x : (k2 ? ym.y : ym.z);
+                    const double d = k0 ? 1.0 : (double)ok - (double)yk, a = k0 ? 0.0 : (double)sk;
+                    const double v = ::fma(d, w0, a);
+                    const bool on = wl < Wn && k < 4;
+                    acc_ok &= !on || __builtin_fabs(v) < (k0 ? limP : limR);
                     // (ds_add_u64 without return: one LDS instruction per value instead of read, 64-bit add, write)
-                    __hip_atomic_fetch_add(ac + 0, acc_fix(w0, scP), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(ac + 1, acc_fix(r1, scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(ac + 2, acc_fix(r2, scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(ac + 3, acc_fix(r3, scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (on) __hip_atomic_fetch_add(acn + k, acc_fix(v, k0 ? scP : scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 wave_lds_sync();
             }
