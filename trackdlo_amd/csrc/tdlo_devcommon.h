@@ -143,6 +143,28 @@ __device__ __forceinline__ double wave_sum(double v) {
     return z;
 }
 
+// Folding butterflies (gfx950 v_permlane32_swap / v_permlane16_swap): fold32(x, y) leaves x[l] + x[l + 32] in lanes 0..31 and y[l - 32] + y[l] in
+// lanes 32..63 -- ONE exchange folds the halves of TWO values; fold16(x, y) does the same for rows 16 lanes apart: rows 0 and 2 receive x's row
+// pairs (0, 1) and (2, 3), rows 1 and 3 y's.  With x == y every lane receives its pair's sum (a plain xor-32 / xor-16 butterfly step).
+__device__ __forceinline__ float fold32(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double fold32(double x, double y) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double fold16(double x, double y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
 // block-wide sum for kBlock threads; scratch holds >= 4 doubles; result valid in every thread
 __device__ __forceinline__ double block_sum(double v, double *scratch) {
     v = wave_sum(v);

@@ -1256,30 +1256,37 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                     }
                 }
             }
-            s0 += __shfl_xor(s0, 32); sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
-            if (shift <= 4) { s0 += __shfl_xor(s0, 16); sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16); }
-            if (shift <= 3) { s0 += row_ror8(s0); sx += row_ror8(sx); sy += row_ror8(sy); sz += row_ror8(sz); }
+            // ---- the slices' partial sums folded together, and the fixed-point tail with ONE value per lane.
+            // s0 (the node's P1 share, which every residual needs) goes through plain butterfly steps: every lane of a node ends up with it.  The three
+            // residual sums are FOLDED: fold32(sx, sy) puts sx's halves into lanes 0..31 and sy's into lanes 32..63 with one exchange, fold16 then
+            // leaves row 0 with Sx, row 2 with Sy, rows 1 and 3 with Sz -- so that each row of 16 lanes converts a different value of its nodes:
+            // row 0 Rx, row 1 Rz, row 2 Ry, row 3 P1 (from s0).  Same pairs added in the same order as the xor-32 / xor-16 / ror-8 butterflies of
+            // before (same bits), in 12 cross-lane instructions instead of 8 trips through the LDS crossbar + 12 more; and the half-rate fp64
+            // instructions of the tail (conversions, the residual's FMA, the range check, acc_fix) are issued once instead of four times.
+            // (32-lane slices come in two: lanes 0..31 convert Rx then Rz, lanes 32..63 Ry then P1.)   R_k = s_k + (o_k - y_k) w0;  P1 = 0 + 1 w0.
+            s0 = fold32(s0, s0);
+            T u = fold32(sx, sy), v = fold32(sz, sz);
+            if (shift <= 4) { s0 = fold16(s0, s0); u = fold16(u, v); }
+            if (shift <= 3) { s0 += row_ror8(s0); u += row_ror8(u); }
             {
-                // ---- fixed-point tail: ONE value per lane.  Behind the butterflies every lane of a node's slices holds the node's four sums, so lane
-                //      (node wl, slice sl) converts value k = sl of its node -- P1, Rx, Ry, Rz -- instead of lanes 0 .. Wn-1 converting four each: the
-                //      same 4 Wn conversions (half-rate fp64 instructions: conversions, the residual's FMA, the range check, acc_fix) in a quarter
-                //      of the instructions.  (32-lane slices have two slices: two values per lane.)  R_k = s_k + (o_k - y_k) w0; P1 = 0 + 1 w0.
                 typedef __attribute__((address_space(3))) long long lds_i64;
                 const V4<T> ym = nodesL[wlo_c + (wl < Wn ? wl : 0)];
                 lds_i64 *acn = (lds_i64 *)(accL + (size_t)(wlo_c + wl) * 4);
                 const double w0 = (double)s0;
+                const int grp = shift == 5 ? (lane >> 5) * 2 : (lane >> 4);          // which value(s) this lane converts: 0: Rx (then Rz), 1: Rz, 2: Ry (then P1), 3: P1
+                const bool mine = wl < Wn && (shift != 3 || (lane & 8) == 0);         // (8-lane slices: both halves of a row hold the totals, the lower one converts)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    if (r == 1 && shift != 5) break;                 // (wave-uniform: 32-lane slices come in two, every lane converts two values)
-                    const int k = sl + 2 * r;
-                    const bool k0 = k == 0, k1 = k == 1, k2 = k == 2;
-                    const T sk = k1 ? sx : (k2 ? sy : sz), ok = k1 ? ox : (k2 ? oy : oz), yk = k1 ? ym.x : (k2 ? ym.y : ym.z);
-                    const double d = k0 ? 1.0 : (double)ok - (double)yk, a = k0 ? 0.0 : (double)sk;
-                    const double v = ::fma(d, w0, a);
-                    const bool on = wl < Wn && k < 4;
-                    acc_ok &= !on || __builtin_fabs(v) < (k0 ? limP : limR);
+                    if (r == 1 && shift != 5) break;                 // (wave-uniform)
+                    const int g = grp + r;                           // 0 Rx, 1 Rz, 2 Ry, 3 P1
+                    const bool gx = g == 0, gy = g == 2, gp = g == 3;
+                    const T sk = r == 0 ? u : v, ok = gx ? ox : (gy ? oy : oz), yk = gx ? ym.x : (gy ? ym.y : ym.z);
+                    const int k = gx ? 1 : (gy ? 2 : (gp ? 0 : 3));
+                    const double d = gp ? 1.0 : (double)ok - (double)yk, a = gp ? 0.0 : (double)sk;
+                    const double val = ::fma(d, w0, a);
+                    acc_ok &= !mine || __builtin_fabs(val) < (gp ? limP : limR);
                     // (ds_add_u64 without return: one LDS instruction per value instead of read, 64-bit add, write)
-                    if (on) __hip_atomic_fetch_add(acn + k, acc_fix(v, k0 ? scP : scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (mine) __hip_atomic_fetch_add(acn + k, acc_fix(val, gp ? scP : scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 wave_lds_sync();
             }
