@@ -2,6 +2,8 @@
 
   * the FUSED PROLOGUE: prune + count scan + setup + scatter of a small cloud in one launch (k_prologue), the host-supplied block read from
     pinned host memory by the kernel -- against the three-kernel form behind a host-to-device copy (TDLO_DIRECT_UPLOAD=0);
+  * LATE PRIORS: tracking_step forms the main registration's priors on the host while that registration's set-up kernel already runs; the first
+    E-step hands them to the M-step -- against priors staged before anything is launched (TDLO_LATE_PRIORS=0);
   * the RESULTS MAILBOX: the finishing M-step writes [Y | state] into pinned host memory and the host waits on that word -- against the
     read-back copy + stream synchronisation (TDLO_HOST_MAILBOX=0).
 Both are implementation routes for the same arithmetic in the same order (trackdlo.cpp:177-273 and the read-back of :440): every result must
@@ -16,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _ctx(B, classic, **kw):
-    keys = ("TDLO_DIRECT_UPLOAD", "TDLO_HOST_MAILBOX")
+    keys = ("TDLO_DIRECT_UPLOAD", "TDLO_HOST_MAILBOX", "TDLO_LATE_PRIORS")
     old = {k: os.environ.get(k) for k in keys}
     try:
         for k in keys:

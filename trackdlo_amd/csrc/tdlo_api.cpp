@@ -161,6 +161,9 @@ struct tdlo_ctx {
     unsigned mbox_epoch = 0;
     bool direct_in = !(getenv("TDLO_DIRECT_UPLOAD") && atoi(getenv("TDLO_DIRECT_UPLOAD")) == 0);   // one frame per call: the set-up kernels read the host-supplied block from pinned host
                                                                                                 // memory themselves (small clouds: the fused prologue); 0: copy + three launches (comparator)
+    double *late_buf = nullptr;           // pinned: [alpha J | alpha (Y_ext - Y0)] of priors that arrive after the set-up kernel was launched (FrameDev::late_aJ)
+    size_t late_doubles = 0;
+    bool late_on = !(getenv("TDLO_LATE_PRIORS") && atoi(getenv("TDLO_LATE_PRIORS")) == 0);   // tracking_step: priors formed beside the second registration's set-up kernel; 0: before it (comparator)
     bool mbox_on = !(getenv("TDLO_HOST_MAILBOX") && atoi(getenv("TDLO_HOST_MAILBOX")) == 0);   // TDLO_HOST_MAILBOX=0: the read-back copy + stream wait of rounds 1-3 (comparator)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
@@ -187,7 +190,7 @@ namespace {
 struct HostProf {
     static constexpr int kN = 16;
     const char *name[kN] = {"set_cloud call", "guide nodes", "prepare_frame #1", "enqueue prologue #1", "enqueue iteration #1", "wait #1", "results #1",
-                            "traverse + priors", "prepare_frame #2", "enqueue prologue #2", "enqueue iteration #2", "wait #2", "results #2", "", "", ""};
+                            "traverse + priors", "prepare_frame #2", "enqueue prologue #2", "enqueue iteration #2", "wait #2", "results #2", "between registrations", "", ""};
     double us[kN] = {};
     long n[kN] = {};
     bool on = getenv("TDLO_TRACK_PROFILE") && atoi(getenv("TDLO_TRACK_PROFILE")) != 0;
@@ -248,6 +251,16 @@ int ensure_pin(tdlo_ctx *c, size_t doubles) {
     c->pin = nullptr; c->pin_doubles = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->pin, doubles * sizeof(double), hipHostMallocDefault));
     c->pin_doubles = doubles;
+    return 0;
+}
+
+int ensure_late(tdlo_ctx *c, size_t doubles) {
+    if (doubles <= c->late_doubles) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->late_buf) hipHostFree(c->late_buf);
+    c->late_buf = nullptr; c->late_doubles = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->late_buf, doubles * sizeof(double), hipHostMallocDefault));
+    c->late_doubles = doubles;
     return 0;
 }
 
@@ -356,6 +369,19 @@ int check_params(tdlo_ctx *c, int M, const tdlo_params *p) {
     return 0;
 }
 
+// J / Y_extended (trackdlo.cpp:240-260) into a frame's staging block: aJ = alpha * diag(J), aYd = alpha * (Y_extended - Y0)
+int stage_priors(tdlo_ctx *c, double *aJ, double *aYd, const double *Y, int M, const double *priors, int K, double alpha) {
+    std::fill(aJ, aJ + M, 0.0);
+    std::fill(aYd, aYd + 3 * M, 0.0);
+    for (int i = 0; i < K; ++i) {
+        const int idx = (int)priors[4 * i];
+        if (idx < 0 || idx >= M) return fail(c, TDLO_E_INVALID, "correspondence prior index out of range");
+        aJ[idx] = alpha;
+        for (int d = 0; d < 3; ++d) aYd[d * M + idx] = alpha * (priors[4 * i + 1 + d] - Y[d * M + idx]);
+    }
+    return 0;
+}
+
 // Fills the host-side upload block [Yin | aJ | aYd | H] for one frame and its FrameDev.
 int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, const tdlo_params *p,
                   const double *priors, int K, const int *vis, int n_vis, const double *H_override,
@@ -367,15 +393,9 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     NodeCarve nc(M);
     double *blk = s.nodeblk;
     std::memcpy(stage + nc.Yin, Y, sizeof(double) * 3 * M);
-    // J / Y_extended (trackdlo.cpp:240-260): aJ = alpha * diag(J), aYd = alpha * (Y_extended - Y0)
-    double *aJ = stage + nc.aJ, *aYd = stage + nc.aYd;
-    std::fill(aJ, aJ + M, 0.0);
-    std::fill(aYd, aYd + 3 * M, 0.0);
-    for (int i = 0; i < K; ++i) {
-        const int idx = (int)priors[4 * i];
-        if (idx < 0 || idx >= M) return fail(c, TDLO_E_INVALID, "correspondence prior index out of range");
-        aJ[idx] = p->alpha;
-        for (int d = 0; d < 3; ++d) aYd[d * M + idx] = p->alpha * (priors[4 * i + 1 + d] - Y[d * M + idx]);
+    {
+        const int prc = stage_priors(c, stage + nc.aJ, stage + nc.aYd, Y, M, priors, K, p->alpha);
+        if (prc) return prc;
     }
     bool lle_band = false;
     if (p->include_lle) {
@@ -522,12 +542,19 @@ void fill_stats(tdlo_stats *st, const IterState &is) {
     st->mstep_retries = is.retries;
 }
 
+// Priors formed by the host while the set-up kernel of the registration runs (tracking_step's second registration: they come out of the first
+// registration's result through traverse_euclidean, 6.5 us of host time that used to sit between the two registrations).  Returns 0 and the
+// K x 4 rows, or an error code.
+typedef std::function<int(const double *&, int &)> LatePriors;
+
 // Shared driver of tdlo_cpd_lle_resident / _batch.
 int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *sigma2, const tdlo_params *p,
-               const double *priors, int K, const int *vis, int n_vis, const double *H_override, tdlo_stats *stats) {
+               const double *priors, int K, const int *vis, int n_vis, const double *H_override, tdlo_stats *stats,
+               const LatePriors *late = nullptr) {
     const auto t_host0 = std::chrono::steady_clock::now();
     int rc = check_params(c, M, p);
     if (rc) return rc;
+    if (late && F != 1) return fail(c, TDLO_E_INVALID, "late priors: one frame per call");
     if (F < 1 || F > c->cfg.max_frames) return fail(c, TDLO_E_INVALID, "bad frame count");
     NodeCarve nc(M);
     // Batches move their host-supplied blocks and their results with ONE copy each way: every small copy is a 4-5 us blit
@@ -574,6 +601,15 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (pass == 0) { c->lle_batch_dense = true; band_batch = false; up = upload_doubles(nc, p, false); ustride = up; }
     }
     c->lle_batch_dense = false;
+    // Late priors ride beside the set-up kernel only where the E-step can hand them to the M-step (the one-frame kernel, which takes the frame
+    // descriptor by value): otherwise they are formed here, before anything is launched, and staged like ordinary ones.
+    bool late_async = late != nullptr && c->fh[0].wide_tile != 0 && c->late_on;
+    if (late && !late_async) {
+        const double *lp = nullptr; int lk = 0;
+        if ((rc = (*late)(lp, lk))) return rc;
+        if ((rc = stage_priors(c, c->pin + nc.aJ, c->pin + nc.aYd, Y, M, lp, lk, p->alpha))) return rc;
+        c->fh[0].has_priors = lk > 0 ? 1 : 0;
+    }
     g_prof.mark(g_prof.base + 2);
     {   // prune, scan and scatter are skipped per LAUNCH: the sorted clouds are reused only when every frame of the call can reuse its own
         // (a frame that skipped its scan while the batch's scatter ran would have its cloud re-scattered from stale start offsets)
@@ -615,6 +651,18 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
     }
     g_prof.mark(g_prof.base + 3);
+    if (late_async) {
+        // the set-up kernel is on its way (it copies the staging block as it is: the priors' part is overwritten by the E-step's copy of what
+        // follows); now the host forms the priors and puts them where the first E-step fetches them
+        const double *lp = nullptr; int lk = 0;
+        rc = (*late)(lp, lk);
+        if (!rc) rc = ensure_late(c, 4 * (size_t)M);
+        if (!rc) rc = stage_priors(c, c->late_buf, c->late_buf + M, Y, M, lp, lk, p->alpha);
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }        // (the set-up kernel reads the pinned staging block: drained before anybody reuses it)
+        c->fh[0].has_priors = lk > 0 ? 1 : 0;
+        c->fh[0].late_aJ = c->late_buf; c->fh[0].late_aYd = c->late_buf + M;
+        g_prof.mark(7);
+    }
     for (int i = 0; i < F; ++i) {           // the slots' sorted clouds now belong to these nodes
         Slot &sl = c->slots[slots[i]];
         if (!c->fh[i].reuse_sorted) { sl.sorted_Y.assign(Y + (size_t)i * 3 * M, Y + (size_t)(i + 1) * 3 * M); sl.sorted_prec = p->precision; sl.sorted_valid = true; }
@@ -912,6 +960,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
     if (c->mbox) hipHostFree(c->mbox);
+    if (c->late_buf) hipHostFree(c->late_buf);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
     if (c->xfer) hipFree(c->xfer);
     if (c->split_buf) hipFree(c->split_buf);
@@ -1994,6 +2043,9 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
         return traverse_euclidean(t->geodesic_coord, guide, Mg, ve, alignment, anchor, out);
     };
     const char *oob = "traverse_euclidean: the reference would index out of bounds for these visible nodes";
+    // The priors of the main registration (:929-995), formed from the pre-processing registration's result.  As a function: the main registration's
+    // set-up kernel does not need them, so run_frames launches it first and calls this while it runs (LatePriors).
+    const LatePriors form_priors = [&](const double *&lp, int &lk) -> int {
     if (Mg == M) {                                                       // all visible / minor occlusion (:929-957)
         const int n1 = trav(0, -1, p1), n2 = trav(1, -1, p2);
         if (n1 <= 0 || n2 <= 0) return fail(c, TDLO_E_TRAVERSE, oob);
@@ -2033,6 +2085,9 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
         if (trav(2, anchor, p1) < 0) return fail(c, TDLO_E_TRAVERSE, oob);
         t->priors = p1;
     }
+    lp = t->priors.data(); lk = (int)(t->priors.size() / 4);
+    return 0;
+    };
 
     // main registration (:998): include_lle = false, priors, alpha, visible_nodes_extended, k_vis
     tdlo_params mp{};
@@ -2040,9 +2095,9 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     mp.tol = t->tol; mp.include_lle = 0; mp.alpha = t->alpha; mp.k_vis = t->k_vis; mp.visibility_threshold = t->visibility_threshold;
     mp.precision = t->precision;
     // prior indices may be fractional after the averaging at :954; the reference truncates (:247)
-    g_prof.mark(7); g_prof.base = 6;
-    rc = tdlo_cpd_lle_resident(c, t->slot, t->Y.data(), M, &t->sigma2, &mp, t->priors.data(), (int)(t->priors.size() / 4),
-                               vis_ext, n_ext, nullptr, &st_main);
+    g_prof.mark(13); g_prof.base = 6;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
     if (stats) stats[1] = st_main;
     return rc;
 }

@@ -104,6 +104,10 @@ struct FrameDev {
     // what is dropped could not have changed a sum's last bit by more than 2^-12 of an ulp.  TDLO_WINDOW=exact: 154 / 1100 bits -- only memberships
     // that are exactly zero in the arithmetic (fp32 flushes below 2^-149, fp64 below 2^-1075) are left out, the rule of rounds 1-3 (comparator).
     double win_e32, win_e64;
+    // Correspondence priors that arrive AFTER the set-up kernel was launched (tracking_step's second registration: the host forms them from the
+    // first registration's result while the set-up kernel already runs): alpha J (M doubles) and alpha (Y_ext - Y0) (3 M doubles) in pinned host
+    // memory; the E-step's workgroup 0 copies them to aJ / aYd in iteration 0, the M-step reads them there.  nullptr: they came with the upload block.
+    const double *late_aJ, *late_aYd;
     double *host_out;
     unsigned long long *host_prog;
     unsigned host_epoch;
