@@ -30,8 +30,17 @@ struct SmallLU {
     int perm[6];
     double det = 1.0;
 
+    // (the interior nodes of a chain all have six neighbours: that size gets loops with constant bounds -- the same operations in the same
+    //  order, unrolled by the compiler; 45 of these factorisations sit in front of every pre-processing registration)
     void factor(const double *src, int n_) {
+        if (n_ == 6) factor_n<6>(src); else factor_n<0>(src, n_);
+    }
+    void solve(const double *b, double *x) const {
+        if (n == 6) solve_n<6>(b, x); else solve_n<0>(b, x);
+    }
+    template <int N> void factor_n(const double *src, int n_ = N) {
         n = n_;
+        const int n = N ? N : n_;
         std::memcpy(a, src, sizeof(double) * n * n);
         det = 1.0;
         for (int i = 0; i < n; ++i) perm[i] = i;
@@ -54,7 +63,8 @@ struct SmallLU {
         }
     }
     // solves A x = b
-    void solve(const double *b, double *x) const {
+    template <int N> void solve_n(const double *b, double *x) const {
+        const int n = N ? N : this->n;
         double y[6];
         for (int i = 0; i < n; ++i) {
             double s = b[perm[i]];
@@ -89,12 +99,17 @@ int chain_neighbours(int half, int M, int idx, int *out, int cap) {   // trackdl
 static int lle_node_weights(int k, const double *Y, int M, int i, int *nb, double *w) {
     const int n = chain_neighbours(k / 2, M, i, nb, 6);
     if (n == 0 || n > 6) return 0;
-    double gram[36];
+    // local Gram matrix of the differences (trackdlo.cpp:128-134): every difference is formed once (it had been formed n times), and the matrix
+    // is symmetric term by term -- (a b) and (b a) round alike, the sums run over d in the same order -- so one triangle is computed and mirrored:
+    // the same 36 values, bit for bit, in a third of the operations
+    double gram[36], df[6][3];
     for (int r = 0; r < n; ++r)
-        for (int s = 0; s < n; ++s) {
+        for (int d = 0; d < 3; ++d) df[r][d] = Y[d * M + i] - Y[d * M + nb[r]];
+    for (int r = 0; r < n; ++r)
+        for (int s = r; s < n; ++s) {
             double acc = 0;
-            for (int d = 0; d < 3; ++d) acc += (Y[d * M + i] - Y[d * M + nb[r]]) * (Y[d * M + i] - Y[d * M + nb[s]]);
-            gram[r * n + s] = acc;
+            for (int d = 0; d < 3; ++d) acc += df[r][d] * df[s][d];
+            gram[r * n + s] = acc; gram[s * n + r] = acc;
         }
     SmallLU lu;
     lu.factor(gram, n);
@@ -127,7 +142,11 @@ void lle_weights(int k, const double *Y, int M, double *L) {
 // products summed in the same ascending order (the terms left out there are exact zeros).
 void lle_regulariser_band(const double *Y, int M, double *Hb) {
     // A(k, c) = (I - L)(k, c) for |c - k| <= 3, stored as Ab[7 k + (c - k + 3)]
-    std::vector<double> Ab((size_t)7 * M, 0.0);
+    double stack_buf[7 * 64];                                 // (no heap at production size)
+    std::vector<double> heap_buf;
+    double *Ab = stack_buf;
+    if (M > 64) { heap_buf.assign((size_t)7 * M, 0.0); Ab = heap_buf.data(); }
+    else std::fill(Ab, Ab + 7 * M, 0.0);
     for (int i = 0; i < M; ++i) {
         int nb[6];
         double w[6];
