@@ -280,9 +280,25 @@ def test_band_mstep_hands_an_indefinite_system_to_the_dense_kernels(oracle):
         move = np.abs(o["Y"] - Y0).max()
         assert move > 0.01                                   # (the indefinite system throws the nodes far: that is the reference's behaviour too)
         assert np.abs(g["Y"] - o["Y"]).max() <= 1e-8 and abs(g["sigma2"] - o["sigma2"]) <= 1e-6 * o["sigma2"]
+        assert g["band_retry"] == 1                          # (round 4: the call itself says so, not only the context's counter)
         # and the context goes back to the banded solve afterwards
         H = IL.T @ IL
         g = ctx.cpd_lle(X, Y0, 2e-5, _params(kw, 1), H=H)
-        assert g["rc"] == 0 and ctx.band_retries() == 1 and ctx.profile_iteration(1)[3] == "k_mstep_band"
+        assert g["rc"] == 0 and g["band_retry"] == 0 and ctx.band_retries() == 1 and ctx.profile_iteration(1)[3] == "k_mstep_band"
+        # the N-split driver repeats the call on the dense kernels as well -- every rank solves the same system, so every rank meets
+        # the same pivot -- in the one-shot form (one rank here) and in the RCCL form (a one-rank communicator made by the library)
+        H = IL.T @ IL - np.eye(M)
+        plain = ctx.cpd_lle(X, Y0, 2e-5, _params(kw, 1), H=H)
+        ctx.xch_bind(0, [ctx.xch_create(1, 64)])
+        s1 = ctx.split_run(Y0, 2e-5, _params(kw, 1), H=H)
+        ctx.xch_unbind()
+        assert s1["rc"] == 0 and s1["band_retry"] == 1 and s1["iters"] == plain["iters"]
+        np.testing.assert_array_equal(s1["Y"], plain["Y"])
+        import os
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        comm = ctx.rccl_comm_init(1, 0, B.rccl_unique_id())
+        s2 = ctx.split_run(Y0, 2e-5, _params(kw, 1), comm=comm, H=H)
+        assert s2["rc"] == 0 and s2["band_retry"] == 1 and np.abs(s2["Y"] - plain["Y"]).max() <= 1e-12
+        assert ctx.band_retries() == 4
     finally:
         ctx.close()
