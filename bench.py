@@ -444,9 +444,9 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
                algorithmic_valu_tflops=round(e_flops / (est_us * 1e-6) / 1e12, 3), valu_peak_tflops=vpeak,
                algorithmic_valu_ratio=round(e_flops / (est_us * 1e-6) / 1e12 / vpeak, 5),
                note="VALU / latency-bound (about 100 flop per byte at M = 50 against a ridge of 20): the HBM fraction is reported as the metric requires.  "
-                    "algorithmic_valu_ratio is SURVEY.md 8(d)'s 24 M N flops / time / vector peak: NOT an achieved fraction -- the kernel skips the "
-                    "exactly-zero memberships outside a wave's node window (about 80 % of the pairs once sigma is millimetres); what the vector ALUs "
-                    "really issue is valu_issue_frac (SQ_INSTS_VALU), present when the PMC child passes ran")
+                    "algorithmic_valu_ratio is SURVEY.md 8(d)'s 24 M N flops / time / vector peak: NOT an achieved fraction -- the kernel leaves out the "
+                    "memberships outside a wave's node window (below 2^-36 / 2^-66 of a point's largest one in fp32 / fp64 mode: about 85 % of the pairs "
+                    "once sigma is millimetres); what the vector ALUs really issue is valu_issue_frac (SQ_INSTS_VALU), present when the PMC child passes ran")
     if est_b2b_us is not None:
         est["avg_launch_us_back_to_back"] = round(est_b2b_us, 3)
     objs = [est]
