@@ -97,6 +97,38 @@ template <bool MAX> __device__ __forceinline__ unsigned wave_minmax_u32(unsigned
 }
 __device__ __forceinline__ float wave_min_nonneg(float v) { return __uint_as_float(wave_minmax_u32<false>(__float_as_uint(v))); }
 __device__ __forceinline__ float wave_max_nonneg(float v) { return __uint_as_float(wave_minmax_u32<true>(__float_as_uint(v))); }
+// Two or three wave-wide maxima of unsigned keys at once (round 4): v_permlane32_swap folds the halves of TWO values with one exchange,
+// v_permlane16_swap the row pairs, four DPP steps finish inside the rows -- rows 0 / 2 / 1 end with the maxima of a / b / c in their lane 15.
+// 13 instructions for three reductions (10 for two) instead of 7 each.  A minimum of non-negative floats is the maximum of the complemented bits.
+__device__ __forceinline__ unsigned fold32_max(unsigned x, unsigned y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned fold16_max(unsigned x, unsigned y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    return r[0] > r[1] ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned rows_max_u32(unsigned u) {          // the maximum of every row of 16 lanes in its lane 15
+#define TDLO_DPP_STEP(CTRL) do { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, CTRL, 0xf, 0xf, false); u = u > o_ ? u : o_; } while (0)
+    TDLO_DPP_STEP(0x111); TDLO_DPP_STEP(0x112); TDLO_DPP_STEP(0x114); TDLO_DPP_STEP(0x118);      // row_shr:1, 2, 4, 8
+#undef TDLO_DPP_STEP
+    return u;
+}
+// (max a, min b) of non-negative floats, wave-uniform
+__device__ __forceinline__ void wave_max_min_nonneg(float a, float b, float &amax, float &bmin) {
+    const unsigned x = fold32_max(__float_as_uint(a), ~__float_as_uint(b));
+    const unsigned z = rows_max_u32(fold16_max(x, x));
+    amax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)z, 15));
+    bmin = __uint_as_float(~(unsigned)__builtin_amdgcn_readlane((int)z, 47));
+}
+// (min a, max b, max c) of non-negative floats, wave-uniform
+__device__ __forceinline__ void wave_min_max_max_nonneg(float a, float b, float c, float &amin, float &bmax, float &cmax) {
+    const unsigned x = fold32_max(~__float_as_uint(a), __float_as_uint(b)), y = fold32_max(__float_as_uint(c), __float_as_uint(c));
+    const unsigned z = rows_max_u32(fold16_max(x, y));
+    amin = __uint_as_float(~(unsigned)__builtin_amdgcn_readlane((int)z, 15));
+    cmax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)z, 31));
+    bmax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)z, 47));
+}
 // fp64: the same butterfly as wave_sum below (v_permlane32_swap / v_permlane16_swap, then DPP rotations inside the rows), result in every
 // lane; min / max are exact, so the order does not matter (the former __shfl_xor tree cost the fp64 E-step 24 LDS round trips per batch)
 template <bool MAX, int CTRL> __device__ __forceinline__ double dpp_minmax_f64(double v) {
@@ -121,6 +153,8 @@ template <bool MAX> __device__ __forceinline__ double wave_minmax_f64(double v) 
 }
 __device__ __forceinline__ double wave_min_nonneg(double v) { return wave_minmax_f64<false>(v); }
 __device__ __forceinline__ double wave_max_nonneg(double v) { return wave_minmax_f64<true>(v); }
+__device__ __forceinline__ void wave_max_min_nonneg(double a, double b, double &amax, double &bmin) { amax = wave_max_nonneg(a); bmin = wave_min_nonneg(b); }
+__device__ __forceinline__ void wave_min_max_max_nonneg(double a, double b, double c, double &amin, double &bmax, double &cmax) { amin = wave_min_nonneg(a); bmax = wave_max_nonneg(b); cmax = wave_max_nonneg(c); }
 
 // wave-wide sum, the total in every lane.  The same pairs in the same order as an xor-32, 16, 8, 4, 2, 1 shuffle tree (identical bits), but
 // without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) lay the two halves / the rows 16 apart of the value side by

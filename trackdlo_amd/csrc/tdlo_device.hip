@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                 if (m < M) { const V4<T> qn = nodesL[m]; Dm[c] = Num<T>::sqrt_fast((qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz)); }
                 dmin_w = tmin(dmin_w, Dm[c]);
             }
-            r2 = wave_max_nonneg(r2); dmin_w = wave_min_nonneg(dmin_w);
+            wave_max_min_nonneg(r2, dmin_w, r2, dmin_w);          // (both reductions in one folded butterfly)
             const T lim = (dmin_w + T(2) * Num<T>::sqrt_fast(r2)) * T(1.0001) + T(1e-30);
             int first = M, last = -1;
 #pragma unroll
@@ -1085,8 +1085,9 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         // ---- node window of this wave
         int wlo = 0, whi = M - 1;
         {
-            const T amin = wave_min_nonneg(valid ? c_lo : Num<T>::inf()), amax = wave_max_nonneg(valid ? c_hi : T(0));   // coord >= 0
-            const T Rwin = Num<T>::sqrt_fast(wave_max_nonneg(valid ? best : T(0)) + R2win);
+            T amin, amax, bmx;                                                                                          // coord >= 0
+            wave_min_max_max_nonneg(valid ? c_lo : Num<T>::inf(), valid ? c_hi : T(0), valid ? best : T(0), amin, amax, bmx);   // (three reductions, one folded butterfly)
+            const T Rwin = Num<T>::sqrt_fast(bmx + R2win);
             int first = M, last = -1;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
