@@ -32,7 +32,7 @@ extern "C" {
 enum {
     TDLO_OK = 0,
     TDLO_E_NO_DEVICE = -1,   /* no usable HIP device / kernel image */
-    TDLO_E_INVALID = -2,     /* bad argument (M < 4, N <= 0, bad slot, unsupported M, ...) */
+    TDLO_E_INVALID = -2,     /* bad argument (M < 4 or M > 1024, N <= 0, bad slot, ...) */
     TDLO_E_HIP = -3,         /* HIP runtime error, see tdlo_last_error */
     TDLO_E_EMPTY = -4,       /* the prune (trackdlo.cpp:177-195) removed every point */
     TDLO_E_NUMERIC = -5,     /* non-finite sigma2 / Y or singular system encountered */
@@ -114,7 +114,8 @@ int tdlo_set_cloud(tdlo_ctx *ctx, int slot, const double *X, int N);
  *   H_override optional M x M column-major matrix used in place of the LLE regulariser
  *              H = (I-L)^T (I-L) of :236-237 (whose weights are numerically ill-defined).
  * Returns 0 or an error; stats->converged carries the reference's bool result.
- * Which kernel solves the M-step (trackdlo.cpp:392-437), by default, for chains of 4 .. 512 nodes:
+ * Chains of 4 .. 1024 nodes (more: TDLO_E_INVALID).  Which kernel solves the M-step (trackdlo.cpp:392-437), by default, for chains of up to 512 nodes
+ * (beyond 512: the one-direction smoother k_mstep_chain_long without the LLE term, the one-workgroup dense elimination with it):
  *   include_lle == 0  the chain smoother (csrc/tdlo_mstep_chain.hip: the same linear system in O(M) through the state-space form of
  *                     the kernel G, one workgroup per frame);  lambda == 0 or TDLO_MSTEP=dense: the dense eliminations k_mstep_fast
  *                     (up to 60 nodes) / k_mstep_mcu (one workgroup per 16 rows) -- comparators of the tests;

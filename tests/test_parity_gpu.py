@@ -102,7 +102,12 @@ def test_per_iteration_trajectory(hip_ctx, prec):
     (3000, 200, 3, dict(priors=True)),                     # blocked M-step in global memory, with the alpha J G term
     (2500, 80, 4, dict(lle=True)),                         # M > 64 with the LLE term: pivoted generic solve
     (6000, 300, 3, {}),                                    # BASELINE.json configs[4] node count (C5)
-    (4000, 512, 2, {}),                                    # largest supported chain
+    (4000, 512, 2, {}),                                    # largest chain of the four-direction smoother (its slots fill a CU's LDS)
+    (4000, 513, 2, {}),                                    # round 4: beyond 512 nodes -- E-step with 16 node chunks, the one-direction smoother k_mstep_chain_long
+    (3000, 600, 2, dict(priors=True)),
+    (5000, 700, 3, dict(vis=True)),
+    (4000, 1024, 2, {}),                                   # largest supported chain
+    (1500, 600, 1, dict(lle=True)),                        # beyond 512 nodes with the LLE term: the one-workgroup dense elimination (O(M^3): served, not tuned)
 ], ids=lambda v: str(v).replace(" ", ""))
 def test_live_oracle_small(hip_ctx, oracle, N, M, iters, opts, prec):
     from trackdlo_amd import synth
@@ -1435,3 +1440,52 @@ def test_fp64_exp2_of_the_estep(hip_ctx):
     ints = -np.arange(0.0, 1075.0)
     assert np.array_equal(hip_ctx.debug_exp2(ints), np.ldexp(1.0, ints.astype(int)))
     assert np.all(hip_ctx.debug_exp2(np.array([-1075.5, -1080.0, -1100.0, -5000.0])) == 0.0)
+
+
+@pytest.mark.gpu
+def test_chains_beyond_512_nodes(oracle):
+    """Round 4 (the reference takes any num_of_nodes, trackdlo.cpp:30-46): up to 1024 nodes.  Beyond 512 the E-step runs with 16
+    node chunks and the M-step without the LLE term is the one-direction smoother k_mstep_chain_long.  Here: the stopping rule through the results
+    mailbox, a batch against single calls (bit for bit), the N-split with a communicator; what is NOT carried says so (the one-shot exchange, 1025 nodes)."""
+    import os
+    from trackdlo_amd import synth, binding as B
+    P = synth.LAUNCH_PARAMS
+    M, N, F = 600, 5000, 3
+    ctx = B.Context(device=0, max_frames=F, max_points=N, max_nodes=M)
+    try:
+        kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=30, tol=2e-4, include_lle=False,
+                  alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
+        Xs, Ys = [], []
+        for f in range(F):
+            X, Y0, _ = synth.scene(N - 300 * f, M, config=77, frame=f)
+            ctx.set_cloud(f, X); Xs.append(X); Ys.append(Y0)
+        g = ctx.cpd_lle_resident(0, Ys[0], 0.0, _params(kw, 1))
+        o = oracle.cpd_lle(Xs[0], Ys[0], 0.0, **kw)
+        assert ctx.profile_iteration(1)[3] == "k_mstep_chain_long"
+        _check(g, o, 1)
+        assert 1 < g["iters"] < 30                                   # (the stopping rule ended it: the early-exit polling ran)
+        kw0 = dict(kw, tol=0.0, max_iter=3)
+        single = [ctx.cpd_lle_resident(f, Ys[f], 0.0, _params(kw0, 0)) for f in range(F)]
+        b = ctx.cpd_lle_batch(np.asarray(Ys), np.zeros(F), _params(kw0, 0))
+        for f in range(F):
+            np.testing.assert_array_equal(b["Y"][f], single[f]["Y"])
+            assert b["sigma2"][f] == single[f]["sigma2"]
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        comm = ctx.rccl_comm_init(1, 0, B.rccl_unique_id())
+        s = ctx.split_run(Ys[0], 0.0, _params(kw0, 1), comm=comm)
+        p = ctx.cpd_lle_resident(0, Ys[0], 0.0, _params(kw0, 1))
+        assert s["rc"] == 0 and np.abs(s["Y"] - p["Y"]).max() <= 1e-12 and s["iters"] == p["iters"]
+        with pytest.raises(B.TdloError):                              # the one-shot exchange's inbox serves up to 512 nodes
+            ctx.xch_create(1, M)
+        ctx.xch_bind(0, [ctx.xch_create(1, 512)])
+        r = ctx.split_run(Ys[0], 0.0, _params(kw0, 1), check=False)
+        ctx.xch_unbind()
+        assert r["rc"] == B.TDLO_E_INVALID
+        X1, Y1, _ = synth.scene(2000, 1025, config=78)
+        r = ctx.cpd_lle(X1, Y1, 0.0, _params(kw0, 0), check=False)
+        assert r["rc"] == B.TDLO_E_INVALID
+        ctx.set_cloud(0, Xs[0])                                       # (the refused call had uploaded its cloud into slot 0)
+        g = ctx.cpd_lle_resident(0, Ys[0], 0.0, _params(kw0, 1))     # and the context stays usable
+        np.testing.assert_array_equal(g["Y"], p["Y"])
+    finally:
+        ctx.close()

@@ -359,7 +359,7 @@ int ensure_nodes(tdlo_ctx *c, Slot &s, int M) {
 int check_params(tdlo_ctx *c, int M, const tdlo_params *p) {
     if (!p) return fail(c, TDLO_E_INVALID, "params is null");
     if (M < 4) return fail(c, TDLO_E_INVALID, "M < 4: the reference's neighbour clamps (trackdlo.cpp:313-321) need at least 4 nodes");
-    if (M > kMaxNodes) return fail(c, TDLO_E_INVALID, "M > 512 is not supported by the E-step tiling");
+    if (M > kMaxNodes) return fail(c, TDLO_E_INVALID, "M > 1024 is not supported by the E-step tiling");
     if (p->max_iter < 0) return fail(c, TDLO_E_INVALID, "max_iter < 0");
     if (p->precision != TDLO_PREC_F32 && p->precision != TDLO_PREC_F64) return fail(c, TDLO_E_INVALID, "bad precision");
     // the kernel G of trackdlo.cpp:233 divides by beta; a negative lambda makes the M-step's system indefinite (the reference's launch files use
@@ -397,7 +397,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         const int prc = stage_priors(c, stage + nc.aJ, stage + nc.aYd, Y, M, priors, K, p->alpha);
         if (prc) return prc;
     }
-    bool lle_band = false;
+    bool lle_band = false, h_banded = false;
     if (p->include_lle) {
         double *H = stage + nc.H;
         // The banded L D L^T in the chain's state (tdlo_mstep_band.hip) serves the registration when (i) H is banded like the
@@ -406,7 +406,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         // the solve's error grows like eps lambda sigma2 K / P1: at h = 1 mm with the pre-processing parameters (beta 3, lambda 1)
         // 1e-13 m, at 0.1 mm 1e-11 m, at 0.01 mm 1e-7 m (scripts/band_gap_study.py); the bound scales with cbrt(lambda beta^4).
         // Everything else (coincident nodes in particular: K is infinite there) keeps the dense pivoted eliminations.
-        if (mstep_band_enabled() && !c->lle_dense_once && !c->lle_batch_dense && p->lambda > 0 && p->beta > 0) {
+        if (mstep_band_enabled() && !c->lle_dense_once && !c->lle_batch_dense && p->lambda > 0 && p->beta > 0 && M <= kChainLdsMaxNodes) {      // (the banded solve keeps a record per unknown in LDS: up to 512 nodes)
             lle_band = true;
             const double hmin = 1e-3 * std::cbrt(p->lambda * std::pow(p->beta / 3.0, 4));
             for (int i = 0; i + 1 < M && lle_band; ++i) {
@@ -433,7 +433,11 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
             }
         } else if (H_override) {
             std::memcpy(H, H_override, sizeof(double) * (size_t)M * M);
+            h_banded = true;
+            for (int j = 0; j < M && h_banded; ++j)
+                for (int i = 0; i < M; ++i) if (std::abs(i - j) > 6 && H_override[(size_t)j * M + i] != 0.0) { h_banded = false; break; }
         } else {
+            h_banded = true;
             std::vector<double> L((size_t)M * M);
             lle_weights(6, Y, M, L.data());                  // trackdlo.cpp:236
             lle_regulariser(L.data(), M, H);                 // :237
@@ -469,6 +473,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     // which M-step: decided here, once per frame (the launchers dispatch on the descriptor, not on the process-wide toggles)
     f.mstep_dense = (mstep_chain_enabled() && p->lambda > 0.0) ? 0 : 1;      // (the chain smoother works in units of 1 / (lambda sigma2))
     f.lle_band = lle_band ? 1 : 0;
+    f.h_banded = h_banded ? 1 : 0;
     f.need_G = ((p->include_lle && !lle_band) || (!p->include_lle && f.mstep_dense)) ? 1 : 0;
     {   // test hook: iteration k of the multi-CU M-steps behaves as if a hand-off had timed out (tests/test_parity_gpu.py)
         static const int force_it = getenv("TDLO_MCU_FORCE_TIMEOUT") ? atoi(getenv("TDLO_MCU_FORCE_TIMEOUT")) : -1;
@@ -1253,7 +1258,7 @@ size_t tdlo_xch_bytes(int nranks, int max_nodes) {
 
 int tdlo_xch_create(tdlo_ctx *c, int nranks, int max_nodes, void **inbox) {
     if (!c) return TDLO_E_INVALID;
-    if (nranks < 1 || nranks > kMaxXchRanks || max_nodes < 4 || max_nodes > kMaxNodes) return fail(c, TDLO_E_INVALID, "tdlo_xch_create: 1..8 ranks, 4..512 nodes");
+    if (nranks < 1 || nranks > kMaxXchRanks || max_nodes < 4 || max_nodes > kChainLdsMaxNodes) return fail(c, TDLO_E_INVALID, "tdlo_xch_create: 1..8 ranks, 4..512 nodes (longer chains: tdlo_split_run with an RCCL communicator)");
     if (c->split_active) return fail(c, TDLO_E_INVALID, "tdlo_xch_create inside a split registration");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1371,6 +1376,8 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     FrameDev &f = c->fh[0];
     // the exchange lives in the one-workgroup M-steps: the chain smoother (no LLE term), the banded L D L^T (LLE term) -- any chain
     // length -- and the dense k_mstep_fast (up to 60 / 64 nodes)
+    if (oneshot && M > kChainLdsMaxNodes)
+        return fail(c, TDLO_E_INVALID, "the one-shot exchange serves chains of up to 512 nodes (the long-chain M-step does not carry it): pass an RCCL communicator");
     if (oneshot && !((!p->include_lle && (!f.mstep_dense || M <= 60)) || (p->include_lle && (f.lle_band || M <= 64))))
         return fail(c, TDLO_E_INVALID, "the one-shot exchange lives in the one-workgroup M-steps: this registration takes a dense multi-workgroup elimination (LLE term on a chain the banded solve cannot take, beyond 64 nodes): pass an RCCL communicator");
     hipStream_t s = c->stream;

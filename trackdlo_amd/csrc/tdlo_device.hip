@@ -101,7 +101,9 @@ __device__ __forceinline__ void fuse_wait(const FrameDev &f, unsigned epoch) {  
 // and copied to its place in the slot's node block (dev_up) by this workgroup -- no host-to-device copy in front of the kernel.
 // FUSED: this is the node workgroup of k_prologue; the counts are scanned by the point workgroups themselves, the kept-point count and the
 // sigma2 initialisation sum are formed at the end from what they published.
-template <typename T, bool FUSED>
+// MAXN: capacity of the static LDS arrays in nodes (the fused prologue serves chains of up to kFuseMaxNodes: its kernel also holds the point
+// workgroups' arrays, and both must fit the 64 KB a kernel may declare statically).
+template <typename T, bool FUSED, int MAXN = kMaxNodes>
 __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, const double *__restrict__ host_up, double *__restrict__ dev_up, int up_doubles,
                                            int yin_off, unsigned fuse_epoch) {
     IterState *st = f.st;
@@ -119,8 +121,8 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
     // counting sort by nearest node: hist[block][node] -> start offset of that (node, block) run.
     // 256 threads = 64 nodes x 4 chunks of blocks; per node an exclusive scan over the blocks in block order.
     const int nb = f.nprune_blocks;
-    __shared__ double sY[3 * kMaxNodes];
-    __shared__ double sc[kMaxNodes];
+    __shared__ double sY[3 * MAXN];
+    __shared__ double sc[MAXN];
     if (host_up) {      // the nodes from pinned host memory, then the whole upload block to its place in device memory: every load of a trip is
         // requested before the first store (a load-store loop pays one PCIe round trip, ~2 us, per trip); 16 bytes per load
         // (the nodes are part of the block: they go to LDS out of the same registers -- ONE round trip over PCIe, ~1.7 us, not two)
@@ -143,8 +145,8 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         const auto Yg = TDLO_AS_GLOBAL(double, f.Yin);
         for (int i = t; i < 3 * M; i += kBlock) sY[i] = Yg[i];
     }
-    __shared__ int stot[kMaxNodes];               // kept points per node -> first index of the node's run
-    __shared__ int csum[kMaxNodes / 64][4][64];   // kept points per (node, quarter of the prune blocks)
+    __shared__ int stot[MAXN];               // kept points per node -> first index of the node's run
+    __shared__ int csum[MAXN / 64][4][64];   // kept points per (node, quarter of the prune blocks)
     const int ml = t & 63, ch = t >> 6;
     const int cb0 = (int)((long long)nb * ch / 4), cb1 = (int)((long long)nb * (ch + 1) / 4);
     const bool reuse = FUSED || (f.reuse_sorted != 0 && !split_mode);      // the sorted cloud of the previous registration serves (or the point workgroups of the fused prologue scan): no counts to scan here
@@ -177,7 +179,10 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         };
         if (M <= 64) pass1(std::integral_constant<int, 1>(), std::integral_constant<int, 16>());
         else if (M <= 256) pass1(std::integral_constant<int, 4>(), std::integral_constant<int, 8>());
-        else pass1(std::integral_constant<int, 8>(), std::integral_constant<int, 8>());
+        else if constexpr (MAXN > 256) {
+            if (M <= 512) pass1(std::integral_constant<int, 8>(), std::integral_constant<int, 8>());
+            else pass1(std::integral_constant<int, MAXN / 64>(), std::integral_constant<int, 4>());
+        }
     }
     SSTAMP(1);
     {
@@ -194,10 +199,12 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
     // FIXED order: every wave's 64 partial sums by the butterfly of wave_sum, the four waves' sums left to right.  (Round 2 had thread 0 walk the
     // M nodes and thread 64 add 256 numbers one after the other: 6000 clocks = 2.5 us of every call.)
     if (!reuse) {
-        const int m0 = 2 * t, m1 = 2 * t + 1;
+        constexpr int NPT = MAXN > 2 * kBlock ? MAXN / kBlock : 2;          // consecutive nodes per thread (two; four for the 1024-node capacity)
         auto tot_of = [&](int m) __attribute__((always_inline)) { const int g = m >> 6, l = m & 63; return m < M ? (csum[g][0][l] + csum[g][1][l]) + (csum[g][2][l] + csum[g][3][l]) : 0; };
-        const int v0 = tot_of(m0), v1 = tot_of(m1);
-        int incl = v0 + v1;
+        int vq[NPT], vsum = 0;
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { vq[q] = tot_of(NPT * t + q); vsum += vq[q]; }
+        int incl = vsum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if ((t & 63) >= d) incl += o; }
         __shared__ int wtot[4];
@@ -208,9 +215,9 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         __syncthreads();
         int base = 0;
         for (int w = 0; w < (t >> 6); ++w) base += wtot[w];
-        const int excl = base + incl - (v0 + v1);
-        if (m0 < M) stot[m0] = excl;
-        if (m1 < M) stot[m1] = excl + v0;
+        int excl = base + incl - vsum;
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { if (NPT * t + q < M) stot[NPT * t + q] = excl; excl += vq[q]; }
         if (t == 0) { sN = wtot[0] + wtot[1] + wtot[2] + wtot[3]; sS = ((wsd[0] + wsd[1]) + wsd[2]) + wsd[3]; }
     }
     if (t == 0 && reuse && !FUSED) { sN = (int)f.keep[0]; sS = f.keep[1]; }
@@ -249,7 +256,10 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         };
         if (M <= 64) pass2(std::integral_constant<int, 1>(), std::integral_constant<int, 16>());
         else if (M <= 256) pass2(std::integral_constant<int, 4>(), std::integral_constant<int, 8>());
-        else pass2(std::integral_constant<int, 8>(), std::integral_constant<int, 8>());
+        else if constexpr (MAXN > 256) {
+            if (M <= 512) pass2(std::integral_constant<int, 8>(), std::integral_constant<int, 8>());
+            else pass2(std::integral_constant<int, MAXN / 64>(), std::integral_constant<int, 4>());
+        }
     }
     SSTAMP(3);
     // centring offset, chain coordinate: the node block is staged in LDS first -- the serial sums below (same
@@ -394,18 +404,23 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         // flat load per multiply-add (this block was 50 us of a 65 us kernel).
         const auto Hg = TDLO_AS_GLOBAL(double, f.H);
         const auto Gr = TDLO_AS_GLOBAL(double, f.G);
+        // (a banded H -- the library's own always is: +-6 nodes -- leaves exact zeros outside the band: the k loop runs over the band only, the same
+        //  sums; at 1024 nodes the full product would be 10^9 multiply-adds on this one workgroup)
+        const int hb = f.h_banded;
         for (int e = t; e < M * M; e += kBlock) {
             const int i = e % M, j = e / M;
+            const int k0 = hb ? (i > 6 ? i - 6 : 0) : 0, k1 = hb ? (i + 6 < M - 1 ? i + 6 : M - 1) : M - 1;
             double a = 0;
 #pragma unroll 8
-            for (int k = 0; k < M; ++k) a += Hg[(size_t)k * M + i] * Gr[(size_t)j * M + k];
+            for (int k = k0; k <= k1; ++k) a += Hg[(size_t)k * M + i] * Gr[(size_t)j * M + k];
             f.HG[e] = a;
         }
         for (int e = t; e < 3 * M; e += kBlock) {
             const int i = e % M, d = e / M;
+            const int k0 = hb ? (i > 6 ? i - 6 : 0) : 0, k1 = hb ? (i + 6 < M - 1 ? i + 6 : M - 1) : M - 1;
             double a = 0;
 #pragma unroll 8
-            for (int k = 0; k < M; ++k) a += Hg[(size_t)k * M + i] * sY[d * M + k];
+            for (int k = k0; k <= k1; ++k) a += Hg[(size_t)k * M + i] * sY[d * M + k];
             f.HY0[e] = a;
         }
     }
@@ -469,7 +484,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const double *__restrict__ host_up, double *__restrict__ dev_up, int up_doubles,
                                                      int yin_off, unsigned epoch) {
     const int nb = f.nprune_blocks;
-    if ((int)blockIdx.x == nb) { setup_body<T, true>(f, 0, host_up, dev_up, up_doubles, yin_off, epoch); return; }
+    if ((int)blockIdx.x == nb) { setup_body<T, true, kFuseMaxNodes>(f, 0, host_up, dev_up, up_doubles, yin_off, epoch); return; }
     __shared__ double scratch[4];
     __shared__ double Yl[3 * kFuseMaxNodes];
     __shared__ double sctr[3];
@@ -1893,7 +1908,7 @@ hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static inline int nch_for(int M) { const int c = (M + kChunk - 1) / kChunk; return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : 8)); }
+static inline int nch_for(int M) { const int c = (M + kChunk - 1) / kChunk; return c <= 1 ? 1 : (c <= 2 ? 2 : (c <= 4 ? 4 : (c <= 8 ? 8 : 16))); }
 
 size_t mstep_lds_bytes(int M) {
     const int nS = 4 * M + 1, ld = M | 1;
@@ -1939,8 +1954,8 @@ template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *
         if (g_estep_ev[0]) hipExtLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, g_estep_ev[0], g_estep_ev[1], 0, fd, fh[0]); \
         else hipLaunchKernelGGL((k_estep<T, NCH, VIS, EB, SINGLE>), grid, block, lds, s, fd, fh[0]); } while (0)
 #define TDLO_E(NCH, VIS) do { if (single) TDLO_E2(NCH, VIS, true); else TDLO_E2(NCH, VIS, false); } while (0)
-    if (vis) { switch (nch) { case 1: TDLO_E(1, true); break; case 2: TDLO_E(2, true); break; case 4: TDLO_E(4, true); break; default: TDLO_E(8, true); } }
-    else     { switch (nch) { case 1: TDLO_E(1, false); break; case 2: TDLO_E(2, false); break; case 4: TDLO_E(4, false); break; default: TDLO_E(8, false); } }
+    if (vis) { switch (nch) { case 1: TDLO_E(1, true); break; case 2: TDLO_E(2, true); break; case 4: TDLO_E(4, true); break; case 8: TDLO_E(8, true); break; default: TDLO_E(16, true); } }
+    else     { switch (nch) { case 1: TDLO_E(1, false); break; case 2: TDLO_E(2, false); break; case 4: TDLO_E(4, false); break; case 8: TDLO_E(8, false); break; default: TDLO_E(16, false); } }
 #undef TDLO_E
 #undef TDLO_E2
     return hipGetLastError();
@@ -1966,7 +1981,7 @@ template <typename T> static hipError_t launch_dmin_T(const FrameDev *fd, const 
     const int gx = dmin_blocks(fh, F);
     const dim3 grid(gx, F), block(kBlock);
 #define TDLO_D(NCH) do { hipLaunchKernelGGL((k_dmin<T, NCH>), grid, block, 0, s, fd, gx); } while (0)
-    switch (nch) { case 1: TDLO_D(1); break; case 2: TDLO_D(2); break; case 4: TDLO_D(4); break; default: TDLO_D(8); }
+    switch (nch) { case 1: TDLO_D(1); break; case 2: TDLO_D(2); break; case 4: TDLO_D(4); break; case 8: TDLO_D(8); break; default: TDLO_D(16); }
 #undef TDLO_D
     return hipGetLastError();
 }
@@ -2008,7 +2023,7 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
     // (M = 61..64 without LLE: the 64-column register tableau has no room for the right-hand sides; the tracer-column
     //  variant of the register path is an order of magnitude less accurate at weak regularisation, so these sizes take
     //  the blocked global-memory path as well)
-    if (M > 60 && !any_lle) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
+    if (M > 60 && M <= kChainLdsMaxNodes && !any_lle) return launch_mstep_big(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s);
     if (M <= 64) {
         const int mc = (M + 3 + 3) / 4;               // columns per wave: M matrix + 3 right-hand sides
         if (mc <= 6) return launch_mstep_fast<T, 4, 6>(fd, fh, F, from_sums, s);
@@ -2019,12 +2034,15 @@ template <typename T> static hipError_t launch_mstep_T(const FrameDev *fd, const
         const size_t lds = mstep_lds_bytes(M);
         TDLO_TRY(set_lds((k_mstep<T, true, kBlock>), lds));
         hipLaunchKernelGGL((k_mstep<T, true, kBlock>), dim3(F), dim3(kBlock), lds, s, fd, from_sums, 0);
-    } else if (from_sums != 2 && mstep_pivot_mcu_enabled()) {
+    } else if (from_sums != 2 && mstep_pivot_mcu_enabled() && M <= kChainLdsMaxNodes) {
         TDLO_TRY(launch_mstep_pivot_mcu(fd, fh, F, from_sums, fh[0].precision == TDLO_PREC_F64, s));
         const size_t lds = mstep_lds_bytes(M);        // redoes an iteration whose hand-offs timed out; otherwise leaves at once
         hipLaunchKernelGGL((k_mstep<T, false, 1024>), dim3(F), dim3(1024), lds, s, fd, from_sums, 1);
     } else {
+        // the one-workgroup elimination with the tableau in global memory: the comparator of the multi-workgroup kernels, and what serves the dense
+        // cases of chains beyond kChainLdsMaxNodes nodes (the LLE term, lambda = 0, TDLO_MSTEP=dense): O(M^3) on one CU -- correct, not fast
         const size_t lds = mstep_lds_bytes(M);
+        TDLO_TRY(set_lds((k_mstep<T, false, 1024>), lds));
         hipLaunchKernelGGL((k_mstep<T, false, 1024>), dim3(F), dim3(1024), lds, s, fd, from_sums, 0);
     }
     return hipGetLastError();
@@ -2087,9 +2105,10 @@ const char *mstep_kernel_name(const FrameDev *fh, int F) {
     const int M = fh[0].M;
     bool any_lle = false;
     for (int i = 0; i < F; ++i) any_lle = any_lle || fh[i].include_lle;
-    if (!any_lle && !fh[0].mstep_dense) return "k_mstep_chain";
+    if (!any_lle && !fh[0].mstep_dense) return M > kChainLdsMaxNodes ? "k_mstep_chain_long" : "k_mstep_chain";
     if (any_lle && fh[0].lle_band) return "k_mstep_band";
     if (M <= 60 && !any_lle) return "k_mstep_fast<MFMA>";
+    if (M > kChainLdsMaxNodes) return "k_mstep<1wg>";
     if (!any_lle) return "k_mstep_mcu";
     if (M <= 64) return "k_mstep_fast<pivoted>";
     if (M <= kLdsSolveMaxM) return "k_mstep<LDS>";

@@ -18,7 +18,9 @@ constexpr int kTileRows32 = 16;      // ... fp32 E-step, chains up to 64 nodes: 
 #define TDLO_TILE_ROWS_LONG 24         // (chains beyond 64 nodes; -DTDLO_TILE_ROWS_LONG=n builds the variants scripts/gpu_c5.py compares)
 #endif
 template <typename T> __host__ __device__ constexpr int tile_rows(int nch) { return nch == 1 ? (sizeof(T) == 4 ? kTileRows32 : kTileRows) : TDLO_TILE_ROWS_LONG; }
-constexpr int kMaxNodes = 512;       // E-step template covers ceil(M/64) in {1,2,4,8}
+constexpr int kMaxNodes = 1024;      // E-step template covers ceil(M/64) in {1,2,4,8,16}
+constexpr int kChainLdsMaxNodes = 512;   // the four-direction chain smoother and the banded LLE solve keep a record per node in LDS (161 / 157 KB at 512 nodes);
+                                         // longer chains: k_mstep_chain_long (one direction, compact records) / the one-workgroup dense elimination
 constexpr int kLdsSolveMaxM = 128;   // M-step keeps [A|B] in LDS up to this M
 constexpr int kMaxXchRanks = 8;      // ranks of the one-shot N-split exchange (one node: 8 GPUs)
 
@@ -85,6 +87,7 @@ struct FrameDev {
     double *keep;           // 2 doubles that outlive a registration: kept points and sum of d2 of the slot's sorted cloud (for reuse_sorted)
     int need_G;             // the M x M kernel matrix is built at setup (dense M-steps: dense LLE path, comparators); the chain smoother and the banded LLE M-step do not read it
     int mstep_dense;        // registrations without the LLE term: 0 the chain smoother, 1 the dense eliminations (comparators) -- decided when the frame is prepared
+    int h_banded;           // the dense LLE M-steps: H is zero beyond +-6 nodes (the library's own always is; an H_override is checked by the host): H G and H Y0 are formed from the band
     int lle_band;           // registrations with the LLE term: 1 the banded L D L^T in the chain's state (tdlo_mstep_band.hip), 0 the dense pivoted eliminations
     double *band;           // lle_band: one 16-double column record per unknown of the state-space system (band_record_doubles(M)), written by k_setup
     double *sums;           // 4M+2 reduced sums (N-split interface)
