@@ -656,6 +656,10 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
     }
     g_prof.mark(g_prof.base + 3);
+    for (int i = 0; i < F; ++i) {           // the slots' sorted clouds now belong to these nodes (recorded as soon as the prologue is enqueued: whatever fails later, the device's sort is this one)
+        Slot &sl = c->slots[slots[i]];
+        if (!c->fh[i].reuse_sorted) { sl.sorted_Y.assign(Y + (size_t)i * 3 * M, Y + (size_t)(i + 1) * 3 * M); sl.sorted_prec = p->precision; sl.sorted_valid = true; }
+    }
     if (late_async) {
         // the set-up kernel is on its way (it copies the staging block as it is: the priors' part is overwritten by the E-step's copy of what
         // follows); now the host forms the priors and puts them where the first E-step fetches them
@@ -667,10 +671,6 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         c->fh[0].has_priors = lk > 0 ? 1 : 0;
         c->fh[0].late_aJ = c->late_buf; c->fh[0].late_aYd = c->late_buf + M;
         g_prof.mark(7);
-    }
-    for (int i = 0; i < F; ++i) {           // the slots' sorted clouds now belong to these nodes
-        Slot &sl = c->slots[slots[i]];
-        if (!c->fh[i].reuse_sorted) { sl.sorted_Y.assign(Y + (size_t)i * 3 * M, Y + (size_t)(i + 1) * 3 * M); sl.sorted_prec = p->precision; sl.sorted_valid = true; }
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     // A batch runs as up to kBatchStreams groups of frames on as many streams, each group one E-step behind the previous
