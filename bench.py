@@ -639,7 +639,7 @@ def bench_frames(args, cfg, env):
         ctx.close()
         return
     # (outside the timed region) how many of the timed calls really pruned: tdlo_stats.sort_reused of each
-    pruned = sum(1 - int((r if F == 1 else r["stats"][0]).get("sort_reused", 0)) for r in timed)
+    pruned = sum(1 - int(bool((r if F == 1 else r["stats"][0]).get("sort_reused", 0))) for r in timed)
     del timed
     n_ranks, ranks = _rank_table(env)
     value = cfg["steps"] * F * EM_ITERS * n_ranks / dt

@@ -83,7 +83,9 @@ typedef struct {
     int mstep_retries;    /* iterations whose dense multi-workgroup elimination (a comparator / fall-back M-step, see tdlo_cpd_lle_resident) ran into
                            * the time limit of an inter-workgroup hand-off and were redone by the one-workgroup elimination (normally 0) */
     int sort_reused;      /* 1: this registration reused the slot's pruned, node-sorted cloud of the previous one (same cloud, same nodes, same
-                           * precision: tdlo_set_sort_reuse) and skipped the prune of trackdlo.cpp:177-195 -- identical results; 0: it pruned */
+                           * precision: tdlo_set_sort_reuse) and skipped the prune of trackdlo.cpp:177-195 -- identical results; 0: it pruned;
+                           * 2 (tdlo_tracker_tracking_step's main registration, every node visible): as 1, and its node-side set-up had been done
+                           * by the pre-processing registration's prologue as well -- it started at its first E-step (TDLO_PAIR_SETUP=0: never) */
     int band_retry;       /* 1: the banded LLE M-step met a non-positive pivot (or a non-finite sigma2) and the call was repeated on the dense
                            * pivoted eliminations, whose result this is (the reference's solver is a general one, trackdlo.cpp:415) */
 } tdlo_stats;

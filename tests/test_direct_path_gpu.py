@@ -143,3 +143,105 @@ def test_tracking_sequences_are_the_same_on_both_routes(prec):
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+
+
+def _pair_ctx(B, on, **kw):
+    old = os.environ.get("TDLO_PAIR_SETUP")
+    try:
+        if on:
+            os.environ.pop("TDLO_PAIR_SETUP", None)
+        else:
+            os.environ["TDLO_PAIR_SETUP"] = "0"
+        return B.Context(device=0, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("TDLO_PAIR_SETUP", None)
+        else:
+            os.environ["TDLO_PAIR_SETUP"] = old
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+@pytest.mark.parametrize("N,M", [(300, 8), (5000, 45), (5000, 64), (9000, 65), (16384, 120), (9000, 256), (16385, 45), (5000, 257)])
+def test_paired_setup_changes_no_bit_of_a_tracking_sequence(N, M, prec):
+    """tracking_step with every node visible: the pre-processing registration's prologue also sets up the main registration (one more
+    workgroup of k_prologue, the slot's second node block; stats.sort_reused == 2), which then starts at its E-step -- against
+    TDLO_PAIR_SETUP=0, where the main registration launches its own set-up kernel.  Frames with occluded nodes in between (no pairing
+    there: the two registrations start from different node sets) and sizes either side of the fused prologue's limits (16 384 points,
+    256 nodes: beyond them nothing is paired)."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    outs, routes = [], []
+    for on in (True, False):
+        ctx = _pair_ctx(B, on, max_points=N, max_nodes=64)
+        try:
+            _, Y0, _ = synth.scene(N, M, config=81)
+            coord = synth.geodesic_coord(Y0)
+            trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+                             P["lambda_pre_proc"], P["lle_weight"], ctx=ctx, precision=prec)
+            trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+            rec, route = [], []
+            for fr in range(10):
+                occl = (0.4, 0.5) if fr in (3, 7) else ((0.0, 0.2) if fr == 5 else None)
+                X, _, v = synth.scene(N, M, config=81, frame=fr, occlude=occl)
+                v = np.arange(M, dtype=np.int32) if v is None else v
+                vext = synth.extend_visible(v, M, coord)
+                trk.tracking_step(X, v, vext)
+                rec.append((trk.get_tracking_result(), trk.get_sigma2(), [s["iters"] for s in trk.last_stats], trk.get_correspondence_pairs(), trk.get_guide_nodes()))
+                route.append((len(vext) == M, trk.last_stats[1]["sort_reused"]))
+            outs.append(rec); routes.append(route)
+        finally:
+            ctx.close()
+    fits = N <= 16384 and M <= 256
+    for all_vis, r in routes[0]:
+        assert r == (2 if (all_vis and fits) else (1 if all_vis else 0)), routes[0]
+    for all_vis, r in routes[1]:
+        assert r == (1 if all_vis else 0), routes[1]
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+
+
+def test_paired_setup_is_dropped_when_the_first_registration_is_repeated_or_fails():
+    """The pre-processing registration is repeated on the dense kernels (an H_pre the banded solve gives up on): the main registration's
+    paired set-up, done by the first attempt's prologue, must still be the right one; and a pre-processing registration that fails must
+    leave nothing behind for the next frame."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 4000, 40
+    outs = []
+    for on in (True, False):
+        ctx = _pair_ctx(B, on, max_points=N, max_nodes=64)
+        try:
+            X, Y0, _ = synth.scene(N, M, config=82)
+            coord = synth.geodesic_coord(Y0)
+            trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+                             P["lambda_pre_proc"], 1e7, ctx=ctx, precision=1)
+            trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+            v = np.arange(M, dtype=np.int32)
+            L = np.zeros((M, M))
+            for i in range(M):
+                nb = [j for j in range(i - 3, i + 4) if j != i and 0 <= j < M]
+                L[i, nb] = 1.0 / len(nb)
+            Hbad = (np.eye(M) - L).T @ (np.eye(M) - L) - np.eye(M)     # indefinite: the banded L D L^T meets a non-positive pivot, the dense kernels solve it (test_mstep_band.py)
+            rec = []
+            r0 = ctx.band_retries()
+            try:
+                trk.tracking_step(X, v, v, None, 0, 0, H_pre=Hbad)
+                rec.append(("ok", trk.get_tracking_result(), trk.get_sigma2(), trk.last_stats[0]["band_retry"]))
+            except B.TdloError as e:
+                rec.append(("err", str(e)))
+            assert ctx.band_retries() == r0 + 1
+            trk.initialize_nodes(Y0)                                    # (the indefinite system threw the nodes far away)
+            far = X + np.array([5.0, 0.0, 0.0])                        # every point pruned: the pre-processing registration fails
+            with pytest.raises(B.TdloError):
+                trk.tracking_step(far, v, v)
+            trk.tracking_step(X, v, v)                                  # and the tracker carries on
+            rec.append(("ok", trk.get_tracking_result(), trk.get_sigma2(), trk.last_stats[1]["sort_reused"]))
+            outs.append(rec)
+        finally:
+            ctx.close()
+    assert outs[0][-1][3] == 2 and outs[1][-1][3] == 1
+    for a, b in zip(*outs):
+        assert a[0] == b[0]
+        if a[0] == "ok":
+            np.testing.assert_array_equal(a[1], b[1]); assert a[2] == b[2]

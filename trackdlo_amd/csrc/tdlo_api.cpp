@@ -51,6 +51,10 @@ struct Slot {
     size_t nodeblk_doubles = 0;
     unsigned *sync = nullptr;        // 256 words, zeroed once: cross-workgroup hand-off state of the multi-CU M-step
     unsigned fuse_epoch = 0;         // launches of the fused prologue on this slot (its grid barrier's flag carries the number)
+    // a second node block: tracking_step with every node visible has the fused prologue of its first registration set up the second one as
+    // well (PairNext) -- the second registration then runs out of this block
+    int cap_nodes2 = 0;
+    double *nodeblk2 = nullptr;
 };
 
 struct NodeCarve {
@@ -165,6 +169,24 @@ struct tdlo_ctx {
     size_t late_doubles = 0;
     bool late_on = !(getenv("TDLO_LATE_PRIORS") && atoi(getenv("TDLO_LATE_PRIORS")) == 0);   // tracking_step: priors formed beside the second registration's set-up kernel; 0: before it (comparator)
     bool mbox_on = !(getenv("TDLO_HOST_MAILBOX") && atoi(getenv("TDLO_HOST_MAILBOX")) == 0);   // TDLO_HOST_MAILBOX=0: the read-back copy + stream wait of rounds 1-3 (comparator)
+    // tracking_step, every node visible: both registrations start from the SAME nodes on the same cloud, and the second one's node-side set-up
+    // (centring, chain links, iteration constants: k_setup's work) depends on nothing the first one produces.  The first registration's fused
+    // prologue then runs it as one more workgroup beside its own (k_prologue, blockIdx = nb + 1) into the slot's second node block, and the
+    // second registration starts at its E-step: one launch and one dependent-dispatch gap less per frame.  TDLO_PAIR_SETUP=0: off (comparator).
+    struct PairNext {
+        int state = 0;                    // 0: nothing; 1: asked for by tracking_step (inputs below); 2: set up on the device (f, up)
+        int slot = 0, M = 0, n_vis = 0;
+        double sigma2 = 0;
+        tdlo_params p{};
+        std::vector<double> Y;
+        FrameDev f{};
+        size_t up = 0;
+        bool has_sums = false;            // the pre-processing registration's first M-step leaves the first E-step's sums for it (FrameDev::pair_sums)
+    } pair;
+    double *pin2 = nullptr;               // pinned: the paired registration's upload block
+    size_t pin2_doubles = 0;
+    bool pair_on = !(getenv("TDLO_PAIR_SETUP") && atoi(getenv("TDLO_PAIR_SETUP")) == 0);
+    bool pair_sums_on = !(getenv("TDLO_PAIR_SUMS") && atoi(getenv("TDLO_PAIR_SUMS")) == 0);     // 0: the paired registration still runs its own first E-step (comparator)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
     // split-mode scratch
@@ -356,6 +378,35 @@ int ensure_nodes(tdlo_ctx *c, Slot &s, int M) {
     return 0;
 }
 
+int ensure_nodes2(tdlo_ctx *c, Slot &s, int M) {
+    if (M <= s.cap_nodes2) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (s.nodeblk2) hipFree(s.nodeblk2);
+    s.nodeblk2 = nullptr; s.cap_nodes2 = 0;
+    const int cap = std::max(M, 16);
+    NodeCarve nc(cap);
+    HIPCHK(c, hipMalloc((void **)&s.nodeblk2, nc.total * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(s.nodeblk2, 0, nc.total * sizeof(double), c->stream));
+    s.cap_nodes2 = cap;
+    return 0;
+}
+
+int ensure_pin2(tdlo_ctx *c, size_t doubles) {
+    if (doubles <= c->pin2_doubles) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pin2) hipHostFree(c->pin2);
+    c->pin2 = nullptr; c->pin2_doubles = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->pin2, doubles * sizeof(double), hipHostMallocDefault));
+    c->pin2_doubles = doubles;
+    return 0;
+}
+
+bool same_params(const tdlo_params &a, const tdlo_params &b) {
+    return a.beta == b.beta && a.lambda == b.lambda && a.lle_weight == b.lle_weight && a.mu == b.mu && a.max_iter == b.max_iter && a.tol == b.tol &&
+           a.include_lle == b.include_lle && a.alpha == b.alpha && a.k_vis == b.k_vis && a.visibility_threshold == b.visibility_threshold &&
+           a.precision == b.precision;
+}
+
 int check_params(tdlo_ctx *c, int M, const tdlo_params *p) {
     if (!p) return fail(c, TDLO_E_INVALID, "params is null");
     if (M < 4) return fail(c, TDLO_E_INVALID, "M < 4: the reference's neighbour clamps (trackdlo.cpp:313-321) need at least 4 nodes");
@@ -385,13 +436,13 @@ int stage_priors(tdlo_ctx *c, double *aJ, double *aYd, const double *Y, int M, c
 // Fills the host-side upload block [Yin | aJ | aYd | H] for one frame and its FrameDev.
 int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, const tdlo_params *p,
                   const double *priors, int K, const int *vis, int n_vis, const double *H_override,
-                  double *stage, FrameDev &f) {
+                  double *stage, FrameDev &f, bool second_block = false) {
     Slot &s = c->slots[slot];
     if (s.N0 <= 0) return fail(c, TDLO_E_INVALID, "no cloud resident in slot (call tdlo_set_cloud)");
-    int rc = ensure_nodes(c, s, M);
+    int rc = second_block ? ensure_nodes2(c, s, M) : ensure_nodes(c, s, M);
     if (rc) return rc;
     NodeCarve nc(M);
-    double *blk = s.nodeblk;
+    double *blk = second_block ? s.nodeblk2 : s.nodeblk;
     std::memcpy(stage + nc.Yin, Y, sizeof(double) * 3 * M);
     {
         const int prc = stage_priors(c, stage + nc.aJ, stage + nc.aYd, Y, M, priors, K, p->alpha);
@@ -579,8 +630,20 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     rc = ensure_pin(c, (size_t)F * std::max(nc.upload, nc.readback + 2) + fdd + 2 * (size_t)F * std::max(nc.readback, (sizeof(IterState) + 7) / 8) + 4);
     if (rc) return rc;
     if (merged) { rc = ensure_xfer(c, (size_t)F * (upload_doubles(nc, p, false) + nc.readback) + fdd); if (rc) return rc; }
+    // tracking_step's second registration whose node-side set-up the first one's prologue has already done (PairNext): same slot, nodes, sigma2 and
+    // parameters as were set up, on the cloud that was sorted for these nodes -- then nothing is staged and no prologue is launched
+    bool paired = false;
+    if (late && c->pair.state == 2) {
+        const tdlo_ctx::PairNext &pn = c->pair;
+        const Slot &sl = c->slots[slots[0]];
+        paired = F == 1 && !priors && !H_override && pn.slot == slots[0] && pn.M == M && pn.n_vis == n_vis && pn.sigma2 == sigma2[0] && same_params(pn.p, *p) &&
+                 std::memcmp(pn.Y.data(), Y, sizeof(double) * 3 * M) == 0 && sl.sorted_valid && sl.sorted_prec == p->precision &&
+                 sl.sorted_Y.size() == 3 * (size_t)M && std::memcmp(sl.sorted_Y.data(), Y, sizeof(double) * 3 * M) == 0 && pn.f.wide_tile != 0;
+        c->pair.state = 0;
+    }
     c->fh.assign(F, FrameDev{});
-    for (int pass = 0; pass < 2; ++pass) {
+    if (paired) { c->fh[0] = c->pair.f; c->fh[0].reuse_sorted = 1; up = c->pair.up; }
+    for (int pass = 0; pass < 2 && !paired; ++pass) {
     for (int i = 0; i < F; ++i) {
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
                            c->pin + (size_t)i * ustride, c->fh[i]);
@@ -608,7 +671,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     c->lle_batch_dense = false;
     // Late priors ride beside the set-up kernel only where the E-step can hand them to the M-step (the one-frame kernel, which takes the frame
     // descriptor by value): otherwise they are formed here, before anything is launched, and staged like ordinary ones.
-    bool late_async = late != nullptr && c->fh[0].wide_tile != 0 && c->late_on;
+    bool late_async = late != nullptr && c->fh[0].wide_tile != 0 && (c->late_on || paired);
     if (late && !late_async) {
         const double *lp = nullptr; int lk = 0;
         if ((rc = (*late)(lp, lk))) return rc;
@@ -643,14 +706,40 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         HIPCHK(c, hipMemcpyAsync(c->xfer, c->pin, ((size_t)F * up + fdd) * sizeof(double), hipMemcpyHostToDevice, s));
         fdp = (const FrameDev *)(c->xfer + (size_t)F * up);
     } else {
-        std::memcpy(c->pin + nc.fdev, c->fh.data(), sizeof(FrameDev));
-        fdp = (const FrameDev *)(c->slots[slots[0]].nodeblk + nc.fdev);
+        if (!paired) std::memcpy(c->pin + nc.fdev, c->fh.data(), sizeof(FrameDev));
+        fdp = (const FrameDev *)((paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk) + nc.fdev);
     }
-    if (!merged && c->direct_in && prologue_direct_ok(c->fh[0])) {
+    double *const nodeblk_used = merged ? nullptr : (paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk);
+    if (paired) {
+        // (set up by the previous call's prologue)
+    } else if (!merged && c->direct_in && prologue_direct_ok(c->fh[0])) {
         // one small frame (or a reused sort): ONE launch reads the block from pinned host memory, puts it in its place and does the whole prologue
         Slot &sl = c->slots[slots[0]];
         if (++sl.fuse_epoch == 0) ++sl.fuse_epoch;
-        HIPCHK(c, launch_prologue_direct(c->fh.data(), c->pin, sl.nodeblk, (int)up, (int)nc.Yin, sl.fuse_epoch, s));
+        // tracking_step asked for the set-up of its second registration to ride along (PairNext): staged like a frame of its own into the second
+        // pinned block / the slot's second node block, one more workgroup of the fused prologue
+        tdlo_ctx::PairNext &pn = c->pair;
+        const FrameDev *f2 = nullptr;
+        if (pn.state == 1) {
+            pn.state = 0;
+            if (!late && !c->fh[0].reuse_sorted && prologue_pair_ok(c->fh[0]) && pn.slot == slots[0] && pn.M == M && !pn.p.include_lle) {
+                const NodeCarve nc2(pn.M);
+                if ((rc = ensure_pin2(c, nc2.upload + 2))) return rc;
+                if ((rc = prepare_frame(c, pn.slot, pn.Y.data(), pn.M, pn.sigma2, &pn.p, nullptr, 0, nullptr, pn.n_vis, nullptr, c->pin2, pn.f, true))) return rc;
+                if (pn.f.wide_tile && !pn.f.mstep_dense && !pn.f.vis_branch) {
+                    pn.up = upload_doubles(nc2, &pn.p, false);
+                    std::memcpy(c->pin2 + nc2.fdev, &pn.f, sizeof(FrameDev));
+                    f2 = &pn.f;
+                    // the two registrations' first E-steps are the same computation (see FrameDev::pair_sums) when they share nodes, sigma2, mu and
+                    // precision and neither weighs by visibility; the banded M-step of THIS registration then hands the sums over
+                    pn.has_sums = p->include_lle && c->fh[0].lle_band && !c->fh[0].vis_branch && p->mu == pn.p.mu && p->precision == pn.p.precision &&
+                                  sigma2[0] == pn.sigma2 && std::memcmp(Y, pn.Y.data(), sizeof(double) * 3 * M) == 0 && p->max_iter > 0 && c->pair_sums_on;
+                    if (pn.has_sums) c->fh[0].pair_sums = sl.nodeblk2 + nc2.sums;
+                }
+            }
+        }
+        HIPCHK(c, launch_prologue_direct(c->fh.data(), c->pin, sl.nodeblk, (int)up, (int)nc.Yin, sl.fuse_epoch, s, f2, c->pin2, sl.nodeblk2, f2 ? (int)pn.up : 0));
+        if (f2) pn.state = 2;
     } else {
         if (!merged) HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
         HIPCHK(c, launch_prune_and_setup(fdp, c->fh.data(), F, s));
@@ -691,8 +780,14 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         gs[g] = c->stream2[g - 1];            // (or a shard) occupies one hardware queue, not four
     }
     bool forked = false;
+    bool sums_first = paired && c->pair.has_sums;      // the first iteration is its M-step alone, from the sums the previous registration's first M-step left
     auto iterate = [&](int n) -> hipError_t {
         for (int it = 0; it < n; ++it) {
+            if (sums_first) {
+                sums_first = false;
+                TDLO_RET(launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s));
+                continue;
+            }
             for (int g = 0; g < NS; ++g) {
                 const FrameDev *fdg = fdp + goff[g], *fhg = c->fh.data() + goff[g];
                 const int Fg = goff[g + 1] - goff[g];
@@ -797,7 +892,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         HIPCHK(c, join());
         if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
         if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up + fdd, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
-        else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+        else HIPCHK(c, hipMemcpyAsync(c->pin, nodeblk_used + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
         if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
         HIPCHK(c, wait_stream(s));
         {
@@ -845,7 +940,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
         // the upload block in pinned memory is consumed by now in stream order; reuse it for the readback
         if (merged) HIPCHK(c, hipMemcpyAsync(c->pin, c->xfer + (size_t)F * up + fdd, (size_t)F * nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
-        else HIPCHK(c, hipMemcpyAsync(c->pin, c->slots[slots[0]].nodeblk + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
+        else HIPCHK(c, hipMemcpyAsync(c->pin, nodeblk_used + nc.Yout, nc.readback * sizeof(double), hipMemcpyDeviceToHost, s));
         if (timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
         HIPCHK(c, wait_stream(s));
     }
@@ -885,7 +980,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (stats) {
             fill_stats(&stats[i], is);
             stats[i].loop_ms = loop_ms; stats[i].total_ms = total_ms; stats[i].host_ms = host_ms;
-            stats[i].sort_reused = c->fh[i].reuse_sorted; stats[i].band_retry = c->lle_dense_once ? 1 : 0;
+            stats[i].sort_reused = paired ? 2 : c->fh[i].reuse_sorted; stats[i].band_retry = c->lle_dense_once ? 1 : 0;
         }
         if (is.status != 0 && worst == 0) worst = is.status;
     }
@@ -957,6 +1052,7 @@ void tdlo_destroy(tdlo_ctx *c) {
         if (s.blksum) hipFree(s.blksum);
         if (s.hist) hipFree(s.hist);
         if (s.nodeblk) hipFree(s.nodeblk);
+        if (s.nodeblk2) hipFree(s.nodeblk2);
         if (s.sync) hipFree(s.sync);
     }
     delete c->pool; c->pool = nullptr;
@@ -964,6 +1060,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->cloud_ws) hipFree(c->cloud_ws);
     if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
+    if (c->pin2) hipHostFree(c->pin2);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->late_buf) hipHostFree(c->late_buf);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
@@ -2038,10 +2135,23 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     pp.precision = t->precision;
     double sigma2_pre = t->sigma2;
     tdlo_stats st_pre{}, st_main{};
+    // the main registration's parameters (:998): include_lle = false, priors, alpha, visible_nodes_extended, k_vis
+    tdlo_params mp{};
+    mp.beta = t->beta; mp.lambda = t->lambda; mp.lle_weight = t->lle_weight; mp.mu = t->mu; mp.max_iter = t->max_iter;
+    mp.tol = t->tol; mp.include_lle = 0; mp.alpha = t->alpha; mp.k_vis = t->k_vis; mp.visibility_threshold = t->visibility_threshold;
+    mp.precision = t->precision;
+    // every node visible: both registrations start from t->Y, and the main one's node-side set-up depends on nothing the pre-processing one
+    // produces -- the pre-processing registration's prologue is asked to do it as well (tdlo_ctx::PairNext; run_frames takes it up if it can)
+    c->pair.state = 0;
+    if (Mg == M && c->pair_on && c->sort_reuse && c->late_on && c->direct_in && check_params(c, M, &mp) == 0) {
+        tdlo_ctx::PairNext &pn = c->pair;
+        pn.slot = t->slot; pn.M = M; pn.n_vis = n_ext; pn.sigma2 = t->sigma2; pn.p = mp; pn.Y = t->Y;
+        pn.state = 1;
+    }
     g_prof.mark(1);
     rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
     if (stats) stats[0] = st_pre;
-    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
+    if (rc) { c->pair.state = 0; (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
 
     std::vector<int> ve(vis_ext, vis_ext + n_ext);
     std::vector<double> p1, p2;
@@ -2096,15 +2206,12 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     return 0;
     };
 
-    // main registration (:998): include_lle = false, priors, alpha, visible_nodes_extended, k_vis
-    tdlo_params mp{};
-    mp.beta = t->beta; mp.lambda = t->lambda; mp.lle_weight = t->lle_weight; mp.mu = t->mu; mp.max_iter = t->max_iter;
-    mp.tol = t->tol; mp.include_lle = 0; mp.alpha = t->alpha; mp.k_vis = t->k_vis; mp.visibility_threshold = t->visibility_threshold;
-    mp.precision = t->precision;
+    // main registration (:998): include_lle = false, priors, alpha, visible_nodes_extended, k_vis (mp, above)
     // prior indices may be fractional after the averaging at :954; the reference truncates (:247)
     g_prof.mark(13); g_prof.base = 6;
     HIPCHK(c, hipSetDevice(c->device));
     rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
+    c->pair.state = 0;
     if (stats) stats[1] = st_main;
     return rc;
 }

@@ -480,11 +480,19 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
 // running beside the others.  All nb + 1 <= 65 workgroups are resident at once (256 CUs), which is what lets them wait for each other.
 // The bits are those of the three-kernel form (same arithmetic, same orders; `test_fused_prologue_equals_the_three_kernel_form`).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// PAIR (tracking_step with every node visible, tdlo_api.cpp PairNext): one more node workgroup, blockIdx = nb + 1, does the same node work for the
+// NEXT registration on this cloud (descriptor f2, its own upload block and node block) -- that registration starts from the same nodes, so the
+// sorted cloud, the counts and the centring offset are the ones formed here, and it needs no prologue of its own.
+template <typename T, bool PAIR>
 __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const double *__restrict__ host_up, double *__restrict__ dev_up, int up_doubles,
-                                                     int yin_off, unsigned epoch) {
+                                                     int yin_off, unsigned epoch, const FrameDev f2, const double *__restrict__ host_up2,
+                                                     double *__restrict__ dev_up2, int up_doubles2) {
     const int nb = f.nprune_blocks;
-    if ((int)blockIdx.x == nb) { setup_body<T, true, kFuseMaxNodes>(f, 0, host_up, dev_up, up_doubles, yin_off, epoch); return; }
+    if ((int)blockIdx.x >= nb) {
+        const bool second = PAIR && (int)blockIdx.x > nb;
+        setup_body<T, true, kFuseMaxNodes>(second ? f2 : f, 0, second ? host_up2 : host_up, second ? dev_up2 : dev_up, second ? up_doubles2 : up_doubles, yin_off, epoch);
+        return;
+    }
     __shared__ double scratch[4];
     __shared__ double Yl[3 * kFuseMaxNodes];
     __shared__ double sctr[3];
@@ -2069,15 +2077,25 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
 bool prologue_direct_ok(const FrameDev &f) {
     return f.reuse_sorted || (f.nprune_blocks <= kFuseMaxBlocks && f.prune_tiles == 1 && f.M <= kFuseMaxNodes);
 }
-hipError_t launch_prologue_direct(const FrameDev *fh, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s) {
+bool prologue_pair_ok(const FrameDev &f) {
+    return !f.reuse_sorted && f.nprune_blocks <= kFuseMaxBlocks && f.prune_tiles == 1 && f.M <= kFuseMaxNodes;
+}
+hipError_t launch_prologue_direct(const FrameDev *fh, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s,
+                                  const FrameDev *f2, const double *host_up2, double *dev_up2, int up_doubles2) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     if (fh[0].reuse_sorted) {
         if (f64) hipLaunchKernelGGL((k_setup<double, true>), dim3(1), dim3(kBlock), 0, s, (const FrameDev *)nullptr, fh[0], 0, host_up, dev_up, up_doubles, yin_off);
         else hipLaunchKernelGGL((k_setup<float, true>), dim3(1), dim3(kBlock), 0, s, (const FrameDev *)nullptr, fh[0], 0, host_up, dev_up, up_doubles, yin_off);
     } else {
-        const dim3 grid(fh[0].nprune_blocks + 1);
-        if (f64) hipLaunchKernelGGL((k_prologue<double>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch);
-        else hipLaunchKernelGGL((k_prologue<float>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch);
+        if (f2) {
+            const dim3 grid(fh[0].nprune_blocks + 2);
+            if (f64) hipLaunchKernelGGL((k_prologue<double, true>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch, *f2, host_up2, dev_up2, up_doubles2);
+            else hipLaunchKernelGGL((k_prologue<float, true>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch, *f2, host_up2, dev_up2, up_doubles2);
+        } else {
+            const dim3 grid(fh[0].nprune_blocks + 1);
+            if (f64) hipLaunchKernelGGL((k_prologue<double, false>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch, fh[0], (const double *)nullptr, (double *)nullptr, 0);
+            else hipLaunchKernelGGL((k_prologue<float, false>), grid, dim3(kBlock), 0, s, fh[0], host_up, dev_up, up_doubles, yin_off, epoch, fh[0], (const double *)nullptr, (double *)nullptr, 0);
+        }
     }
     return hipGetLastError();
 }

@@ -110,7 +110,14 @@ struct FrameDev {
     // Correspondence priors that arrive AFTER the set-up kernel was launched (tracking_step's second registration: the host forms them from the
     // first registration's result while the set-up kernel already runs): alpha J (M doubles) and alpha (Y_ext - Y0) (3 M doubles) in pinned host
     // memory; the E-step's workgroup 0 copies them to aJ / aYd in iteration 0, the M-step reads them there.  nullptr: they came with the upload block.
+    // (a registration whose first iteration starts from given sums -- from_sums == 1 -- has no E-step in front of its first M-step: the chain
+    //  smoother then reads them from here itself and keeps them in aJ / aYd for the iterations that follow)
     const double *late_aJ, *late_aYd;
+    // tracking_step with every node visible (tdlo_api.cpp, PairNext): the first E-step of the main registration would repeat the first E-step of
+    // the pre-processing registration to the bit -- same cloud, same nodes, sigma2, mu, precision, no visibility term, and the sums are integers.
+    // The pre-processing registration's M-step of iteration 0 stores the 4M + 1 sums it has read here (the main registration's `sums`), and that
+    // registration starts with its M-step.  nullptr: off.
+    double *pair_sums;
     double *host_out;
     unsigned long long *host_prog;
     unsigned host_epoch;
@@ -174,7 +181,9 @@ __host__ __device__ inline int band_rec_pos(int q) { return (q & 3) * 4 + (q >> 
 // launchers implemented in tdlo_device.hip
 hipError_t launch_prune_and_setup(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
 bool prologue_direct_ok(const FrameDev &f);
-hipError_t launch_prologue_direct(const FrameDev *frames_host, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s);
+bool prologue_pair_ok(const FrameDev &f);      // the fused form itself (not the reused-sort set-up): a second registration's set-up can ride along
+hipError_t launch_prologue_direct(const FrameDev *fh, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s,
+                                  const FrameDev *f2 = nullptr, const double *host_up2 = nullptr, double *dev_up2 = nullptr, int up_doubles2 = 0);
 hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
 hipError_t launch_iteration_timed(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
                                   hipEvent_t m_start, hipEvent_t m_stop);

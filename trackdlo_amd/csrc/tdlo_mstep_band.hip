@@ -177,6 +177,9 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
     }
     for (int i = t; i < kZero; i += MB) { zero0[i] = 0.0; if (tw) zero1[i] = 0.0; }
     __syncthreads();
+    if (SINGLE && !XCH && from_sums == 0 && f.pair_sums != nullptr && itn == 0) {      // tracking_step's main registration starts from these (FrameDev::pair_sums)
+        for (int i = t; i < nS; i += MB) f.pair_sums[i] = S[i];
+    }
     if (from_sums == 2) {       // split mode, export only
         acc_clear_other<MB>(f, itn, t);
         for (int i = t; i < nS; i += MB) f.sums[i] = S[i];

@@ -177,8 +177,10 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     const auto ndg = TDLO_AS_GLOBAL(V4<T>, f.nodes);
     const auto Yg = TDLO_AS_GLOBAL(double, f.Y);
     const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
-    const auto aJg = TDLO_AS_GLOBAL(double, f.aJ);
-    const auto aYg = TDLO_AS_GLOBAL(double, f.aYd);
+    // (late priors of a registration that starts from given sums: no E-step has copied them yet -- read from pinned host memory here, kept below)
+    const bool late_src = SINGLE && !XCH && from_sums == 1 && f.late_aJ != nullptr;
+    const auto aJg = TDLO_AS_GLOBAL(double, late_src ? f.late_aJ : f.aJ);
+    const auto aYg = TDLO_AS_GLOBAL(double, late_src ? f.late_aYd : f.aYd);
     const auto chg = TDLO_AS_GLOBAL(dbl2, f.chain);
 
     // slot -> (node, link into the step, does the step observe its node); li == 0: identity (a direction's first step from the prior or
@@ -261,6 +263,19 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         }
         q0 = load_slot(t);
     }
+    // given sums (from_sums == 1: the N-split's reduced sums; tracking_step's paired registration): the first five elements per thread -- chains
+    // of up to 256 nodes -- requested with everything else
+    double ss[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (from_sums == 1) {
+        const auto sums = TDLO_AS_GLOBAL(double, f.sums);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int i = t + u * MB; ss[u] = sums[i < nS ? i : nS - 1]; }
+    }
+    double kq[4] = {0.0, 0.0, 0.0, 0.0};              // late priors, element t + u MB of [alpha J | alpha (Y_ext - Y0)]: likewise
+    if (late_src && pri) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = t + u * MB, ic = i < 4 * M ? i : 4 * M - 1; kq[u] = ic < M ? aJg[ic] : aYg[ic - M]; }
+    }
     const double pinf0 = chg[0].x, pinf1 = chg[0].y;  // sf2, s^2 sf2
     const double c2 = f.lambda * sigma2, rc2 = fast_rcp(c2);
     const double cp0 = c2 * chg[1].x, cp1 = c2 * chg[1].y;  // Pinf^-1 in the units of the filter (P = covariance / c); reciprocals from k_setup
@@ -282,7 +297,15 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         for (int u = 0; u < 9; ++u) { const int i = t + u * MB; if (i < nS) S[i] = sq[u]; }
     } else {
         const auto sums = TDLO_AS_GLOBAL(double, f.sums);
-        for (int i = t; i < nS; i += MB) S[i] = sums[i];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int i = t + u * MB; if (i < nS) S[i] = ss[u]; }
+        for (int i = t + 5 * MB; i < nS; i += MB) S[i] = sums[i];
+        if (late_src && pri) {      // ... and to their place in device memory for the iterations that follow
+            double *aJw = (double *)f.aJ, *aYw = (double *)f.aYd;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = t + u * MB; if (i < M) aJw[i] = kq[u]; else if (i < 4 * M) aYw[i - M] = kq[u]; }
+            for (int i = t + 4 * MB; i < 4 * M; i += MB) aYw[i - M] = aYg[i - M];
+        }
     }
     __syncthreads();
     if (from_sums == 2) {       // split mode, export only
