@@ -8,6 +8,7 @@ timeout 900 python -m pytest tests/test_direct_path_gpu.py tests/test_sort_reuse
 g++ -O2 -std=c++17 scripts/ubench/track_cpp.cpp -o scripts/ubench/track_cpp -Ltrackdlo_amd -ltrackdlo_hip -Wl,-rpath,$R/trackdlo_amd || exit 1
 for rep in 1 2 3; do
   echo "pair on:  $(scripts/ubench/track_cpp 2>&1 | tail -1)" | tee -a $O/time.log
+  echo "pair on, M-step launched with its priors: $(TDLO_SPEC_MSTEP=0 scripts/ubench/track_cpp 2>&1 | tail -1)" | tee -a $O/time.log
   echo "pair on, own first E-step: $(TDLO_PAIR_SUMS=0 scripts/ubench/track_cpp 2>&1 | tail -1)" | tee -a $O/time.log
   echo "pair off: $(TDLO_PAIR_SETUP=0 scripts/ubench/track_cpp 2>&1 | tail -1)" | tee -a $O/time.log
 done

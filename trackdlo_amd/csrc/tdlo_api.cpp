@@ -182,10 +182,13 @@ struct tdlo_ctx {
         FrameDev f{};
         size_t up = 0;
         bool has_sums = false;            // the pre-processing registration's first M-step leaves the first E-step's sums for it (FrameDev::pair_sums)
+        int spec = 0;                     // 1: its first M-step is already on the stream, waiting for the priors (FrameDev::spec_flag)
+        unsigned spec_epoch = 0;          // ... under this mailbox epoch
     } pair;
     double *pin2 = nullptr;               // pinned: the paired registration's upload block
     size_t pin2_doubles = 0;
     bool pair_on = !(getenv("TDLO_PAIR_SETUP") && atoi(getenv("TDLO_PAIR_SETUP")) == 0);
+    bool spec_on = !(getenv("TDLO_SPEC_MSTEP") && atoi(getenv("TDLO_SPEC_MSTEP")) == 0);        // 0: the paired registration's first M-step is launched when its priors exist (comparator)
     bool pair_sums_on = !(getenv("TDLO_PAIR_SUMS") && atoi(getenv("TDLO_PAIR_SUMS")) == 0);     // 0: the paired registration still runs its own first E-step (comparator)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
@@ -399,6 +402,16 @@ int ensure_pin2(tdlo_ctx *c, size_t doubles) {
     HIPCHK(c, hipHostMalloc((void **)&c->pin2, doubles * sizeof(double), hipHostMallocDefault));
     c->pin2_doubles = doubles;
     return 0;
+}
+
+// the word a speculatively launched M-step waits on (FrameDev::spec_flag): the last double of the late-priors buffer
+unsigned long long *spec_flag_word(tdlo_ctx *c) { return (unsigned long long *)(c->late_buf + c->late_doubles - 1); }
+void spec_release(tdlo_ctx *c, unsigned epoch, bool go) {
+    __atomic_store_n(spec_flag_word(c), ((unsigned long long)epoch << 32) | (go ? 1ull : 2ull), __ATOMIC_RELEASE);
+}
+// whatever happens to the call that launched it, a waiting M-step is told to leave
+void spec_abort(tdlo_ctx *c) {
+    if (c->pair.spec) { spec_release(c, c->pair.spec_epoch, false); c->pair.spec = 0; }
 }
 
 bool same_params(const tdlo_params &a, const tdlo_params &b) {
@@ -641,6 +654,15 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
                  sl.sorted_Y.size() == 3 * (size_t)M && std::memcmp(sl.sorted_Y.data(), Y, sizeof(double) * 3 * M) == 0 && pn.f.wide_tile != 0;
         c->pair.state = 0;
     }
+    // its first M-step may already be waiting on the stream (launched by the previous call, below): released when the priors are staged, told to
+    // leave on every other way out of this function
+    struct SpecGuard {
+        tdlo_ctx *c; unsigned epoch = 0; bool live = false;
+        void release(bool go) { if (live) { spec_release(c, epoch, go); live = false; } }
+        ~SpecGuard() { release(false); }
+    } sg{c};
+    if (late && c->pair.spec) { sg.epoch = c->pair.spec_epoch; sg.live = true; c->pair.spec = 0; }
+    if (!paired) sg.release(false);
     c->fh.assign(F, FrameDev{});
     if (paired) { c->fh[0] = c->pair.f; c->fh[0].reuse_sorted = 1; up = c->pair.up; }
     for (int pass = 0; pass < 2 && !paired; ++pass) {
@@ -690,11 +712,12 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     const bool use_mbox = !merged && c->mbox_on && p->max_iter > 0 &&
                           ((!p->include_lle && !c->fh[0].mstep_dense) || (p->include_lle && c->fh[0].lle_band));
     unsigned epoch = 0;
+    if (!use_mbox) sg.release(false);
     if (use_mbox) {
         rc = ensure_mbox(c, nc.readback + 4);
         if (rc) return rc;
-        epoch = ++c->mbox_epoch;
-        if (epoch == 0) epoch = ++c->mbox_epoch;
+        if (sg.live) epoch = sg.epoch;         // (the waiting M-step reports under the epoch it was launched with)
+        else { epoch = ++c->mbox_epoch; if (epoch == 0) epoch = ++c->mbox_epoch; }
         c->fh[0].host_out = c->mbox; c->fh[0].host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); c->fh[0].host_epoch = epoch;
     }
     hipStream_t s = c->stream;
@@ -756,7 +779,8 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         rc = (*late)(lp, lk);
         if (!rc) rc = ensure_late(c, 4 * (size_t)M);
         if (!rc) rc = stage_priors(c, c->late_buf, c->late_buf + M, Y, M, lp, lk, p->alpha);
-        if (rc) { (void)hipStreamSynchronize(s); return rc; }        // (the set-up kernel reads the pinned staging block: drained before anybody reuses it)
+        if (rc) { sg.release(false); (void)hipStreamSynchronize(s); return rc; }        // (the set-up kernel reads the pinned staging block: drained before anybody reuses it)
+        if (lk <= 0) sg.release(false);                    // (it was launched expecting priors)
         c->fh[0].has_priors = lk > 0 ? 1 : 0;
         c->fh[0].late_aJ = c->late_buf; c->fh[0].late_aYd = c->late_buf + M;
         g_prof.mark(7);
@@ -785,7 +809,8 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         for (int it = 0; it < n; ++it) {
             if (sums_first) {
                 sums_first = false;
-                TDLO_RET(launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s));
+                if (sg.live) sg.release(true);             // it is on the stream already: the priors are staged, off it goes
+                else TDLO_RET(launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s));
                 continue;
             }
             for (int g = 0; g < NS; ++g) {
@@ -864,9 +889,28 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         // word of the chunk BEFORE the one it has just enqueued, so that the GPU never idles (kernels of a finished registration are no-ops)
         c->fh[0].host_report_it = 1;           // (the frame descriptor travels by value with every launch of the one-frame kernels)
         HIPCHK(c, iterate(1));
+        if (!late && c->pair.state == 2 && c->pair.has_sums && c->spec_on && c->mbox_on && !timing && c->pair.p.max_iter > 0) {
+            // tracking_step's main registration starts with its M-step (PairNext::has_sums): launched NOW, behind this registration's first
+            // iteration -- a steady-state tracker converges in it -- and ahead of the priors it needs (FrameDev::spec_flag)
+            tdlo_ctx::PairNext &pn = c->pair;
+            Slot &sl = c->slots[slots[0]];
+            const NodeCarve nc2(pn.M);
+            if ((rc = ensure_late(c, 4 * (size_t)pn.M + 2))) return rc;         // (may drain the stream: before anything waits on it)
+            unsigned e2 = ++c->mbox_epoch;
+            if (e2 == 0) e2 = ++c->mbox_epoch;
+            FrameDev fs = pn.f;
+            fs.reuse_sorted = 1; fs.has_priors = 1;
+            fs.late_aJ = c->late_buf; fs.late_aYd = c->late_buf + pn.M;
+            fs.host_out = c->mbox; fs.host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); fs.host_epoch = e2;
+            fs.host_report_it = (pn.p.tol <= 0.0 || pn.p.max_iter <= 2 * kChunkIters) ? 0 : 1;
+            fs.spec_flag = spec_flag_word(c); fs.spec_prev = c->fh[0].st; fs.spec_epoch = e2;
+            HIPCHK(c, launch_mstep_chain((const FrameDev *)(sl.nodeblk2 + nc2.fdev), &fs, 1, 1, fs.precision == TDLO_PREC_F64, s));
+            pn.spec = 1; pn.spec_epoch = e2;
+        }
         g_prof.mark(g_prof.base + 4);
         bool stop = false;
-        if ((rc = mbox_done(1, false, &stop))) return rc;
+        if ((rc = mbox_done(1, false, &stop))) { spec_abort(c); return rc; }
+        if (!stop) c->pair.spec = 0;           // (this registration goes on: the waiting M-step has seen that and left)
         g_prof.mark(g_prof.base + 5);
         int launched = 1, chunk = 0;
         while (launched < p->max_iter && !stop) {
@@ -957,6 +1001,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             numeric = numeric || is.status == TDLO_E_NUMERIC;
         }
         if (numeric) {
+            c->pair.spec = 0;                  // (a paired M-step launched ahead has seen the error status and left)
             c->lle_dense_once = true;
             ++c->band_retries;
             const int rr = run_frames(c, F, slots, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
@@ -985,6 +1030,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (is.status != 0 && worst == 0) worst = is.status;
     }
     g_prof.mark(g_prof.base + 6);
+    if (worst != 0 && !late) c->pair.spec = 0;
     if (worst == TDLO_E_EMPTY) return fail(c, worst, "every point was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
     if (worst == TDLO_E_NUMERIC) return fail(c, worst, "non-finite or non-positive sigma2, or singular M-step system");
     return TDLO_OK;
@@ -2151,7 +2197,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     g_prof.mark(1);
     rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
     if (stats) stats[0] = st_pre;
-    if (rc) { c->pair.state = 0; (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
+    if (rc) { c->pair.state = 0; spec_abort(c); (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
 
     std::vector<int> ve(vis_ext, vis_ext + n_ext);
     std::vector<double> p1, p2;
@@ -2211,7 +2257,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     g_prof.mark(13); g_prof.base = 6;
     HIPCHK(c, hipSetDevice(c->device));
     rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
-    c->pair.state = 0;
+    c->pair.state = 0; spec_abort(c);
     if (stats) stats[1] = st_main;
     return rc;
 }

@@ -118,6 +118,14 @@ struct FrameDev {
     // The pre-processing registration's M-step of iteration 0 stores the 4M + 1 sums it has read here (the main registration's `sums`), and that
     // registration starts with its M-step.  nullptr: off.
     double *pair_sums;
+    // ... and that first M-step is LAUNCHED right behind the pre-processing registration's first iteration, before the host has the priors it
+    // needs (they come out of the pre-processing registration's result through traverse_euclidean): it leaves at once unless that registration
+    // (spec_prev) has finished without an error, and otherwise waits for the host to raise spec_flag (pinned host memory) to spec_epoch << 32 | 1
+    // -- priors are in late_aJ / late_aYd -- or | 2 -- leave, nothing is touched.  Gives up after 2 s (the host then finds the stream drained
+    // without a report: an error).  What it saves is the launch: enqueue + dispatch latency, ~6 us between the two registrations.  nullptr: off.
+    const unsigned long long *spec_flag;
+    const IterState *spec_prev;
+    unsigned spec_epoch;
     double *host_out;
     unsigned long long *host_prog;
     unsigned host_epoch;

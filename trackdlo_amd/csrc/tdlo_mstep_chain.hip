@@ -216,6 +216,25 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
     // for the iteration counter (M <= 512: at most 9 elements per thread).  Requested before the slot: its index arithmetic
     // runs while these are in flight.
+    if (SINGLE && !XCH && f.spec_flag != nullptr) {      // launched ahead of its priors (FrameDev::spec_flag)
+        const auto pv = TDLO_AS_GLOBAL(IterState, f.spec_prev);
+        if (!(pv->done != 0 && pv->status == 0)) return;
+        if (t == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+            int go = 0;
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(f.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)(v >> 32) == f.spec_epoch && (v & 3ull) != 0ull) { go = (v & 3ull) == 1ull; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            red[31] = go ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const bool go = red[31] != 0.0;
+        __syncthreads();
+        if (!go) return;
+    }
     const int itn = stg->it;
     double sq[9];
     // (the first element without a branch -- index clamped, the accumulators exist in every mode: inside a conditional block the compiler sums the
