@@ -377,6 +377,16 @@ int tdlo_debug_mstep_lle_dense(int on);
  * solver is a general one (trackdlo.cpp:415); the caller sees the dense kernels' result, and tdlo_stats.band_retry = 1 on that call
  * (tdlo_cpd_lle*, tdlo_split_run in both forms: the ranks solve the same system and repeat together).  -1 for a null context. */
 long long tdlo_debug_band_retries(tdlo_ctx *ctx);
+/* Test aid: the 13 diagonals of H = (I - L)^T (I - L) (see tdlo_calc_lle_regulariser) formed by the DEVICE routine that tdlo_tracker_tracking_step's
+ * main registration ends with (csrc/tdlo_lle_dev.h; 1 .. 256 nodes): Hb[13 i + u] = H(i, i - 6 + u), the host routine's values bit for bit. */
+int tdlo_debug_lle_band_device(tdlo_ctx *ctx, const double *Y, int M, double *Hb);
+/* Test aid: how often tdlo_tracker_tracking_step took its short cuts on this context (none changes a bit of any result; each has an environment
+ * switch that turns it off, read when the context is made).  which = 0: main registrations whose node-side set-up had ridden in the
+ * pre-processing registration's prologue (every node visible; TDLO_PAIR_SETUP=0); 1: ... that started from the first E-step's sums handed over
+ * by the pre-processing registration instead of repeating that E-step (TDLO_PAIR_SUMS=0); 2: ... whose first M-step had been launched ahead of
+ * its priors and was released when they were staged (TDLO_SPEC_MSTEP=0); 3: pre-processing registrations whose LLE regulariser had been formed
+ * on the device by the M-step that finished the previous frame (TDLO_LLE_NEXT=0).  -1 for a null context or an unknown counter. */
+long long tdlo_debug_route_count(tdlo_ctx *ctx, int which);
 /* Test aid: provokes a HIP runtime error inside the library (an invalid copy) and reports it like any other: returns TDLO_E_HIP with the
  * text in tdlo_last_error.  The calls that follow must be unaffected -- HIP keeps a per-thread "last error" that the launch checks of a later
  * call would otherwise read (tests/test_parity_gpu.py::test_a_hip_error_does_not_leak_into_the_next_call). */

@@ -145,19 +145,22 @@ def test_tracking_sequences_are_the_same_on_both_routes(prec):
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
 
 
-def _pair_ctx(B, on, **kw):
-    old = os.environ.get("TDLO_PAIR_SETUP")
+def _pair_ctx(B, on, off=("TDLO_PAIR_SETUP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD"), **kw):
+    """on: every short cut of tracking_step; else the switches in `off` set to 0 (read when the context is made)."""
+    keys = ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD")
+    old = {k: os.environ.get(k) for k in keys}
     try:
-        if on:
-            os.environ.pop("TDLO_PAIR_SETUP", None)
-        else:
-            os.environ["TDLO_PAIR_SETUP"] = "0"
-        return B.Context(device=0, **kw)
+        for k in keys:
+            os.environ.pop(k, None)
+            if not on and k in off:
+                os.environ[k] = "0"
+        return B.Context(device=0, timing=False, **kw)      # (with the stream events of tdlo_set_timing nothing is launched ahead of its priors)
     finally:
-        if old is None:
-            os.environ.pop("TDLO_PAIR_SETUP", None)
-        else:
-            os.environ["TDLO_PAIR_SETUP"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
@@ -245,3 +248,48 @@ def test_paired_setup_is_dropped_when_the_first_registration_is_repeated_or_fail
         assert a[0] == b[0]
         if a[0] == "ok":
             np.testing.assert_array_equal(a[1], b[1]); assert a[2] == b[2]
+
+
+@pytest.mark.parametrize("off", [("TDLO_PAIR_SUMS",), ("TDLO_SPEC_MSTEP",), ("TDLO_LLE_NEXT",), ("TDLO_DIRECT_CLOUD",),
+                                 ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD")],
+                         ids=["own first E-step", "M-step launched with its priors", "host LLE", "cloud copied", "none of the short cuts"])
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_each_short_cut_of_tracking_step_changes_no_bit(prec, off):
+    """The short cuts of a tracking_step whose nodes are all visible -- set-up paired into the first prologue, first E-step's sums handed over,
+    first M-step launched ahead of its priors, the next frame's LLE regulariser formed on the device, the cloud read from pinned host memory by the
+    prologue -- switched off one at a time and all together:
+    20 frames (the first ones take several iterations in both registrations, so the M-step launched ahead finds the pre-processing registration
+    unfinished and leaves; occluded frames in between), same nodes, sigma2, iteration counts, priors and guide nodes, bit for bit; and the
+    counters say that the routes were really taken."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 5000, 45
+    outs, counts = [], []
+    for on in (True, False):
+        ctx = _pair_ctx(B, on, off=off, max_points=N, max_nodes=64)
+        try:
+            _, Y0, _ = synth.scene(N, M, config=83)
+            coord = synth.geodesic_coord(Y0)
+            trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+                             P["lambda_pre_proc"], P["lle_weight"], ctx=ctx, precision=prec)
+            trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+            rec = []
+            for fr in range(20):
+                occl = (0.4, 0.5) if fr in (6, 13) else None
+                X, _, v = synth.scene(N, M, config=83, frame=min(fr, 9), occlude=occl)      # (the rope moves for ten frames, then rests: registrations that converge in their first iteration)
+                v = np.arange(M, dtype=np.int32) if v is None else v
+                vext = synth.extend_visible(v, M, coord)
+                trk.tracking_step(X, v, vext)
+                rec.append((trk.get_tracking_result(), trk.get_sigma2(), [s["iters"] for s in trk.last_stats], trk.get_correspondence_pairs(), trk.get_guide_nodes()))
+            outs.append(rec); counts.append(ctx.route_counts())
+        finally:
+            ctx.close()
+    full, cut = counts
+    assert full[0] >= 16 and full[1] == full[0] and 0 < full[2] <= full[1] and full[3] >= 14, counts
+    if "TDLO_PAIR_SETUP" in off: assert cut[0] == 0 and cut[1] == 0 and cut[2] == 0, counts
+    elif "TDLO_PAIR_SUMS" in off: assert cut[1] == 0 and cut[2] == 0 and cut[0] == full[0], counts
+    elif "TDLO_SPEC_MSTEP" in off: assert cut[2] == 0 and cut[1] == full[1], counts
+    if "TDLO_LLE_NEXT" in off: assert cut[3] == 0, counts
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])

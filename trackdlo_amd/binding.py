@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -177,6 +177,10 @@ def load_library(path: str | None = None):
     lib.tdlo_debug_mstep_lle_dense.restype = ci
     lib.tdlo_debug_band_retries.argtypes = [vp]
     lib.tdlo_debug_band_retries.restype = C.c_longlong
+    lib.tdlo_debug_lle_band_device.argtypes = [vp, vp, ci, vp]
+    lib.tdlo_debug_lle_band_device.restype = ci
+    lib.tdlo_debug_route_count.argtypes = [vp, ci]
+    lib.tdlo_debug_route_count.restype = C.c_longlong
     lib.tdlo_debug_fail_hip.argtypes = [vp]
     lib.tdlo_debug_fail_hip.restype = ci
     lib.tdlo_set_timing.argtypes = [vp, ci]
@@ -417,6 +421,17 @@ class Context:
         n = C.c_int(0); me = C.c_int(0)
         self._chk(self.lib.tdlo_rccl_comm_count(C.c_void_p(comm), C.byref(n), C.byref(me)))
         return n.value, me.value
+
+    def lle_band_device(self, Y):
+        """The 13 diagonals of the LLE regulariser [M x 13] formed by the device routine (tdlo_debug_lle_band_device)."""
+        Y = _f64(Y); M = Y.shape[0]
+        Hb = np.zeros((M, 13))
+        self._chk(self.lib.tdlo_debug_lle_band_device(self.h, _ptr(Y), M, _ptr(Hb)))
+        return Hb
+
+    def route_counts(self):
+        """[paired set-ups, first iterations from handed-over sums, M-steps released from their wait, device-formed LLE regularisers used] (tdlo_debug_route_count)."""
+        return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in range(4)]
 
     def band_retries(self):
         """Calls of this context that were repeated on the dense pivoted kernels after the banded LLE solve gave up (tdlo_debug_band_retries)."""

@@ -55,6 +55,12 @@ struct Slot {
     // well (PairNext) -- the second registration then runs out of this block
     int cap_nodes2 = 0;
     double *nodeblk2 = nullptr;
+    // the LLE regulariser (13 diagonals) of the nodes the last tracking_step left behind, formed on the device by the M-step that finished its
+    // main registration (FrameDev::lle_next): serves the next pre-processing registration if it starts from exactly those nodes
+    double *hb_next = nullptr;
+    int hb_next_cap = 0;
+    std::vector<double> hb_next_Y;
+    bool hb_next_valid = false;
 };
 
 struct NodeCarve {
@@ -158,6 +164,8 @@ struct tdlo_ctx {
     bool lle_batch_dense = false;         // run_frames: a frame of this batch cannot take the banded LLE solve, all of them are staged for the dense kernels
     bool lle_dense_once = false;          // run_frames' retry: the banded LLE solve reported a numeric failure, this call repeats with the dense pivoted kernels
     long long band_retries = 0;           // how often that happened (tdlo_debug_band_retries)
+    long long route_count[4] = {0, 0, 0, 0};   // tdlo_debug_route_count: 0 paired set-ups taken up, 1 first iterations started from the handed-over sums,
+                                               // 2 M-steps released from their wait for priors, 3 pre-processing registrations served by a device-formed H
     bool sort_reuse = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);   // tdlo_set_sort_reuse: a slot's sorted cloud may serve the next registration of the same nodes
     // results mailbox in pinned host memory (FrameDev::host_out / host_prog): [read-back block | progress word], written by the one-workgroup M-steps
     double *mbox = nullptr;
@@ -188,6 +196,14 @@ struct tdlo_ctx {
     double *pin2 = nullptr;               // pinned: the paired registration's upload block
     size_t pin2_doubles = 0;
     bool pair_on = !(getenv("TDLO_PAIR_SETUP") && atoi(getenv("TDLO_PAIR_SETUP")) == 0);
+    // tracking_step: the frame's cloud staged in pinned host memory and read from there by the fused prologue's point workgroups (FrameDev::Xhost)
+    // instead of a host-to-device copy in front of it (a 9 us copy on the stream, 8 us of host time for the call); cloud_pending: staged for this
+    // slot and not yet on the device.  TDLO_DIRECT_CLOUD=0: the copy (comparator)
+    double *cloud_pin = nullptr;
+    size_t cloud_pin_doubles = 0;
+    int cloud_pending = -1;
+    bool cloud_direct_on = !(getenv("TDLO_DIRECT_CLOUD") && atoi(getenv("TDLO_DIRECT_CLOUD")) == 0);
+    bool lle_next_on = !(getenv("TDLO_LLE_NEXT") && atoi(getenv("TDLO_LLE_NEXT")) == 0);        // 0: the host forms every LLE regulariser (comparator)
     bool spec_on = !(getenv("TDLO_SPEC_MSTEP") && atoi(getenv("TDLO_SPEC_MSTEP")) == 0);        // 0: the paired registration's first M-step is launched when its priors exist (comparator)
     bool pair_sums_on = !(getenv("TDLO_PAIR_SUMS") && atoi(getenv("TDLO_PAIR_SUMS")) == 0);     // 0: the paired registration still runs its own first E-step (comparator)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
@@ -394,6 +410,37 @@ int ensure_nodes2(tdlo_ctx *c, Slot &s, int M) {
     return 0;
 }
 
+int ensure_hb_next(tdlo_ctx *c, Slot &s, int M) {
+    if (M <= s.hb_next_cap) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (s.hb_next) hipFree(s.hb_next);
+    s.hb_next = nullptr; s.hb_next_cap = 0; s.hb_next_valid = false;
+    const int cap = std::max(M, 64);
+    HIPCHK(c, hipMalloc((void **)&s.hb_next, sizeof(double) * 13 * (size_t)cap));
+    s.hb_next_cap = cap;
+    return 0;
+}
+
+int ensure_cloud_pin(tdlo_ctx *c, size_t doubles) {
+    if (doubles <= c->cloud_pin_doubles) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->cloud_pin) hipHostFree(c->cloud_pin);
+    c->cloud_pin = nullptr; c->cloud_pin_doubles = 0;
+    const size_t cap = (doubles + 4095) & ~(size_t)4095;
+    HIPCHK(c, hipHostMalloc((void **)&c->cloud_pin, cap * sizeof(double), hipHostMallocDefault));
+    c->cloud_pin_doubles = cap;
+    return 0;
+}
+
+// a cloud staged in pinned memory that no prologue has taken to the device goes there by a copy
+int flush_pending_cloud(tdlo_ctx *c) {
+    if (c->cloud_pending < 0) return 0;
+    Slot &s = c->slots[c->cloud_pending];
+    c->cloud_pending = -1;
+    HIPCHK(c, hipMemcpyAsync(s.Xraw, c->cloud_pin, 3 * (size_t)s.N0 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
 int ensure_pin2(tdlo_ctx *c, size_t doubles) {
     if (doubles <= c->pin2_doubles) return 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -461,7 +508,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         const int prc = stage_priors(c, stage + nc.aJ, stage + nc.aYd, Y, M, priors, K, p->alpha);
         if (prc) return prc;
     }
-    bool lle_band = false, h_banded = false;
+    bool lle_band = false, h_banded = false, hb_resident = false;
     if (p->include_lle) {
         double *H = stage + nc.H;
         // The banded L D L^T in the chain's state (tdlo_mstep_band.hip) serves the registration when (i) H is banded like the
@@ -492,6 +539,9 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
             if (H_override) {
                 for (int i = 0; i < M; ++i)
                     for (int u = 0; u < 13; ++u) { const int j = i - 6 + u; Hb[(size_t)13 * i + u] = (j >= 0 && j < M) ? H_override[(size_t)j * M + i] : 0.0; }
+            } else if (c->lle_next_on && !second_block && s.hb_next_valid && s.hb_next_Y.size() == 3 * (size_t)M &&
+                       std::memcmp(s.hb_next_Y.data(), Y, sizeof(double) * 3 * M) == 0) {
+                hb_resident = true;                          // formed on the device at the end of the previous tracking_step (FrameDev::lle_next): the same values
             } else {
                 lle_regulariser_band(Y, M, Hb);              // trackdlo.cpp:236-237, O(M)
             }
@@ -592,6 +642,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
     f.sync = s.sync;
     f.st = (IterState *)(blk + nc.st);
+    if (hb_resident) f.Hb = s.hb_next;
     return 0;
 }
 
@@ -664,7 +715,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (late && c->pair.spec) { sg.epoch = c->pair.spec_epoch; sg.live = true; c->pair.spec = 0; }
     if (!paired) sg.release(false);
     c->fh.assign(F, FrameDev{});
-    if (paired) { c->fh[0] = c->pair.f; c->fh[0].reuse_sorted = 1; up = c->pair.up; }
+    if (paired) { c->fh[0] = c->pair.f; c->fh[0].reuse_sorted = 1; up = c->pair.up; ++c->route_count[0]; if (c->pair.has_sums) ++c->route_count[1]; }
     for (int pass = 0; pass < 2 && !paired; ++pass) {
     for (int i = 0; i < F; ++i) {
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
@@ -691,6 +742,13 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (pass == 0) { c->lle_batch_dense = true; band_batch = false; up = upload_doubles(nc, p, false); ustride = up; }
     }
     c->lle_batch_dense = false;
+    if (!merged && !paired && p->include_lle && c->fh[0].lle_band && c->slots[slots[0]].hb_next != nullptr && c->fh[0].Hb == c->slots[slots[0]].hb_next)
+        { up = nc.Hb; ++c->route_count[3]; }      // H's 13 diagonals are on the device already (Slot::hb_next): they do not travel
+    // tracking_step's main registration: the M-step that finishes it leaves the next frame's LLE regulariser behind (FrameDev::lle_next; the
+    // buffer was sized by tracking_step before anything was launched)
+    const bool lle_next = late != nullptr && !merged && c->lle_next_on && !p->include_lle && !c->fh[0].mstep_dense && M <= 256 && p->max_iter > 0 &&
+                          c->slots[slots[0]].hb_next_cap >= M;
+    if (lle_next) { c->fh[0].lle_next = c->slots[slots[0]].hb_next; c->slots[slots[0]].hb_next_valid = false; }
     // Late priors ride beside the set-up kernel only where the E-step can hand them to the M-step (the one-frame kernel, which takes the frame
     // descriptor by value): otherwise they are formed here, before anything is launched, and staged like ordinary ones.
     bool late_async = late != nullptr && c->fh[0].wide_tile != 0 && (c->late_on || paired);
@@ -733,6 +791,12 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         fdp = (const FrameDev *)((paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk) + nc.fdev);
     }
     double *const nodeblk_used = merged ? nullptr : (paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk);
+    if (c->cloud_pending >= 0) {
+        // tracking_step staged this frame's cloud in pinned host memory: the fused prologue reads it from there; any other route gets a copy first
+        const bool fused = !merged && !paired && c->direct_in && c->cloud_pending == slots[0] && !c->fh[0].reuse_sorted && prologue_pair_ok(c->fh[0]);
+        if (fused) { c->fh[0].Xhost = c->cloud_pin; c->cloud_pending = -1; }
+        else if ((rc = flush_pending_cloud(c))) return rc;
+    }
     if (paired) {
         // (set up by the previous call's prologue)
     } else if (!merged && c->direct_in && prologue_direct_ok(c->fh[0])) {
@@ -762,6 +826,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             }
         }
         HIPCHK(c, launch_prologue_direct(c->fh.data(), c->pin, sl.nodeblk, (int)up, (int)nc.Yin, sl.fuse_epoch, s, f2, c->pin2, sl.nodeblk2, f2 ? (int)pn.up : 0));
+        c->fh[0].Xhost = nullptr;          // (the cloud is in Xraw for everything that follows)
         if (f2) pn.state = 2;
     } else {
         if (!merged) HIPCHK(c, hipMemcpyAsync(c->slots[slots[0]].nodeblk, c->pin, up * sizeof(double), hipMemcpyHostToDevice, s));
@@ -809,7 +874,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         for (int it = 0; it < n; ++it) {
             if (sums_first) {
                 sums_first = false;
-                if (sg.live) sg.release(true);             // it is on the stream already: the priors are staged, off it goes
+                if (sg.live) { sg.release(true); ++c->route_count[2]; }      // it is on the stream already: the priors are staged, off it goes
                 else TDLO_RET(launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s));
                 continue;
             }
@@ -904,6 +969,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             fs.host_out = c->mbox; fs.host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); fs.host_epoch = e2;
             fs.host_report_it = (pn.p.tol <= 0.0 || pn.p.max_iter <= 2 * kChunkIters) ? 0 : 1;
             fs.spec_flag = spec_flag_word(c); fs.spec_prev = c->fh[0].st; fs.spec_epoch = e2;
+            if (c->lle_next_on && pn.M <= 256 && sl.hb_next_cap >= pn.M) fs.lle_next = sl.hb_next;      // (as the registration itself will set it, above)
             HIPCHK(c, launch_mstep_chain((const FrameDev *)(sl.nodeblk2 + nc2.fdev), &fs, 1, 1, fs.precision == TDLO_PREC_F64, s));
             pn.spec = 1; pn.spec_epoch = e2;
         }
@@ -1021,6 +1087,11 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             if (p->max_iter > 0 && is.it > 0) std::memcpy(Y + (size_t)i * 3 * M, rb, sizeof(double) * 3 * M);
             sigma2[i] = is.sigma2;
         }
+        if (lle_next && i == 0 && is.status == 0 && is.done != 0 && is.it > 0) {      // (the finishing M-step has formed H of exactly these nodes)
+            Slot &sl = c->slots[slots[0]];
+            sl.hb_next_Y.assign(Y, Y + 3 * (size_t)M);
+            sl.hb_next_valid = true;
+        }
         if (p->max_iter == 0) { is.converged = 1; }
         if (stats) {
             fill_stats(&stats[i], is);
@@ -1030,6 +1101,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (is.status != 0 && worst == 0) worst = is.status;
     }
     g_prof.mark(g_prof.base + 6);
+    c->fh[0].lle_next = nullptr; c->fh[0].spec_flag = nullptr;      // (the measurement entry points relaunch from these descriptors)
     if (worst != 0 && !late) c->pair.spec = 0;
     if (worst == TDLO_E_EMPTY) return fail(c, worst, "every point was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
     if (worst == TDLO_E_NUMERIC) return fail(c, worst, "non-finite or non-positive sigma2, or singular M-step system");
@@ -1099,6 +1171,7 @@ void tdlo_destroy(tdlo_ctx *c) {
         if (s.hist) hipFree(s.hist);
         if (s.nodeblk) hipFree(s.nodeblk);
         if (s.nodeblk2) hipFree(s.nodeblk2);
+        if (s.hb_next) hipFree(s.hb_next);
         if (s.sync) hipFree(s.sync);
     }
     delete c->pool; c->pool = nullptr;
@@ -1107,6 +1180,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
     if (c->pin2) hipHostFree(c->pin2);
+    if (c->cloud_pin) hipHostFree(c->cloud_pin);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->late_buf) hipHostFree(c->late_buf);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
@@ -1960,6 +2034,23 @@ int tdlo_debug_read_cloud(tdlo_ctx *c, int slot, double *out, int max_points, do
 int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
+
+long long tdlo_debug_route_count(tdlo_ctx *c, int which) { return (c && which >= 0 && which < 4) ? c->route_count[which] : -1; }
+
+int tdlo_debug_lle_band_device(tdlo_ctx *c, const double *Y, int M, double *Hb) {
+    if (!c) return TDLO_E_INVALID;
+    if (!Y || !Hb || M < 1 || M > 256) return fail(c, TDLO_E_INVALID, "tdlo_debug_lle_band_device: 1 .. 256 nodes");
+    HIPCHK(c, hipSetDevice(c->device));
+    double *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, sizeof(double) * 16 * (size_t)M));
+    hipError_t e = hipMemcpyAsync(d, Y, sizeof(double) * 3 * M, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_lle_band_debug(d, M, d + 3 * M, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(Hb, d + 3 * M, sizeof(double) * 13 * M, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return TDLO_OK;
+}
 int tdlo_debug_fail_hip(tdlo_ctx *c) {
     if (!c) return TDLO_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2161,7 +2252,16 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     t->priors.clear();                                                   // :908
     int rc = TDLO_OK;
     g_prof.start(); g_prof.base = 0;
-    if (X) rc = set_cloud_impl(c, t->slot, X, N, false);                 // X_orig by value: one upload for both registrations (X stays the caller's
+    if (X && N > 0 && c->cloud_direct_on && c->direct_in && N <= 16384) {
+        // a cloud the fused prologue can take (up to 64 point workgroups): staged in pinned host memory, read from there by the prologue itself
+        HIPCHK(c, hipSetDevice(c->device));
+        Slot &s = c->slots[t->slot];
+        if ((rc = flush_pending_cloud(c)) || (rc = ensure_points(c, s, N)) || (rc = ensure_cloud_pin(c, 3 * (size_t)N))) return rc;
+        std::memcpy(c->cloud_pin, X, 3 * (size_t)N * sizeof(double));
+        s.N0 = N; s.sorted_valid = false;
+        c->cloud_pending = t->slot;
+    }
+    else if (X) rc = set_cloud_impl(c, t->slot, X, N, false);            // X_orig by value: one upload for both registrations (X stays the caller's
                                                                          // until this function returns; the first registration's read-back waits for the copy)
     else if (c->slots[t->slot].N0 <= 0) rc = fail(c, TDLO_E_INVALID, "X is NULL and no cloud is resident in the tracker's slot");
     if (rc) return rc;
@@ -2188,6 +2288,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     mp.precision = t->precision;
     // every node visible: both registrations start from t->Y, and the main one's node-side set-up depends on nothing the pre-processing one
     // produces -- the pre-processing registration's prologue is asked to do it as well (tdlo_ctx::PairNext; run_frames takes it up if it can)
+    if (c->lle_next_on && M <= 256 && (rc = ensure_hb_next(c, c->slots[t->slot], M))) return rc;
     c->pair.state = 0;
     if (Mg == M && c->pair_on && c->sort_reuse && c->late_on && c->direct_in && check_params(c, M, &mp) == 0) {
         tdlo_ctx::PairNext &pn = c->pair;
@@ -2197,7 +2298,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     g_prof.mark(1);
     rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
     if (stats) stats[0] = st_pre;
-    if (rc) { c->pair.state = 0; spec_abort(c); (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
+    if (rc) { c->pair.state = 0; spec_abort(c); (void)flush_pending_cloud(c); (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
 
     std::vector<int> ve(vis_ext, vis_ext + n_ext);
     std::vector<double> p1, p2;
@@ -2258,6 +2359,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     HIPCHK(c, hipSetDevice(c->device));
     rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
     c->pair.state = 0; spec_abort(c);
+    if (c->cloud_pending >= 0) { const int frc = flush_pending_cloud(c); if (!rc) rc = frc; }
     if (stats) stats[1] = st_main;
     return rc;
 }

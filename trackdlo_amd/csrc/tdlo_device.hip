@@ -512,7 +512,11 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
     const int n = b * kBlock + t;
     const bool valid = n < N0;
     double x = 0, y = 0, z = 0;
-    if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
+    {   // (a cloud that is still in pinned host memory -- tracking_step, FrameDev::Xhost -- goes to its place in device memory from here)
+        const auto src = TDLO_AS_GLOBAL(double, f.Xhost != nullptr ? f.Xhost : f.Xraw);
+        if (valid) { x = src[n]; y = src[(size_t)N0 + n]; z = src[2 * (size_t)N0 + n]; }
+        if (f.Xhost != nullptr && valid) { double *xw = (double *)f.Xraw; xw[n] = x; xw[(size_t)N0 + n] = y; xw[2 * (size_t)N0 + n] = z; }
+    }
     __syncthreads();
     PSTAMP(1);
     // ---- prune + nearest node (k_prune_pass1)

@@ -52,6 +52,8 @@ struct FrameDev {
     int precision, nprune_blocks, eb, wide_tile;    // eb: E-step workgroup size (256 or 512); wide_tile: 64-row transposition tile (one frame of moderate size)
     double tol, beta, lambda, lle_weight, mu, alpha, k_vis, vis_thr, sigma2_in;
     // cloud
+    const double *Xhost;    // k_prologue only: the cloud still in PINNED HOST memory (N0 x 3 column-major) -- its point workgroups read it from there
+                            // and put it in Xraw themselves: no host-to-device copy in front of the frame's first kernel.  nullptr: Xraw holds it
     const double *Xraw;     // N0 x 3 column-major as uploaded
     void *Xs;               // pruned, centred SoA in compute precision: x[ldx] y[ldx] z[ldx]
     unsigned short *bucket; // N0: nearest node of a kept point, 0xffff = pruned
@@ -126,6 +128,10 @@ struct FrameDev {
     const unsigned long long *spec_flag;
     const IterState *spec_prev;
     unsigned spec_epoch;
+    // The M-step that finishes this registration (k_mstep_chain, chains of up to 256 nodes) then forms the 13 diagonals of the LLE regulariser
+    // H = (I - L)^T (I - L) (trackdlo.cpp:236-237) of the nodes it leaves behind, here -- the host's values bit for bit (tdlo_lle_dev.h): the
+    // next frame's pre-processing registration starts from exactly these nodes when every node is visible.  nullptr: off.
+    double *lle_next;
     double *host_out;
     unsigned long long *host_prog;
     unsigned host_epoch;
@@ -215,6 +221,7 @@ hipError_t launch_mstep_pivot_mcu(const FrameDev *frames_dev, const FrameDev *fr
 bool mstep_pivot_mcu_enabled();
 // tdlo_mstep_chain.hip: M-step without the LLE term as a Kalman / Rauch-Tung-Striebel smoother along the chain, any M
 hipError_t launch_mstep_chain(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
+hipError_t launch_lle_band_debug(const double *Y_dev, int M, double *Hb_dev, hipStream_t s);      // test aid: the device form of lle_regulariser_band (tdlo_lle_dev.h), M <= 256
 bool mstep_chain_enabled();
 int mstep_set_dense(int on);      // returns the previous setting
 // tdlo_mstep_band.hip: M-step with the LLE term as a banded L D L^T in the chain's state (f, f'), any M

@@ -55,6 +55,7 @@
 // system is not of this form, and TDLO_MSTEP=dense selects them as comparators for the tests.
 #include <type_traits>
 #include "tdlo_devcommon.h"
+#include "tdlo_lle_dev.h"
 #include <atomic>
 #include <cstdlib>
 #include <hip/hip_ext.h>
@@ -145,7 +146,10 @@ struct ChainCarve {
     }
 };
 
-template <typename T, bool SINGLE, bool XCH>
+// TRK: the extras of tracking_step's main registration (one frame, no exchange) -- late priors read from pinned host memory when no E-step has
+// run yet, the launch ahead of its priors (FrameDev::spec_flag), the next frame's LLE regulariser at the end (FrameDev::lle_next).  The plain
+// instantiation is the kernel of the registrations proper, unchanged.
+template <typename T, bool SINGLE, bool XCH, bool TRK = false>
 __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
     constexpr int MB = kCB;
     const FrameDev &f = SINGLE ? f0 : frames[blockIdx.x];
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     const auto Yg = TDLO_AS_GLOBAL(double, f.Y);
     const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
     // (late priors of a registration that starts from given sums: no E-step has copied them yet -- read from pinned host memory here, kept below)
-    const bool late_src = SINGLE && !XCH && from_sums == 1 && f.late_aJ != nullptr;
+    const bool late_src = TRK && from_sums == 1 && f.late_aJ != nullptr;
     const auto aJg = TDLO_AS_GLOBAL(double, late_src ? f.late_aJ : f.aJ);
     const auto aYg = TDLO_AS_GLOBAL(double, late_src ? f.late_aYd : f.aYd);
     const auto chg = TDLO_AS_GLOBAL(dbl2, f.chain);
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
     // for the iteration counter (M <= 512: at most 9 elements per thread).  Requested before the slot: its index arithmetic
     // runs while these are in flight.
-    if (SINGLE && !XCH && f.spec_flag != nullptr) {      // launched ahead of its priors (FrameDev::spec_flag)
+    if (TRK && f.spec_flag != nullptr) {      // launched ahead of its priors (FrameDev::spec_flag)
         const auto pv = TDLO_AS_GLOBAL(IterState, f.spec_prev);
         if (!(pv->done != 0 && pv->status == 0)) return;
         if (t == 0) {
@@ -814,6 +818,13 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 #endif
     }
     if (!XCH && t < 64 && __builtin_amdgcn_readfirstlane(pub)) host_publish(f, st, lane, true);      // progress (and, from the M-step that finishes the registration, the results) into pinned host memory
+    if (TRK && f.lle_next != nullptr) {
+        // the M-step that finishes the registration without an error goes on (the host has its results already) to form the LLE regulariser
+        // of the nodes it leaves behind: the next frame's pre-processing registration starts from them (tdlo_lle_dev.h)
+        if (t == 0) red[30] = (st->done != 0 && st->status == 0) ? 1.0 : 0.0;
+        __syncthreads();
+        if (red[30] != 0.0 && M <= 256) lle_band_device<MB>(f.Yout, M, f.lle_next, slots, t);
+    }
 #undef CSTAMP
 }
 
@@ -1019,6 +1030,10 @@ template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd,
         if (F != 1) return hipErrorInvalidValue;
         if ((e = set_lds_c(k_mstep_chain<T, true, true>, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_mstep_chain<T, true, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
+    } else if (F == 1 && (fh[0].spec_flag != nullptr || fh[0].lle_next != nullptr || (from_sums == 1 && fh[0].late_aJ != nullptr))) {
+        if ((e = set_lds_c(k_mstep_chain<T, true, false, true>, lds)) != hipSuccess) return e;
+        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false, true>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
+        else hipLaunchKernelGGL((k_mstep_chain<T, true, false, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
     } else if (F == 1) {
         if ((e = set_lds_c(k_mstep_chain<T, true, false>, lds)) != hipSuccess) return e;
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
@@ -1028,6 +1043,17 @@ template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd,
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, false, false>), dim3(F), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
         else hipLaunchKernelGGL((k_mstep_chain<T, false, false>), dim3(F), dim3(kCB), lds, s, fd, fh[0], from_sums);
     }
+    return hipGetLastError();
+}
+
+// test aid (tdlo_debug_lle_band_device): lle_band_device on its own
+__global__ __launch_bounds__(kCB) void k_lle_band_debug(const double *__restrict__ Y, int M, double *__restrict__ Hb) {
+    __shared__ double Ab[7 * 256];
+    lle_band_device<kCB>(Y, M, Hb, Ab, threadIdx.x);
+}
+hipError_t launch_lle_band_debug(const double *Y, int M, double *Hb, hipStream_t s) {
+    if (M < 1 || M > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lle_band_debug, dim3(1), dim3(kCB), 0, s, Y, M, Hb);
     return hipGetLastError();
 }
 
