@@ -21,12 +21,17 @@ if len(est) < 40:
     print("too few E-steps in the trace"); sys.exit(0)
 # two registrations per frame -> two E-steps per frame (steady state: one iteration each).  Frame k = activity between E-step 2k-? ... use cloud copies
 big = [i for i in starts if ev[i][1] - ev[i][0] > 3000]           # the 120 KB cloud copy takes several us
+first = "cloud copy"
+if len(big) < 10:
+    # no cloud copies (the fused prologue reads the cloud from pinned host memory itself): a frame starts with its prologue
+    big = [i for i, e in enumerate(ev) if "k_prologue" in e[2]]
+    first = "prologue"
 if len(big) < 10:
     big = starts
 k = len(big) // 2
 lo, hi = big[k], big[k + 1]
 t0 = ev[lo][0]
-print(f"frame {k} of {len(big)}: {hi - lo} activities, span {(ev[hi][0] - t0) / 1e3:.1f} us (start of this frame's cloud copy to start of the next one's)")
+print(f"frame {k} of {len(big)}: {hi - lo} activities, span {(ev[hi][0] - t0) / 1e3:.1f} us (start of this frame's {first} to start of the next one's)")
 prev_end = None
 busy = 0
 for e in ev[lo:hi]:

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     // given sums (from_sums == 1: the N-split's reduced sums; tracking_step's paired registration): the first five elements per thread -- chains
     // of up to 256 nodes -- requested with everything else
     double ss[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (from_sums == 1) {
+    if (TRK && from_sums == 1) {
         const auto sums = TDLO_AS_GLOBAL(double, f.sums);
 #pragma unroll
         for (int u = 0; u < 5; ++u) { const int i = t + u * MB; ss[u] = sums[i < nS ? i : nS - 1]; }
@@ -320,9 +320,13 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         for (int u = 0; u < 9; ++u) { const int i = t + u * MB; if (i < nS) S[i] = sq[u]; }
     } else {
         const auto sums = TDLO_AS_GLOBAL(double, f.sums);
+        if (TRK) {
 #pragma unroll
-        for (int u = 0; u < 5; ++u) { const int i = t + u * MB; if (i < nS) S[i] = ss[u]; }
-        for (int i = t + 5 * MB; i < nS; i += MB) S[i] = sums[i];
+            for (int u = 0; u < 5; ++u) { const int i = t + u * MB; if (i < nS) S[i] = ss[u]; }
+            for (int i = t + 5 * MB; i < nS; i += MB) S[i] = sums[i];
+        } else {
+            for (int i = t; i < nS; i += MB) S[i] = sums[i];
+        }
         if (late_src && pri) {      // ... and to their place in device memory for the iterations that follow
             double *aJw = (double *)f.aJ, *aYw = (double *)f.aYd;
 #pragma unroll
