@@ -578,9 +578,15 @@ def _preproc_leg(ctx, B, synth):
         out["tracking_step_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3 / 200, 4)
     finally:
         ctx.set_sort_reuse(prev)
-    out["tracking_step_sort_reused"] = reused       # [pre-processing registration, main registration] of a frame
-    out["tracking_step_note"] = ("host buffers in, results out, production tolerance (tol = 2e-4: a steady-state frame converges in a few iterations); sorted-cloud "
-                                 "reuse ON (library default): the main registration reuses the pre-processing registration's sort when every node is visible")
+    out["tracking_step_sort_reused"] = reused       # [pre-processing registration, main registration] of a frame (2: reused, and set up by the first prologue)
+    if hasattr(ctx, "route_counts"):
+        out["tracking_step_routes"] = ctx.route_counts()   # [paired set-ups, first iterations from the handed-over sums, M-steps released from their wait, device-formed LLE regularisers] over the 205 frames
+    out["tracking_step_note"] = ("host buffers in, results out, production tolerance (tol = 2e-4: a steady-state frame converges in its first iteration); sorted-cloud "
+                                 "reuse ON (library default).  Every node visible: the main registration reuses the pre-processing registration's sort, its "
+                                 "set-up rides in that registration's prologue, its first iteration starts from that registration's first E-step sums (the same "
+                                 "computation), its first M-step is launched ahead of its priors, the cloud is read from pinned host memory by the prologue and "
+                                 "the next frame's LLE regulariser is formed on the device: 4 kernels and no copy per frame (include/trackdlo_hip.h, "
+                                 "tdlo_tracker_tracking_step); every short cut is bit-identical to the plain route (tests/test_direct_path_gpu.py)")
     return out
 
 

@@ -72,6 +72,12 @@ sec() { echo "== $1"; shift; "$@" 2>&1 | grep -v amdgpu.ids; local rc=${PIPESTAT
   sec "track C++ caller: mailbox only (TDLO_DIRECT_UPLOAD=0)" env TDLO_DIRECT_UPLOAD=0 scripts/ubench/track_cpp
   sec "track C++ caller: fused prologue only (TDLO_HOST_MAILBOX=0)" env TDLO_HOST_MAILBOX=0 scripts/ubench/track_cpp
   sec "track C++ caller: without the sorted-cloud reuse (TDLO_REUSE_SORT=0)" env TDLO_REUSE_SORT=0 scripts/ubench/track_cpp
+  sec "track C++ caller: cloud copied in front of the prologue (TDLO_DIRECT_CLOUD=0)" env TDLO_DIRECT_CLOUD=0 scripts/ubench/track_cpp
+  sec "track C++ caller: LLE regulariser on the host (TDLO_LLE_NEXT=0)" env TDLO_LLE_NEXT=0 scripts/ubench/track_cpp
+  sec "track C++ caller: main registration's M-step launched with its priors (TDLO_SPEC_MSTEP=0)" env TDLO_SPEC_MSTEP=0 scripts/ubench/track_cpp
+  sec "track C++ caller: main registration runs its own first E-step (TDLO_PAIR_SUMS=0)" env TDLO_PAIR_SUMS=0 scripts/ubench/track_cpp
+  sec "track C++ caller: main registration launches its own set-up (TDLO_PAIR_SETUP=0)" env TDLO_PAIR_SETUP=0 scripts/ubench/track_cpp
+  sec "track C++ caller: round 4's first form (TDLO_PAIR_SETUP=0 TDLO_LLE_NEXT=0 TDLO_DIRECT_CLOUD=0)" env TDLO_PAIR_SETUP=0 TDLO_LLE_NEXT=0 TDLO_DIRECT_CLOUD=0 scripts/ubench/track_cpp
   sec "c5_5it" env ITERS=5 timeout 200 python scripts/gpu_c5.py
   sec "pcie" timeout 200 python scripts/gpu_pcie.py
 } > $O/measured.log 2>&1
