@@ -695,6 +695,14 @@ def bench_frames(args, cfg, env):
             out["em_iters_per_s_f64"] = round(n64 * EM_ITERS / (time.perf_counter() - t1), 2)
             e64, m64, i64, _ = ctx.profile_iteration(100)
             out["f64_kernels_us"] = dict(estep=round(e64, 3), mstep=None if m64 is None else round(m64, 3), iteration=round(i64, 3))
+        if args.config == "c2" and F == 1 and not cfg.get("leg") and n_ranks == 1 and not args.no_legs and args.pmc != "child":
+            # (before the CPU baseline: its worker threads keep spinning for a while after their last job, and tracking_step is a microsecond ping-pong
+            #  between this thread and the GPU)
+            out["sustained"] = _sustained(ctx, step)
+            try:
+                out["preproc"] = _preproc_leg(ctx, B, synth)
+            except Exception as e:
+                out["preproc"] = dict(error=f"{type(e).__name__}: {e}")
         cpu = None
         if n_ranks == 1 and not args.no_cpu_baseline:
             X0, Y00, _ = synth.scene(N, M, config=cfg_id, frame=0)
@@ -704,12 +712,6 @@ def bench_frames(args, cfg, env):
             cpu = _cpu_baseline(cfg, X0, Y00, kw, g)
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         out["cpu_baseline"] = cpu
-        if args.config == "c2" and F == 1 and not cfg.get("leg") and n_ranks == 1 and not args.no_legs and args.pmc != "child":
-            out["sustained"] = _sustained(ctx, step)
-            try:
-                out["preproc"] = _preproc_leg(ctx, B, synth)
-            except Exception as e:
-                out["preproc"] = dict(error=f"{type(e).__name__}: {e}")
     ctx.close()
     return out if rank == 0 else None
 

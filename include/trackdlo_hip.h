@@ -276,7 +276,27 @@ int tdlo_tracker_get_correspondence_pairs(const tdlo_tracker *t, double *out, in
  * signature are unused by its body and therefore not part of the ABI.  H_pre: optional override of
  * the pre-processing registration's LLE matrix (n_vis_ext x n_vis_ext).  stats may be NULL;
  * otherwise stats[0] = pre-processing registration (:927), stats[1] = main registration (:998). */
-/* X == NULL: use the cloud already resident in the tracker's slot (tdlo_set_cloud / tdlo_depth_to_cloud); N ignored. */
+/* X == NULL: use the cloud already resident in the tracker's slot (tdlo_set_cloud / tdlo_depth_to_cloud); N ignored.
+ *
+ * How a frame is run (nothing of this changes a bit of any result; each item has an environment switch, read when the context is made, that
+ * turns it off -- the comparators of tests/test_direct_path_gpu.py; tdlo_debug_route_count counts how often each was taken):
+ *  - X (up to 16 384 points) is copied into the context's pinned staging buffer and read from THERE by the first kernel of the frame, which
+ *    also puts it in the slot's device buffer: no host-to-device copy on the stream (TDLO_DIRECT_CLOUD=0: hipMemcpyAsync as tdlo_set_cloud).
+ *    X is the caller's again when the function returns, as before.
+ *  - With every node visible (n_vis_ext == num_of_nodes) both registrations start from the same nodes Y_ on the same cloud
+ *    (:913-927 and :998).  The main registration then (a) reuses the pre-processing registration's pruned, sorted cloud (tdlo_set_sort_reuse),
+ *    (b) has its node-side set-up done by one more workgroup of the pre-processing registration's prologue (TDLO_PAIR_SETUP=0: a kernel of
+ *    its own), (c) starts from the sums of the pre-processing registration's first E-step instead of repeating it -- same cloud, nodes,
+ *    sigma2, mu, no visibility term, and the sums are integers: the same bits (TDLO_PAIR_SUMS=0) -- and (d) has its first M-step
+ *    launched right behind the pre-processing registration's first iteration; it waits on the device for the priors that the host
+ *    forms from that registration's result (:929-995) and leaves untouched if that registration needs more iterations or ends on an
+ *    error (TDLO_SPEC_MSTEP=0: launched when the priors exist).  stats[1].sort_reused is 2 on such a frame.
+ *  - The M-step that finishes the main registration also forms H = (I - L)^T (I - L) (:236-237) of the nodes it leaves behind, on the
+ *    device, bit for bit what tdlo_calc_lle_regulariser gives (tdlo_debug_lle_band_device); the next frame's pre-processing registration
+ *    uses it if it starts from exactly those nodes (every node visible, no H_pre) instead of waiting for the host's 6 x 6 factorisations
+ *    (TDLO_LLE_NEXT=0).
+ * A steady-state frame at production size (5 000 points, 45 nodes, both registrations converging in their first iteration) is then FOUR
+ * kernels and no copy.  The calls of a context must come from one thread at a time (as for every entry point). */
 int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N,
                                const int *visible_nodes, int n_vis,
                                const int *visible_nodes_extended, int n_vis_ext,
