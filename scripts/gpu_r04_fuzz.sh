@@ -6,6 +6,7 @@ O=gpurun_out/$tag; mkdir -p $O
 {
   echo "== tracker fuzz, TDLO_SWEEP_SCALE=$scale ($((50 * scale)) sequences per precision)"
   TDLO_SWEEP_SCALE=$scale timeout 1500 python -m pytest tests/test_fuzz_gpu.py -m gpu -q 2>&1 | grep -E "passed|failed|MISMATCH|Error" | head -20
+  echo "== tracking_step's short cuts on against off, bit for bit"; timeout 900 python scripts/gpu_fuzz_routes.py $((25 * scale)) 2>&1 | tail -8
   echo "== chain smoother sweep (fp64 mode)"; timeout 900 python scripts/gpu_fuzz_chain.py 400 2>&1 | tail -8
   echo "== banded LLE M-step sweep"; timeout 900 python scripts/gpu_fuzz_band.py 1500 2>&1 | tail -8
   echo "== batches against single calls, bit for bit"; timeout 900 python scripts/gpu_fuzz_batch.py 200 2>&1 | tail -5

@@ -28,3 +28,13 @@ def test_tracker_fuzz_block_of_25_sequences(block, prec):
     r = _harness("gpu_fuzz_tracker").run(25, 25 * block, prec, verbose=False)
     assert r["bad"] == 0, r
     assert r["frames"] >= 40, r            # (the sequences really ran: most of the 150 frames are compared)
+
+
+@pytest.mark.parametrize("block", range(_SWEEP))
+def test_route_fuzz_block_of_25_sequences(block):
+    """tracking_step's short cuts of round 4 (cloud read from pinned host memory, paired set-up, handed-over sums, M-step launched ahead of its
+    priors, device-formed LLE regulariser) all on against all off, over random sequences with the library's own H: every result the same bits,
+    every error the same error (scripts/gpu_fuzz_routes.py)."""
+    r = _harness("gpu_fuzz_routes").run(25, 25 * block, verbose=False)
+    assert r["bad"] == 0, r
+    assert r["frames"] >= 100 and min(r["routes"]) > 0, r
