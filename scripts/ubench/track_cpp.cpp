@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../include/trackdlo_hip.h"
 static unsigned long long rs = 88172645463325252ull;
@@ -24,6 +25,25 @@ int main() {
     tdlo_stats st[2];
     for (int r = 0; r < 20; ++r) if (tdlo_tracker_tracking_step(t, X.data(), N, vis.data(), M, vis.data(), M, nullptr, st)) { std::printf("FAIL %s\n", tdlo_last_error(ctx)); return 1; }
     const int R = 2000;
+    if (getenv("MOVE") && atoi(getenv("MOVE")) > 0) {
+        // a rope that keeps moving: 16 clouds (own noise each) along a sway of MOVE tenths of a millimetre per frame in y -- the registrations take
+        // more than one iteration, and every frame's cloud comes from a different buffer
+        const double amp = 1e-4 * atoi(getenv("MOVE"));
+        const int K = 16;
+        std::vector<std::vector<double>> Xs(K, std::vector<double>(3 * (size_t)N));
+        for (int k = 0; k < K; ++k) {
+            const double off = amp * (k < K / 2 ? k : K - k);
+            for (int n = 0; n < N; ++n) { const int i = (int)(ur() * (M - 1)); const double tt = ur(); for (int d = 0; d < 3; ++d) Xs[k][(size_t)d * N + n] = (double)(float)((1 - tt) * Y0[d * M + i] + tt * Y0[d * M + i + 1] + 0.002 * nr() + (d == 1 ? 0.005 + off : 0.0)); }
+        }
+        for (int r = 0; r < 64; ++r) tdlo_tracker_tracking_step(t, Xs[r % K].data(), N, vis.data(), M, vis.data(), M, nullptr, st);
+        long it0 = 0, it1 = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < R; ++r) { tdlo_tracker_tracking_step(t, Xs[r % K].data(), N, vis.data(), M, vis.data(), M, nullptr, st); it0 += st[0].iters; it1 += st[1].iters; }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / R;
+        std::printf("C++ caller: tracking_step N=%d M=%d, rope moving %.1f mm per frame: %.4f ms/frame (iterations per frame: pre %.2f, main %.2f)\n", N, M, amp * 1e3, ms, it0 / (double)R, it1 / (double)R);
+        tdlo_tracker_destroy(t); tdlo_destroy(ctx);
+        return 0;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < R; ++r) tdlo_tracker_tracking_step(t, X.data(), N, vis.data(), M, vis.data(), M, nullptr, st);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / R;
