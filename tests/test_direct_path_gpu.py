@@ -147,7 +147,7 @@ def test_tracking_sequences_are_the_same_on_both_routes(prec):
 
 def _pair_ctx(B, on, off=("TDLO_PAIR_SETUP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD"), **kw):
     """on: every short cut of tracking_step; else the switches in `off` set to 0 (read when the context is made)."""
-    keys = ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD")
+    keys = ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_ITER_HINT")
     old = {k: os.environ.get(k) for k in keys}
     try:
         for k in keys:
@@ -250,14 +250,14 @@ def test_paired_setup_is_dropped_when_the_first_registration_is_repeated_or_fail
             np.testing.assert_array_equal(a[1], b[1]); assert a[2] == b[2]
 
 
-@pytest.mark.parametrize("off", [("TDLO_PAIR_SUMS",), ("TDLO_SPEC_MSTEP",), ("TDLO_LLE_NEXT",), ("TDLO_DIRECT_CLOUD",),
-                                 ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD")],
-                         ids=["own first E-step", "M-step launched with its priors", "host LLE", "cloud copied", "none of the short cuts"])
+@pytest.mark.parametrize("off", [("TDLO_PAIR_SUMS",), ("TDLO_SPEC_MSTEP",), ("TDLO_LLE_NEXT",), ("TDLO_DIRECT_CLOUD",), ("TDLO_ITER_HINT",),
+                                 ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_ITER_HINT")],
+                         ids=["own first E-step", "M-step launched with its priors", "host LLE", "cloud copied", "one iteration before the host looks", "none of the short cuts"])
 @pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
 def test_each_short_cut_of_tracking_step_changes_no_bit(prec, off):
     """The short cuts of a tracking_step whose nodes are all visible -- set-up paired into the first prologue, first E-step's sums handed over,
     first M-step launched ahead of its priors, the next frame's LLE regulariser formed on the device, the cloud read from pinned host memory by the
-    prologue -- switched off one at a time and all together:
+    prologue, as many iterations enqueued up front as the previous frame took -- switched off one at a time and all together:
     20 frames (the first ones take several iterations in both registrations, so the M-step launched ahead finds the pre-processing registration
     unfinished and leaves; occluded frames in between), same nodes, sigma2, iteration counts, priors and guide nodes, bit for bit; and the
     counters say that the routes were really taken."""

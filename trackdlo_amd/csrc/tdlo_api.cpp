@@ -203,6 +203,11 @@ struct tdlo_ctx {
     size_t cloud_pin_doubles = 0;
     int cloud_pending = -1;
     bool cloud_direct_on = !(getenv("TDLO_DIRECT_CLOUD") && atoi(getenv("TDLO_DIRECT_CLOUD")) == 0);
+    // early exit, one frame per call: how many iterations go out before the host first looks at the registration's state.  1 unless the caller
+    // knows better -- tracking_step passes what the same registration took in the previous frame (consecutive frames of a tracker take about
+    // the same number; capped: a wrong guess costs a no-op iteration, ~4 us, per iteration too many).  Consumed by the next run_frames.
+    int iter_hint = 0, iter_hint_next = 0;      // (_next: of the registration whose first M-step this one launches ahead, PairNext::spec)
+    bool iter_hint_on = !(getenv("TDLO_ITER_HINT") && atoi(getenv("TDLO_ITER_HINT")) == 0);
     bool lle_next_on = !(getenv("TDLO_LLE_NEXT") && atoi(getenv("TDLO_LLE_NEXT")) == 0);        // 0: the host forms every LLE regulariser (comparator)
     bool spec_on = !(getenv("TDLO_SPEC_MSTEP") && atoi(getenv("TDLO_SPEC_MSTEP")) == 0);        // 0: the paired registration's first M-step is launched when its priors exist (comparator)
     bool pair_sums_on = !(getenv("TDLO_PAIR_SUMS") && atoi(getenv("TDLO_PAIR_SUMS")) == 0);     // 0: the paired registration still runs its own first E-step (comparator)
@@ -674,6 +679,9 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     const auto t_host0 = std::chrono::steady_clock::now();
     int rc = check_params(c, M, p);
     if (rc) return rc;
+    const int iter_hint = c->iter_hint_on ? c->iter_hint : 0;
+    if (!c->iter_hint_on) c->iter_hint_next = 0;
+    c->iter_hint = 0;
     if (late && F != 1) return fail(c, TDLO_E_INVALID, "late priors: one frame per call");
     if (F < 1 || F > c->cfg.max_frames) return fail(c, TDLO_E_INVALID, "bad frame count");
     NodeCarve nc(M);
@@ -952,8 +960,9 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         // early exit (trackdlo.cpp:424-428), decided on the device and read from the mailbox: the first iteration is checked eagerly (a tracker
         // in steady state converges in it); after that iterations go out in chunks of 1, 1, 2, 4, 4, ... and the host looks at the progress
         // word of the chunk BEFORE the one it has just enqueued, so that the GPU never idles (kernels of a finished registration are no-ops)
-        c->fh[0].host_report_it = 1;           // (the frame descriptor travels by value with every launch of the one-frame kernels)
-        HIPCHK(c, iterate(1));
+        const int first = std::max(1, std::min(std::min(iter_hint, 4), p->max_iter));
+        c->fh[0].host_report_it = first;       // (the frame descriptor travels by value with every launch of the one-frame kernels)
+        HIPCHK(c, iterate(first));
         if (!late && c->pair.state == 2 && c->pair.has_sums && c->spec_on && c->mbox_on && !timing && c->pair.p.max_iter > 0) {
             // tracking_step's main registration starts with its M-step (PairNext::has_sums): launched NOW, behind this registration's first
             // iteration -- a steady-state tracker converges in it -- and ahead of the priors it needs (FrameDev::spec_flag)
@@ -967,7 +976,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             fs.reuse_sorted = 1; fs.has_priors = 1;
             fs.late_aJ = c->late_buf; fs.late_aYd = c->late_buf + pn.M;
             fs.host_out = c->mbox; fs.host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); fs.host_epoch = e2;
-            fs.host_report_it = (pn.p.tol <= 0.0 || pn.p.max_iter <= 2 * kChunkIters) ? 0 : 1;
+            fs.host_report_it = (pn.p.tol <= 0.0 || pn.p.max_iter <= 2 * kChunkIters) ? 0 : std::max(1, std::min(std::min(c->iter_hint_next, 4), pn.p.max_iter));
             fs.spec_flag = spec_flag_word(c); fs.spec_prev = c->fh[0].st; fs.spec_epoch = e2;
             if (c->lle_next_on && pn.M <= 256 && sl.hb_next_cap >= pn.M) fs.lle_next = sl.hb_next;      // (as the registration itself will set it, above)
             HIPCHK(c, launch_mstep_chain((const FrameDev *)(sl.nodeblk2 + nc2.fdev), &fs, 1, 1, fs.precision == TDLO_PREC_F64, s));
@@ -975,10 +984,10 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         }
         g_prof.mark(g_prof.base + 4);
         bool stop = false;
-        if ((rc = mbox_done(1, false, &stop))) { spec_abort(c); return rc; }
+        if ((rc = mbox_done(first, false, &stop))) { spec_abort(c); return rc; }
         if (!stop) c->pair.spec = 0;           // (this registration goes on: the waiting M-step has seen that and left)
         g_prof.mark(g_prof.base + 5);
-        int launched = 1, chunk = 0;
+        int launched = first, chunk = 0;
         while (launched < p->max_iter && !stop) {
             const int n = std::min(chunk < 2 ? 1 : (chunk == 2 ? 2 : kChunkIters), p->max_iter - launched);
             c->fh[0].host_report_it = launched + n;      // the chunk's last M-step reports (a store to host memory costs an M-step ~1 us: not every one)
@@ -2161,6 +2170,8 @@ struct tdlo_tracker {
     std::vector<double> geodesic_coord;
     std::vector<double> priors;         // K x 4 row-major
     double visibility_threshold;
+    int last_iters[2] = {0, 0};         // iterations the two registrations of the previous frame took: how many are enqueued before the host looks (tdlo_ctx::iter_hint;
+                                        // the larger of the last two frames' counts was tried instead: no difference)
 };
 
 extern "C" {
@@ -2296,9 +2307,11 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
         pn.state = 1;
     }
     g_prof.mark(1);
+    c->iter_hint = t->last_iters[0]; c->iter_hint_next = t->last_iters[1];
     rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
+    t->last_iters[0] = rc ? 0 : st_pre.iters;
     if (stats) stats[0] = st_pre;
-    if (rc) { c->pair.state = 0; spec_abort(c); (void)flush_pending_cloud(c); (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
+    if (rc) { c->pair.state = 0; c->iter_hint = 0; c->iter_hint_next = 0; spec_abort(c); (void)flush_pending_cloud(c); (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
 
     std::vector<int> ve(vis_ext, vis_ext + n_ext);
     std::vector<double> p1, p2;
@@ -2357,7 +2370,10 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     // prior indices may be fractional after the averaging at :954; the reference truncates (:247)
     g_prof.mark(13); g_prof.base = 6;
     HIPCHK(c, hipSetDevice(c->device));
+    c->iter_hint = t->last_iters[1];
     rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
+    t->last_iters[1] = rc ? 0 : st_main.iters;
+    c->iter_hint = 0; c->iter_hint_next = 0;
     c->pair.state = 0; spec_abort(c);
     if (c->cloud_pending >= 0) { const int frc = flush_pending_cloud(c); if (!rc) rc = frc; }
     if (stats) stats[1] = st_main;
