@@ -52,8 +52,6 @@ struct FrameDev {
     int precision, nprune_blocks, eb, wide_tile;    // eb: E-step workgroup size (256 or 512); wide_tile: 64-row transposition tile (one frame of moderate size)
     double tol, beta, lambda, lle_weight, mu, alpha, k_vis, vis_thr, sigma2_in;
     // cloud
-    const double *Xhost;    // k_prologue only: the cloud still in PINNED HOST memory (N0 x 3 column-major) -- its point workgroups read it from there
-                            // and put it in Xraw themselves: no host-to-device copy in front of the frame's first kernel.  nullptr: Xraw holds it
     const double *Xraw;     // N0 x 3 column-major as uploaded
     void *Xs;               // pruned, centred SoA in compute precision: x[ldx] y[ldx] z[ldx]
     unsigned short *bucket; // N0: nearest node of a kept point, 0xffff = pruned
@@ -115,6 +113,17 @@ struct FrameDev {
     // (a registration whose first iteration starts from given sums -- from_sums == 1 -- has no E-step in front of its first M-step: the chain
     //  smoother then reads them from here itself and keeps them in aJ / aYd for the iterations that follow)
     const double *late_aJ, *late_aYd;
+    double *host_out;
+    unsigned long long *host_prog;
+    unsigned host_epoch;
+    int host_report_it;     // an M-step that does not finish the registration reports its progress only when it has completed this iteration (0: never)
+    // one-shot exchange of the N-split (tdlo_xch_*, tdlo_split_run without a communicator): every rank's inbox as a device
+    // pointer valid on THIS device (own inbox included); xch_nranks == 0: no exchange
+    unsigned long long *xch_inbox[kMaxXchRanks];
+    int xch_rank, xch_nranks, xch_mcap;
+    unsigned xch_epoch;     // tag of this registration: flags carry (epoch << 32 | iteration + 1)
+    // ---- tracking_step's short cuts (round 4, second step).  At the END of the descriptor: the offsets of everything above are those of the
+    //      kernels measured before (with fields inserted in the middle C2 came out 0.8 % slower in an A/B on one box, 13.80 against 13.62 us per iteration; with them here: level)
     // tracking_step with every node visible (tdlo_api.cpp, PairNext): the first E-step of the main registration would repeat the first E-step of
     // the pre-processing registration to the bit -- same cloud, same nodes, sigma2, mu, precision, no visibility term, and the sums are integers.
     // The pre-processing registration's M-step of iteration 0 stores the 4M + 1 sums it has read here (the main registration's `sums`), and that
@@ -132,15 +141,8 @@ struct FrameDev {
     // H = (I - L)^T (I - L) (trackdlo.cpp:236-237) of the nodes it leaves behind, here -- the host's values bit for bit (tdlo_lle_dev.h): the
     // next frame's pre-processing registration starts from exactly these nodes when every node is visible.  nullptr: off.
     double *lle_next;
-    double *host_out;
-    unsigned long long *host_prog;
-    unsigned host_epoch;
-    int host_report_it;     // an M-step that does not finish the registration reports its progress only when it has completed this iteration (0: never)
-    // one-shot exchange of the N-split (tdlo_xch_*, tdlo_split_run without a communicator): every rank's inbox as a device
-    // pointer valid on THIS device (own inbox included); xch_nranks == 0: no exchange
-    unsigned long long *xch_inbox[kMaxXchRanks];
-    int xch_rank, xch_nranks, xch_mcap;
-    unsigned xch_epoch;     // tag of this registration: flags carry (epoch << 32 | iteration + 1)
+    const double *Xhost;    // k_prologue only: the cloud still in PINNED HOST memory (N0 x 3 column-major) -- its point workgroups read it from there
+                            // and put it in Xraw themselves: no host-to-device copy in front of the frame's first kernel.  nullptr: Xraw holds it
 };
 
 // Inbox layout in 64-bit words (R ranks, node capacity Mc); rank r writes the [r] entries of every peer's inbox:
