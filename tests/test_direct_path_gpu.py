@@ -293,3 +293,49 @@ def test_each_short_cut_of_tracking_step_changes_no_bit(prec, off):
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("hint", [True, False], ids=["iteration hint", "one iteration first"])
+def test_an_m_step_that_gave_up_waiting_is_made_up_for(hint):
+    """The main registration's first M-step is launched ahead of its priors and waits for them on the device -- for at most 2 s.  If the host
+    thread is held up for longer (a debugger, a stopped process) the kernel leaves without touching anything, and the host, finding the stream
+    drained without a report, looks at the registration's state on the device and launches what is missing the ordinary way.  The test hook
+    TDLO_SPEC_FORCE_TIMEOUT=1 tells the waiting kernel to leave where it would have been released: the same 20 frames, bit for bit."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 5000, 45
+    outs, counts = [], []
+    for force in (False, True):
+        keys = {"TDLO_SPEC_FORCE_TIMEOUT": "1" if force else None, "TDLO_ITER_HINT": None if hint else "0"}
+        old = {k: os.environ.get(k) for k in keys}
+        try:
+            for k, v in keys.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+            ctx = B.Context(device=0, max_points=N, max_nodes=64, timing=False)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        try:
+            _, Y0, _ = synth.scene(N, M, config=84)
+            coord = synth.geodesic_coord(Y0)
+            trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+                             P["lambda_pre_proc"], P["lle_weight"], ctx=ctx)
+            trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+            rec = []
+            v = np.arange(M, dtype=np.int32)
+            for fr in range(20):
+                X, _, _ = synth.scene(N, M, config=84, frame=fr if fr < 12 and fr % 3 else 5)      # a rope that moves, rests, moves: iteration counts 1 .. several
+                trk.tracking_step(X, v, v)
+                rec.append((trk.get_tracking_result(), trk.get_sigma2(), [s["iters"] for s in trk.last_stats], trk.get_correspondence_pairs()))
+            outs.append(rec); counts.append(ctx.route_counts())
+        finally:
+            ctx.close()
+    assert counts[0][2] > 0 and counts[1][2] == counts[0][2], counts          # (the hook acts exactly where a release would have happened)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3])

@@ -209,6 +209,7 @@ struct tdlo_ctx {
     int iter_hint = 0, iter_hint_next = 0;      // (_next: of the registration whose first M-step this one launches ahead, PairNext::spec)
     bool iter_hint_on = !(getenv("TDLO_ITER_HINT") && atoi(getenv("TDLO_ITER_HINT")) == 0);
     bool lle_next_on = !(getenv("TDLO_LLE_NEXT") && atoi(getenv("TDLO_LLE_NEXT")) == 0);        // 0: the host forms every LLE regulariser (comparator)
+    bool spec_force_timeout = getenv("TDLO_SPEC_FORCE_TIMEOUT") && atoi(getenv("TDLO_SPEC_FORCE_TIMEOUT")) != 0;   // test hook, see run_frames
     bool spec_on = !(getenv("TDLO_SPEC_MSTEP") && atoi(getenv("TDLO_SPEC_MSTEP")) == 0);        // 0: the paired registration's first M-step is launched when its priors exist (comparator)
     bool pair_sums_on = !(getenv("TDLO_PAIR_SUMS") && atoi(getenv("TDLO_PAIR_SUMS")) == 0);     // 0: the paired registration still runs its own first E-step (comparator)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
@@ -878,11 +879,16 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     }
     bool forked = false;
     bool sums_first = paired && c->pair.has_sums;      // the first iteration is its M-step alone, from the sums the previous registration's first M-step left
+    bool spec_released = false;                        // ... and that M-step had been launched ahead and was released by this call
+    int enqueued = 0;                                  // iterations this call has put on the stream (or released)
+    // test hook: the M-step launched ahead is told to leave instead of being released, as if it had given up waiting (2 s without the host)
+    const bool spec_force_timeout = c->spec_force_timeout;
     auto iterate = [&](int n) -> hipError_t {
         for (int it = 0; it < n; ++it) {
+            ++enqueued;
             if (sums_first) {
                 sums_first = false;
-                if (sg.live) { sg.release(true); ++c->route_count[2]; }      // it is on the stream already: the priors are staged, off it goes
+                if (sg.live) { sg.release(!spec_force_timeout); spec_released = true; ++c->route_count[2]; }      // it is on the stream already: the priors are staged, off it goes
                 else TDLO_RET(launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s));
                 continue;
             }
@@ -917,7 +923,19 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     bool have_readback = false;            // the results are already in pinned memory (early exit after the first iteration; the mailbox)
     auto mbox_done = [&](int min_it, bool need_done, bool *done) -> int {     // 0, or an error code
         unsigned long long w = 0;
-        const int wr = mbox_wait(c, epoch, min_it, need_done, &w);
+        int wr = mbox_wait(c, epoch, min_it, need_done, &w);
+        if (wr == 1 && spec_released) {
+            // The M-step launched ahead of its priors gave up waiting for them (this thread was held up for more than the kernel's 2 s) and left
+            // without touching anything; what was enqueued behind it ran as a registration that does its own first E-step.  The state on the
+            // device says where that stands: the iterations this call believes to be on the stream are made up, the ordinary way.
+            spec_released = false;
+            IterState is;
+            HIPCHK(c, hipMemcpy(&is, c->fh[0].st, sizeof is, hipMemcpyDeviceToHost));
+            int have = is.it;
+            if (!is.done && have == 0 && enqueued > 0) { HIPCHK(c, launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s)); have = 1; }
+            for (; !is.done && have < enqueued; ++have) HIPCHK(c, launch_iteration(fdp, c->fh.data(), 1, s));
+            wr = mbox_wait(c, epoch, min_it, need_done, &w);
+        }
         if (wr < 0) return wr;
         if (wr == 1) return fail(c, TDLO_E_HIP, "the stream drained, but the M-step did not report the state of the registration");
         *done = (w >> 31) & 1u;

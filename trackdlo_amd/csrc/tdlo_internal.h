@@ -133,7 +133,7 @@ struct FrameDev {
     // needs (they come out of the pre-processing registration's result through traverse_euclidean): it leaves at once unless that registration
     // (spec_prev) has finished without an error, and otherwise waits for the host to raise spec_flag (pinned host memory) to spec_epoch << 32 | 1
     // -- priors are in late_aJ / late_aYd -- or | 2 -- leave, nothing is touched.  Gives up after 2 s (the host then finds the stream drained
-    // without a report: an error).  What it saves is the launch: enqueue + dispatch latency, ~6 us between the two registrations.  nullptr: off.
+    // without a report and makes up for it: run_frames, mbox_done).  What it saves is the launch: enqueue + dispatch latency, ~6 us between the two registrations.  nullptr: off.
     const unsigned long long *spec_flag;
     const IterState *spec_prev;
     unsigned spec_epoch;
