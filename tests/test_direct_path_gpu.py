@@ -339,3 +339,39 @@ def test_an_m_step_that_gave_up_waiting_is_made_up_for(hint):
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
         np.testing.assert_array_equal(a[3], b[3])
+
+
+def test_a_batch_does_not_take_the_device_formed_regulariser():
+    """After a tracking_step the slot holds the LLE regulariser of the tracker's nodes, formed on the device.  A single registration with the LLE
+    term of exactly those nodes uses it where it lies; a BATCH moves every frame's H into its transfer buffer and therefore has to form it
+    on the host -- both must give the single call's bits (a batch that skipped the host's H without pointing at the device's would run on
+    whatever the staging buffer held)."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 3000, 40
+    ctx = B.Context(device=0, max_frames=2, max_points=N, max_nodes=64, timing=False)
+    try:
+        X, Y0, _ = synth.scene(N, M, config=85)
+        coord = synth.geodesic_coord(Y0)
+        trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+                         P["lambda_pre_proc"], P["lle_weight"], ctx=ctx, precision=1)
+        trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+        v = np.arange(M, dtype=np.int32)
+        for _ in range(3):
+            trk.tracking_step(X, v, v)
+        Yt = trk.get_tracking_result()
+        pp = B.make_params(P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], P["mu"], max_iter=6, tol=0.0, include_lle=True, alpha=0.0, k_vis=0.0,
+                           visibility_threshold=0.01, precision=B.PREC_F64)
+        used = ctx.route_counts()[3]
+        single = ctx.cpd_lle_resident(0, Yt, 2e-5, pp)
+        assert ctx.route_counts()[3] == used + 1                         # (the single call took the device-formed H)
+        ctx.set_cloud(1, X)
+        batch = ctx.cpd_lle_batch([Yt, Yt], [2e-5, 2e-5], pp)
+        assert ctx.route_counts()[3] == used + 1
+        np.testing.assert_array_equal(np.asarray(batch["Y"][0]), single["Y"])
+        np.testing.assert_array_equal(np.asarray(batch["Y"][1]), single["Y"])
+        _, Hb = B.calc_lle_regulariser(Yt)
+        plain = ctx.cpd_lle_resident(0, Yt, 2e-5, pp, H=B.calc_lle_regulariser(Yt)[0])      # the host's H handed in: the same registration
+        np.testing.assert_array_equal(plain["Y"], single["Y"])
+    finally:
+        ctx.close()

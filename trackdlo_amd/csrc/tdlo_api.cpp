@@ -502,7 +502,7 @@ int stage_priors(tdlo_ctx *c, double *aJ, double *aYd, const double *Y, int M, c
 // Fills the host-side upload block [Yin | aJ | aYd | H] for one frame and its FrameDev.
 int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, const tdlo_params *p,
                   const double *priors, int K, const int *vis, int n_vis, const double *H_override,
-                  double *stage, FrameDev &f, bool second_block = false) {
+                  double *stage, FrameDev &f, bool second_block = false, bool hb_may_stay = true) {      // hb_may_stay: f.Hb may point at Slot::hb_next (a batch moves every frame's Hb into its transfer buffer instead)
     Slot &s = c->slots[slot];
     if (s.N0 <= 0) return fail(c, TDLO_E_INVALID, "no cloud resident in slot (call tdlo_set_cloud)");
     int rc = second_block ? ensure_nodes2(c, s, M) : ensure_nodes(c, s, M);
@@ -545,7 +545,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
             if (H_override) {
                 for (int i = 0; i < M; ++i)
                     for (int u = 0; u < 13; ++u) { const int j = i - 6 + u; Hb[(size_t)13 * i + u] = (j >= 0 && j < M) ? H_override[(size_t)j * M + i] : 0.0; }
-            } else if (c->lle_next_on && !second_block && s.hb_next_valid && s.hb_next_Y.size() == 3 * (size_t)M &&
+            } else if (c->lle_next_on && hb_may_stay && !second_block && s.hb_next_valid && s.hb_next_Y.size() == 3 * (size_t)M &&
                        std::memcmp(s.hb_next_Y.data(), Y, sizeof(double) * 3 * M) == 0) {
                 hb_resident = true;                          // formed on the device at the end of the previous tracking_step (FrameDev::lle_next): the same values
             } else {
@@ -728,7 +728,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     for (int pass = 0; pass < 2 && !paired; ++pass) {
     for (int i = 0; i < F; ++i) {
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
-                           c->pin + (size_t)i * ustride, c->fh[i]);
+                           c->pin + (size_t)i * ustride, c->fh[i], false, !merged);
         if (rc) return rc;
         if (merged) {
             FrameDev &f = c->fh[i];
@@ -976,7 +976,8 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         }
     } else if (use_mbox) {
         // early exit (trackdlo.cpp:424-428), decided on the device and read from the mailbox: the first iteration is checked eagerly (a tracker
-        // in steady state converges in it); after that iterations go out in chunks of 1, 1, 2, 4, 4, ... and the host looks at the progress
+        // in steady state converges in it) -- or the first `iter_hint` iterations, when the caller knows how many the registration took last time
+        // (tdlo_ctx::iter_hint) --; after that iterations go out in chunks of 1, 1, 2, 4, 4, ... and the host looks at the progress
         // word of the chunk BEFORE the one it has just enqueued, so that the GPU never idles (kernels of a finished registration are no-ops)
         const int first = std::max(1, std::min(std::min(iter_hint, 4), p->max_iter));
         c->fh[0].host_report_it = first;       // (the frame descriptor travels by value with every launch of the one-frame kernels)
