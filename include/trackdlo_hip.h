@@ -295,7 +295,7 @@ int tdlo_tracker_get_correspondence_pairs(const tdlo_tracker *t, double *out, in
  *    device, bit for bit what tdlo_calc_lle_regulariser gives (tdlo_debug_lle_band_device); the next frame's pre-processing registration
  *    uses it if it starts from exactly those nodes (every node visible, no H_pre) instead of waiting for the host's 6 x 6 factorisations
  *    (TDLO_LLE_NEXT=0).
- *  - Each registration enqueues as many iterations up front as the same registration took in the previous frame (1 .. 4) before the host
+ *  - Each registration enqueues as many iterations up front as the same registration took in the previous frame (1 .. 8) before the host
  *    looks at its state (trackdlo.cpp:424-428 is decided on the device; kernels of a finished registration are no-ops): consecutive frames
  *    take about the same number, and the GPU neither idles between iterations nor runs more than a no-op or two (TDLO_ITER_HINT=0: one).
  * A steady-state frame at production size (5 000 points, 45 nodes, both registrations converging in their first iteration) is then FOUR

@@ -81,6 +81,9 @@ sec() { echo "== $1"; shift; "$@" 2>&1 | grep -v amdgpu.ids; local rc=${PIPESTAT
   sec "track C++ caller: every frame a new cloud of a moving rope (MOVE=10: 1 mm per frame, fresh noise)" env MOVE=10 scripts/ubench/track_cpp
   sec "track C++ caller: the same, round 4's first form (TDLO_PAIR_SETUP=0 TDLO_LLE_NEXT=0 TDLO_DIRECT_CLOUD=0)" env MOVE=10 TDLO_PAIR_SETUP=0 TDLO_LLE_NEXT=0 TDLO_DIRECT_CLOUD=0 scripts/ubench/track_cpp
   sec "track C++ caller: the same, copy route (TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0)" env MOVE=10 TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0 scripts/ubench/track_cpp
+  sec "track C++ caller: nodes 18-24 hidden (the registrations start from different node sets: no pairing; the pre-processing one takes ~6 iterations)" env OCCL=1 scripts/ubench/track_cpp
+  sec "track C++ caller: the same with a moving rope" env OCCL=1 MOVE=10 scripts/ubench/track_cpp
+  sec "track C++ caller: the same, copy route (TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0)" env OCCL=1 MOVE=10 TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0 scripts/ubench/track_cpp
   sec "c5_5it" env ITERS=5 timeout 200 python scripts/gpu_c5.py
   sec "pcie" timeout 200 python scripts/gpu_pcie.py
 } > $O/measured.log 2>&1

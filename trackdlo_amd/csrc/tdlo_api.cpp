@@ -27,6 +27,7 @@ namespace {
 
 constexpr int kMaxEstepBlocks = 4096;      // (upper bound of TDLO_ESTEP_BLOCKS / tdlo_config.estep_blocks; the defaults are 512 and 1024)
 constexpr int kBatchStreams = 4;       // streams a batch of frames is spread over (run_frames); more than 4 lose (measured: 6 or 8 fall below one stream)
+constexpr int kIterHintMax = 8;        // tdlo_ctx::iter_hint: at most this many iterations go out before the host first looks
 constexpr int kChunkIters = 4;          // EM iterations per early-exit polling chunk; the first chunks are shorter (1, 1, 2):
                                         // a tracker in steady state converges in one or two iterations
 
@@ -979,7 +980,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         // in steady state converges in it) -- or the first `iter_hint` iterations, when the caller knows how many the registration took last time
         // (tdlo_ctx::iter_hint) --; after that iterations go out in chunks of 1, 1, 2, 4, 4, ... and the host looks at the progress
         // word of the chunk BEFORE the one it has just enqueued, so that the GPU never idles (kernels of a finished registration are no-ops)
-        const int first = std::max(1, std::min(std::min(iter_hint, 4), p->max_iter));
+        const int first = std::max(1, std::min(std::min(iter_hint, kIterHintMax), p->max_iter));
         c->fh[0].host_report_it = first;       // (the frame descriptor travels by value with every launch of the one-frame kernels)
         HIPCHK(c, iterate(first));
         if (!late && c->pair.state == 2 && c->pair.has_sums && c->spec_on && c->mbox_on && !timing && c->pair.p.max_iter > 0) {
@@ -995,7 +996,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             fs.reuse_sorted = 1; fs.has_priors = 1;
             fs.late_aJ = c->late_buf; fs.late_aYd = c->late_buf + pn.M;
             fs.host_out = c->mbox; fs.host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); fs.host_epoch = e2;
-            fs.host_report_it = (pn.p.tol <= 0.0 || pn.p.max_iter <= 2 * kChunkIters) ? 0 : std::max(1, std::min(std::min(c->iter_hint_next, 4), pn.p.max_iter));
+            fs.host_report_it = (pn.p.tol <= 0.0 || pn.p.max_iter <= 2 * kChunkIters) ? 0 : std::max(1, std::min(std::min(c->iter_hint_next, kIterHintMax), pn.p.max_iter));
             fs.spec_flag = spec_flag_word(c); fs.spec_prev = c->fh[0].st; fs.spec_epoch = e2;
             if (c->lle_next_on && pn.M <= 256 && sl.hb_next_cap >= pn.M) fs.lle_next = sl.hb_next;      // (as the registration itself will set it, above)
             HIPCHK(c, launch_mstep_chain((const FrameDev *)(sl.nodeblk2 + nc2.fdev), &fs, 1, 1, fs.precision == TDLO_PREC_F64, s));
