@@ -265,3 +265,18 @@ def test_band_regulariser_is_the_dense_one_bit_for_bit(oracle):
         Lo = oracle.calc_lle_weights(Y, 6)
         Ho = (np.eye(M) - Lo).T @ (np.eye(M) - Lo)
         np.testing.assert_allclose(H, Ho, rtol=0, atol=1e-6 * max(1.0, np.abs(Ho).max()))
+
+
+def test_device_lle_routine_compiled_for_the_host_matches_the_host_routine(tmp_path):
+    """csrc/tdlo_lle_dev.h -- the routine the GPU runs at the end of a tracking_step to form the next frame's LLE regulariser -- compiled for the host
+    with one "thread" against tdlo_calc_lle_regulariser, bit for bit over 600 chains (ordinary, straight, coincident nodes, 1 .. 256 nodes): the
+    CPU-side check of its logic (tests/cpp/lle_dev_host_test.cpp); the GPU build is checked by tests/test_lle_device_gpu.py."""
+    import subprocess
+    exe = str(tmp_path / "lle_dev_host_test")
+    lib_dir = os.path.join(ROOT, "trackdlo_amd")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", os.path.join(ROOT, "tests", "cpp", "lle_dev_host_test.cpp"), "-o", exe,
+                        "-L" + lib_dir, "-ltrackdlo_hip", "-Wl,-rpath," + lib_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "600 chains, 0 with a differing bit" in r.stdout
