@@ -39,7 +39,8 @@ int main() {
     const int nv = (int)vis.size();
     tdlo_stats st[2];
     for (int r = 0; r < 20; ++r) if (tdlo_tracker_tracking_step(t, X.data(), N, vis.data(), nv, vis.data(), nv, nullptr, st)) { std::printf("FAIL %s\n", tdlo_last_error(ctx)); return 1; }
-    const int R = 2000;
+    const int R = getenv("FRAMES") ? atoi(getenv("FRAMES")) : 2000;      // (FRAMES=500000: a soak run)
+    long fails = 0;
     if (getenv("MOVE") && atoi(getenv("MOVE")) > 0) {
         // a rope that keeps moving: 16 clouds (own noise each) along a sway of MOVE tenths of a millimetre per frame in y -- the registrations take
         // more than one iteration, and every frame's cloud comes from a different buffer
@@ -53,16 +54,18 @@ int main() {
         for (int r = 0; r < 64; ++r) tdlo_tracker_tracking_step(t, Xs[r % K].data(), N, vis.data(), nv, vis.data(), nv, nullptr, st);
         long it0 = 0, it1 = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        for (int r = 0; r < R; ++r) { tdlo_tracker_tracking_step(t, Xs[r % K].data(), N, vis.data(), nv, vis.data(), nv, nullptr, st); it0 += st[0].iters; it1 += st[1].iters; }
+        for (int r = 0; r < R; ++r) { if (tdlo_tracker_tracking_step(t, Xs[r % K].data(), N, vis.data(), nv, vis.data(), nv, nullptr, st)) { if (!fails++) std::printf("FAIL at frame %d: %s\n", r, tdlo_last_error(ctx)); } it0 += st[0].iters; it1 += st[1].iters; }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / R;
         std::printf("C++ caller: tracking_step N=%d M=%d%s, rope moving %.1f mm per frame: %.4f ms/frame (iterations per frame: pre %.2f, main %.2f)\n", N, M, occl ? ", nodes 18-24 hidden" : "", amp * 1e3, ms, it0 / (double)R, it1 / (double)R);
+        if (fails) std::printf("%ld frames FAILED\n", fails);
         tdlo_tracker_destroy(t); tdlo_destroy(ctx);
-        return 0;
+        return fails ? 1 : 0;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < R; ++r) tdlo_tracker_tracking_step(t, X.data(), N, vis.data(), nv, vis.data(), nv, nullptr, st);
+    for (int r = 0; r < R; ++r) if (tdlo_tracker_tracking_step(t, X.data(), N, vis.data(), nv, vis.data(), nv, nullptr, st)) { if (!fails++) std::printf("FAIL at frame %d: %s\n", r, tdlo_last_error(ctx)); }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / R;
     std::printf("C++ caller: tracking_step N=%d M=%d%s: %.4f ms/frame (pre %d it host %.3f ms, main %d it host %.3f ms)\n", N, M, occl ? ", nodes 18-24 hidden" : "", ms, st[0].iters, st[0].host_ms, st[1].iters, st[1].host_ms);
+    if (fails) std::printf("%ld frames FAILED\n", fails);
     tdlo_tracker_destroy(t); tdlo_destroy(ctx);
-    return 0;
+    return fails ? 1 : 0;
 }
