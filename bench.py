@@ -285,7 +285,7 @@ def _compact(full):
     if "sustained" in full:
         o["sustained_iters_per_s"] = full["sustained"].get("sustained_iters_per_s")
     pre = full.get("preproc") or {}
-    for k in ("tracking_step_ms_per_frame", "em_iters_per_s"):
+    for k in ("tracking_step_ms_per_frame", "tracking_step_moving_ms_per_frame", "em_iters_per_s"):
         if k in pre:
             o["preproc_" + k if k == "em_iters_per_s" else k] = pre[k]
     o["ranks"] = full.get("ranks")
@@ -576,6 +576,18 @@ def _preproc_leg(ctx, B, synth):
         for _ in range(200):
             trk.tracking_step(X, vis, vis)
         out["tracking_step_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3 / 200, 4)
+        # the same with a NEW cloud in every frame -- fresh noise, the rope swaying 1 mm per frame in y, sixteen clouds in turn --: the registrations
+        # take two or three iterations each (the figure above is the steady state: the same cloud again, one iteration each)
+        Xm = [synth.scene(N, M, config=2, frame=100 + k, shift=(0.0, 0.005 + 0.001 * (k if k < 8 else 16 - k), 0.0))[0] for k in range(16)]
+        for k in range(32):
+            trk.tracking_step(Xm[k % 16], vis, vis)
+        its = [0, 0]
+        t0 = time.perf_counter()
+        for k in range(200):
+            trk.tracking_step(Xm[k % 16], vis, vis)
+            its[0] += trk.last_stats[0]["iters"]; its[1] += trk.last_stats[1]["iters"]
+        out["tracking_step_moving_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3 / 200, 4)
+        out["tracking_step_moving_iters_per_frame"] = [round(its[0] / 200, 2), round(its[1] / 200, 2)]
     finally:
         ctx.set_sort_reuse(prev)
     out["tracking_step_sort_reused"] = reused       # [pre-processing registration, main registration] of a frame (2: reused, and set up by the first prologue)
