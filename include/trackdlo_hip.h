@@ -291,6 +291,14 @@ int tdlo_tracker_get_correspondence_pairs(const tdlo_tracker *t, double *out, in
  *    launched right behind the pre-processing registration's first iteration; it waits on the device for the priors that the host
  *    forms from that registration's result (:929-995) and leaves untouched if that registration needs more iterations or ends on an
  *    error (TDLO_SPEC_MSTEP=0: launched when the priors exist).  stats[1].sort_reused is 2 on such a frame.
+ *  - With HIDDEN nodes (n_vis_ext < num_of_nodes) the registrations start from different node sets and share nothing -- but the main
+ *    registration's prune, sort, set-up, per-node minimum distances and first E-step (:177-389 of the :998 call) depend on nothing the
+ *    pre-processing registration produces.  They are launched on a second stream, into a second set of buffers of the context (the cloud
+ *    is read from the same pinned staging buffer), as soon as the pre-processing registration's first iterations are on the first one,
+ *    and run beside its iterations (6-7 with a stretch of the rope hidden); the first M-step waits behind them for the priors, as in (d),
+ *    and the main registration stays on the second stream (TDLO_AHEAD=0: launched when the pre-processing registration has returned;
+ *    tdlo_debug_route_count(ctx, 4)).  Such a frame does not leave the next frame's H behind (next item).  Clouds of up to 16 384 points,
+ *    chains of up to 256 nodes.
  *  - The M-step that finishes the main registration also forms H = (I - L)^T (I - L) (:236-237) of the nodes it leaves behind, on the
  *    device, bit for bit what tdlo_calc_lle_regulariser gives (tdlo_debug_lle_band_device); the next frame's pre-processing registration
  *    uses it if it starts from exactly those nodes (every node visible, no H_pre) instead of waiting for the host's 6 x 6 factorisations
@@ -408,7 +416,8 @@ int tdlo_debug_lle_band_device(tdlo_ctx *ctx, const double *Y, int M, double *Hb
  * pre-processing registration's prologue (every node visible; TDLO_PAIR_SETUP=0); 1: ... that started from the first E-step's sums handed over
  * by the pre-processing registration instead of repeating that E-step (TDLO_PAIR_SUMS=0); 2: ... whose first M-step had been launched ahead of
  * its priors and was released when they were staged (TDLO_SPEC_MSTEP=0); 3: pre-processing registrations whose LLE regulariser had been formed
- * on the device by the M-step that finished the previous frame (TDLO_LLE_NEXT=0).  -1 for a null context or an unknown counter. */
+ * on the device by the M-step that finished the previous frame (TDLO_LLE_NEXT=0); 4: main registrations of frames with hidden nodes whose first
+ * iteration had run on the second stream beside the pre-processing registration (TDLO_AHEAD=0).  -1 for a null context or an unknown counter. */
 long long tdlo_debug_route_count(tdlo_ctx *ctx, int which);
 /* Test aid: provokes a HIP runtime error inside the library (an invalid copy) and reports it like any other: returns TDLO_E_HIP with the
  * text in tdlo_last_error.  The calls that follow must be unaffected -- HIP keeps a per-thread "last error" that the launch checks of a later

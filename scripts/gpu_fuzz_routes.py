@@ -1,5 +1,6 @@
 """Randomised tracking_step sequences on the product's two routes: every short cut of round 4 on (cloud read from pinned host memory, paired
-set-up, first E-step's sums handed over, first M-step launched ahead of its priors, the next frame's LLE regulariser formed on the device, the iteration hint) against
+set-up, first E-step's sums handed over, first M-step launched ahead of its priors, the next frame's LLE regulariser formed on the device, the iteration hint,
+the main registration's first iteration beside the pre-processing registration when nodes are hidden) against
 all of them off -- the library's own H on both sides (no H_pre: the device-formed regulariser is in play), random chain length, cloud size (down
 to a few dozen points), noise, motion (frames that converge at once and frames that take many iterations), occlusion pattern per frame, both
 precisions, eight frames with the state carried over.  Every result must be the same BITS, and an error must be the same error.
@@ -9,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trackdlo_amd import synth, binding as B
 P = synth.LAUNCH_PARAMS
-KEYS = ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_ITER_HINT")
+KEYS = ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_ITER_HINT", "TDLO_AHEAD")
 
 
 def _ctx(on):

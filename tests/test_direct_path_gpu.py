@@ -147,7 +147,7 @@ def test_tracking_sequences_are_the_same_on_both_routes(prec):
 
 def _pair_ctx(B, on, off=("TDLO_PAIR_SETUP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD"), **kw):
     """on: every short cut of tracking_step; else the switches in `off` set to 0 (read when the context is made)."""
-    keys = ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_ITER_HINT")
+    keys = ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_ITER_HINT", "TDLO_AHEAD")
     old = {k: os.environ.get(k) for k in keys}
     try:
         for k in keys:
@@ -375,3 +375,126 @@ def test_a_batch_does_not_take_the_device_formed_regulariser():
         np.testing.assert_array_equal(plain["Y"], single["Y"])
     finally:
         ctx.close()
+
+
+def _ahead_ctx(B, ahead, force_timeout=False, hint=True, **kw):
+    """ahead=False: TDLO_AHEAD=0 -- the main registration of a frame with hidden nodes is launched when the pre-processing one has returned."""
+    keys = {"TDLO_AHEAD": None if ahead else "0", "TDLO_SPEC_FORCE_TIMEOUT": "1" if force_timeout else None}
+    keys["TDLO_ITER_HINT"] = None if hint else "0"
+    for k in ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_LATE_PRIORS", "TDLO_HOST_MAILBOX", "TDLO_DIRECT_UPLOAD"):
+        keys.setdefault(k, None)
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for k, v in keys.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        return B.Context(device=0, timing=False, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+_OCCL = {2: (0.4, 0.5), 3: (0.4, 0.5), 5: (0.0, 0.2), 6: (0.8, 1.0), 8: (0.3, 0.65), 9: (0.3, 0.65), 10: (0.3, 0.65), 13: (0.45, 0.55)}
+
+
+def _ahead_sequence(B, synth, ctx, N, M, prec, k_vis=None, frames=16, config=86):
+    P = synth.LAUNCH_PARAMS
+    _, Y0, _ = synth.scene(N, M, config=config)
+    coord = synth.geodesic_coord(Y0)
+    trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"] if k_vis is None else k_vis, P["mu"], 30, P["tol"],
+                     P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], ctx=ctx, precision=prec)
+    trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+    rec, hidden = [], 0
+    for fr in range(frames):
+        X, _, v = synth.scene(N, M, config=config, frame=min(fr, 11), occlude=_OCCL.get(fr))      # (the rope moves, then rests)
+        v = np.arange(M, dtype=np.int32) if v is None else v
+        vext = synth.extend_visible(v, M, coord)
+        hidden += len(vext) != M and len(X) <= 16384 and M <= 256      # (frames the short cut can take: the fused prologue's limits)
+        trk.tracking_step(X, v, vext)
+        rec.append((trk.get_tracking_result(), trk.get_sigma2(), [s["iters"] for s in trk.last_stats], trk.get_correspondence_pairs(), trk.get_guide_nodes(),
+                    [s["sort_reused"] for s in trk.last_stats]))
+    return rec, hidden
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+@pytest.mark.parametrize("N,M,k_vis", [(5000, 45, None), (5000, 45, 0.0), (300, 8, None), (16384, 120, None), (9000, 256, None), (17500, 45, None), (24000, 45, None), (5000, 257, None)])
+def test_main_registration_beside_the_pre_processing_one_changes_no_bit(N, M, k_vis, prec):
+    """tracking_step with hidden nodes (PairNext::ahead): the main registration's prologue, k_dmin and first E-step run on the second stream, in the
+    context's twin slot, beside the pre-processing registration, its first M-step waits behind them for the priors -- against TDLO_AHEAD=0, where
+    the main registration is launched when the pre-processing one has returned.  Head, tail and mid-section hidden, runs of hidden frames, frames with
+    every node visible in between (those take the paired route), a moving and a resting rope, with and without the visibility term (k_vis = 0: no
+    k_dmin), sizes either side of the fused prologue's limits (beyond them nothing is launched ahead): same nodes, sigma2, iteration counts, priors and
+    guide nodes, bit for bit; the counter says the route was taken in every frame with hidden nodes."""
+    from trackdlo_amd import binding as B, synth
+    outs, counts, hid = [], [], 0
+    for ahead in (True, False):
+        ctx = _ahead_ctx(B, ahead, max_points=N, max_nodes=64)
+        try:
+            rec, hid = _ahead_sequence(B, synth, ctx, N, M, prec, k_vis)
+            outs.append(rec); counts.append(ctx.route_counts())
+        finally:
+            ctx.close()
+    assert hid >= 7 or N > 16384 or M > 256          # (17 500 points: the frames with a stretch hidden fall below the prologue's limit, the others do not; 24 000: none does)
+    assert counts[0][4] == hid and counts[1][4] == 0, (counts, hid)
+    assert counts[0][:2] == counts[1][:2], counts                       # (the frames with every node visible pair up either way)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+        assert a[5] == b[5]
+
+
+@pytest.mark.parametrize("hint", [True, False], ids=["iteration hint", "one iteration first"])
+def test_an_m_step_launched_beside_the_pre_processing_registration_that_gives_up_is_made_up_for(hint):
+    """The M-step launched ahead on the second stream waits for the priors for at most 2 s; if it leaves (test hook TDLO_SPEC_FORCE_TIMEOUT=1: it is
+    told to where it would have been released) it clears the sums of the E-step in front of it, and the host, finding the stream drained without a
+    report, launches ordinary iterations: the same frames, bit for bit."""
+    from trackdlo_amd import binding as B, synth
+    outs, counts = [], []
+    for force in (False, True):
+        ctx = _ahead_ctx(B, True, force_timeout=force, hint=hint, max_points=5000, max_nodes=64)
+        try:
+            rec, hid = _ahead_sequence(B, synth, ctx, 5000, 45, 0, config=87)
+            outs.append(rec); counts.append(ctx.route_counts())
+        finally:
+            ctx.close()
+    assert counts[0][4] == hid and counts[1][4] == hid, counts
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+
+
+def test_a_failing_frame_with_hidden_nodes_leaves_nothing_behind():
+    """A frame with hidden nodes whose pre-processing registration fails (every point pruned) after the main registration's first iteration has
+    been launched beside it: the waiting M-step is told to leave, the call reports the error, and the tracker carries on -- like the run without
+    the short cut, bit for bit."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 4000, 40
+    outs = []
+    for ahead in (True, False):
+        ctx = _ahead_ctx(B, ahead, max_points=N, max_nodes=64)
+        try:
+            _, Y0, _ = synth.scene(N, M, config=88)
+            coord = synth.geodesic_coord(Y0)
+            trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"],
+                             P["lambda_pre_proc"], P["lle_weight"], ctx=ctx)
+            trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+            rec = []
+            for fr in range(8):
+                X, _, v = synth.scene(N, M, config=88, frame=fr, occlude=(0.4, 0.55))
+                vext = synth.extend_visible(v, M, coord)
+                if fr in (2, 5):
+                    with pytest.raises(B.TdloError):
+                        trk.tracking_step(X + np.array([5.0, 0.0, 0.0]), v, vext)      # every point pruned
+                trk.tracking_step(X, v, vext)
+                rec.append((trk.get_tracking_result(), trk.get_sigma2(), [s["iters"] for s in trk.last_stats]))
+            outs.append(rec)
+            assert ctx.route_counts()[4] == (8 if ahead else 0)
+        finally:
+            ctx.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]

@@ -430,8 +430,9 @@ class Context:
         return Hb
 
     def route_counts(self):
-        """[paired set-ups, first iterations from handed-over sums, M-steps released from their wait, device-formed LLE regularisers used] (tdlo_debug_route_count)."""
-        return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in range(4)]
+        """[paired set-ups, first iterations from handed-over sums, M-steps released from their wait, device-formed LLE regularisers used,
+        main registrations whose first iteration ran beside the pre-processing one] (tdlo_debug_route_count)."""
+        return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in range(5)]
 
     def band_retries(self):
         """Calls of this context that were repeated on the dense pivoted kernels after the banded LLE solve gave up (tdlo_debug_band_retries)."""

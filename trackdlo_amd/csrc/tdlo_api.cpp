@@ -165,8 +165,9 @@ struct tdlo_ctx {
     bool lle_batch_dense = false;         // run_frames: a frame of this batch cannot take the banded LLE solve, all of them are staged for the dense kernels
     bool lle_dense_once = false;          // run_frames' retry: the banded LLE solve reported a numeric failure, this call repeats with the dense pivoted kernels
     long long band_retries = 0;           // how often that happened (tdlo_debug_band_retries)
-    long long route_count[4] = {0, 0, 0, 0};   // tdlo_debug_route_count: 0 paired set-ups taken up, 1 first iterations started from the handed-over sums,
-                                               // 2 M-steps released from their wait for priors, 3 pre-processing registrations served by a device-formed H
+    long long route_count[5] = {0, 0, 0, 0, 0};   // tdlo_debug_route_count: 0 paired set-ups taken up, 1 first iterations started from the handed-over sums,
+                                               // 2 M-steps released from their wait for priors, 3 pre-processing registrations served by a device-formed H,
+                                               // 4 main registrations whose first iteration ran beside the pre-processing registration (PairNext::ahead)
     bool sort_reuse = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);   // tdlo_set_sort_reuse: a slot's sorted cloud may serve the next registration of the same nodes
     // results mailbox in pinned host memory (FrameDev::host_out / host_prog): [read-back block | progress word], written by the one-workgroup M-steps
     double *mbox = nullptr;
@@ -191,12 +192,24 @@ struct tdlo_ctx {
         FrameDev f{};
         size_t up = 0;
         bool has_sums = false;            // the pre-processing registration's first M-step leaves the first E-step's sums for it (FrameDev::pair_sums)
+        // tracking_step with HIDDEN nodes: the two registrations start from different node sets, so nothing is shared -- but the main registration's
+        // prologue (prune, sort, set-up), k_dmin and first E-step depend on nothing the pre-processing registration produces either.  state 3 = asked
+        // for by tracking_step: the pre-processing registration's run_frames, once its own first iterations are on the stream, launches them on a
+        // SECOND stream into the context's twin slot (own cloud buffers, own node block; the cloud is read from the same pinned staging buffer), with
+        // the first M-step behind them waiting for the priors (FrameDev::spec_flag, spec_prev == nullptr; FrameDev::late_mstep).  They run beside the
+        // pre-processing registration's 6-7 iterations; the main registration (state 2, ahead) then only releases that M-step and stays on the second
+        // stream.  TDLO_AHEAD=0: off (comparator).
+        bool ahead = false;
+        bool cloud_in_pin = false;        // (request) this frame's cloud is in tdlo_ctx::cloud_pin
         int spec = 0;                     // 1: its first M-step is already on the stream, waiting for the priors (FrameDev::spec_flag)
         unsigned spec_epoch = 0;          // ... under this mailbox epoch
     } pair;
     double *pin2 = nullptr;               // pinned: the paired registration's upload block
     size_t pin2_doubles = 0;
     bool pair_on = !(getenv("TDLO_PAIR_SETUP") && atoi(getenv("TDLO_PAIR_SETUP")) == 0);
+    Slot twin;                            // PairNext::ahead: the main registration's cloud buffers and node block while it runs beside the pre-processing one
+    bool twin_busy = false;               // something launched ahead into the twin slot may still be running on the second stream (drained before its staging block is reused)
+    bool ahead_on = !(getenv("TDLO_AHEAD") && atoi(getenv("TDLO_AHEAD")) == 0);
     // tracking_step: the frame's cloud staged in pinned host memory and read from there by the fused prologue's point workgroups (FrameDev::Xhost)
     // instead of a host-to-device copy in front of it (a 9 us copy on the stream, 8 us of host time for the call); cloud_pending: staged for this
     // slot and not yet on the device.  TDLO_DIRECT_CLOUD=0: the copy (comparator)
@@ -327,7 +340,7 @@ int ensure_mbox(tdlo_ctx *c, size_t doubles) {
 // only that).  *word = the progress word seen.  Returns 0; 1 when the stream has drained without that report (the caller falls back on the
 // read-back copy); a negative code for a HIP error on the stream.  The wait spins on pinned host memory -- the M-step's own store is the
 // earliest moment the host can know -- and looks at the stream only every 0.5 ms, so that a faulting kernel cannot hang the caller.
-int mbox_wait(tdlo_ctx *c, unsigned epoch, int min_it, bool need_done, unsigned long long *word) {
+int mbox_wait(tdlo_ctx *c, hipStream_t stream, unsigned epoch, int min_it, bool need_done, unsigned long long *word) {
     const unsigned long long *w = (const unsigned long long *)(c->mbox + c->mbox_doubles - 2);
     auto t_chk = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
@@ -340,7 +353,7 @@ int mbox_wait(tdlo_ctx *c, unsigned epoch, int min_it, bool need_done, unsigned 
             const auto now = std::chrono::steady_clock::now();
             if (std::chrono::duration<double, std::micro>(now - t_chk).count() > 500.0) {
                 t_chk = now;
-                const hipError_t e = hipStreamQuery(c->stream);
+                const hipError_t e = hipStreamQuery(stream);
                 if (e == hipSuccess) {          // drained: whatever was going to be reported has been (the kernel's stores precede its completion)
                     const unsigned long long v2 = __atomic_load_n(w, __ATOMIC_ACQUIRE);
                     if ((unsigned)(v2 >> 32) == epoch && (((v2 >> 31) & 1u) || (!need_done && (int)(v2 & 0x7fffffffu) >= min_it))) { *word = v2; return 0; }
@@ -504,7 +517,7 @@ int stage_priors(tdlo_ctx *c, double *aJ, double *aYd, const double *Y, int M, c
 int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, const tdlo_params *p,
                   const double *priors, int K, const int *vis, int n_vis, const double *H_override,
                   double *stage, FrameDev &f, bool second_block = false, bool hb_may_stay = true) {      // hb_may_stay: f.Hb may point at Slot::hb_next (a batch moves every frame's Hb into its transfer buffer instead)
-    Slot &s = c->slots[slot];
+    Slot &s = slot < 0 ? c->twin : c->slots[slot];      // (slot < 0: the context's twin slot, PairNext::ahead)
     if (s.N0 <= 0) return fail(c, TDLO_E_INVALID, "no cloud resident in slot (call tdlo_set_cloud)");
     int rc = second_block ? ensure_nodes2(c, s, M) : ensure_nodes(c, s, M);
     if (rc) return rc;
@@ -674,6 +687,56 @@ void fill_stats(tdlo_stats *st, const IterState &is) {
 // K x 4 rows, or an error code.
 typedef std::function<int(const double *&, int &)> LatePriors;
 
+// PairNext::ahead (tracking_step with hidden nodes; called by the pre-processing registration's run_frames once its own first iterations are on the
+// first stream): the main registration's fused prologue, k_dmin and first E-step on the SECOND stream, in the context's twin slot -- they read
+// the frame's cloud from the pinned staging buffer like the pre-processing registration's own prologue -- and its first M-step behind them, waiting
+// for the priors.  Returns 0 whether or not it launched anything (PairNext::state == 2 && ahead says it did); a negative code for a HIP error.
+int launch_ahead(tdlo_ctx *c) {
+    tdlo_ctx::PairNext &pn = c->pair;
+    const int M = pn.M;
+    const int N0 = c->slots[pn.slot].N0;
+    const NodeCarve nc(M);
+    if (!pn.cloud_in_pin || N0 <= 0 || pn.p.include_lle || pn.p.max_iter <= 0 || M > kChainLdsMaxNodes) return 0;
+    if (c->late_doubles < 4 * (size_t)M + 2 || c->mbox_doubles < nc.readback + 4 || c->cloud_pin_doubles < 3 * (size_t)N0) return 0;      // (sized by tracking_step before anything was launched)
+    if (!c->stream2[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2[0], hipStreamNonBlocking));
+    hipStream_t sb = c->stream2[0];
+    Slot &tw = c->twin;
+    const size_t need_hist = (size_t)((N0 + kBlock - 1) / kBlock) * M;
+    const bool grow = N0 > tw.cap_points || M > tw.cap_nodes || need_hist > tw.hist_ints || nc.upload + 2 > c->pin2_doubles;
+    if (grow || c->twin_busy) HIPCHK(c, hipStreamSynchronize(sb));      // (buffers about to be replaced, or a staging block an abandoned launch may still be reading)
+    c->twin_busy = false;
+    int rc;
+    if ((rc = ensure_points(c, tw, N0))) return rc;
+    tw.N0 = N0; tw.sorted_valid = false;
+    if ((rc = ensure_pin2(c, nc.upload + 2))) return rc;
+    FrameDev &f = pn.f;
+    if ((rc = prepare_frame(c, -1, pn.Y.data(), M, pn.sigma2, &pn.p, nullptr, 0, nullptr, pn.n_vis, nullptr, c->pin2, f, false))) return rc;
+    if (grow) HIPCHK(c, hipStreamSynchronize(c->stream));               // (new buffers are cleared on the first stream)
+    if (!f.wide_tile || f.mstep_dense || f.reuse_sorted || !prologue_pair_ok(f)) return 0;      // not this frame: the main registration takes the ordinary route
+    pn.up = upload_doubles(nc, &pn.p, false);
+    f.Xhost = c->cloud_pin;
+    std::memcpy(c->pin2 + nc.fdev, &f, sizeof(FrameDev));
+    if (++tw.fuse_epoch == 0) ++tw.fuse_epoch;
+    c->twin_busy = true;
+    HIPCHK(c, launch_prologue_direct(&f, c->pin2, tw.nodeblk, (int)pn.up, (int)nc.Yin, tw.fuse_epoch, sb));
+    f.Xhost = nullptr;                      // (the cloud is in the twin's Xraw for everything that follows)
+    f.late_mstep = 1;                       // the priors do not exist yet: this E-step leaves them alone, the M-step reads them itself
+    const FrameDev *fdb = (const FrameDev *)(tw.nodeblk + nc.fdev);
+    if (f.vis_branch) HIPCHK(c, launch_estep_only(fdb, &f, 1, 1, sb));
+    HIPCHK(c, launch_estep_only(fdb, &f, 1, 0, sb));
+    unsigned e2 = ++c->mbox_epoch;
+    if (e2 == 0) e2 = ++c->mbox_epoch;
+    FrameDev fs = f;
+    fs.reuse_sorted = 1; fs.has_priors = 1;
+    fs.late_aJ = c->late_buf; fs.late_aYd = c->late_buf + M;
+    fs.host_out = c->mbox; fs.host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); fs.host_epoch = e2;
+    fs.host_report_it = (pn.p.tol <= 0.0 || pn.p.max_iter <= 2 * kChunkIters) ? 0 : std::max(1, std::min(std::min(c->iter_hint_next, kIterHintMax), pn.p.max_iter));
+    fs.spec_flag = spec_flag_word(c); fs.spec_prev = nullptr; fs.spec_epoch = e2;
+    HIPCHK(c, launch_mstep_chain(fdb, &fs, 1, 0, fs.precision == TDLO_PREC_F64, sb));
+    pn.has_sums = false; pn.spec = 1; pn.spec_epoch = e2; pn.ahead = true; pn.state = 2;
+    return 0;
+}
+
 // Shared driver of tdlo_cpd_lle_resident / _batch.
 int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *sigma2, const tdlo_params *p,
                const double *priors, int K, const int *vis, int n_vis, const double *H_override, tdlo_stats *stats,
@@ -707,13 +770,16 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     // tracking_step's second registration whose node-side set-up the first one's prologue has already done (PairNext): same slot, nodes, sigma2 and
     // parameters as were set up, on the cloud that was sorted for these nodes -- then nothing is staged and no prologue is launched
     bool paired = false;
+    bool ahead = false;           // ... or whose whole first iteration up to the M-step has run beside the previous registration, in the twin slot (PairNext::ahead)
     if (late && c->pair.state == 2) {
         const tdlo_ctx::PairNext &pn = c->pair;
         const Slot &sl = c->slots[slots[0]];
-        paired = F == 1 && !priors && !H_override && pn.slot == slots[0] && pn.M == M && pn.n_vis == n_vis && pn.sigma2 == sigma2[0] && same_params(pn.p, *p) &&
-                 std::memcmp(pn.Y.data(), Y, sizeof(double) * 3 * M) == 0 && sl.sorted_valid && sl.sorted_prec == p->precision &&
-                 sl.sorted_Y.size() == 3 * (size_t)M && std::memcmp(sl.sorted_Y.data(), Y, sizeof(double) * 3 * M) == 0 && pn.f.wide_tile != 0;
-        c->pair.state = 0;
+        const bool same = F == 1 && !priors && !H_override && pn.slot == slots[0] && pn.M == M && pn.n_vis == n_vis && pn.sigma2 == sigma2[0] && same_params(pn.p, *p) &&
+                          std::memcmp(pn.Y.data(), Y, sizeof(double) * 3 * M) == 0 && pn.f.wide_tile != 0;
+        if (pn.ahead) paired = ahead = same && c->stream2[0] != nullptr;
+        else paired = same && sl.sorted_valid && sl.sorted_prec == p->precision &&
+                      sl.sorted_Y.size() == 3 * (size_t)M && std::memcmp(sl.sorted_Y.data(), Y, sizeof(double) * 3 * M) == 0;
+        c->pair.state = 0; c->pair.ahead = false;
     }
     // its first M-step may already be waiting on the stream (launched by the previous call, below): released when the priors are staged, told to
     // leave on every other way out of this function
@@ -725,7 +791,11 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     if (late && c->pair.spec) { sg.epoch = c->pair.spec_epoch; sg.live = true; c->pair.spec = 0; }
     if (!paired) sg.release(false);
     c->fh.assign(F, FrameDev{});
-    if (paired) { c->fh[0] = c->pair.f; c->fh[0].reuse_sorted = 1; up = c->pair.up; ++c->route_count[0]; if (c->pair.has_sums) ++c->route_count[1]; }
+    if (paired) {
+        c->fh[0] = c->pair.f; c->fh[0].reuse_sorted = 1; up = c->pair.up;
+        if (ahead) ++c->route_count[4];
+        else { ++c->route_count[0]; if (c->pair.has_sums) ++c->route_count[1]; }
+    }
     for (int pass = 0; pass < 2 && !paired; ++pass) {
     for (int i = 0; i < F; ++i) {
         rc = prepare_frame(c, slots[i], Y + (size_t)i * 3 * M, M, sigma2[i], p, priors, K, vis, n_vis, H_override,
@@ -756,8 +826,9 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         { up = nc.Hb; ++c->route_count[3]; }      // H's 13 diagonals are on the device already (Slot::hb_next): they do not travel
     // tracking_step's main registration: the M-step that finishes it leaves the next frame's LLE regulariser behind (FrameDev::lle_next; the
     // buffer was sized by tracking_step before anything was launched)
-    const bool lle_next = late != nullptr && !merged && c->lle_next_on && !p->include_lle && !c->fh[0].mstep_dense && M <= 256 && p->max_iter > 0 &&
-                          c->slots[slots[0]].hb_next_cap >= M;
+    const bool lle_next = late != nullptr && !merged && !ahead && c->lle_next_on && !p->include_lle && !c->fh[0].mstep_dense && M <= 256 && p->max_iter > 0 &&
+                          c->slots[slots[0]].hb_next_cap >= M;      // (ahead: its first M-step is on the second stream already, without this job -- and the next frame's
+                                                                    //  pre-processing registration, on the first stream, must not race it)
     if (lle_next) { c->fh[0].lle_next = c->slots[slots[0]].hb_next; c->slots[slots[0]].hb_next_valid = false; }
     // Late priors ride beside the set-up kernel only where the E-step can hand them to the M-step (the one-frame kernel, which takes the frame
     // descriptor by value): otherwise they are formed here, before anything is launched, and staged like ordinary ones.
@@ -788,7 +859,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         else { epoch = ++c->mbox_epoch; if (epoch == 0) epoch = ++c->mbox_epoch; }
         c->fh[0].host_out = c->mbox; c->fh[0].host_prog = (unsigned long long *)(c->mbox + c->mbox_doubles - 2); c->fh[0].host_epoch = epoch;
     }
-    hipStream_t s = c->stream;
+    hipStream_t s = ahead ? c->stream2[0] : c->stream;      // (a registration that began on the second stream stays there: its kernels are ordered by the stream)
     const bool timing = c->timing;
     if (timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     const FrameDev *fdp;          // this call's descriptors on the device
@@ -798,9 +869,9 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         fdp = (const FrameDev *)(c->xfer + (size_t)F * up);
     } else {
         if (!paired) std::memcpy(c->pin + nc.fdev, c->fh.data(), sizeof(FrameDev));
-        fdp = (const FrameDev *)((paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk) + nc.fdev);
+        fdp = (const FrameDev *)((ahead ? c->twin.nodeblk : (paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk)) + nc.fdev);
     }
-    double *const nodeblk_used = merged ? nullptr : (paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk);
+    double *const nodeblk_used = merged ? nullptr : (ahead ? c->twin.nodeblk : (paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk));
     if (c->cloud_pending >= 0) {
         // tracking_step staged this frame's cloud in pinned host memory: the fused prologue reads it from there; any other route gets a copy first
         const bool fused = !merged && !paired && c->direct_in && c->cloud_pending == slots[0] && !c->fh[0].reuse_sorted && prologue_pair_ok(c->fh[0]);
@@ -879,7 +950,8 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         gs[g] = c->stream2[g - 1];            // (or a shard) occupies one hardware queue, not four
     }
     bool forked = false;
-    bool sums_first = paired && c->pair.has_sums;      // the first iteration is its M-step alone, from the sums the previous registration's first M-step left
+    bool sums_first = paired && !ahead && c->pair.has_sums;      // the first iteration is its M-step alone, from the sums the previous registration's first M-step left
+    bool ahead_first = ahead;                          // the first iteration is on the second stream already: its M-step waits for the priors staged above
     bool spec_released = false;                        // ... and that M-step had been launched ahead and was released by this call
     int enqueued = 0;                                  // iterations this call has put on the stream (or released)
     // test hook: the M-step launched ahead is told to leave instead of being released, as if it had given up waiting (2 s without the host)
@@ -887,10 +959,16 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     auto iterate = [&](int n) -> hipError_t {
         for (int it = 0; it < n; ++it) {
             ++enqueued;
-            if (sums_first) {
-                sums_first = false;
-                if (sg.live) { sg.release(!spec_force_timeout); spec_released = true; ++c->route_count[2]; }      // it is on the stream already: the priors are staged, off it goes
-                else TDLO_RET(launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s));
+            if (sums_first || ahead_first) {
+                const bool from_given = sums_first;
+                sums_first = false; ahead_first = false;
+                if (sg.live) { sg.release(!spec_force_timeout); spec_released = true; if (!ahead) ++c->route_count[2]; }      // it is on the stream already: the priors are staged, off it goes
+                else if (from_given) TDLO_RET(launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s));
+                else {          // (ahead, and the waiting M-step was sent away -- no priors after all --: it has cleared its E-step's sums, an ordinary iteration follows it)
+                    c->fh[0].late_mstep = 0;
+                    TDLO_RET(launch_iteration(fdp, c->fh.data(), 1, s));
+                }
+                c->fh[0].late_mstep = 0;               // (later M-steps find the priors in the node block, where the first one put them)
                 continue;
             }
             for (int g = 0; g < NS; ++g) {
@@ -924,7 +1002,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     bool have_readback = false;            // the results are already in pinned memory (early exit after the first iteration; the mailbox)
     auto mbox_done = [&](int min_it, bool need_done, bool *done) -> int {     // 0, or an error code
         unsigned long long w = 0;
-        int wr = mbox_wait(c, epoch, min_it, need_done, &w);
+        int wr = mbox_wait(c, s, epoch, min_it, need_done, &w);
         if (wr == 1 && spec_released) {
             // The M-step launched ahead of its priors gave up waiting for them (this thread was held up for more than the kernel's 2 s) and left
             // without touching anything; what was enqueued behind it ran as a registration that does its own first E-step.  The state on the
@@ -933,9 +1011,10 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             IterState is;
             HIPCHK(c, hipMemcpy(&is, c->fh[0].st, sizeof is, hipMemcpyDeviceToHost));
             int have = is.it;
-            if (!is.done && have == 0 && enqueued > 0) { HIPCHK(c, launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s)); have = 1; }
+            // (ahead: the M-step that left has cleared its E-step's sums -- ordinary iterations from the start)
+            if (!ahead && !is.done && have == 0 && enqueued > 0) { HIPCHK(c, launch_mstep_chain(fdp, c->fh.data(), 1, 1, c->fh[0].precision == TDLO_PREC_F64, s)); have = 1; }
             for (; !is.done && have < enqueued; ++have) HIPCHK(c, launch_iteration(fdp, c->fh.data(), 1, s));
-            wr = mbox_wait(c, epoch, min_it, need_done, &w);
+            wr = mbox_wait(c, s, epoch, min_it, need_done, &w);
         }
         if (wr < 0) return wr;
         if (wr == 1) return fail(c, TDLO_E_HIP, "the stream drained, but the M-step did not report the state of the registration");
@@ -1001,11 +1080,15 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             if (c->lle_next_on && pn.M <= 256 && sl.hb_next_cap >= pn.M) fs.lle_next = sl.hb_next;      // (as the registration itself will set it, above)
             HIPCHK(c, launch_mstep_chain((const FrameDev *)(sl.nodeblk2 + nc2.fdev), &fs, 1, 1, fs.precision == TDLO_PREC_F64, s));
             pn.spec = 1; pn.spec_epoch = e2;
+        } else if (!late && c->pair.state == 3) {
+            // tracking_step with hidden nodes: the main registration's first iteration goes out NOW, on the second stream, beside this registration
+            c->pair.state = 0; c->pair.ahead = false;
+            if (c->spec_on && c->mbox_on && !timing && c->pair.slot == slots[0] && (rc = launch_ahead(c))) { spec_abort(c); return rc; }
         }
         g_prof.mark(g_prof.base + 4);
         bool stop = false;
         if ((rc = mbox_done(first, false, &stop))) { spec_abort(c); return rc; }
-        if (!stop) c->pair.spec = 0;           // (this registration goes on: the waiting M-step has seen that and left)
+        if (!stop && !c->pair.ahead) c->pair.spec = 0;           // (this registration goes on: the waiting M-step has seen that and left; one launched AHEAD keeps waiting)
         g_prof.mark(g_prof.base + 5);
         int launched = first, chunk = 0;
         while (launched < p->max_iter && !stop) {
@@ -1096,7 +1179,8 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             numeric = numeric || is.status == TDLO_E_NUMERIC;
         }
         if (numeric) {
-            c->pair.spec = 0;                  // (a paired M-step launched ahead has seen the error status and left)
+            if (c->pair.ahead) { spec_abort(c); c->pair.state = 0; c->pair.ahead = false; }      // (the repeat is another call: the main registration takes the ordinary route)
+            else c->pair.spec = 0;             // (a paired M-step launched ahead has seen the error status and left)
             c->lle_dense_once = true;
             ++c->band_retries;
             const int rr = run_frames(c, F, slots, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
@@ -1125,13 +1209,14 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (stats) {
             fill_stats(&stats[i], is);
             stats[i].loop_ms = loop_ms; stats[i].total_ms = total_ms; stats[i].host_ms = host_ms;
-            stats[i].sort_reused = paired ? 2 : c->fh[i].reuse_sorted; stats[i].band_retry = c->lle_dense_once ? 1 : 0;
+            stats[i].sort_reused = ahead ? 0 : (paired ? 2 : c->fh[i].reuse_sorted); stats[i].band_retry = c->lle_dense_once ? 1 : 0;      // (ahead: its own prune and sort, in the twin slot)
         }
         if (is.status != 0 && worst == 0) worst = is.status;
     }
     g_prof.mark(g_prof.base + 6);
     c->fh[0].lle_next = nullptr; c->fh[0].spec_flag = nullptr;      // (the measurement entry points relaunch from these descriptors)
-    if (worst != 0 && !late) c->pair.spec = 0;
+    if (worst != 0 && !late && !c->pair.ahead) c->pair.spec = 0;      // (ahead: tracking_step tells the waiting M-step to leave)
+    if (ahead) c->twin_busy = false;       // (what may still be on the second stream are no-op iterations on the twin slot's device buffers)
     if (worst == TDLO_E_EMPTY) return fail(c, worst, "every point was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
     if (worst == TDLO_E_NUMERIC) return fail(c, worst, "non-finite or non-positive sigma2, or singular M-step system");
     return TDLO_OK;
@@ -1192,6 +1277,8 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &q : c->stream2) if (q) hipStreamSynchronize(q);
+    c->slots.push_back(c->twin);          // (freed with the others)
     for (auto &s : c->slots) {
         if (s.Xraw) hipFree(s.Xraw);
         if (s.Xs) hipFree(s.Xs);
@@ -2064,7 +2151,7 @@ int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
-long long tdlo_debug_route_count(tdlo_ctx *c, int which) { return (c && which >= 0 && which < 4) ? c->route_count[which] : -1; }
+long long tdlo_debug_route_count(tdlo_ctx *c, int which) { return (c && which >= 0 && which < 5) ? c->route_count[which] : -1; }
 
 int tdlo_debug_lle_band_device(tdlo_ctx *c, const double *Y, int M, double *Hb) {
     if (!c) return TDLO_E_INVALID;
@@ -2283,6 +2370,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     t->priors.clear();                                                   // :908
     int rc = TDLO_OK;
     g_prof.start(); g_prof.base = 0;
+    bool staged = false;          // this frame's cloud is in the pinned staging buffer
     if (X && N > 0 && c->cloud_direct_on && c->direct_in && N <= 16384) {
         // a cloud the fused prologue can take (up to 64 point workgroups): staged in pinned host memory, read from there by the prologue itself
         HIPCHK(c, hipSetDevice(c->device));
@@ -2291,6 +2379,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
         std::memcpy(c->cloud_pin, X, 3 * (size_t)N * sizeof(double));
         s.N0 = N; s.sorted_valid = false;
         c->cloud_pending = t->slot;
+        staged = true;
     }
     else if (X) rc = set_cloud_impl(c, t->slot, X, N, false);            // X_orig by value: one upload for both registrations (X stays the caller's
                                                                          // until this function returns; the first registration's read-back waits for the copy)
@@ -2320,18 +2409,32 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     // every node visible: both registrations start from t->Y, and the main one's node-side set-up depends on nothing the pre-processing one
     // produces -- the pre-processing registration's prologue is asked to do it as well (tdlo_ctx::PairNext; run_frames takes it up if it can)
     if (c->lle_next_on && M <= 256 && (rc = ensure_hb_next(c, c->slots[t->slot], M))) return rc;
-    c->pair.state = 0;
+    c->pair.state = 0; c->pair.ahead = false;
     if (Mg == M && c->pair_on && c->sort_reuse && c->late_on && c->direct_in && check_params(c, M, &mp) == 0) {
         tdlo_ctx::PairNext &pn = c->pair;
         pn.slot = t->slot; pn.M = M; pn.n_vis = n_ext; pn.sigma2 = t->sigma2; pn.p = mp; pn.Y = t->Y;
         pn.state = 1;
+    } else if (Mg != M && staged && c->ahead_on && c->pair_on && c->late_on && c->direct_in && c->spec_on && c->mbox_on && !c->timing && M <= 256 &&
+               mp.max_iter > 0 && check_params(c, M, &mp) == 0) {
+        // hidden nodes: the registrations start from different node sets, but the main one's prologue, k_dmin and first E-step need nothing the
+        // pre-processing one produces -- they are asked to run beside it (PairNext::ahead; the pre-processing registration's run_frames launches
+        // them).  What they will point at is sized here, before anything is launched: the larger registration's mailbox and late-priors buffer
+        const NodeCarve ncm(M);
+        if ((rc = ensure_mbox(c, ncm.readback + 4)) || (rc = ensure_late(c, 4 * (size_t)M + 2))) return rc;
+        tdlo_ctx::PairNext &pn = c->pair;
+        pn.slot = t->slot; pn.M = M; pn.n_vis = n_ext; pn.sigma2 = t->sigma2; pn.p = mp; pn.Y = t->Y; pn.cloud_in_pin = true;
+        pn.state = 3;
     }
     g_prof.mark(1);
     c->iter_hint = t->last_iters[0]; c->iter_hint_next = t->last_iters[1];
     rc = tdlo_cpd_lle_resident(c, t->slot, t->guide_nodes.data(), Mg, &sigma2_pre, &pp, nullptr, 0, nullptr, 0, H_pre, &st_pre);
     t->last_iters[0] = rc ? 0 : st_pre.iters;
     if (stats) stats[0] = st_pre;
-    if (rc) { c->pair.state = 0; c->iter_hint = 0; c->iter_hint_next = 0; spec_abort(c); (void)flush_pending_cloud(c); (void)hipStreamSynchronize(c->stream); return rc; }        // (an early error return may not have waited for the cloud's copy yet)
+    if (rc) {        // (an early error return may not have waited for the cloud's copy yet; what was launched ahead is told to leave and drained)
+        c->pair.state = 0; c->pair.ahead = false; c->iter_hint = 0; c->iter_hint_next = 0; spec_abort(c); (void)flush_pending_cloud(c); (void)hipStreamSynchronize(c->stream);
+        if (c->twin_busy && c->stream2[0]) { (void)hipStreamSynchronize(c->stream2[0]); c->twin_busy = false; }
+        return rc;
+    }
 
     std::vector<int> ve(vis_ext, vis_ext + n_ext);
     std::vector<double> p1, p2;
@@ -2394,7 +2497,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
     t->last_iters[1] = rc ? 0 : st_main.iters;
     c->iter_hint = 0; c->iter_hint_next = 0;
-    c->pair.state = 0; spec_abort(c);
+    c->pair.state = 0; c->pair.ahead = false; spec_abort(c);
     if (c->cloud_pending >= 0) { const int frc = flush_pending_cloud(c); if (!rc) rc = frc; }
     if (stats) stats[1] = st_main;
     return rc;

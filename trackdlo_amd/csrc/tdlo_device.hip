@@ -928,7 +928,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const size_t ld = f.ldx;
     // first wave of loads: iteration state, this wave's first points, nodes for the LDS copy
     const int done = stg->done;
-    if (SINGLE && f.late_aJ != nullptr && blockIdx.x == 0 && stg->it == 0) {
+    if (SINGLE && f.late_aJ != nullptr && f.late_mstep == 0 && blockIdx.x == 0 && stg->it == 0) {
         // (tracking_step's second registration) the priors the host formed while the set-up kernel ran: to their place in the node block, for the
         // M-step of this and every later iteration
         double *dj = (double *)f.aJ, *dy = (double *)f.aYd;

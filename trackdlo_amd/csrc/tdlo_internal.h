@@ -143,6 +143,12 @@ struct FrameDev {
     double *lle_next;
     const double *Xhost;    // k_prologue only: the cloud still in PINNED HOST memory (N0 x 3 column-major) -- its point workgroups read it from there
                             // and put it in Xraw themselves: no host-to-device copy in front of the frame's first kernel.  nullptr: Xraw holds it
+    // tracking_step with hidden nodes (tdlo_api.cpp, PairNext::ahead): the main registration's prologue, k_dmin and first E-step run on a second
+    // stream BESIDE the pre-processing registration (they depend on nothing it produces), and its first M-step waits behind them for the priors
+    // (spec_flag with spec_prev == nullptr: it waits for the host's word only).  That E-step ran before the priors existed and has not copied
+    // them: 1 = the chain smoother reads late_aJ / late_aYd itself although it starts from the accumulators (from_sums == 0) and keeps them in
+    // aJ / aYd for the iterations that follow; the E-step leaves them alone
+    int late_mstep;
 };
 
 // Inbox layout in 64-bit words (R ranks, node capacity Mc); rank r writes the [r] entries of every peer's inbox:

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     const auto Yg = TDLO_AS_GLOBAL(double, f.Y);
     const auto Y0g = TDLO_AS_GLOBAL(double, f.Y0);
     // (late priors of a registration that starts from given sums: no E-step has copied them yet -- read from pinned host memory here, kept below)
-    const bool late_src = TRK && from_sums == 1 && f.late_aJ != nullptr;
+    // (... or whose own first E-step ran before the priors existed: FrameDev::late_mstep)
+    const bool late_src = TRK && f.late_aJ != nullptr && (from_sums == 1 || f.late_mstep != 0);
     const auto aJg = TDLO_AS_GLOBAL(double, late_src ? f.late_aJ : f.aJ);
     const auto aYg = TDLO_AS_GLOBAL(double, late_src ? f.late_aYd : f.aYd);
     const auto chg = TDLO_AS_GLOBAL(dbl2, f.chain);
@@ -221,8 +222,10 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     // for the iteration counter (M <= 512: at most 9 elements per thread).  Requested before the slot: its index arithmetic
     // runs while these are in flight.
     if (TRK && f.spec_flag != nullptr) {      // launched ahead of its priors (FrameDev::spec_flag)
-        const auto pv = TDLO_AS_GLOBAL(IterState, f.spec_prev);
-        if (!(pv->done != 0 && pv->status == 0)) return;
+        if (f.spec_prev != nullptr) {             // (nullptr: launched on a stream of its own beside that registration -- the host's word alone decides)
+            const auto pv = TDLO_AS_GLOBAL(IterState, f.spec_prev);
+            if (!(pv->done != 0 && pv->status == 0)) return;
+        }
         if (t == 0) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
             int go = 0;
@@ -237,7 +240,12 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         __syncthreads();
         const bool go = red[31] != 0.0;
         __syncthreads();
-        if (!go) return;
+        if (!go) {
+            // sent away with this registration's own first E-step already behind it (FrameDev::late_mstep): the sums nobody takes are cleared, so
+            // that the registration can start over the ordinary way (its first E-step adds to parity 0 again)
+            if (f.late_mstep != 0 && from_sums == 0) acc_clear_other<MB>(f, 1, t);
+            return;
+        }
     }
     const int itn = stg->it;
     double sq[9];
@@ -327,12 +335,12 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         } else {
             for (int i = t; i < nS; i += MB) S[i] = sums[i];
         }
-        if (late_src && pri) {      // ... and to their place in device memory for the iterations that follow
-            double *aJw = (double *)f.aJ, *aYw = (double *)f.aYd;
+    }
+    if (late_src && pri) {      // the late priors to their place in device memory for the iterations that follow
+        double *aJw = (double *)f.aJ, *aYw = (double *)f.aYd;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = t + u * MB; if (i < M) aJw[i] = kq[u]; else if (i < 4 * M) aYw[i - M] = kq[u]; }
-            for (int i = t + 4 * MB; i < 4 * M; i += MB) aYw[i - M] = aYg[i - M];
-        }
+        for (int u = 0; u < 4; ++u) { const int i = t + u * MB; if (i < M) aJw[i] = kq[u]; else if (i < 4 * M) aYw[i - M] = kq[u]; }
+        for (int i = t + 4 * MB; i < 4 * M; i += MB) aYw[i - M] = aYg[i - M];
     }
     __syncthreads();
     if (from_sums == 2) {       // split mode, export only
@@ -1034,7 +1042,7 @@ template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd,
         if (F != 1) return hipErrorInvalidValue;
         if ((e = set_lds_c(k_mstep_chain<T, true, true>, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_mstep_chain<T, true, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
-    } else if (F == 1 && (fh[0].spec_flag != nullptr || fh[0].lle_next != nullptr || (from_sums == 1 && fh[0].late_aJ != nullptr))) {
+    } else if (F == 1 && (fh[0].spec_flag != nullptr || fh[0].lle_next != nullptr || ((from_sums == 1 || fh[0].late_mstep != 0) && fh[0].late_aJ != nullptr))) {
         if ((e = set_lds_c(k_mstep_chain<T, true, false, true>, lds)) != hipSuccess) return e;
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false, true>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
         else hipLaunchKernelGGL((k_mstep_chain<T, true, false, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
