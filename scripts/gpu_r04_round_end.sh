@@ -43,6 +43,10 @@ run track_timeline $O/track_timeline_run.log bash scripts/gpu_r04_track_trace.sh
 cp gpurun_out/r04_track_trace_${tag}_tl/timeline.txt $O/tracking_step_timeline.txt 2>/dev/null || FAILED="$FAILED timeline_copy"
 run track_timeline_classic $O/track_timeline_classic_run.log bash scripts/gpu_r04_track_trace.sh ${tag}_tlc TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0
 cp gpurun_out/r04_track_trace_${tag}_tlc/timeline.txt $O/tracking_step_timeline_copy_route.txt 2>/dev/null
+run track_timeline_hidden $O/track_timeline_hidden_run.log bash scripts/gpu_r04_track_trace.sh ${tag}_tlh OCCL=1
+cp gpurun_out/r04_track_trace_${tag}_tlh/timeline.txt $O/tracking_step_timeline_hidden_nodes.txt 2>/dev/null || FAILED="$FAILED timeline_hidden_copy"
+run track_timeline_hidden_after $O/track_timeline_hidden_after_run.log bash scripts/gpu_r04_track_trace.sh ${tag}_tlha OCCL=1 TDLO_AHEAD=0
+cp gpurun_out/r04_track_trace_${tag}_tlha/timeline.txt $O/tracking_step_timeline_hidden_nodes_ahead_off.txt 2>/dev/null
 # 3. HBM traffic: separate PMC passes (never together with a trace), C2
 cd /tmp
 run pmc_fetch $O/pmc_fetch.log timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p_fetch -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs --pmc off </dev/null
@@ -81,8 +85,11 @@ sec() { echo "== $1"; shift; "$@" 2>&1 | grep -v amdgpu.ids; local rc=${PIPESTAT
   sec "track C++ caller: every frame a new cloud of a moving rope (MOVE=10: 1 mm per frame, fresh noise)" env MOVE=10 scripts/ubench/track_cpp
   sec "track C++ caller: the same, round 4's first form (TDLO_PAIR_SETUP=0 TDLO_LLE_NEXT=0 TDLO_DIRECT_CLOUD=0)" env MOVE=10 TDLO_PAIR_SETUP=0 TDLO_LLE_NEXT=0 TDLO_DIRECT_CLOUD=0 scripts/ubench/track_cpp
   sec "track C++ caller: the same, copy route (TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0)" env MOVE=10 TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0 scripts/ubench/track_cpp
-  sec "track C++ caller: nodes 18-24 hidden (the registrations start from different node sets: no pairing; the pre-processing one takes ~6 iterations)" env OCCL=1 scripts/ubench/track_cpp
-  sec "track C++ caller: the same with a moving rope" env OCCL=1 MOVE=10 scripts/ubench/track_cpp
+  sec "track C++ caller: nodes 18-24 hidden (the registrations start from different node sets: no pairing; the pre-processing one takes ~6 iterations; the main one's first iteration runs beside it on the second stream)" env OCCL=1 scripts/ubench/track_cpp
+  sec "track C++ caller: the same, main registration launched when the pre-processing one has returned (TDLO_AHEAD=0)" env OCCL=1 TDLO_AHEAD=0 scripts/ubench/track_cpp
+  sec "track C++ caller: nodes 18-24 hidden, host profile" env OCCL=1 TDLO_TRACK_PROFILE=1 scripts/ubench/track_cpp
+  sec "track C++ caller: nodes 18-24 hidden with a moving rope" env OCCL=1 MOVE=10 scripts/ubench/track_cpp
+  sec "track C++ caller: the same, TDLO_AHEAD=0" env OCCL=1 MOVE=10 TDLO_AHEAD=0 scripts/ubench/track_cpp
   sec "track C++ caller: the same, copy route (TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0)" env OCCL=1 MOVE=10 TDLO_HOST_MAILBOX=0 TDLO_DIRECT_UPLOAD=0 scripts/ubench/track_cpp
   sec "c5_5it" env ITERS=5 timeout 200 python scripts/gpu_c5.py
   sec "pcie" timeout 200 python scripts/gpu_pcie.py
