@@ -25,9 +25,12 @@ first = "cloud copy"
 if len(big) < 10:
     # no cloud copies (the fused prologue reads the cloud from pinned host memory itself): a frame starts with its prologue
     big = [i for i, e in enumerate(ev) if "k_prologue" in e[2]]
-    # (a frame with hidden nodes has two: the main registration's runs on the second stream beside the pre-processing registration -- a frame
-    #  starts with the first of a pair less than 30 us apart)
-    big = [i for k, i in enumerate(big) if k == 0 or ev[i][0] - ev[big[k - 1]][0] > 30000]
+    # (a frame with hidden nodes has two: the main registration has its own -- on the second stream beside the pre-processing registration)
+    starts_, seen_chain = [], True
+    for i, e in enumerate(ev):          # a frame starts with the first prologue after a chain M-step (the main registration's) has started
+        if "k_mstep_chain" in e[2]: seen_chain = True
+        elif "k_prologue" in e[2] and seen_chain: starts_.append(i); seen_chain = False
+    big = starts_
     first = "prologue"
 if len(big) < 10:
     big = starts
