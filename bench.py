@@ -88,6 +88,7 @@ LEGS = {
     "c5": dict(steps=40, warmup=3, cpu_iters=3, cpu_repeats=1),
 }
 SUSTAINED_SECONDS = 3.0
+SHADER_CLOCK_HZ = 2.4e9      # nominal engine clock (MI355X_MICROARCH.md); a lone wave keeps it
 LANE_ISSUE_PEAK = FP32_VECTOR_TFLOPS * 1e12 / 2.0      # lane-instructions per second: one FMA per lane and cycle is two of the peak's flops
 # what a full GPU really issues (scripts/ubench/valu_rate.hip, profiles/r03_valu_rate.txt: 8 waves per SIMD, eight independent chains per
 # wave): v_fma_f32 53 T lane-instructions/s -- the clock falls from 2.4 to ~1.87 GHz under that load --, compares / selects / conversions /
@@ -234,7 +235,7 @@ def _flush_c_stdio():
 LINE_LIMIT = 4096       # bytes of the final stdout line (the driver keeps 8 KB of stdout; round 3's 25.7 KB line scrolled out of it)
 DETAIL_FILE = "bench_detail.json"
 _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes_per_launch",
-              "algorithmic_flops_per_launch", "share_of_gpu_time", "iteration_us", "valu_issue_frac", "traffic_over_algorithmic")
+              "algorithmic_flops_per_launch", "share_of_gpu_time", "iteration_us", "valu_issue_frac", "clocks_per_node", "traffic_over_algorithmic")
 
 
 def _compact_roofline(r):
@@ -327,6 +328,8 @@ def _apply_live_traffic(live, roof, roof_all):
             if m.get("valu_insts"):
                 # VALU instructions the kernel really issued per launch (all its waves) x 64 lanes / its duration / the lane-issue peak
                 o["valu_insts_per_launch"] = m["valu_insts"]
+                if not o["kernel"].startswith("k_estep"):
+                    continue        # a one-workgroup M-step against a 256-CU issue peak is noise: its number is clocks_per_node
                 o["valu_issue_frac"] = round(m["valu_insts"] * 64.0 / (o["avg_launch_us"] * 1e-6) / LANE_ISSUE_PEAK, 5)
                 o["valu_issue_frac_source"] = "this run: rocprofv3 --pmc SQ_INSTS_VALU (a third child pass), instructions x 64 lanes / avg_launch_us / (fp32 vector peak / 2)"
                 o["valu_issue_frac_of_sustained_fma_rate"] = round(m["valu_insts"] * 64.0 / (o["avg_launch_us"] * 1e-6) / LANE_ISSUE_SUSTAINED, 5)
@@ -480,6 +483,10 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
     tot = sum(o["avg_launch_us"] for o in objs)
     for o in objs:
         o["share_of_gpu_time"] = round(o["avg_launch_us"] / tot, 4)
+        if o["kernel"].startswith("k_mstep"):
+            # what one can act on in a one-workgroup M-step: shader clocks of the launch per chain node (the critical wave issues one dependent
+            # instruction per ~8 clocks; nominal 2.4 GHz -- the phase split is scripts/gpu_chain_stamps.py / gpu_band_stamps.py, profiles/*_measured.log)
+            o["clocks_per_node"] = round(o["avg_launch_us"] * 1e-6 * SHADER_CLOCK_HZ / M, 1)
     objs.sort(key=lambda o: -o["avg_launch_us"])
     dom = dict(objs[0])
     dom["iteration_us"] = round(iter_us, 3)
