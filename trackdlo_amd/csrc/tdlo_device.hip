@@ -35,6 +35,49 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 // prune, trackdlo.cpp:177-195, fused with the sigma2 initialisation sum of :263-273
 // ------------------------------------------------------------------------------------------------
+// One point against the M nodes staged in LDS (Yl: x | y | z, M each, kPrunePad doubles readable behind them): the smallest |y_m - x|^2 with the
+// FIRST index that attains it (strict <, as the reference's loop keeps the first minimum), and the sum of all M values in node order (:263-273).
+// Per node the compiler had made 3 subtractions, 3 multiply-adds, a compare, THREE selects (a 64-bit select is two v_cndmask_b32) and the sum's
+// add, with the next compare waiting for the selected minimum, and it waited for every group's LDS reads right after requesting them.  Here the
+// minimum is one v_min_f64 (a NaN or an infinite value leaves it alone exactly as the failed compare did), compare and index select hang off the
+// OLD minimum (loop-carried chain: one instruction), and a group's coordinates are requested one group ahead (no index clamp: the reads behind
+// the chain's end land in the pad and are never used).  Same values, same order of the sum: the bits of before.
+constexpr int kPrunePad = 4;
+__device__ __forceinline__ void nearest_node(const double *Yl, int M, double x, double y, double z, double &best_o, int &a0_o, double &sum_o) {
+    double best = 1e300, sum = 0;
+    int a0 = 0;
+    double nx[4], ny[4], nz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { nx[k] = Yl[k]; ny[k] = Yl[M + k]; nz[k] = Yl[2 * M + k]; }
+    int m0 = 0;
+    for (; m0 + 4 <= M; m0 += 4) {
+        double qx[4], qy[4], qz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { qx[k] = nx[k]; qy[k] = ny[k]; qz[k] = nz[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { nx[k] = Yl[m0 + 4 + k]; ny[k] = Yl[M + m0 + 4 + k]; nz[k] = Yl[2 * M + m0 + 4 + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double dx = qx[k] - x, dy = qy[k] - y, dz = qz[k] - z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            a0 = d2 < best ? m0 + k : a0;
+            best = __builtin_fmin(best, d2);
+            sum += d2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (m0 + k < M) {                               // (wave-uniform)
+            const double dx = nx[k] - x, dy = ny[k] - y, dz = nz[k] - z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            a0 = d2 < best ? m0 + k : a0;
+            best = __builtin_fmin(best, d2);
+            sum += d2;
+        }
+    }
+    best_o = best; a0_o = a0; sum_o = sum;
+}
+
 __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restrict__ frames) {
     const FrameDev &f = frames[blockIdx.y];
     if ((int)blockIdx.x >= f.nprune_blocks) return;
@@ -52,15 +95,9 @@ __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restri
         const bool valid = n < N0;
         double x = 0, y = 0, z = 0;
         if (valid) { x = f.Xraw[n]; y = f.Xraw[(size_t)N0 + n]; z = f.Xraw[2 * (size_t)N0 + n]; }
-        double best = 1e300, sum = 0;
-        int a0 = 0;
-#pragma unroll 4
-        for (int m = 0; m < M; ++m) {
-            const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < best) { best = d2; a0 = m; }
-            sum += d2;
-        }
+        double best, sum;
+        int a0;
+        nearest_node(Yl, M, x, y, z, best, a0, sum);
         const bool keep = valid && (::sqrt(best) < 0.1);
         // the kept points are stored sorted by their nearest node (stable), which makes the points of a
         // wave spatially coherent: the E-step then only touches the few nodes with non-zero membership
@@ -425,30 +462,14 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         }
     }
     SSTAMP(6);
-    if (FUSED) {
-        // the point workgroups have published their counts and their shares of the sigma2 initialisation sum: the kept-point count (integers: any
-        // order) and the sum in the order of the unfused kernel -- thread b holds workgroup b's share, the butterfly of wave_sum, the waves left
-        // to right (up to 64 workgroups: only wave 0 holds anything)
-        fuse_wait(f, fuse_epoch);
-        const int nbp = f.nprune_blocks;
-        int cnt = 0;
-        for (int i = t; i < nbp * M; i += kBlock) cnt += __hip_atomic_load(f.hist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double sh = 0.0;
-        if (t < nbp) sh = __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)f.blksum + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-        const double ssum = wave_sum(sh);
-        __shared__ int wcn[4];
-        __shared__ double wsd2[4];
-        if ((t & 63) == 0) { wcn[t >> 6] = cnt; wsd2[t >> 6] = ssum; }
-        __syncthreads();
-        if (t == 0) { sN = wcn[0] + wcn[1] + wcn[2] + wcn[3]; sS = ((wsd2[0] + wsd2[1]) + wsd2[2]) + wsd2[3]; }
-        __syncthreads();
-        SSTAMP(7);
-    }
+    // (FUSED: the kept-point count, the sigma2 initialisation sum and with them the iteration-0 state are formed by point workgroup 0 of
+    //  k_prologue, which has the counts in its registers behind the grid barrier anyway -- fused_iter0; this workgroup used to wait for the
+    //  barrier and fetch the counts here: two more memory round trips, ~4 300 clocks, at the end of the kernel's longest workgroup)
+    SSTAMP(7);
+    if (FUSED) return;
     if (t == 0) {
         const int N = sN;
-        if ((!reuse || FUSED) && !split_mode) { f.keep[0] = (double)N; f.keep[1] = sS; }
+        if (!reuse && !split_mode) { f.keep[0] = (double)N; f.keep[1] = sS; }
         st->N = N; st->sum_d2 = sS;
         st->it = 0; st->converged = 1; st->crit = 0; st->Np = 0;
         st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0;
@@ -483,6 +504,22 @@ __global__ __launch_bounds__(kBlock) void k_setup(const FrameDev *__restrict__ f
 // PAIR (tracking_step with every node visible, tdlo_api.cpp PairNext): one more node workgroup, blockIdx = nb + 1, does the same node work for the
 // NEXT registration on this cloud (descriptor f2, its own upload block and node block) -- that registration starts from the same nodes, so the
 // sorted cloud, the counts and the centring offset are the ones formed here, and it needs no prologue of its own.
+// The registration's iteration-0 state from the kept-point count N and the sigma2 initialisation sum (:263-273): what the last lines of
+// setup_body write, for the fused prologue (one thread of point workgroup 0; split_mode does not exist there)
+__device__ __forceinline__ void fused_iter0(const FrameDev &f, int N, double sS) {
+    IterState *st = f.st;
+    f.keep[0] = (double)N; f.keep[1] = sS;
+    st->N = N; st->sum_d2 = sS;
+    st->it = 0; st->converged = 1; st->crit = 0; st->Np = 0;
+    st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0;
+    if (N == 0) { st->status = TDLO_E_EMPTY; st->done = 1; st->sigma2 = f.sigma2_in; }
+    else {
+        double sigma2 = f.sigma2_in;
+        if (sigma2 == 0) sigma2 = sS / (3.0 * (double)f.M * (double)N);     // :271-273
+        set_iter_consts(f, st, sigma2, (double)N);
+    }
+}
+
 template <typename T, bool PAIR>
 __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const double *__restrict__ host_up, double *__restrict__ dev_up, int up_doubles,
                                                      int yin_off, unsigned epoch, const FrameDev f2, const double *__restrict__ host_up2,
@@ -494,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
         return;
     }
     __shared__ double scratch[4];
-    __shared__ double Yl[3 * kFuseMaxNodes];
+    __shared__ double Yl[3 * kFuseMaxNodes + kPrunePad];
     __shared__ double sctr[3];
     __shared__ int lh[kFuseMaxNodes], base[kFuseMaxNodes], wtot[4];
     __shared__ unsigned long long lmask[4 * kFuseMaxNodes];      // per (wave, node): which lanes of the wave keep a point nearest to that node
@@ -520,15 +557,9 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
     __syncthreads();
     PSTAMP(1);
     // ---- prune + nearest node (k_prune_pass1)
-    double best = 1e300, sum = 0;
-    int a0 = 0;
-#pragma unroll 4
-    for (int m = 0; m < M; ++m) {
-        const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        if (d2 < best) { best = d2; a0 = m; }
-        sum += d2;
-    }
+    double best, sum;
+    int a0;
+    nearest_node(Yl, M, x, y, z, best, a0, sum);
     const bool keep = valid && (::sqrt(best) < 0.1);
     const int bk = keep ? a0 : 0xffff;
     if (keep) atomicAdd(&lh[a0], 1);
@@ -550,23 +581,44 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
     fuse_wait(f, epoch);
     PSTAMP(4);
     // ---- this workgroup's start offsets: thread = node
+    int Nk = 0;
+    double Sk = 0.0;
     {
         int tot = 0, pre = 0;
+        // (workgroup 0 also forms the registration's iteration-0 state, fused_iter0: thread i asks for workgroup i's share of the sigma2
+        //  initialisation sum in the same round trip as the counts)
+        unsigned long long sh0 = 0ull;
+        if (b == 0 && t < nb) sh0 = __hip_atomic_load((unsigned long long *)f.blksum + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t < M) {
-#pragma unroll 8
-            for (int bb = 0; bb < nb; ++bb) {
-                const int v = __hip_atomic_load(f.hist + (size_t)bb * M + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tot += v; pre += bb < b ? v : 0;
-            }
+            // (the counts other workgroups published: agent-scope loads, ~1900 clocks each trip -- eight at a time were three trips in a row at
+            //  production size (20 point workgroups).  All of a tier's loads are requested before any is added, the index clamped instead of tested)
+            auto gather = [&](auto KC) __attribute__((always_inline)) {
+                constexpr int K = decltype(KC)::value;
+                int v[K];
+#pragma unroll
+                for (int bb = 0; bb < K; ++bb) v[bb] = __hip_atomic_load(f.hist + (size_t)(bb < nb ? bb : nb - 1) * M + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int bb = 0; bb < K; ++bb) { tot += bb < nb ? v[bb] : 0; pre += bb < b ? v[bb] : 0; }      // (b < nb: a clamped repeat never counts in front of b)
+            };
+            if (nb <= 8) gather(std::integral_constant<int, 8>());
+            else if (nb <= 16) gather(std::integral_constant<int, 16>());
+            else if (nb <= 32) gather(std::integral_constant<int, 32>());
+            else gather(std::integral_constant<int, kFuseMaxBlocks>());
         }
         int incl = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
         if (lane == 63) wtot[w] = incl;
+        __shared__ double wsd2[4];
+        if (b == 0) {           // the sum in the order of the unfused kernel: thread i holds workgroup i's share, the butterfly of wave_sum, the waves left to right
+            const double ssum = wave_sum(__longlong_as_double((long long)sh0));
+            if (lane == 0) wsd2[w] = ssum;
+        }
         __syncthreads();
         int bs = 0;
         for (int q = 0; q < w; ++q) bs += wtot[q];
         if (t < M) base[t] = bs + incl - tot + pre;
+        if (b == 0 && t == 0) { Nk = wtot[0] + wtot[1] + wtot[2] + wtot[3]; Sk = ((wsd2[0] + wsd2[1]) + wsd2[2]) + wsd2[3]; }
     }
     __syncthreads();
     PSTAMP(5);
@@ -586,6 +638,12 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
     }
     PSTAMP(6);
 #undef PSTAMP
+    if (b == 0 && t == 0) {
+        // the kept-point count (the nodes' totals: integers, any order) and the sigma2 initialisation sum -> iteration-0 state of the registration
+        // (of both registrations of a pair: same cloud, same nodes, their own parameters and sigma2); one thread, behind the scatter: nobody waits for it
+        fused_iter0(f, Nk, Sk);
+        if (PAIR) fused_iter0(f2, Nk, Sk);
+    }
 }
 
 template <typename T>
@@ -2066,7 +2124,7 @@ hipError_t launch_prune_and_setup(const FrameDev *fd, const FrameDev *fh, int F,
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     bool reuse = true;                      // every frame's sorted cloud serves as it is: neither prune nor scatter
     for (int i = 0; i < F; ++i) reuse = reuse && fh[i].reuse_sorted;
-    if (!reuse) hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
+    if (!reuse) hipLaunchKernelGGL(k_prune_pass1, dim3(gx, F), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * (3 * fh[0].M + kPrunePad), s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double, false>), dim3(F), dim3(kBlock), 0, s, fd, fh[0], 0, (const double *)nullptr, (double *)nullptr, 0, 0);
     else hipLaunchKernelGGL((k_setup<float, false>), dim3(F), dim3(kBlock), 0, s, fd, fh[0], 0, (const double *)nullptr, (double *)nullptr, 0, 0);
     if (!reuse) {
@@ -2154,7 +2212,7 @@ hipError_t launch_estep_only(const FrameDev *fd, const FrameDev *fh, int F, int 
 
 hipError_t launch_split_setup(const FrameDev *fd, const FrameDev *fh, hipStream_t s) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
-    hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * 3 * fh[0].M, s, fd);
+    hipLaunchKernelGGL(k_prune_pass1, dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * ((fh[0].M + 3) & ~3) + sizeof(double) * (3 * fh[0].M + kPrunePad), s, fd);
     if (f64) hipLaunchKernelGGL((k_setup<double, false>), dim3(1), dim3(kBlock), 0, s, fd, fh[0], 1, (const double *)nullptr, (double *)nullptr, 0, 0);
     else hipLaunchKernelGGL((k_setup<float, false>), dim3(1), dim3(kBlock), 0, s, fd, fh[0], 1, (const double *)nullptr, (double *)nullptr, 0, 0);
     if (f64) hipLaunchKernelGGL((k_prune_scatter<double>), dim3(fh[0].nprune_blocks, 1), dim3(kBlock), sizeof(int) * 5 * fh[0].M, s, fd);
