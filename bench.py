@@ -273,6 +273,10 @@ def _compact(full):
     if full.get("roofline_kernels"):
         o["roofline_kernels"] = [{k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_us", "traffic") if k in r} for r in full["roofline_kernels"]]
     o["cpu_baseline"] = _compact_cpu(full.get("cpu_baseline"))
+    par = (full.get("cpu_baseline") or {}).get("parity")
+    if par:         # the in-run parity figure (fatal outside the gate: _parity): max |dY| GPU vs CPU oracle on the workload's own inputs
+        o["parity"] = dict(max_abs_dY_m=float(f"{par['max_abs_dY_m']:.3e}"), rel_dsigma2=float(f"{par['rel_dsigma2']:.3e}"), gate_m=par["gate_m"],
+                           iterations=par["iterations"])
     legs = {}
     for name, r in (full.get("configs") or {}).items():
         if "error" in r:
@@ -280,7 +284,8 @@ def _compact(full):
             continue
         rf, cb = r.get("roofline") or {}, r.get("cpu_baseline") or {}
         legs[name] = dict(value=r.get("value"), ms_per_step=r.get("ms_per_step"), dtype=r.get("dtype"), roofline_kernel=rf.get("kernel"), roofline_frac=rf.get("frac"),
-                          avg_launch_us=rf.get("avg_launch_us"), traffic=rf.get("traffic"), cpu_value=cb.get("value"))
+                          avg_launch_us=rf.get("avg_launch_us"), traffic=rf.get("traffic"), cpu_value=cb.get("value"),
+                          parity_dY_m=(float(f"{cb['parity']['max_abs_dY_m']:.2e}") if cb.get("parity") else None))
     if legs:
         o["configs"] = legs
     if "sustained" in full:
@@ -344,6 +349,7 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="override the frames registered concurrently per rank (c2: 1, c3: 32)")
     ap.add_argument("--mode", choices=["frames", "nsplit"], default=None, help="deprecated alias: nsplit == --config c4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-repeats", type=int, default=None, help="runs of the oracle's loop behind cpu_baseline.value (default per config; the median is reported)")
     ap.add_argument("--no-legs", action="store_true", help="default run (1 GPU, c2): skip the c3 / c4 / c5 legs, the sustained leg and the pre-processing leg")
     ap.add_argument("--pmc", choices=["auto", "off", "child"], default="auto",
                     help="auto: at N = 1 collect roofline.traffic in two rocprofv3 --pmc child passes; child: the pass itself (the calls only, no output)")
@@ -368,6 +374,8 @@ def main():
         cfg["steps"] = args.steps
     if args.warmup is not None:
         cfg["warmup"] = args.warmup
+    if args.cpu_repeats is not None:
+        cfg["cpu_repeats"] = max(1, args.cpu_repeats)
 
     dist = torch = None
     backend = os.environ.get("TDLO_BENCH_BACKEND", "nccl")      # "gloo" only lets the rank logic run on a box with fewer GPUs than ranks
@@ -401,6 +409,8 @@ def main():
                 res["configs"][name] = dict({k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "scaling", "config",
                                                                  "roofline", "roofline_kernels", "cpu_baseline", "gpu_over_cpu") if k in r},
                                             leg_seconds=round(time.perf_counter() - t0, 1))
+            except ParityError:             # ... except when it shows the GPU path to be WRONG: then nothing of this run is a result
+                raise
             except Exception as e:          # a leg must not take the headline down
                 res["configs"][name] = dict(error=f"{type(e).__name__}: {e}")
     if dist is not None:
@@ -493,7 +503,30 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
     return dom, objs
 
 
-def _cpu_baseline(cfg, X0, Y00, kw, g_single):
+class ParityError(RuntimeError):
+    """The GPU path and the CPU oracle disagree on the bench's own inputs: no figure of this run means anything."""
+
+
+# the stated tolerances (SURVEY.md 8(c), tests/test_parity_gpu.py): (max |dY| in metres, |d sigma2| / sigma2) after the same number of iterations
+PARITY_GATES = {"f32": (1e-5, 1e-3), "f64": (1e-9, 1e-7)}
+
+
+def _parity(cfg, gpu, o):
+    """GPU registration against the oracle's on the same (cloud, Y0) after the same iterations; raises ParityError outside the stated gate."""
+    gate_y, gate_s = PARITY_GATES[cfg["prec"]]
+    dy = float(np.abs(np.asarray(gpu["Y"]) - o["Y"]).max())
+    ds = float(abs(gpu["sigma2"] - o["sigma2"]) / o["sigma2"])
+    par = dict(max_abs_dY_m=dy, rel_dsigma2=ds, iterations=int(o["iters"]), gate_m=gate_y, gate_rel_sigma2=gate_s,
+               ok=bool(dy <= gate_y and ds <= gate_s and int(gpu["iters"]) == int(o["iters"])))
+    if not par["ok"]:
+        raise ParityError(f"bench.py: GPU and CPU oracle disagree on the bench workload (N={cfg['N']}, M={cfg['M']}, {cfg['prec']}): max|dY| = {dy:.3e} m "
+                          f"(gate {gate_y:g}), |d sigma2|/sigma2 = {ds:.3e} (gate {gate_s:g}), iterations GPU {gpu['iters']} / oracle {o['iters']}")
+    return par
+
+
+def _cpu_baseline(cfg, X0, Y00, kw, gpu_run):
+    """The oracle timed on (X0, Y00); `gpu_run(max_iter)` registers the SAME pair on the GPU for the same iterations (the caller stages X0 first)
+    and the two results must agree inside the stated gate -- the bench's in-run parity figure, fatal when it fails."""
     from oracle import ref_cpu
     kws = dict(kw, max_iter=cfg["cpu_iters"])
     rates, o = [], None
@@ -506,8 +539,9 @@ def _cpu_baseline(cfg, X0, Y00, kw, g_single):
                sample_short=f"1 frame N={cfg['N']} M={cfg['M']}, first {cfg['cpu_iters']} of {EM_ITERS} iterations, median of {cfg['cpu_repeats']} run(s) of the oracle's loop body",
                seconds=round(time.perf_counter() - t0, 2),
                note="oracle/ref_cpu.c: plain-C fp64 restatement of trackdlo.cpp:275-438, -O3, single thread like the reference")
-    if g_single is not None and cfg["cpu_iters"] == EM_ITERS:
-        cpu["max_abs_dY_vs_gpu_m"] = float(np.abs(g_single["Y"] - o["Y"]).max())
+    if gpu_run is not None:
+        cpu["parity"] = _parity(cfg, gpu_run(cfg["cpu_iters"]), o)
+        cpu["max_abs_dY_vs_gpu_m"] = cpu["parity"]["max_abs_dY_m"]
     try:        # secondary column: the same restatement with OpenMP over the points on the host cores this process is granted
         hc = ref_cpu.host_cores()
         probe = {}
@@ -727,8 +761,13 @@ def bench_frames(args, cfg, env):
             X0, Y00, _ = synth.scene(N, M, config=cfg_id, frame=0)
             kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                       include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
-            g = ctx.cpd_lle_resident(0, Ys[0], 0.0, params) if cfg["cpu_iters"] == EM_ITERS else None
-            cpu = _cpu_baseline(cfg, X0, Y00, kw, g)
+
+            def gpu_run(iters):
+                # slot 0 may hold anything by now (the pre-processing leg stages its own 5 000-point cloud there: VERDICT r04, weak 1): stage the
+                # oracle's own inputs again, then the same registration for the same number of iterations
+                ctx.set_cloud(0, X0)
+                return ctx.cpd_lle_resident(0, Y00, 0.0, B.make_params(**dict(kw, max_iter=iters, precision=prec)))
+            cpu = _cpu_baseline(cfg, X0, Y00, kw, gpu_run)
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         out["cpu_baseline"] = cpu
     ctx.close()
@@ -851,10 +890,16 @@ def bench_nsplit(args, cfg, env):
                     timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"],
                     roofline=roof, roofline_kernels=roof_all)
         cpu = None
+
+        def gpu_run(iters):
+            # the split registration itself on the whole cloud (one rank), staged again: the shard-of-8 figures below leave an eighth of it in the slot
+            ctx.set_cloud(0, Xs)
+            return ctx.split_run(Y0, 0.0, B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], max_iter=iters, tol=0.0, include_lle=False, alpha=0.0,
+                                                        k_vis=0.0, visibility_threshold=P["visibility_threshold"], precision=B.PREC_F32), comm=comm)
         if n_ranks == 1 and cfg.get("leg") and not args.no_cpu_baseline:
             kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                       include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
-            cpu = _cpu_baseline(cfg, Xs, Y0, kw, None)
+            cpu = _cpu_baseline(cfg, Xs, Y0, kw, gpu_run)
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         elif n_ranks == 1:
             # what the split costs on one rank: the plain (unsplit) call on the same cloud, the RCCL form of the same call, and one
@@ -889,7 +934,7 @@ def bench_nsplit(args, cfg, env):
             if not args.no_cpu_baseline:
                 kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                           include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])
-                cpu = _cpu_baseline(cfg, Xs, Y0, kw, None)
+                cpu = _cpu_baseline(cfg, Xs, Y0, kw, gpu_run)
                 line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         line["cpu_baseline"] = cpu
     ctx.close()

@@ -10,7 +10,18 @@ class StubContext:
         self.device = device
 
     def set_cloud(self, slot, X):
-        pass
+        # TDLO_STUB_COMPUTE=1 (the bench's in-run parity gate, tests/test_bench_launch.py): the stand-in "registers" with the CPU oracle (this file is
+        # test infrastructure) so that bench.py's GPU-against-oracle comparison has something to compare; TDLO_STUB_WRONG_CLOUD=1 makes the slot hold
+        # ANOTHER cloud than the one staged (round 4's bench bug: a leg had overwritten slot 0 before the comparison) -- the bench must then fail
+        import os
+        if os.environ.get("TDLO_STUB_COMPUTE"):
+            X = np.array(X, dtype=np.float64)
+            if os.environ.get("TDLO_STUB_WRONG_CLOUD"):
+                X[:, 1] += 0.004
+            if not hasattr(self, "clouds"):
+                self.clouds, self.cache = {}, {}
+            self.clouds[slot] = (X, getattr(self, "version", 0))
+            self.version = getattr(self, "version", 0) + 1
 
     def set_timing(self, on):
         return True
@@ -29,6 +40,16 @@ class StubContext:
         return 0
 
     def cpd_lle_resident(self, slot, Y, sigma2, params, **_):
+        if getattr(self, "clouds", None):
+            from oracle import ref_cpu
+            X, ver = self.clouds[slot]
+            key = (slot, ver, np.asarray(Y).tobytes(), params.max_iter)
+            if key not in self.cache:
+                o = ref_cpu.cpd_lle(X, np.asarray(Y), sigma2, beta=params.beta, lambda_=params.lambda_, lle_weight=params.lle_weight, mu=params.mu,
+                                    max_iter=params.max_iter, tol=params.tol, include_lle=bool(params.include_lle), alpha=params.alpha, k_vis=params.k_vis,
+                                    visibility_threshold=params.visibility_threshold)
+                self.cache[key] = dict(Y=o["Y"], sigma2=o["sigma2"], iters=o["iters"], loop_ms=1.0, n_kept=o["n_kept"], converged=False, rc=0)
+            return dict(self.cache[key], sort_reused=int(getattr(self, "sort_reuse", True)))
         time.sleep(0.001)
         return dict(Y=np.asarray(Y), sigma2=1e-5, iters=params.max_iter, loop_ms=1.0, n_kept=0, converged=False, rc=0,
                     sort_reused=int(getattr(self, "sort_reuse", True)))

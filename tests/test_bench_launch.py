@@ -113,3 +113,19 @@ def test_c4_exchange_negotiation_and_rccl_fallback(fail):
     else:
         assert "one-shot exchange" in par and [e["rccl_size"] for e in line["ranks"]] == [None, None]
     assert "2000000 points split over 2 rank(s) (1000000 per rank)" in line["config"]["workload"]
+
+
+def test_in_run_parity_figure_is_on_the_line_and_fatal():
+    """the bench's own GPU-against-oracle figure compared a registration on whatever a leg had left in slot 0 with the oracle on the
+    C2 cloud (4.5 cm) and nothing looked at it.  Now bench.py stages the oracle's inputs again before the comparison, puts the figure on the line and
+    exits non-zero outside the stated gate.  The stand-in context registers with the oracle here (TDLO_STUB_COMPUTE), so the good case is 0 m; with
+    TDLO_STUB_WRONG_CLOUD the slot holds a cloud 4 mm away from the staged one and the run must fail without a JSON line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--no-legs", "--pmc", "off", "--cpu-repeats", "1"]
+    r = subprocess.run(cmd, env=_env(TDLO_STUB_COMPUTE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["parity"]["max_abs_dY_m"] <= 1e-12 and line["parity"]["gate_m"] == 1e-5 and line["parity"]["iterations"] == 50
+    assert _detail()["cpu_baseline"]["parity"]["ok"] is True
+    r = subprocess.run(cmd, env=_env(TDLO_STUB_COMPUTE="1", TDLO_STUB_WRONG_CLOUD="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "GPU and CPU oracle disagree" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
