@@ -18,7 +18,7 @@ cd $S
 /opt/rocm/bin/hipcc $F -c tdlo_reg.hip -o $B/tdlo_reg.o &
 /opt/rocm/bin/hipcc $F -x hip -c tdlo_api.cpp -o $B/tdlo_api.o &
 /opt/rocm/bin/hipcc $F -x hip -c tdlo_rccl.cpp -o $B/tdlo_rccl.o &
-g++ -O3 -std=c++17 -fPIC $* -c tdlo_host.cpp -o $B/tdlo_host.o &
+g++ -O3 -std=c++17 -fPIC -ffp-contract=off $* -c tdlo_host.cpp -o $B/tdlo_host.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/scripts/tmp/libtrackdlo_$name.so $B/*.o -ldl
 ls -la $R/scripts/tmp/libtrackdlo_$name.so

@@ -498,3 +498,78 @@ def test_a_failing_frame_with_hidden_nodes_leaves_nothing_behind():
             ctx.close()
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+
+
+def _fuse_ctx(B, nth, ahead=True, classic=False, **kw):
+    """nth > 0: the context's nth fused-prologue launch withholds one arrival at its grid barrier (TDLO_FUSE_FORCE_TIMEOUT), so the waiting
+    workgroups give the launch up after 2 s; classic: the copy + three-kernel route from the start (TDLO_DIRECT_UPLOAD=0)."""
+    keys = {"TDLO_FUSE_FORCE_TIMEOUT": str(nth) if nth else None, "TDLO_AHEAD": None if ahead else "0", "TDLO_DIRECT_UPLOAD": "0" if classic else None}
+    for k in ("TDLO_PAIR_SETUP", "TDLO_PAIR_SUMS", "TDLO_SPEC_MSTEP", "TDLO_LLE_NEXT", "TDLO_DIRECT_CLOUD", "TDLO_LATE_PRIORS", "TDLO_HOST_MAILBOX", "TDLO_SPEC_FORCE_TIMEOUT", "TDLO_ITER_HINT"):
+        keys.setdefault(k, None)
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for k, v in keys.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        return B.Context(device=0, timing=False, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f64"])
+def test_an_abandoned_grid_barrier_sends_the_call_to_the_three_kernel_route(prec):
+    """VERDICT r04 missing 4 / ADVICE r04 medium: the fused prologue's grid barrier spun without bound.  Now a workgroup that has waited 2 s abandons
+    the launch, the registration ends with an internal status, and tdlo_cpd_lle_resident repeats the call on the copy + three-kernel route: the
+    caller gets that route's bits, one repeat is counted, the context stays usable and never launches the fused prologue again."""
+    import time
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 5000, 45
+    X, Y0, v = synth.scene(N, M, config=72, occlude=(0.4, 0.6), outliers=7)
+    vext = synth.extend_visible(v, M, synth.geodesic_coord(Y0))
+    p_main = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 50, 2e-4, False, 0.0, P["k_vis"], P["visibility_threshold"], precision=prec)
+    p_lle = B.make_params(P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"], P["mu"], 6, 0.0, True, precision=prec)
+    hit, ref = _fuse_ctx(B, 2, max_points=N, max_nodes=64), _fuse_ctx(B, 0, classic=True, max_points=N, max_nodes=64)
+    try:
+        for c in (hit, ref):
+            c.set_sort_reuse(False)
+            c.set_cloud(0, X)
+        for k, (p, kw) in enumerate([(p_main, dict(visible_nodes=vext)), (p_lle, {}), (p_main, dict(visible_nodes=vext)), (p_lle, {})]):
+            t0 = time.perf_counter()
+            a = hit.cpd_lle_resident(0, Y0, 0.0 if k % 2 == 0 else 3e-5, p, **kw)
+            dt = time.perf_counter() - t0
+            b = ref.cpd_lle_resident(0, Y0, 0.0 if k % 2 == 0 else 3e-5, p, **kw)
+            _same(a, b)
+            ca, oa = hit.debug_read_cloud(N); cb, ob = ref.debug_read_cloud(N)
+            np.testing.assert_array_equal(ca, cb); np.testing.assert_array_equal(oa, ob)
+            assert hit.route_counts()[5] == (0 if k == 0 else 1)
+            assert (dt > 1.9) == (k == 1), (k, dt)          # the second call waited out the barrier's limit, no other call did
+    finally:
+        hit.close(); ref.close()
+
+
+@pytest.mark.parametrize("nth,ahead", [(1, True), (3, True), (4, True), (4, False)],
+                         ids=["paired prologue", "pre-processing prologue of a frame with hidden nodes", "prologue launched ahead in the twin slot", "main registration's own prologue"])
+def test_tracking_step_survives_an_abandoned_grid_barrier(nth, ahead):
+    """The same inside tracking_step (trackdlo.cpp:900-999), at every place a fused prologue is launched from: the pre-processing registration's
+    (with the main registration's set-up riding along when every node is visible), the main registration's own in a frame with hidden nodes, and
+    the one launched ahead on the second stream into the twin slot.  Sixteen frames, the nth fused launch abandoned: every frame's nodes, sigma2,
+    iteration counts, priors and guide nodes are those of a context on the three-kernel route, bit for bit."""
+    from trackdlo_amd import binding as B, synth
+    outs, counts = [], []
+    for classic in (False, True):
+        ctx = _fuse_ctx(B, 0 if classic else nth, ahead=ahead, classic=classic, max_points=5000, max_nodes=64)
+        try:
+            rec, _ = _ahead_sequence(B, synth, ctx, 5000, 45, 0, config=89)
+            outs.append(rec); counts.append(ctx.route_counts())
+        finally:
+            ctx.close()
+    assert counts[0][5] == 1 and counts[1][5] == 0, counts
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])

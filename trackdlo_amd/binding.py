@@ -431,8 +431,9 @@ class Context:
 
     def route_counts(self):
         """[paired set-ups, first iterations from handed-over sums, M-steps released from their wait, device-formed LLE regularisers used,
-        main registrations whose first iteration ran beside the pre-processing one] (tdlo_debug_route_count)."""
-        return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in range(5)]
+        main registrations whose first iteration ran beside the pre-processing one, calls repeated on the three-kernel route after the fused
+        prologue's grid barrier was abandoned] (tdlo_debug_route_count)."""
+        return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in range(6)]
 
     def band_retries(self):
         """Calls of this context that were repeated on the dense pivoted kernels after the banded LLE solve gave up (tdlo_debug_band_retries)."""

@@ -165,9 +165,16 @@ struct tdlo_ctx {
     bool lle_batch_dense = false;         // run_frames: a frame of this batch cannot take the banded LLE solve, all of them are staged for the dense kernels
     bool lle_dense_once = false;          // run_frames' retry: the banded LLE solve reported a numeric failure, this call repeats with the dense pivoted kernels
     long long band_retries = 0;           // how often that happened (tdlo_debug_band_retries)
-    long long route_count[5] = {0, 0, 0, 0, 0};   // tdlo_debug_route_count: 0 paired set-ups taken up, 1 first iterations started from the handed-over sums,
+    long long route_count[6] = {0, 0, 0, 0, 0, 0};   // tdlo_debug_route_count: 0 paired set-ups taken up, 1 first iterations started from the handed-over sums,
                                                // 2 M-steps released from their wait for priors, 3 pre-processing registrations served by a device-formed H,
-                                               // 4 main registrations whose first iteration ran beside the pre-processing registration (PairNext::ahead)
+                                               // 4 main registrations whose first iteration ran beside the pre-processing registration (PairNext::ahead),
+                                               // 5 calls repeated on the three-kernel route because the fused prologue's grid barrier was abandoned (fuse_fallback)
+    // The fused prologue (k_prologue) needs all its workgroups resident at once; its grid barrier gives up after 2 s (tdlo_device.hip, fuse_wait) and
+    // the registration then ends with TDLO_E_FUSE: the call is repeated on the copy + three-kernel route and this context stops using the fused
+    // prologue (a GPU that could not co-schedule <= 66 workgroups once -- masked or partitioned CUs, long-running kernels of other processes -- is
+    // not asked again; every wait costs the caller 2 s).  TDLO_FUSE_FORCE_TIMEOUT=n (test hook): the context's n-th fused launch withholds one arrival.
+    bool fuse_on = true;
+    int fuse_force_timeout = getenv("TDLO_FUSE_FORCE_TIMEOUT") ? atoi(getenv("TDLO_FUSE_FORCE_TIMEOUT")) : 0;
     bool sort_reuse = !(getenv("TDLO_REUSE_SORT") && atoi(getenv("TDLO_REUSE_SORT")) == 0);   // tdlo_set_sort_reuse: a slot's sorted cloud may serve the next registration of the same nodes
     // results mailbox in pinned host memory (FrameDev::host_out / host_prog): [read-back block | progress word], written by the one-workgroup M-steps
     double *mbox = nullptr;
@@ -306,8 +313,18 @@ hipError_t wait_stream(hipStream_t s) {
     return hipStreamSynchronize(s);
 }
 
+// Before a buffer kernels may still be reading or polling is replaced: the first stream, and the second one while something launched ahead
+// into the twin slot may still run there (an abandoned launch keeps polling the spec word / reading the staged cloud for up to 2 s: ADVICE r04)
+hipError_t drain_for_realloc(tdlo_ctx *c) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    if (c->stream2[0]) return hipStreamSynchronize(c->stream2[0]);      // (cheap when idle; only the growth path comes here)
+    return hipSuccess;
+}
+
 int ensure_pin(tdlo_ctx *c, size_t doubles) {
     if (doubles <= c->pin_doubles) return 0;
+    HIPCHK(c, drain_for_realloc(c));
     if (c->pin) hipHostFree(c->pin);
     c->pin = nullptr; c->pin_doubles = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->pin, doubles * sizeof(double), hipHostMallocDefault));
@@ -317,17 +334,18 @@ int ensure_pin(tdlo_ctx *c, size_t doubles) {
 
 int ensure_late(tdlo_ctx *c, size_t doubles) {
     if (doubles <= c->late_doubles) return 0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, drain_for_realloc(c));
     if (c->late_buf) hipHostFree(c->late_buf);
     c->late_buf = nullptr; c->late_doubles = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->late_buf, doubles * sizeof(double), hipHostMallocDefault));
+    std::memset(c->late_buf, 0, doubles * sizeof(double));        // (its last word is the spec flag a kernel launched ahead compares with its epoch)
     c->late_doubles = doubles;
     return 0;
 }
 
 int ensure_mbox(tdlo_ctx *c, size_t doubles) {
     if (doubles <= c->mbox_doubles) return 0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));         // (kernels of an earlier call may still report their progress into the old one)
+    HIPCHK(c, drain_for_realloc(c));         // (kernels of an earlier call may still report their progress into the old one)
     if (c->mbox) hipHostFree(c->mbox);
     c->mbox = nullptr; c->mbox_doubles = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->mbox, doubles * sizeof(double), hipHostMallocDefault));
@@ -381,7 +399,7 @@ int ensure_xfer(tdlo_ctx *c, size_t doubles) {
 
 int ensure_points(tdlo_ctx *c, Slot &s, int n) {
     if (n <= s.cap_points) return 0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, drain_for_realloc(c));
     if (s.Xraw) hipFree(s.Xraw);
     if (s.Xs) hipFree(s.Xs);
     if (s.bucket) hipFree(s.bucket);
@@ -443,7 +461,7 @@ int ensure_hb_next(tdlo_ctx *c, Slot &s, int M) {
 
 int ensure_cloud_pin(tdlo_ctx *c, size_t doubles) {
     if (doubles <= c->cloud_pin_doubles) return 0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, drain_for_realloc(c));
     if (c->cloud_pin) hipHostFree(c->cloud_pin);
     c->cloud_pin = nullptr; c->cloud_pin_doubles = 0;
     const size_t cap = (doubles + 4095) & ~(size_t)4095;
@@ -463,7 +481,7 @@ int flush_pending_cloud(tdlo_ctx *c) {
 
 int ensure_pin2(tdlo_ctx *c, size_t doubles) {
     if (doubles <= c->pin2_doubles) return 0;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, drain_for_realloc(c));
     if (c->pin2) hipHostFree(c->pin2);
     c->pin2 = nullptr; c->pin2_doubles = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->pin2, doubles * sizeof(double), hipHostMallocDefault));
@@ -479,6 +497,38 @@ void spec_release(tdlo_ctx *c, unsigned epoch, bool go) {
 // whatever happens to the call that launched it, a waiting M-step is told to leave
 void spec_abort(tdlo_ctx *c) {
     if (c->pair.spec) { spec_release(c, c->pair.spec_epoch, false); c->pair.spec = 0; }
+}
+
+// the number the next fused prologue on this slot carries in its barrier word ((epoch << 1) | abandoned: 31 bits, never 0); bit 31 of the kernel
+// argument is the test hook that withholds one arrival
+unsigned next_fuse_epoch(tdlo_ctx *c, Slot &sl) {
+    sl.fuse_epoch = sl.fuse_epoch >= 0x7fffffffu ? 1u : sl.fuse_epoch + 1u;
+    if (c->fuse_force_timeout > 0 && --c->fuse_force_timeout == 0) return sl.fuse_epoch | 0x80000000u;
+    return sl.fuse_epoch;
+}
+
+// A registration came back with TDLO_E_FUSE: its fused prologue's grid barrier was abandoned (not all workgroups of the launch became resident
+// within 2 s).  Nothing of the caller's has been touched.  Everything in flight is told to leave and drained, what the abandoned launch left
+// half-made is invalidated (the slots' sorted clouds, the barrier's arrival counter), and the context takes the copy + three-kernel route from now on.
+void fuse_fallback(tdlo_ctx *c) {
+    spec_abort(c);
+    c->pair.state = 0; c->pair.ahead = false; c->pair.has_sums = false;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream2[0]) (void)hipStreamSynchronize(c->stream2[0]);
+    c->twin_busy = false;
+    auto reset = [&](Slot &sl) {
+        sl.sorted_valid = false;
+        if (sl.sync) (void)hipMemsetAsync(sl.sync + 100, 0, 2 * sizeof(unsigned), c->stream);      // arrivals, barrier word (the epochs go on counting)
+    };
+    for (Slot &sl : c->slots) reset(sl);
+    reset(c->twin);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    if (c->fuse_on)
+        std::fprintf(stderr, "trackdlo_hip: the fused prologue's workgroups were not co-resident within 2 s (device %d); this context now uses the "
+                             "copy + three-kernel route (see INTEGRATION.md, co-residency)\n", c->device);
+    c->fuse_on = false;
+    ++c->route_count[5];
 }
 
 bool same_params(const tdlo_params &a, const tdlo_params &b) {
@@ -712,13 +762,13 @@ int launch_ahead(tdlo_ctx *c) {
     FrameDev &f = pn.f;
     if ((rc = prepare_frame(c, -1, pn.Y.data(), M, pn.sigma2, &pn.p, nullptr, 0, nullptr, pn.n_vis, nullptr, c->pin2, f, false))) return rc;
     if (grow) HIPCHK(c, hipStreamSynchronize(c->stream));               // (new buffers are cleared on the first stream)
-    if (!f.wide_tile || f.mstep_dense || f.reuse_sorted || !prologue_pair_ok(f)) return 0;      // not this frame: the main registration takes the ordinary route
+    if (!f.wide_tile || f.mstep_dense || f.reuse_sorted || !c->fuse_on || !prologue_pair_ok(f)) return 0;      // not this frame: the main registration takes the ordinary route
     pn.up = upload_doubles(nc, &pn.p, false);
     f.Xhost = c->cloud_pin;
     std::memcpy(c->pin2 + nc.fdev, &f, sizeof(FrameDev));
-    if (++tw.fuse_epoch == 0) ++tw.fuse_epoch;
+    const unsigned fep = next_fuse_epoch(c, tw);
     c->twin_busy = true;
-    HIPCHK(c, launch_prologue_direct(&f, c->pin2, tw.nodeblk, (int)pn.up, (int)nc.Yin, tw.fuse_epoch, sb));
+    HIPCHK(c, launch_prologue_direct(&f, c->pin2, tw.nodeblk, (int)pn.up, (int)nc.Yin, fep, sb));
     f.Xhost = nullptr;                      // (the cloud is in the twin's Xraw for everything that follows)
     f.late_mstep = 1;                       // the priors do not exist yet: this E-step leaves them alone, the M-step reads them itself
     const FrameDev *fdb = (const FrameDev *)(tw.nodeblk + nc.fdev);
@@ -874,16 +924,16 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     double *const nodeblk_used = merged ? nullptr : (ahead ? c->twin.nodeblk : (paired ? c->slots[slots[0]].nodeblk2 : c->slots[slots[0]].nodeblk));
     if (c->cloud_pending >= 0) {
         // tracking_step staged this frame's cloud in pinned host memory: the fused prologue reads it from there; any other route gets a copy first
-        const bool fused = !merged && !paired && c->direct_in && c->cloud_pending == slots[0] && !c->fh[0].reuse_sorted && prologue_pair_ok(c->fh[0]);
+        const bool fused = !merged && !paired && c->direct_in && c->fuse_on && c->cloud_pending == slots[0] && !c->fh[0].reuse_sorted && prologue_pair_ok(c->fh[0]);
         if (fused) { c->fh[0].Xhost = c->cloud_pin; c->cloud_pending = -1; }
         else if ((rc = flush_pending_cloud(c))) return rc;
     }
     if (paired) {
         // (set up by the previous call's prologue)
-    } else if (!merged && c->direct_in && prologue_direct_ok(c->fh[0])) {
+    } else if (!merged && c->direct_in && (c->fuse_on || c->fh[0].reuse_sorted) && prologue_direct_ok(c->fh[0])) {
         // one small frame (or a reused sort): ONE launch reads the block from pinned host memory, puts it in its place and does the whole prologue
         Slot &sl = c->slots[slots[0]];
-        if (++sl.fuse_epoch == 0) ++sl.fuse_epoch;
+        const unsigned fep = c->fh[0].reuse_sorted ? 0u : next_fuse_epoch(c, sl);      // (a reused sort: the set-up workgroup alone, no barrier)
         // tracking_step asked for the set-up of its second registration to ride along (PairNext): staged like a frame of its own into the second
         // pinned block / the slot's second node block, one more workgroup of the fused prologue
         tdlo_ctx::PairNext &pn = c->pair;
@@ -906,7 +956,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
                 }
             }
         }
-        HIPCHK(c, launch_prologue_direct(c->fh.data(), c->pin, sl.nodeblk, (int)up, (int)nc.Yin, sl.fuse_epoch, s, f2, c->pin2, sl.nodeblk2, f2 ? (int)pn.up : 0));
+        HIPCHK(c, launch_prologue_direct(c->fh.data(), c->pin, sl.nodeblk, (int)up, (int)nc.Yin, fep, s, f2, c->pin2, sl.nodeblk2, f2 ? (int)pn.up : 0));
         c->fh[0].Xhost = nullptr;          // (the cloud is in Xraw for everything that follows)
         if (f2) pn.state = 2;
     } else {
@@ -1214,9 +1264,16 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         if (is.status != 0 && worst == 0) worst = is.status;
     }
     g_prof.mark(g_prof.base + 6);
-    c->fh[0].lle_next = nullptr; c->fh[0].spec_flag = nullptr;      // (the measurement entry points relaunch from these descriptors)
+    {   // the measurement and debug entry points relaunch from these descriptors: nothing of this call's hand-overs may ride along (a stale mailbox
+        // epoch, late priors copied again at it == 0, another registration's sums overwritten through pair_sums: ADVICE r04)
+        FrameDev &f0 = c->fh[0];
+        f0.lle_next = nullptr; f0.spec_flag = nullptr; f0.spec_prev = nullptr;
+        f0.host_prog = nullptr; f0.host_out = nullptr; f0.host_epoch = 0; f0.host_report_it = 0;
+        f0.late_aJ = nullptr; f0.late_aYd = nullptr; f0.late_mstep = 0; f0.pair_sums = nullptr; f0.Xhost = nullptr;
+    }
     if (worst != 0 && !late && !c->pair.ahead) c->pair.spec = 0;      // (ahead: tracking_step tells the waiting M-step to leave)
     if (ahead) c->twin_busy = false;       // (what may still be on the second stream are no-op iterations on the twin slot's device buffers)
+    if (worst == TDLO_E_FUSE) return TDLO_E_FUSE;      // the fused prologue's barrier was abandoned: the entry point repeats the call on the three-kernel route (fuse_fallback)
     if (worst == TDLO_E_EMPTY) return fail(c, worst, "every point was pruned (no point within 0.1 m of a node, trackdlo.cpp:190)");
     if (worst == TDLO_E_NUMERIC) return fail(c, worst, "non-finite or non-positive sigma2, or singular M-step system");
     return TDLO_OK;
@@ -1346,7 +1403,13 @@ int tdlo_cpd_lle_resident(tdlo_ctx *c, int slot, double *Y, int M, double *sigma
     if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
     if (!Y || !sigma2) return fail(c, TDLO_E_INVALID, "null Y / sigma2");
     HIPCHK(c, hipSetDevice(c->device));
-    return run_frames(c, 1, &slot, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+    int rc = run_frames(c, 1, &slot, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+    if (rc == TDLO_E_FUSE) {          // Y, sigma2 and the slot's cloud are untouched: once more, without the fused prologue
+        fuse_fallback(c);
+        rc = run_frames(c, 1, &slot, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+        if (rc == TDLO_E_FUSE) rc = fail(c, TDLO_E_HIP, "the fused prologue reported a time-out on the route that does not use it");
+    }
+    return rc;
 }
 
 int tdlo_cpd_lle(tdlo_ctx *c, const double *X, int N, double *Y, int M, double *sigma2, const tdlo_params *p,
@@ -2151,7 +2214,7 @@ int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
-long long tdlo_debug_route_count(tdlo_ctx *c, int which) { return (c && which >= 0 && which < 5) ? c->route_count[which] : -1; }
+long long tdlo_debug_route_count(tdlo_ctx *c, int which) { return (c && which >= 0 && which < 6) ? c->route_count[which] : -1; }
 
 int tdlo_debug_lle_band_device(tdlo_ctx *c, const double *Y, int M, double *Hb) {
     if (!c) return TDLO_E_INVALID;
@@ -2371,7 +2434,7 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     int rc = TDLO_OK;
     g_prof.start(); g_prof.base = 0;
     bool staged = false;          // this frame's cloud is in the pinned staging buffer
-    if (X && N > 0 && c->cloud_direct_on && c->direct_in && N <= 16384) {
+    if (X && N > 0 && c->cloud_direct_on && c->direct_in && c->fuse_on && N <= 16384) {
         // a cloud the fused prologue can take (up to 64 point workgroups): staged in pinned host memory, read from there by the prologue itself
         HIPCHK(c, hipSetDevice(c->device));
         Slot &s = c->slots[t->slot];
@@ -2410,11 +2473,11 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     // produces -- the pre-processing registration's prologue is asked to do it as well (tdlo_ctx::PairNext; run_frames takes it up if it can)
     if (c->lle_next_on && M <= 256 && (rc = ensure_hb_next(c, c->slots[t->slot], M))) return rc;
     c->pair.state = 0; c->pair.ahead = false;
-    if (Mg == M && c->pair_on && c->sort_reuse && c->late_on && c->direct_in && check_params(c, M, &mp) == 0) {
+    if (Mg == M && c->pair_on && c->sort_reuse && c->late_on && c->direct_in && c->fuse_on && check_params(c, M, &mp) == 0) {
         tdlo_ctx::PairNext &pn = c->pair;
         pn.slot = t->slot; pn.M = M; pn.n_vis = n_ext; pn.sigma2 = t->sigma2; pn.p = mp; pn.Y = t->Y;
         pn.state = 1;
-    } else if (Mg != M && staged && c->ahead_on && c->pair_on && c->late_on && c->direct_in && c->spec_on && c->mbox_on && !c->timing && M <= 256 &&
+    } else if (Mg != M && staged && c->ahead_on && c->pair_on && c->late_on && c->direct_in && c->fuse_on && c->spec_on && c->mbox_on && !c->timing && M <= 256 &&
                mp.max_iter > 0 && check_params(c, M, &mp) == 0) {
         // hidden nodes: the registrations start from different node sets, but the main one's prologue, k_dmin and first E-step need nothing the
         // pre-processing one produces -- they are asked to run beside it (PairNext::ahead; the pre-processing registration's run_frames launches
@@ -2495,6 +2558,14 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     HIPCHK(c, hipSetDevice(c->device));
     c->iter_hint = t->last_iters[1];
     rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
+    if (rc == TDLO_E_FUSE) {
+        // the main registration's own fused prologue (hidden nodes: in the slot, or launched ahead in the twin slot) was abandoned: Y_, sigma2_ and the
+        // cloud in the slot are untouched -- once more on the three-kernel route, the priors formed again from the same guide nodes
+        fuse_fallback(c);
+        t->priors.clear();
+        rc = run_frames(c, 1, &t->slot, t->Y.data(), M, &t->sigma2, &mp, nullptr, 0, vis_ext, n_ext, nullptr, &st_main, &form_priors);
+        if (rc == TDLO_E_FUSE) rc = fail(c, TDLO_E_HIP, "the fused prologue reported a time-out on the route that does not use it");
+    }
     t->last_iters[1] = rc ? 0 : st_main.iters;
     c->iter_hint = 0; c->iter_hint_next = 0;
     c->pair.state = 0; c->pair.ahead = false; spec_abort(c);

@@ -112,24 +112,50 @@ __global__ __launch_bounds__(kBlock) void k_prune_pass1(const FrameDev *__restri
 
 // ---- the fused prologue's grid barrier (k_prologue: up to 64 point workgroups + one node workgroup, all resident at once) ------------------
 // The point workgroups publish their counts with agent-scope stores, wait for them to be performed (vmcnt) and take a ticket; the last one
-// re-arms the counter and raises the flag to this launch's epoch.  Everybody who needs the counts spins on the flag (agent-scope loads) and
-// reads them with agent-scope loads.  (A release fence per workgroup would be an L2 write-back each: tdlo_device.hip, k_dmin.)
+// re-arms the counter and RELEASES the launch: the barrier word goes to (epoch << 1).  Everybody who needs the counts spins on the word
+// (agent-scope loads) and reads them with agent-scope loads.  (A release fence per workgroup would be an L2 write-back each: k_dmin.)
+// The wait is bounded (round 5; the reference's cpd_lle is straight-line CPU code and cannot hang, trackdlo.cpp:161-441): co-residency of the
+// launch's workgroups is an assumption -- a GPU with masked or partitioned CUs, or one kept busy by other long-running kernels, may leave some of
+// them unscheduled while the resident ones spin.  After kFuseSpinTicks (2 s, like every other in-kernel wait of the library) a waiting workgroup
+// ABANDONS the launch: the word goes to (epoch << 1) | 1.  Releasing and abandoning are both compare-and-swaps from a value of ANOTHER epoch, so
+// an epoch's outcome is decided exactly once and every workgroup of the launch -- those scheduled late included -- follows the same one; an
+// abandoned launch ends its registration(s) with TDLO_E_FUSE (fused_fail), the M-step behind it reports that to the host, and the host repeats
+// the call on the three-kernel route (tdlo_api.cpp, fuse_fallback).
 constexpr int kFuseMaxBlocks = 64;       // point workgroups of the fused prologue: clouds of up to 16 384 points
 constexpr int kFuseMaxNodes = 256;       // thread = node in its offset computation
-__device__ __forceinline__ void fuse_arrive(const FrameDev &f, unsigned nblk, unsigned epoch) {      // all threads of a point workgroup
+constexpr unsigned long long kFuseSpinTicks = 200000000ull;      // s_memrealtime ticks (100 MHz): 2 s
+constexpr unsigned kFuseWithhold = 0x80000000u;                  // test hook in the epoch argument (TDLO_FUSE_FORCE_TIMEOUT): the last point workgroup takes no ticket
+// decides epoch's outcome unless it is decided already; returns the decided word
+__device__ __forceinline__ unsigned fuse_decide(unsigned *word, unsigned epoch, unsigned want) {
+    unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((v >> 1) != epoch) {
+        if (__hip_atomic_compare_exchange_strong(word, &v, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return want;
+    }
+    return v;
+}
+__device__ __forceinline__ void fuse_arrive(const FrameDev &f, unsigned nblk, unsigned epoch, bool withhold) {      // all threads of a point workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !withhold) {
         const unsigned old = __hip_atomic_fetch_add(f.sync + 100, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == nblk - 1u) {
             __hip_atomic_store(f.sync + 100, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(f.sync + 101, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)fuse_decide(f.sync + 101, epoch, epoch << 1);
         }
     }
 }
-__device__ __forceinline__ void fuse_wait(const FrameDev &f, unsigned epoch) {                        // all threads of a workgroup
-    if (threadIdx.x == 0) while (__hip_atomic_load(f.sync + 101, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+__device__ __forceinline__ bool fuse_wait(const FrameDev &f, unsigned epoch, int *ok_lds) {           // all threads of a workgroup; false: the launch was abandoned
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned v, spins = 0;
+        while (((v = __hip_atomic_load(f.sync + 101, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 31u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > kFuseSpinTicks) { v = fuse_decide(f.sync + 101, epoch, (epoch << 1) | 1u); break; }
+        }
+        *ok_lds = (int)((v & 1u) ^ 1u);
+    }
     __syncthreads();
+    return *ok_lds != 0;
 }
 
 // One workgroup per frame: scan of the prune counts, centring, chain coordinate + kernel G
@@ -520,11 +546,23 @@ __device__ __forceinline__ void fused_iter0(const FrameDev &f, int N, double sS)
     }
 }
 
+// An abandoned launch (fuse_wait): the registration ends here, before its first iteration -- every kernel behind the prologue is a no-op on a
+// registration that is done, and the first M-step reports the status to the host (host_publish)
+__device__ __forceinline__ void fused_fail(const FrameDev &f) {
+    IterState *st = f.st;
+    f.keep[0] = 0.0; f.keep[1] = 0.0;
+    st->N = 0; st->sum_d2 = 0.0;
+    st->it = 0; st->converged = 0; st->crit = 0; st->Np = 0;
+    st->retries = 0; st->retry_pending = 0; st->sigma2 = f.sigma2_in;
+    st->status = TDLO_E_FUSE; st->done = 1;
+}
+
 template <typename T, bool PAIR>
 __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const double *__restrict__ host_up, double *__restrict__ dev_up, int up_doubles,
-                                                     int yin_off, unsigned epoch, const FrameDev f2, const double *__restrict__ host_up2,
+                                                     int yin_off, unsigned epoch_arg, const FrameDev f2, const double *__restrict__ host_up2,
                                                      double *__restrict__ dev_up2, int up_doubles2) {
     const int nb = f.nprune_blocks;
+    const unsigned epoch = epoch_arg & ~kFuseWithhold;
     if ((int)blockIdx.x >= nb) {
         const bool second = PAIR && (int)blockIdx.x > nb;
         setup_body<T, true, kFuseMaxNodes>(second ? f2 : f, 0, second ? host_up2 : host_up, second ? dev_up2 : dev_up, second ? up_doubles2 : up_doubles, yin_off, epoch);
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
     __shared__ double scratch[4];
     __shared__ double Yl[3 * kFuseMaxNodes + kPrunePad];
     __shared__ double sctr[3];
-    __shared__ int lh[kFuseMaxNodes], base[kFuseMaxNodes], wtot[4];
+    __shared__ int lh[kFuseMaxNodes], base[kFuseMaxNodes], wtot[4], fuse_ok;
     __shared__ unsigned long long lmask[4 * kFuseMaxNodes];      // per (wave, node): which lanes of the wave keep a point nearest to that node
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x;
     const int N0 = f.N0, M = f.M;
@@ -576,9 +614,13 @@ __global__ __launch_bounds__(kBlock) void k_prologue(const FrameDev f, const dou
         a = wave_sum(a);
         if (lane == 0) sctr[d] = a / M;
     }
-    fuse_arrive(f, (unsigned)nb, epoch);
+    fuse_arrive(f, (unsigned)nb, epoch, (epoch_arg & kFuseWithhold) != 0u && b == nb - 1);
     PSTAMP(3);
-    fuse_wait(f, epoch);
+    if (!fuse_wait(f, epoch, &fuse_ok)) {
+        // abandoned (this workgroup or another one waited out the limit): the counts are incomplete, nothing may be scattered from them
+        if (b == 0 && t == 0) { fused_fail(f); if (PAIR) fused_fail(f2); }
+        return;
+    }
     PSTAMP(4);
     // ---- this workgroup's start offsets: thread = node
     int Nk = 0;

@@ -140,6 +140,9 @@ void lle_weights(int k, const double *Y, int M, double *L) {
 // that column does not exist.  O(M) instead of the M x M matrices of lle_weights + lle_regulariser (two 16 KB fills and a heap allocation at
 // M = 45 in front of every pre-processing registration); every value is the dense routines' bit for bit -- the same weights, and the same
 // products summed in the same ascending order (the terms left out there are exact zeros).
+// The device forms the same 13 diagonals itself for the next frame (tdlo_lle_dev.h, `#pragma clang fp contract(off)`) and the library assumes the
+// two are the same BITS (Slot::hb_next): this file must be compiled without fused multiply-adds -- the Makefile and scripts/build_variant.sh pass
+// -ffp-contract=off (GCC's default is `fast`, which contracts as soon as -march / -mfma allows it).
 void lle_regulariser_band(const double *Y, int M, double *Hb) {
     // A(k, c) = (I - L)(k, c) for |c - k| <= 3, stored as Ab[7 k + (c - k + 3)]
     double stack_buf[7 * 64];                                 // (no heap at production size)

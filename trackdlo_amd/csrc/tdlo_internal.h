@@ -23,6 +23,9 @@ constexpr int kChainLdsMaxNodes = 512;   // the four-direction chain smoother an
                                          // longer chains: k_mstep_chain_long (one direction, compact records) / the one-workgroup dense elimination
 constexpr int kLdsSolveMaxM = 128;   // M-step keeps [A|B] in LDS up to this M
 constexpr int kMaxXchRanks = 8;      // ranks of the one-shot N-split exchange (one node: 8 GPUs)
+// IterState::status of a registration whose fused prologue was abandoned at its grid barrier (tdlo_device.hip, fuse_wait).  Internal: the entry
+// points repeat the call on the three-kernel route (tdlo_api.cpp, fuse_fallback); no caller ever sees the code.
+#define TDLO_E_FUSE (-100)
 
 // Mutable per-iteration state of one registration, device resident (trackdlo.cpp:275-438 loop state).
 struct IterState {

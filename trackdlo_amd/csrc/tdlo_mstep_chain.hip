@@ -231,7 +231,11 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
             int go = 0;
             for (;;) {
                 const unsigned long long v = __hip_atomic_load(f.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned)(v >> 32) == f.spec_epoch && (v & 3ull) != 0ull) { go = (v & 3ull) == 1ull; break; }
+                if ((unsigned)(v >> 32) == f.spec_epoch && (v & 3ull) != 0ull) {
+                    go = (v & 3ull) == 1ull;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // the priors staged before the word was released (system scope, as xch_wait does)
+                    break;
+                }
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
                 __builtin_amdgcn_s_sleep(4);
             }
