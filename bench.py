@@ -30,6 +30,8 @@ The default run (--gpus 1, config c2) also carries, after the headline measureme
   configs           short legs of the other BASELINE configurations on this GPU: c3 (32-frame batch), c4 (N = 2 000 000 on one rank through the
                     split driver), c5 (M = 300, fp64) -- each {value, ms_per_step, roofline, roofline_kernels, cpu_baseline}
   sustained         >= 3 s of back-to-back C2 calls (sustained_iters_per_s): the same quantity as `value` over a span a GPU-activity sampler sees
+  frame_from_depth  the whole device-born frame (trackdlo_node.cpp:195-369): depth image -> cloud -> visibility pre-pass -> tracking_step, ms per frame at
+                    640 x 480 and 1280 x 720, images copied from pageable memory / read in place from the context's pinned buffers
   preproc           the pre-processing registration of tracking_step (include_lle: trackdlo.cpp:925-927) at production size (N = 5 000, M = 45):
                     its per-iteration kernels (the banded LLE M-step k_mstep_band among them) and tracking_step's ms per frame
 (--no-legs switches them off.)
@@ -294,6 +296,13 @@ def _compact(full):
     for k in ("tracking_step_ms_per_frame", "tracking_step_moving_ms_per_frame", "em_iters_per_s"):
         if k in pre:
             o["preproc_" + k if k == "em_iters_per_s" else k] = pre[k]
+    ffd = full.get("frame_from_depth") or {}
+    if "640x480" in ffd:          # depth image -> cloud -> visibility pre-pass -> tracking_step, images in the context's pinned buffers / pageable host memory
+        o["frame_from_depth_ms"] = ffd["640x480"].get("frame_from_depth_ms_pinned")
+        o["frame_from_depth_ms_pageable"] = ffd["640x480"].get("frame_from_depth_ms_pageable")
+        o["depth_to_cloud_ms"] = ffd["640x480"].get("depth_to_cloud_ms_pinned")
+        if "1280x720" in ffd:
+            o["frame_from_depth_720p_ms"] = ffd["1280x720"].get("frame_from_depth_ms_pinned")
     o["ranks"] = full.get("ranks")
     o["detail"] = DETAIL_FILE
     # the line must stay under the limit whatever a future leg adds: optional parts go first
@@ -643,6 +652,52 @@ def _preproc_leg(ctx, B, synth):
     return out
 
 
+def _frame_from_depth_leg(ctx, B, synth):
+    """The whole device-born frame, the span the reference itself logs (trackdlo_node.cpp:195-369, ROS_INFO at :249-252 / :372-375): depth image + mask ->
+    back-projection + voxel grid (tdlo_depth_to_cloud) -> visibility pre-pass -> tracking_step on the resident cloud (X = NULL).  640 x 480 (the synthetic
+    scenes' stream) and the reference camera's 1280 x 720 (launch/realsense_node.launch:7-12); images handed over in pageable host memory (copied) and
+    in the context's pinned image buffers (tdlo_image_buffers: read in place by the kernel)."""
+    P = synth.LAUNCH_PARAMS
+    M = 30            # 0.58 m of rope: fits the image at 0.6 m
+    out = dict(workload=f"depth image + mask -> cloud (leaf 8 mm) -> visibility pre-pass -> tracking_step, M={M}, trackdlo.launch parameters, tol = {P['tol']}; ms per frame, "
+                        "host buffers in, nodes out")
+    for shape in ((480, 640), (720, 1280)):
+        depth, mask, cam, Y0 = synth.depth_scene(M, config=9, frame=3, rows=shape[0], cols=shape[1])
+        a = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        coord = synth.geodesic_coord(Y0)
+        trk = B.trackdlo(M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 50, P["tol"], P["beta_pre_proc"],
+                         P["lambda_pre_proc"], P["lle_weight"], ctx=ctx)
+        trk.initialize_nodes(Y0); trk.initialize_geodesic_coord(coord)
+        dpin, mpin = ctx.image_buffers(*shape)
+        dpin[:] = depth; mpin[:] = mask
+        key = f"{shape[1]}x{shape[0]}"
+        res = dict(masked_pixels=int(np.count_nonzero(mask)))
+
+        def rate(fn, n=200):
+            for _ in range(10):
+                fn()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            return round((time.perf_counter() - t0) * 1e3 / n, 4)
+
+        for tag, (d_, m_) in (("pageable", (depth, mask)), ("pinned", (dpin, mpin))):
+            def cloud():
+                return ctx.depth_to_cloud(0, d_, m_, *a, 0.008, fetch=False)
+
+            def frame():
+                cloud()
+                _, vis, vext = ctx.visibility_prepass(0, trk.get_tracking_result(), P["visibility_threshold"], 0.06, coord)
+                trk.tracking_step(None, vis, vext)
+            res[f"depth_to_cloud_ms_{tag}"] = rate(cloud)
+            res[f"frame_from_depth_ms_{tag}"] = rate(frame)
+        res["points"] = int(cloud()[1])
+        if hasattr(ctx, "cloud_route_counts"):
+            res["cloud_routes"] = ctx.cloud_route_counts()      # [served by the one-launch kernel, passed on to the multi-launch form]
+        out[key] = res
+    return out
+
+
 def bench_frames(args, cfg, env):
     """c2 / c3 / c5: every rank registers its own frame(s); no data-path collective."""
     from trackdlo_amd import binding as B, synth
@@ -756,6 +811,11 @@ def bench_frames(args, cfg, env):
                 out["preproc"] = _preproc_leg(ctx, B, synth)
             except Exception as e:
                 out["preproc"] = dict(error=f"{type(e).__name__}: {e}")
+            if not os.environ.get("TDLO_BENCH_STUB"):
+                try:
+                    out["frame_from_depth"] = _frame_from_depth_leg(ctx, B, synth)
+                except Exception as e:
+                    out["frame_from_depth"] = dict(error=f"{type(e).__name__}: {e}")
         cpu = None
         if n_ranks == 1 and not args.no_cpu_baseline:
             X0, Y00, _ = synth.scene(N, M, config=cfg_id, frame=0)

@@ -336,6 +336,19 @@ int tdlo_reg(tdlo_ctx *ctx, int slot, const double *pts, int N, double *Y, doubl
 int tdlo_depth_to_cloud(tdlo_ctx *ctx, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
                         double fx, double fy, double cx, double cy, double leaf_size,
                         double *X_out, int x_capacity, int *n_out, int *n_raw_out);
+/* Up to 32 704 masked pixels (a 1280 x 720 frame of the reference's camera, launch/realsense_node.launch:7-12, holds about 30 000 on the rope) the
+ * whole step is ONE kernel launch (csrc/tdlo_cloud.hip, k_cloud_fused: compaction, back-projection and bounding box per 4096-pixel tile, then the
+ * workgroup that finishes last sorts cell index | pixel rank in LDS, 4 bits a pass, and forms the centroids) whose last workgroup reports the counts through
+ * pinned host memory; more masked pixels, a grid whose cell-index bits + rank bits exceed 32, or PCL's pass-through case take the multi-launch
+ * form (bounding box, host round trip, radix sort passes, centroids) -- the same bits either way (TDLO_CLOUD_FUSED=0 forces it; tdlo_debug_route_count
+ * 6 / 7 count the calls the one-launch kernel served / passed on).
+ *
+ * tdlo_image_buffers: pinned host buffers of the context for a rows x cols depth image and mask (valid until the next call with a larger image, or
+ * tdlo_destroy).  A caller that lets its driver / segmentation write into them -- e.g. cv::Mat(rows, cols, CV_16UC1, depth) and
+ * cv::Mat(rows, cols, CV_8UC1, mask) as the destinations of the conversions at trackdlo_node.cpp:167-190 -- and passes exactly these pointers
+ * to tdlo_depth_to_cloud has the kernel read the images where they are, over PCIe (the mask once, coalesced; depth only where the mask is set):
+ * no host-to-device copy of 3 bytes per pixel.  Any other pointers are copied to the device first, as before. */
+int tdlo_image_buffers(tdlo_ctx *ctx, int rows, int cols, unsigned short **depth, unsigned char **mask);
 
 /* ---- caller-side visibility pre-pass ----------------------------------- */
 /* What the ROS node computes right before tracking_step (trackdlo/src/trackdlo_node.cpp:257-277, :345-360):
@@ -419,6 +432,8 @@ int tdlo_debug_lle_band_device(tdlo_ctx *ctx, const double *Y, int M, double *Hb
  * on the device by the M-step that finished the previous frame (TDLO_LLE_NEXT=0); 4: main registrations of frames with hidden nodes whose first
  * iteration had run on the second stream beside the pre-processing registration (TDLO_AHEAD=0).  -1 for a null context or an unknown counter. */
 long long tdlo_debug_route_count(tdlo_ctx *ctx, int which);
+/* Phase stamps (s_memtime) of the last depth -> cloud launch's finishing workgroup; only a -DTDLO_CLOUD_STAMPS build writes them. */
+int tdlo_debug_cloud_stamps(tdlo_ctx *ctx, unsigned long long *out, int n);
 /* Test aid: provokes a HIP runtime error inside the library (an invalid copy) and reports it like any other: returns TDLO_E_HIP with the
  * text in tdlo_last_error.  The calls that follow must be unaffected -- HIP keeps a per-thread "last error" that the launch checks of a later
  * call would otherwise read (tests/test_parity_gpu.py::test_a_hip_error_does_not_leak_into_the_next_call). */

@@ -1,0 +1,138 @@
+"""GPU suite for depth image -> cloud -> voxel grid in one launch (k_cloud_fused, round 5; SURVEY.md 8(f) row 2, trackdlo_node.cpp:195-241).
+
+The one-launch kernel, the multi-launch form it replaces (TDLO_CLOUD_FUSED=0) and the CPU oracle perform the same float operations in the same order:
+same count, same order, same doubles.  Sizes: the 640 x 480 stream of the synthetic scenes, the reference camera's 1280 x 720
+(launch/realsense_node.launch:7-12), ragged images; the cases the one-launch kernel passes on (more than 32 704 masked pixels, too many cell-index
+bits, PCL's pass-through) must come back through the multi-launch form with the same bits and be counted as passed on.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(B, fused=True, **kw):
+    old = os.environ.get("TDLO_CLOUD_FUSED")
+    try:
+        if fused:
+            os.environ.pop("TDLO_CLOUD_FUSED", None)
+        else:
+            os.environ["TDLO_CLOUD_FUSED"] = "0"
+        return B.Context(device=0, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("TDLO_CLOUD_FUSED", None)
+        else:
+            os.environ["TDLO_CLOUD_FUSED"] = old
+
+
+def _args(cam):
+    return (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+
+
+@pytest.mark.parametrize("shape,M,leaf,zero,taken", [
+    (None, 50, 0.008, 0, True), (None, 30, 0.005, 0, True), (None, 30, 0.02, 7, True), ((720, 1280), 50, 0.008, 0, True), ((720, 1280), 30, 0.005, 0, True),
+    ((120, 161), 50, 0.008, 0, True), ((97, 4099), 30, 0.008, 0, True), ((1, 77), 30, 0.008, 0, True),
+    (None, 50, 0.0015, 0, False),          # 2.7 M cells: cell-index bits + rank bits > 32 -> passed on
+    ((720, 1280), 50, 0.003, 0, False),    # 15 rank bits + 19 cell-index bits
+])
+def test_one_launch_equals_multi_launch_and_oracle(oracle, shape, M, leaf, zero, taken):
+    from trackdlo_amd import binding as B, synth
+    kw = dict(rows=shape[0], cols=shape[1]) if shape else {}
+    depth, mask, cam, _ = synth.depth_scene(M, config=9, frame=M, zero_depth_pixels=zero, **kw)
+    if shape and shape[0] < 100:
+        mask[:] = 0; mask[0, ::3] = 255; mask[-1, -1] = 255          # (the rope is not in such an image: some pixels of the wall instead)
+    Xo, nraw_o = oracle.depth_to_cloud(depth, mask, *_args(cam), leaf)
+    one, multi = _ctx(B), _ctx(B, fused=False)
+    try:
+        for rep in range(2):                                          # (the second call finds the kernel's state words as the first one left them)
+            Xg, n, nraw = one.depth_to_cloud(0, depth, mask, *_args(cam), leaf)
+            Xm, nm, nrawm = multi.depth_to_cloud(0, depth, mask, *_args(cam), leaf)
+            assert nraw == nrawm == nraw_o and n == nm == Xo.shape[0]
+            assert np.array_equal(Xg, Xo) and np.array_equal(Xm, Xo)
+        assert one.cloud_route_counts() == ([2, 0] if taken else [0, 2]) and multi.cloud_route_counts() == [0, 0]
+        # the resident cloud is what came back
+        p = B.make_params(0.35, 50000.0, 10.0, 0.1, 1, 0.0, False)
+        if n >= 4:
+            Y0 = Xo[np.linspace(0, n - 1, 8).astype(int)]
+            a = one.cpd_lle_resident(0, Y0, 0.0, p, check=False); b = multi.cpd_lle_resident(0, Y0, 0.0, p, check=False)
+            assert a["n_kept"] == b["n_kept"] and np.array_equal(a["Y"], b["Y"])
+    finally:
+        one.close(); multi.close()
+
+
+def test_images_in_the_pinned_buffers_are_read_in_place(oracle):
+    """tdlo_image_buffers: the caller writes depth and mask into the context's pinned buffers and the kernel reads them there; frames of two sizes
+    in turn (the buffers are re-made for the larger one), and a frame changed in place between two calls."""
+    from trackdlo_amd import binding as B, synth
+    ctx = _ctx(B)
+    try:
+        for shape, frame in (((480, 640), 1), ((720, 1280), 2), ((480, 640), 3), ((720, 1280), 4)):
+            depth, mask, cam, _ = synth.depth_scene(40, config=9, frame=frame, rows=shape[0], cols=shape[1])
+            d, m = ctx.image_buffers(*shape)
+            d[:] = depth; m[:] = mask
+            Xo, nraw_o = oracle.depth_to_cloud(depth, mask, *_args(cam), 0.008)
+            Xg, n, nraw = ctx.depth_to_cloud(0, d, m, *_args(cam), 0.008)
+            assert nraw == nraw_o and np.array_equal(Xg, Xo)
+            m[: shape[0] // 2] = 0; mask[: shape[0] // 2] = 0          # the upper half of the frame loses its segmentation
+            Xo, nraw_o = oracle.depth_to_cloud(depth, mask, *_args(cam), 0.008)
+            Xg, n, nraw = ctx.depth_to_cloud(0, d, m, *_args(cam), 0.008)
+            assert nraw == nraw_o and np.array_equal(Xg, Xo)
+        assert ctx.cloud_route_counts() == [8, 0]
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_images(oracle, seed):
+    """Speckle masks over random depth: many cells with one point, cells whose points lie rows apart, invalid depth, the box spanning the
+    whole frustum -- taken by the one-launch kernel whenever the bits allow, equal to the oracle either way."""
+    from trackdlo_amd import binding as B, synth
+    rng = np.random.default_rng(500 + seed)
+    rows, cols = [(480, 640), (720, 1280), (333, 517)][seed % 3]
+    cam = dict(fx=600.0 * cols / 640, fy=600.0 * cols / 640, cx=cols / 2.0 - 3.5, cy=rows / 2.0 + 1.25)
+    near = rng.integers(400, 800)
+    depth = (near + rng.integers(0, [30, 200, 1500][seed % 3], size=(rows, cols))).astype(np.uint16)
+    mask = (rng.random((rows, cols)) < [0.02, 0.03, 0.15][seed // 3 % 3]).astype(np.uint8) * rng.integers(1, 256, size=(rows, cols)).astype(np.uint8)
+    depth[rng.random((rows, cols)) < 0.001] = 0
+    leaf = [0.008, 0.02, 0.05][seed % 3]
+    Xo, nraw_o = oracle.depth_to_cloud(depth, mask, *_args(cam), leaf)
+    ctx = _ctx(B)
+    try:
+        Xg, n, nraw = ctx.depth_to_cloud(0, depth, mask, *_args(cam), leaf)
+        assert nraw == nraw_o and n == Xo.shape[0] and np.array_equal(Xg, Xo)
+        assert sum(ctx.cloud_route_counts()) == 1
+    finally:
+        ctx.close()
+
+
+def test_cases_the_one_launch_kernel_passes_on(oracle):
+    from trackdlo_amd import binding as B, synth
+    depth, mask, cam, _ = synth.depth_scene(30, config=9)
+    ctx = _ctx(B)
+    try:
+        X, n, nraw = ctx.depth_to_cloud(0, depth, np.zeros_like(mask), *_args(cam), 0.008)      # nothing segmented: the kernel itself reports 0 points
+        assert n == 0 and nraw == 0 and X.shape == (0, 3) and ctx.cloud_route_counts() == [1, 0]
+        Xo, _ = oracle.depth_to_cloud(depth, mask, *_args(cam), 1e-5)                           # cell count overflows int32: PCL's pass-through
+        X, n, nraw = ctx.depth_to_cloud(0, depth, mask, *_args(cam), 1e-5)
+        assert n == nraw == Xo.shape[0] and np.array_equal(X, Xo) and ctx.cloud_route_counts() == [1, 1]
+        full = np.full_like(mask, 255)                                                          # every pixel: 307 200 > 32 704
+        Xo, _ = oracle.depth_to_cloud(depth, full, *_args(cam), 0.02)
+        X, n, nraw = ctx.depth_to_cloud(0, depth, full, *_args(cam), 0.02)
+        assert nraw == depth.size and np.array_equal(X, Xo) and ctx.cloud_route_counts() == [1, 2]
+        exact = np.zeros_like(mask); exact.reshape(-1)[np.arange(32704) * 9] = 1                # exactly the kernel's limit, then one more
+        for extra in (0, 1):
+            if extra:
+                exact.reshape(-1)[5] = 1
+            Xo, nr = oracle.depth_to_cloud(depth, exact, *_args(cam), 0.05)
+            X, n, nraw = ctx.depth_to_cloud(0, depth, exact, *_args(cam), 0.05)
+            assert nraw == nr == 32704 + extra and np.array_equal(X, Xo)
+        assert ctx.cloud_route_counts() == [2, 3]
+        one = np.zeros_like(mask); one[100, 200] = 255                                          # a single pixel
+        Xo, _ = oracle.depth_to_cloud(depth, one, *_args(cam), 0.008)
+        X, n, _ = ctx.depth_to_cloud(0, depth, one, *_args(cam), 0.008)
+        assert n == 1 and np.array_equal(X, Xo) and ctx.cloud_route_counts() == [3, 3]
+    finally:
+        ctx.close()

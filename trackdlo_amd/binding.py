@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -195,6 +195,8 @@ def load_library(path: str | None = None):
     lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
     lib.tdlo_reg.argtypes = [vp, ci, vp, ci, vp, C.POINTER(cd), ci, cd, ci]
     lib.tdlo_depth_to_cloud.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, C.POINTER(ci), C.POINTER(ci)]
+    lib.tdlo_image_buffers.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(vp)]
+    lib.tdlo_debug_cloud_stamps.argtypes = [vp, vp, ci]
     if path is None:
         _lib = lib
     return lib
@@ -435,6 +437,15 @@ class Context:
         prologue's grid barrier was abandoned] (tdlo_debug_route_count)."""
         return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in range(6)]
 
+    def cloud_stamps(self, n=8):
+        out = (C.c_ulonglong * n)()
+        self._chk(self.lib.tdlo_debug_cloud_stamps(self.h, out, n))
+        return [int(v) for v in out]
+
+    def cloud_route_counts(self):
+        """[depth -> cloud calls served by the one-launch kernel, calls it passed on to the multi-launch form] (tdlo_debug_route_count 6 / 7)."""
+        return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in (6, 7)]
+
     def band_retries(self):
         """Calls of this context that were repeated on the dense pivoted kernels after the banded LLE solve gave up (tdlo_debug_band_retries)."""
         return int(self.lib.tdlo_debug_band_retries(self.h))
@@ -455,6 +466,15 @@ class Context:
         Y = np.zeros((M, 3), order="F"); s2 = C.c_double(0.0)
         self._chk(self.lib.tdlo_reg(self.h, slot, _ptr(X), X.shape[0] if X is not None else 0, _ptr(Y), C.byref(s2), int(M), float(mu), int(max_iter)))
         return Y, s2.value
+
+    def image_buffers(self, rows, cols):
+        """The context's pinned image buffers as numpy views (depth uint16 [rows x cols], mask uint8 [rows x cols]): images written into them and
+        handed to depth_to_cloud as they are get read by the kernel where they lie (tdlo_image_buffers)."""
+        d = C.c_void_p(); m = C.c_void_p()
+        self._chk(self.lib.tdlo_image_buffers(self.h, int(rows), int(cols), C.byref(d), C.byref(m)))
+        depth = np.ctypeslib.as_array(C.cast(d, C.POINTER(C.c_uint16)), shape=(rows, cols))
+        mask = np.ctypeslib.as_array(C.cast(m, C.POINTER(C.c_uint8)), shape=(rows, cols))
+        return depth, mask
 
     def depth_to_cloud(self, slot, depth, mask, fx, fy, cx, cy, leaf_size, *, fetch=True):
         """trackdlo_node.cpp:195-241: masked back-projection + pcl::VoxelGrid; the result becomes the slot's resident cloud.

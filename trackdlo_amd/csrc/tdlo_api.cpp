@@ -159,6 +159,19 @@ struct tdlo_ctx {
     size_t reg_ws_cap = 0;
     void *cloud_ws = nullptr;        // depth -> cloud workspace (images, sort buffers)
     size_t cloud_ws_cap = 0;
+    // depth -> cloud in one launch (k_cloud_fused): its own workspace behind the same images, the pinned words the kernel reports through, and the
+    // pinned image buffers a caller may fill directly (tdlo_image_buffers: the kernel then reads the images over PCIe, no copy).  TDLO_CLOUD_FUSED=0:
+    // the multi-launch form (comparator)
+    void *cloud_fws = nullptr;
+    size_t cloud_fws_cap = 0;
+    bool cloud_fused_first = true;   // the kernel's state words have to be initialised (first launch, after a failed one, after a reallocation)
+    unsigned long long *cloud_res = nullptr;
+    unsigned cloud_epoch = 0;
+    char *img_pin = nullptr;
+    size_t img_pin_cap = 0;
+    int img_pin_rows = 0, img_pin_cols = 0;
+    bool cloud_fused_on = !(getenv("TDLO_CLOUD_FUSED") && atoi(getenv("TDLO_CLOUD_FUSED")) == 0);
+    long long cloud_route[2] = {0, 0};   // tdlo_debug_route_count 6 / 7: depth -> cloud calls served by the one-launch kernel / sent on to the multi-launch form by it
     size_t pin_doubles = 0;
     std::string err;
     int last_F = 0;
@@ -1350,6 +1363,9 @@ void tdlo_destroy(tdlo_ctx *c) {
     delete c->pool; c->pool = nullptr;
     if (c->fd) hipFree(c->fd);
     if (c->cloud_ws) hipFree(c->cloud_ws);
+    if (c->cloud_fws) hipFree(c->cloud_fws);
+    if (c->cloud_res) hipHostFree(c->cloud_res);
+    if (c->img_pin) hipHostFree(c->img_pin);
     if (c->reg_ws) hipFree(c->reg_ws);
     if (c->pin) hipHostFree(c->pin);
     if (c->pin2) hipHostFree(c->pin2);
@@ -1937,6 +1953,53 @@ int tdlo_reg(tdlo_ctx *c, int slot, const double *pts, int N, double *Y, double 
     return TDLO_OK;
 }
 
+// Waits for the one-launch kernel's word in pinned host memory (epoch << 32 | status); like mbox_wait, the stream is looked at every 0.5 ms so that
+// a faulting kernel cannot hang the caller.  Returns the status (1, 2, 3), 0 when the stream drained without the word, or a negative code.
+static int cloud_wait(tdlo_ctx *c, hipStream_t st, unsigned epoch) {
+    auto t_chk = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned long long v = __atomic_load_n(c->cloud_res, __ATOMIC_ACQUIRE);
+        if ((unsigned)(v >> 32) == epoch) return (int)(unsigned)v;
+        if ((spins & 255u) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (std::chrono::duration<double, std::micro>(now - t_chk).count() > 500.0) {
+                t_chk = now;
+                const hipError_t e = hipStreamQuery(st);
+                if (e == hipSuccess) {
+                    const unsigned long long v2 = __atomic_load_n(c->cloud_res, __ATOMIC_ACQUIRE);
+                    return (unsigned)(v2 >> 32) == epoch ? (int)(unsigned)v2 : 0;
+                }
+                if (e != hipErrorNotReady) return fail(c, TDLO_E_HIP, std::string("stream: ") + hipGetErrorString(e));
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
+static size_t img_depth_bytes(size_t P) { return (P * 2 + 255) & ~(size_t)255; }
+static size_t img_mask_bytes(size_t P) { return (P + 255) & ~(size_t)255; }
+
+int tdlo_image_buffers(tdlo_ctx *c, int rows, int cols, unsigned short **depth, unsigned char **mask) {
+    if (!c) return TDLO_E_INVALID;
+    if (rows <= 0 || cols <= 0 || (long long)rows * cols > (1ll << 26) || !depth || !mask) return fail(c, TDLO_E_INVALID, "bad image");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t P = (size_t)rows * cols, need = img_depth_bytes(P) + img_mask_bytes(P);
+    if (need > c->img_pin_cap) {
+        HIPCHK(c, drain_for_realloc(c));
+        if (c->img_pin) hipHostFree(c->img_pin);
+        c->img_pin = nullptr; c->img_pin_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->img_pin, need, hipHostMallocDefault));
+        std::memset(c->img_pin, 0, need);
+        c->img_pin_cap = need;
+    }
+    c->img_pin_rows = rows; c->img_pin_cols = cols;
+    *depth = (unsigned short *)c->img_pin;
+    *mask = (unsigned char *)(c->img_pin + img_depth_bytes(P));
+    return TDLO_OK;
+}
+
 int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
                         double fx, double fy, double cx, double cy, double leaf_size,
                         double *X_out, int x_capacity, int *n_out, int *n_raw_out) {
@@ -1948,7 +2011,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     Slot &s = c->slots[slot];
     hipStream_t st = c->stream;
     const int P = rows * cols;
-    const size_t img = (((size_t)P * 2 + 255) & ~(size_t)255) + (((size_t)P + 255) & ~(size_t)255);
+    const size_t img = img_depth_bytes(P) + img_mask_bytes(P);
     const size_t need = img + cloud_ws_bytes(P);
     if (need > c->cloud_ws_cap) {
         HIPCHK(c, hipStreamSynchronize(st));
@@ -1959,54 +2022,94 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     }
     int rc = ensure_pin(c, 16);
     if (rc) return rc;
+    if (c->cloud_pending >= 0 && (rc = flush_pending_cloud(c))) return rc;      // (a cloud tracking_step staged for this slot is superseded; its copy is harmless and ordered)
     char *base = (char *)c->cloud_ws;
-    unsigned short *d_depth = (unsigned short *)base;
-    unsigned char *d_mask = (unsigned char *)(base + (((size_t)P * 2 + 255) & ~(size_t)255));
+    const unsigned short *d_depth = (unsigned short *)base;
+    const unsigned char *d_mask = (unsigned char *)(base + img_depth_bytes(P));
     char *ws = base + img;
-    // the last 64 ints of the workspace: bounding box (6 ordered floats), masked-pixel count, output count
-    unsigned *d_bbox = (unsigned *)(ws + cloud_ws_bytes(P) - 256);
-    int *d_total = (int *)(d_bbox + 8);
-    unsigned *hb = (unsigned *)c->pin;
-    hb[0] = hb[1] = hb[2] = ~0u; hb[3] = hb[4] = hb[5] = 0u; hb[6] = 0u; hb[7] = 0u; hb[8] = 0u;
     const double cam[4] = {fx, fy, cx, cy};
-    HIPCHK(c, hipMemcpyAsync(d_depth, depth, (size_t)P * 2, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_mask, mask, (size_t)P, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_bbox, hb, 9 * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    HIPCHK(c, launch_cloud_bbox(d_depth, d_mask, P, cols, cam, d_bbox, ws, st));
-    HIPCHK(c, hipMemcpyAsync(hb, d_bbox, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const int nraw = (int)hb[6];
-    if (n_raw_out) *n_raw_out = nraw;
-    if (n_out) *n_out = 0;
-    s.N0 = 0; s.sorted_valid = false;
-    if (nraw == 0) return TDLO_OK;
-    auto decode = [](unsigned o) { const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; std::memcpy(&f, &u, 4); return f; };
-    float mn[3], mx[3];
-    for (int d = 0; d < 3; ++d) { mn[d] = decode(hb[d]); mx[d] = decode(hb[3 + d]); }
-    // pcl/filters/impl/voxel_grid.hpp applyFilter: leaf-size check, min_b / div_b / divb_mul (float arithmetic)
-    const float leaf = (float)leaf_size, inv = 1.0f / leaf;
-    long long dd[3]; int min_b[3], div_b[3];
-    for (int d = 0; d < 3; ++d) {
-        dd[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
-        min_b[d] = (int)std::floor(mn[d] * inv);
-        div_b[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+    // images the caller wrote into the context's pinned buffers (tdlo_image_buffers) are read where they are; anything else is copied first
+    const bool in_place = c->img_pin != nullptr && (const char *)depth == c->img_pin && (const char *)mask == c->img_pin + img_depth_bytes(P) &&
+                          c->img_pin_rows == rows && c->img_pin_cols == cols;
+    if (in_place) { d_depth = depth; d_mask = mask; }
+    else {
+        HIPCHK(c, hipMemcpyAsync((void *)d_depth, depth, (size_t)P * 2, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((void *)d_mask, mask, (size_t)P, hipMemcpyHostToDevice, st));
     }
-    const int nodown = (dd[0] * dd[1] * dd[2] > 2147483647ll) ? 1 : 0;
-    const long long cells = nodown ? 1 : (long long)div_b[0] * div_b[1] * div_b[2];
-    if (cells >= 0xffffffffll) return fail(c, TDLO_E_INVALID, "voxel grid has too many cells");
-    int passes = 1;
-    while (passes < 4 && (1ll << (8 * passes)) <= cells) ++passes;      // every valid key must stay below the all-ones sentinel
-    rc = ensure_points(c, s, nraw);
-    if (rc) return rc;
-    HIPCHK(c, launch_cloud_voxels(d_depth, d_mask, P, cols, cam, min_b, div_b[0], div_b[0] * div_b[1], inv, nodown, passes, nraw,
-                                  ws, d_total, s.cap_points, s.Xraw, st));
-    HIPCHK(c, hipMemcpyAsync(hb, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const int n = (int)hb[0];
-    if (n < 0 || n > s.cap_points) return fail(c, TDLO_E_HIP, "voxel grid produced an impossible point count");
+    if (n_out) *n_out = 0;
+    if (n_raw_out) *n_raw_out = 0;
+    s.N0 = 0; s.sorted_valid = false;
+    const float leaf = (float)leaf_size, inv = 1.0f / leaf;
+    int n = -1, nraw = 0;
+    if (c->cloud_fused_on && cloud_fused_ok(P)) {
+        // ---- one launch (k_cloud_fused); its last workgroup reports through pinned host memory
+        const size_t fneed = cloud_fused_ws_bytes(P);
+        if (fneed > c->cloud_fws_cap) {
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (c->cloud_fws) hipFree(c->cloud_fws);
+            c->cloud_fws = nullptr; c->cloud_fws_cap = 0;
+            HIPCHK(c, hipMalloc(&c->cloud_fws, fneed));
+            c->cloud_fws_cap = fneed; c->cloud_fused_first = true;
+        }
+        if (!c->cloud_res) {
+            HIPCHK(c, hipHostMalloc((void **)&c->cloud_res, 32 * sizeof(unsigned long long), hipHostMallocDefault));      // [0..1] the report, [4..] phase stamps of an instrumented build
+            std::memset(c->cloud_res, 0, 32 * sizeof(unsigned long long));
+        }
+        if ((rc = ensure_points(c, s, cloud_fused_max_points()))) return rc;      // (an output point per masked pixel at most; sized once)
+        if (++c->cloud_epoch == 0) ++c->cloud_epoch;
+        HIPCHK(c, launch_cloud_fused(d_depth, d_mask, P, cols, cam, inv, ws, c->cloud_fws, c->cloud_fused_first, s.Xraw, s.cap_points, c->cloud_res, c->cloud_epoch, st));
+        c->cloud_fused_first = false;
+        const int status = cloud_wait(c, st, c->cloud_epoch);
+        if (status < 0) { c->cloud_fused_first = true; return status; }
+        if (status == 0) { c->cloud_fused_first = true; return fail(c, TDLO_E_HIP, "the stream drained, but the depth -> cloud kernel did not report"); }
+        const unsigned long long w1 = __atomic_load_n(c->cloud_res + 1, __ATOMIC_RELAXED);
+        nraw = (int)(unsigned)(w1 >> 32);
+        if (status == 1) { n = (int)(unsigned)w1; ++c->cloud_route[0]; }
+        else if (status == 3) return fail(c, TDLO_E_HIP, "voxel grid produced more points than the slot holds");
+        else ++c->cloud_route[1];                 // not taken (too many masked pixels / cells, pass-through): the multi-launch form below
+    }
+    if (n < 0) {
+        // ---- the multi-launch form: bounding box + count, a host round trip, compaction, radix sort passes, centroids
+        // the last 64 ints of the workspace: bounding box (6 ordered floats), masked-pixel count, output count
+        unsigned *d_bbox = (unsigned *)(ws + cloud_ws_bytes(P) - 256);
+        int *d_total = (int *)(d_bbox + 8);
+        unsigned *hb = (unsigned *)c->pin;
+        hb[0] = hb[1] = hb[2] = ~0u; hb[3] = hb[4] = hb[5] = 0u; hb[6] = 0u; hb[7] = 0u; hb[8] = 0u;
+        HIPCHK(c, hipMemcpyAsync(d_bbox, hb, 9 * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        HIPCHK(c, launch_cloud_bbox(d_depth, d_mask, P, cols, cam, d_bbox, ws, st));
+        HIPCHK(c, hipMemcpyAsync(hb, d_bbox, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        nraw = (int)hb[6];
+        if (n_raw_out) *n_raw_out = nraw;
+        if (nraw == 0) return TDLO_OK;
+        auto decode = [](unsigned o) { const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; std::memcpy(&f, &u, 4); return f; };
+        float mn[3], mx[3];
+        for (int d = 0; d < 3; ++d) { mn[d] = decode(hb[d]); mx[d] = decode(hb[3 + d]); }
+        // pcl/filters/impl/voxel_grid.hpp applyFilter: leaf-size check, min_b / div_b / divb_mul (float arithmetic)
+        long long dd[3]; int min_b[3], div_b[3];
+        for (int d = 0; d < 3; ++d) {
+            dd[d] = (long long)((mx[d] - mn[d]) * inv) + 1;
+            min_b[d] = (int)std::floor(mn[d] * inv);
+            div_b[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+        }
+        const int nodown = (dd[0] * dd[1] * dd[2] > 2147483647ll) ? 1 : 0;
+        const long long cells = nodown ? 1 : (long long)div_b[0] * div_b[1] * div_b[2];
+        if (cells >= 0xffffffffll) return fail(c, TDLO_E_INVALID, "voxel grid has too many cells");
+        int passes = 1;
+        while (passes < 4 && (1ll << (8 * passes)) <= cells) ++passes;      // every valid key must stay below the all-ones sentinel
+        rc = ensure_points(c, s, nraw);
+        if (rc) return rc;
+        HIPCHK(c, launch_cloud_voxels(d_depth, d_mask, P, cols, cam, min_b, div_b[0], div_b[0] * div_b[1], inv, nodown, passes, nraw,
+                                      ws, d_total, s.cap_points, s.Xraw, st));
+        HIPCHK(c, hipMemcpyAsync(hb, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        n = (int)hb[0];
+        if (n < 0 || n > s.cap_points) return fail(c, TDLO_E_HIP, "voxel grid produced an impossible point count");
+    }
+    if (n_raw_out) *n_raw_out = nraw;
     s.N0 = n; s.sorted_valid = false;
     if (n_out) *n_out = n;
-    if (X_out) {
+    if (X_out && n > 0) {
         if (n > x_capacity) return fail(c, TDLO_E_INVALID, "X_out too small for the down-sampled cloud");
         HIPCHK(c, hipMemcpyAsync(X_out, s.Xraw, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -2214,7 +2317,10 @@ int tdlo_debug_mstep_dense(int on) { return mstep_set_dense(on); }
 int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
-long long tdlo_debug_route_count(tdlo_ctx *c, int which) { return (c && which >= 0 && which < 6) ? c->route_count[which] : -1; }
+long long tdlo_debug_route_count(tdlo_ctx *c, int which) {
+    if (!c || which < 0 || which > 7) return -1;
+    return which < 6 ? c->route_count[which] : c->cloud_route[which - 6];
+}
 
 int tdlo_debug_lle_band_device(tdlo_ctx *c, const double *Y, int M, double *Hb) {
     if (!c) return TDLO_E_INVALID;
@@ -2258,6 +2364,14 @@ int tdlo_debug_stamps(tdlo_ctx *c, int slot, unsigned long long *out, int n) {
     HIPCHK(c, hipMemcpyAsync(c->pin, c->fh[dbg_frame].dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(out, c->pin, sizeof(unsigned long long) * n);
+    return TDLO_OK;
+}
+
+int tdlo_debug_cloud_stamps(tdlo_ctx *c, unsigned long long *out, int n) {
+    if (!c || !out || n < 0 || n > 24) return TDLO_E_INVALID;
+    if (!c->cloud_fws) return fail(c, TDLO_E_INVALID, "no depth -> cloud call yet");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, (const char *)c->cloud_fws + 64, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));      // (24 words behind the 16 state words)
     return TDLO_OK;
 }
 

@@ -21,6 +21,7 @@
 // The result is written as the slot's raw cloud (N x 3 column-major doubles), i.e. exactly what tdlo_set_cloud
 // would have uploaded, so cpd_lle / tracking_step run on it without a host round trip of the cloud.
 #include "tdlo_internal.h"
+#include "tdlo_devcommon.h"
 #include <cstdint>
 
 namespace tdlo {
@@ -273,6 +274,496 @@ __global__ __launch_bounds__(kCB) void k_cloud_centroid(const unsigned short *__
 }
 
 }  // namespace
+
+// =================================================================================================================================================
+// The whole of depth image -> cloud -> voxel grid in ONE launch (round 5; VERDICT r04 item 3: the multi-launch form above is a bounding-box launch,
+// a host round trip for the masked-pixel count and the box, and ~15 more dependent launches to sort a few thousand keys: 0.28 ms per 640 x 480 frame,
+// 4.7 x the whole tracking_step behind it).
+//
+//   phase A, every workgroup (1024 threads, a tile of 4096 pixels): mask -> compaction in pixel order inside the tile (thread = 4 consecutive
+//     pixels, one 32-bit mask word), back-projection of the masked pixels (the arithmetic of trackdlo_node.cpp:220-224), the tile's points
+//     {x, y, z} as floats into the tile's own region of the workspace (agent-scope 16-byte stores), the tile's count, the bounding box by atomic
+//     min / max on order-preserving bits -- then a ticket.  Nobody waits for anybody: the workgroup that draws the LAST ticket carries on alone
+//     (no co-residency assumption, nothing to time out).
+//   phase B, that one workgroup: tile offsets (block scan of the counts), the grid of pcl::VoxelGrid from the box (the float arithmetic of
+//     voxel_grid.hpp's applyFilter, as the host does it for the multi-launch form), every point's cell index, and
+//     a stable LSD radix sort of (cell index << rb | rank in pixel order) -- ONE 32-bit word per point, all of it in LDS (up to 32 704 points, the
+//     words of a thread in registers between the phases of a pass): 4-bit digits, thread t owns R consecutive words, so equal digits are ordered
+//     by (thread, word of the thread) and no lane needs another to rank its words (matching the lanes of a wave by digit costs 8 ballots and
+//     ~320 clocks a 64-word round; LDS atomics on a digit most of a round's lanes share -- neighbouring pixels fall into one cell -- serialise):
+//     byte counters per (digit, thread) by LDS atomics, one block scan in digit-major order, places by LDS atomics with return.
+//     Then the coordinates in sorted order into LDS (all three at once up to 10 900 points, else one at a time), one thread per run of
+//     consecutive sorted positions: centroids as float sums in input (= pixel) order straight out of LDS, written as the slot's raw cloud, and the
+//     counts to a pinned results word the host waits on.
+//   Not taken (the last workgroup says so and the host runs the multi-launch form): more than 32 704 masked pixels, cell-index bits + rank bits
+//   beyond 32, "leaf size too small" (voxel_grid.hpp's pass-through), more than 4095 tiles.
+// The images are read where they are: device memory after a copy, or -- tdlo_image_buffers -- pinned host memory the caller filled (the mask is
+// read once, coalesced, straight over PCIe; depth only where the mask is set).
+// Bit-exact to the multi-launch form and to the oracle: the same float operations in the same order.
+namespace {
+
+constexpr int kFT = 1024;                // threads per workgroup
+constexpr int kFW = kFT / 64;            // waves
+constexpr int kFPix = 4 * kFT;           // pixels per tile
+constexpr int kFNmax = 32704;            // points the in-LDS sort takes (the CU's 160 KB: 4 bytes a point, 32 KB of counters, ~150 bytes of statics)
+constexpr int kFR = (kFNmax + kFT - 1) / kFT;      // sort words per thread (register resident between the phases of a pass): 32
+constexpr int kFTmax = 4095;             // tiles (their offsets live in the counters' area before the sort)
+constexpr size_t kFLdsE = (size_t)kFNmax * 4, kFLdsCnt = 16 * kFT * 2;
+static_assert(kFLdsCnt >= (size_t)(kFTmax + 1) * 4 && kFLdsCnt >= 8 * 512, "the tile offsets and the head bits live in the counters' area");
+constexpr size_t kFLds = kFLdsE + kFLdsCnt;         // 163 584 B; with the kernel's static LDS (132 B) just inside the CU's 163 840
+
+struct FusedCloud {
+    const unsigned short *depth; const unsigned char *mask;     // padded to 8 bytes beyond P pixels
+    int P, cols, T;
+    Cam cam;
+    float inv_leaf;
+    float *ex, *ey, *ez;                 // P each: tile b's points at [b * kFPix ...)
+    float *cx, *cy, *cz;                 // kFNmax each: the same points compacted (rank = position in pixel order)
+    int *tcnt;                           // T
+    unsigned *state;                     // [0..2] box min, [3..5] box max (order-preserving bits), [6] tickets; re-armed by the last workgroup
+    double *X; int cap;                  // the slot's raw cloud and its capacity in points
+    unsigned long long *res;             // pinned host: [1] = n_raw << 32 | n, then [0] = epoch << 32 | status (1 done, 2 not taken, 3 capacity)
+    unsigned epoch;
+};
+
+__device__ __forceinline__ float ordered_decode(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
+    return v;
+}
+// exclusive scan over the 1024 threads (wtot: 16 ints of LDS, free again on return); *total = sum
+__device__ __forceinline__ int block_excl_scan_i(int v, int *wtot, int t, int *total) {
+    const int lane = t & 63, w = t >> 6;
+    const int incl = wave_incl_scan_i(v, lane);
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kFW; ++i) { const int x = wtot[i]; off += i < w ? x : 0; tot += x; }
+    __syncthreads();
+    *total = tot;
+    return off + incl - v;
+}
+__device__ __forceinline__ int bits_for(unsigned long long values) { return values <= 2ull ? 1 : 64 - __builtin_clzll(values - 1ull); }   // bits that hold 0 .. values - 1
+// smallest position >= from whose head bit is set, n if there is none (H: one bit per sorted position, nothing set at or beyond n)
+__device__ __forceinline__ int next_head(const unsigned long long *H, int from, int n) {
+    if (from >= n) return n;
+    int wi = from >> 6;
+    unsigned long long m = H[wi] >> (from & 63);
+    if (m) return from + (int)__builtin_ctzll(m);
+    const int nw = (n + 63) >> 6;
+    for (++wi; wi < nw; ++wi) { m = H[wi]; if (m) return (wi << 6) + (int)__builtin_ctzll(m); }
+    return n;
+}
+
+struct FusedGrid { int min_b[3]; int mul1, mul2, rb, kb, take; };
+
+__global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    unsigned *E = (unsigned *)fsm;                                           // kFNmax sort words (through sw(): bank swizzle)
+    unsigned *cnt32 = (unsigned *)(fsm + kFLdsE);                            // 32 KB: per (digit, thread) counts as bytes, then start offsets as 16-bit words
+    int *toff = (int *)cnt32;                                                // (before the sort) T + 1 tile offsets
+    __shared__ int wtot[kFW];
+    __shared__ unsigned sbox[8];
+    __shared__ int slast;
+    __shared__ FusedGrid sgrid;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x;
+#ifdef TDLO_CLOUD_STAMPS      // phase stamps of the last workgroup (instrumented build only, scripts/gpu_cloud_stamps.py): 64-bit words behind the state words
+#define FSTAMP(i) do { __syncthreads(); if (t == 0) ((unsigned long long *)(a.state + 16))[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
+    // ================= phase A: this tile
+    {
+        const int p0 = b * kFPix + 4 * t;
+        unsigned m4 = 0;
+        if (p0 < a.P) m4 = *(const unsigned *)(a.mask + p0);
+        if (p0 + 4 > a.P) {                                                   // (the last word of the image: bytes beyond it do not count)
+            const int keep = a.P - p0;
+            m4 = keep <= 0 ? 0u : (m4 & (0xffffffffu >> (8 * (4 - keep))));
+        }
+        const int k0 = (m4 & 0xffu) != 0u, k1 = (m4 & 0xff00u) != 0u, k2 = (m4 & 0xff0000u) != 0u, k3 = (m4 & 0xff000000u) != 0u;
+        const int c = k0 + k1 + k2 + k3;
+        uint2 d4 = make_uint2(0u, 0u);
+        if (c) d4 = *(const uint2 *)(a.depth + p0);
+        int total;
+        int rnk = block_excl_scan_i(c, wtot, t, &total);
+        unsigned mn[3] = {~0u, ~0u, ~0u}, mx[3] = {0u, 0u, 0u};
+        if (c) {
+            int i = p0 / a.cols, j = p0 - i * a.cols;
+            const size_t dst = (size_t)b * kFPix;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool on = (k == 0 ? k0 : (k == 1 ? k1 : (k == 2 ? k2 : k3))) != 0;
+                if (on) {
+                    const unsigned dv = ((k < 2 ? d4.x : d4.y) >> (16 * (k & 1))) & 0xffffu;
+                    const double pc_z = (double)dv / 1000.0;                              // trackdlo_node.cpp:220
+                    const float x = (float)(((double)j - a.cam.cx) * pc_z / a.cam.fx);    // :222
+                    const float y = (float)(((double)i - a.cam.cy) * pc_z / a.cam.fy);    // :223
+                    const float z = (float)pc_z;                                          // :224
+                    __hip_atomic_store(a.ex + dst + rnk, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.ey + dst + rnk, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.ez + dst + rnk, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ++rnk;
+                    const unsigned o0 = ordered_bits(x), o1 = ordered_bits(y), o2 = ordered_bits(z);
+                    mn[0] = o0 < mn[0] ? o0 : mn[0]; mx[0] = o0 > mx[0] ? o0 : mx[0];
+                    mn[1] = o1 < mn[1] ? o1 : mn[1]; mx[1] = o1 > mx[1] ? o1 : mx[1];
+                    mn[2] = o2 < mn[2] ? o2 : mn[2]; mx[2] = o2 > mx[2] ? o2 : mx[2];
+                }
+                if (++j == a.cols) { j = 0; ++i; }
+            }
+        }
+        if (__ballot(c != 0) != 0ull) {                                       // (wave-uniform)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const unsigned u = __shfl_xor(mn[d], o), v = __shfl_xor(mx[d], o);
+                    mn[d] = u < mn[d] ? u : mn[d]; mx[d] = v > mx[d] ? v : mx[d];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    (void)__hip_atomic_fetch_min(a.state + d, mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_max(a.state + 3 + d, mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (t == 0) __hip_atomic_store(a.tcnt + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's stores and atomics have been performed
+        __syncthreads();
+        if (t == 0) slast = __hip_atomic_fetch_add(a.state + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.T - 1);
+        __syncthreads();
+        if (!slast) return;
+    }
+
+    // ================= phase B: the workgroup with the last ticket
+    FSTAMP(0);
+    // ---- the tiles' offsets, the count, the box
+    int n;
+    {
+        int carry = 0;
+        for (int b0 = 0; b0 < a.T; b0 += kFT) {
+            const int bb = b0 + t;
+            const int c = bb < a.T ? __hip_atomic_load(a.tcnt + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            if (b0 == 0 && t < 6) sbox[t] = __hip_atomic_load(a.state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the same round trip)
+            int tot;
+            const int ex = block_excl_scan_i(c, wtot, t, &tot);
+            if (bb < a.T) toff[bb] = carry + ex;
+            carry += tot;
+        }
+        n = carry;
+        if (t == 0) toff[a.T] = n;
+    }
+    // ---- pcl/filters/impl/voxel_grid.hpp applyFilter: leaf-size check, min_b / div_b / divb_mul in float arithmetic (one thread; the others wait)
+    const float inv = a.inv_leaf;
+    if (t == 0 && n > 0) {
+        int min_b[3], div_b[3];
+        bool take = n <= kFNmax;
+        long long ddp = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float mn = ordered_decode(sbox[d]), mx = ordered_decode(sbox[3 + d]);
+            const float ext = (mx - mn) * inv;
+            if (!(ext >= 0.0f && ext < 2147483000.0f)) take = false;             // (the host's arithmetic decides what happens out there)
+            const long long dd = (long long)(take ? ext : 0.0f) + 1;
+            ddp = (ddp > 2147483647ll || dd > 2147483647ll) ? 4294967296ll : ddp * dd;
+            const float lo = floorf(mn * inv), hi = floorf(mx * inv);
+            if (!(lo > -2147483000.0f && hi < 2147483000.0f)) take = false;
+            min_b[d] = take ? (int)lo : 0;
+            div_b[d] = take ? (int)hi - min_b[d] + 1 : 1;
+        }
+        if (ddp > 2147483647ll) take = false;                                     // "leaf size too small": the pass-through of the multi-launch form
+        const long long cells = (long long)div_b[0] * div_b[1] * div_b[2];
+        const int rb = bits_for((unsigned long long)n), kb = bits_for((unsigned long long)(cells > 0 ? cells : 1));
+        if (cells <= 0 || cells > 2147483647ll || rb + kb > 32) take = false;
+        sgrid.min_b[0] = min_b[0]; sgrid.min_b[1] = min_b[1]; sgrid.min_b[2] = min_b[2];
+        sgrid.mul1 = div_b[0]; sgrid.mul2 = div_b[0] * div_b[1]; sgrid.rb = rb; sgrid.kb = kb; sgrid.take = take ? 1 : 0;
+    }
+    __syncthreads();
+    FSTAMP(1);
+    auto finish = [&](unsigned status, int n_out) __attribute__((always_inline)) {
+        // re-arm the box and the tickets for the next launch; the counts to the host, then the word it waits on
+        if (t < 3) __hip_atomic_store(a.state + t, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (t < 7) __hip_atomic_store(a.state + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                     // every wave's stores to X have been performed
+        if (t == 0) {
+            __hip_atomic_store(a.res + 1, ((unsigned long long)(unsigned)n << 32) | (unsigned)n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.res, ((unsigned long long)a.epoch << 32) | status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    if (n == 0) { finish(1u, 0); return; }
+    if (!sgrid.take) { finish(2u, 0); return; }
+    const int mb0 = sgrid.min_b[0], mb1 = sgrid.min_b[1], mb2 = sgrid.min_b[2], mul1 = sgrid.mul1, mul2 = sgrid.mul2, rb = sgrid.rb, kb = sgrid.kb;
+    // word i of the sort lives at E[sw(i)]: thread t owns the R consecutive words [t R, t R + R) and the 64 lanes of a wave read them R words apart --
+    // with the 32 words of a block rotated by the block's number they fall into different banks whatever R is
+    auto sw = [](int i) __attribute__((always_inline)) { return i ^ ((i >> 5) & 31); };
+    const int R = (n + kFT - 1) / kFT;                                        // sort words per thread (the last threads' words beyond n do not exist)
+
+    // ---- where every rank's point lies: E[rank] = its index in the tiles' regions
+    for (int bb = w; bb < a.T; bb += kFW) {
+        const int o = toff[bb], c = toff[bb + 1] - o;
+        for (int i = lane; i < c; i += 64) E[o + i] = (unsigned)(bb * kFPix + i);
+    }
+    __syncthreads();
+    FSTAMP(2);
+    // ---- gather (rank = r * 1024 + t: coalesced), cell index, sort word; the compacted copy the centroids will read.
+    //      (One CU pulls about 10 bytes a clock from memory: 12 bytes a point, requested four points at a time, is what this step costs.)
+    {
+        unsigned src[4], word[4];
+        float px[4], py[4], pz[4];
+        for (int r0 = 0; r0 < R; r0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int g = (r0 + k) * kFT + t; src[k] = g < n ? E[g] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                px[k] = __hip_atomic_load(a.ex + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                py[k] = __hip_atomic_load(a.ey + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pz[k] = __hip_atomic_load(a.ez + src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g = (r0 + k) * kFT + t;
+                word[k] = 0u;
+                if (g < n) {
+                    const int i0 = (int)(floorf(px[k] * inv) - (float)mb0);      // voxel_grid.hpp: ijk = floor(p * inv_leaf) - min_b
+                    const int i1 = (int)(floorf(py[k] * inv) - (float)mb1);
+                    const int i2 = (int)(floorf(pz[k] * inv) - (float)mb2);
+                    word[k] = ((unsigned)(i0 + i1 * mul1 + i2 * mul2) << rb) | (unsigned)g;
+                    a.cx[g] = px[k]; a.cy[g] = py[k]; a.cz[g] = pz[k];
+                }
+            }
+            __syncthreads();                                                 // (the source map's words of this batch have been read by everybody: the sort words take their place, swizzled)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int g = (r0 + k) * kFT + t; if (g < n) E[sw(g)] = word[k]; }
+            __syncthreads();
+        }
+    }
+    FSTAMP(3);
+    // ---- stable LSD radix sort of the n words on the cell-index bits [rb, rb + kb), 4 bits a pass.  Thread t owns the words [t R, t R + R): the
+    //      order of equal digits is (thread, word of the thread), so a thread needs no other lane to rank its words -- per pass: its words into
+    //      registers; per (digit, thread) byte counters by LDS atomics without return (four threads share a 32-bit word); one block scan over the
+    //      16 x 1024 counters in digit-major order leaves every (digit, thread)'s start as a 16-bit word; each word's place is what an LDS atomic
+    //      WITH return hands back from that start (the atomics of a lane are performed in program order: the thread's words keep their order)
+    unsigned reg[kFR];
+    for (int sh = 0; sh < kb; sh += 4) {
+        const int shift = rb + sh;
+#pragma unroll
+        for (int r0 = 0; r0 < kFR; r0 += 4)
+            if (r0 < R) {                                                    // (wave-uniform)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int i = t * R + r0 + k; reg[r0 + k] = (r0 + k < R && i < n) ? E[sw(i)] : 0u; }
+            }
+        {   // counters to zero: 16 KB
+            uint4 *z = (uint4 *)cnt32;
+            z[t] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r0 = 0; r0 < kFR; r0 += 4)
+            if (r0 < R) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = t * R + r0 + k;
+                    if (r0 + k < R && i < n) {
+                        const unsigned d = (reg[r0 + k] >> shift) & 15u;
+                        (void)__hip_atomic_fetch_add(cnt32 + ((d * kFT + t) >> 2), 1u << (8 * (t & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        __syncthreads();
+        if (sh == 0) FSTAMP(16);
+        {   // exclusive scan in (digit, thread) order: scan thread t holds the counters 16 t .. 16 t + 15
+            const uint4 c4 = ((const uint4 *)cnt32)[t];
+            const unsigned cw[4] = {c4.x, c4.y, c4.z, c4.w};
+            int c[16], sum = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { c[i] = (int)((cw[i >> 2] >> (8 * (i & 3))) & 255u); sum += c[i]; }
+            int tot;
+            int run = block_excl_scan_i(sum, wtot, t, &tot);                 // (its barriers also separate the reads of the byte counters from the stores below)
+            unsigned o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const unsigned lo = (unsigned)run; run += c[2 * i]; const unsigned hi = (unsigned)run; run += c[2 * i + 1]; o[i] = lo | (hi << 16); }
+            uint4 *ob = (uint4 *)cnt32;
+            ob[2 * t] = make_uint4(o[0], o[1], o[2], o[3]);
+            ob[2 * t + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+        __syncthreads();
+        if (sh == 0) FSTAMP(17);
+#pragma unroll
+        for (int r0 = 0; r0 < kFR; r0 += 4)
+            if (r0 < R) {
+                unsigned old[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = t * R + r0 + k;
+                    old[k] = 0u;
+                    if (r0 + k < R && i < n) {
+                        const unsigned d = (reg[r0 + k] >> shift) & 15u;
+                        old[k] = __hip_atomic_fetch_add(cnt32 + ((d * kFT + t) >> 1), 1u << (16 * (t & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = t * R + r0 + k;
+                    if (r0 + k < R && i < n) E[sw((int)((old[k] >> (16 * (t & 1))) & 0xffffu))] = reg[r0 + k];
+                }
+            }
+        __syncthreads();
+        FSTAMP(8 + (sh >> 2));
+    }
+    FSTAMP(4);
+    // ---- one output point per cell, ascending cell index.  The sorted words into registers once more, position p = w S + r 64 + lane this time
+    //      (a wave-round = 64 consecutive positions), and the head bits: sorted position p starts a cell's run
+    const int S = R * 64;
+    unsigned long long *H = (unsigned long long *)cnt32;                     // <= 512 words
+#pragma unroll
+    for (int r0 = 0; r0 < kFR; r0 += 4)
+        if (r0 < R) {
+            unsigned prevw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = w * S + (r0 + k) * 64 + lane;
+                const bool in = r0 + k < R && p < n;
+                reg[r0 + k] = in ? E[sw(p)] : 0u;
+                prevw[k] = (in && p > 0) ? E[sw(p - 1)] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = w * S + (r0 + k) * 64 + lane;
+                const unsigned long long hm = __ballot(r0 + k < R && p < n && (p == 0 || (prevw[k] >> rb) != (reg[r0 + k] >> rb)));
+                if (lane == 0 && r0 + k < R) H[p >> 6] = hm;
+            }
+        }
+    __syncthreads();
+    // thread t takes the runs that start in the sorted positions [t q, t q + q), q <= 32
+    const int q = R;
+    const int p_lo = t * q < n ? t * q : n, p_hi = (t + 1) * q < n ? (t + 1) * q : n;
+    int heads = 0;
+    if (p_lo < p_hi) {                                                       // head bits in [p_lo, p_hi): at most two words of H
+        const int w0 = p_lo >> 6, w1 = (p_hi - 1) >> 6;
+        const unsigned long long m0 = H[w0] >> (p_lo & 63);
+        if (w0 == w1) heads = __popcll(m0 << (63 - ((p_hi - 1) & 63) + (p_lo & 63)));
+        else heads = __popcll(m0) + __popcll(H[w1] << (63 - ((p_hi - 1) & 63)));
+    }
+    int ncell;
+    const int out0 = block_excl_scan_i(heads, wtot, t, &ncell);
+    FSTAMP(5);
+    if (ncell > a.cap) { finish(3u, ncell); return; }
+    // The coordinates of every sorted position into LDS (the sort words live in registers by now: their LDS is free) -- all three at once when they
+    // fit, else one coordinate at a time --, then CentroidPoint's float sums in input order along each run, straight out of LDS, eight values
+    // requested at a time
+    float *V = (float *)E;
+    const unsigned rmask = (1u << rb) - 1u;
+    auto stage = [&](const float *cd, float *Vd) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r0 = 0; r0 < kFR; r0 += 4)
+            if (r0 < R) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const unsigned g = reg[r0 + k] & rmask; v[k] = cd[g < (unsigned)n ? g : 0u]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const int p = w * S + (r0 + k) * 64 + lane; if (r0 + k < R && p < n) Vd[p] = v[k]; }
+            }
+    };
+    if (3 * n <= kFNmax) {
+        __syncthreads();
+        stage(a.cx, V); stage(a.cy, V + n); stage(a.cz, V + 2 * n);
+        __syncthreads();
+        if (ncell == 0) { }      // (n > 0: never)
+        const float *Vx = V, *Vy = V + n, *Vz = V + 2 * n;
+        const size_t ld = (size_t)ncell;
+        int out = out0;
+        for (int p = next_head(H, p_lo, n); p < p_hi;) {
+            const int e = next_head(H, p + 1, n);
+            float sx = Vx[p], sy = Vy[p], sz = Vz[p];
+            int j = p + 1;
+            for (; j + 4 <= e; j += 4) {
+                float vx[4], vy[4], vz[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { vx[k] = Vx[j + k]; vy[k] = Vy[j + k]; vz[k] = Vz[j + k]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { sx += vx[k]; sy += vy[k]; sz += vz[k]; }
+            }
+            for (; j < e; ++j) { sx += Vx[j]; sy += Vy[j]; sz += Vz[j]; }
+            const float cf = (float)(e - p);
+            a.X[out] = (double)__fdiv_rn(sx, cf); a.X[ld + out] = (double)__fdiv_rn(sy, cf); a.X[2 * ld + out] = (double)__fdiv_rn(sz, cf);
+            ++out;
+            p = e;
+        }
+        FSTAMP(12);
+    } else {
+        for (int d = 0; d < 3; ++d) {
+            __syncthreads();
+            stage(d == 0 ? a.cx : (d == 1 ? a.cy : a.cz), V);
+            __syncthreads();
+            if (d == 0) FSTAMP(19);
+            double *Xd = a.X + (size_t)d * (size_t)ncell;
+            int out = out0;
+            for (int p = next_head(H, p_lo, n); p < p_hi;) {
+                const int e = next_head(H, p + 1, n);
+                float sum = V[p];
+                int j = p + 1;
+                for (; j + 8 <= e; j += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = V[j + k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) sum += v[k];
+                }
+                for (; j < e; ++j) sum += V[j];
+                Xd[out++] = (double)__fdiv_rn(sum, (float)(e - p));
+                p = e;
+            }
+            FSTAMP(12 + d);
+        }
+    }
+    FSTAMP(6);
+    finish(1u, ncell);
+#undef FSTAMP
+}
+
+}  // namespace
+
+size_t cloud_fused_ws_bytes(int P) {       // beside the multi-launch form's workspace: state words, compacted points, tile counts
+    const size_t T = ((size_t)P + kFPix - 1) / kFPix;
+    return 256 + 3 * (size_t)kFNmax * sizeof(float) + ((T * sizeof(int) + 255) & ~(size_t)255);
+}
+int cloud_fused_max_points() { return kFNmax; }
+bool cloud_fused_ok(int P) { return ((size_t)P + kFPix - 1) / kFPix <= (size_t)kFTmax; }
+
+// ws: the multi-launch form's workspace (three of its four P-word sort buffers serve as the tiles' regions), fws: cloud_fused_ws_bytes(P)
+// bytes kept by the kernels themselves between the launches (first == true: the state words are initialised by a copy in front of the launch)
+hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], float inv_leaf, void *ws, void *fws,
+                              bool first, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_cloud_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFLds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    FusedCloud a;
+    a.depth = depth; a.mask = mask; a.P = P; a.cols = cols; a.T = (P + kFPix - 1) / kFPix;
+    a.cam = Cam{cam[0], cam[1], cam[2], cam[3]};
+    a.inv_leaf = inv_leaf;
+    a.ex = (float *)ws; a.ey = a.ex + P; a.ez = a.ey + P;
+    a.state = (unsigned *)fws;                                   // (at a fixed place: another image size finds the words re-armed by the last launch)
+    a.cx = (float *)((char *)fws + 256); a.cy = a.cx + kFNmax; a.cz = a.cy + kFNmax;
+    a.tcnt = (int *)(a.cz + kFNmax);
+    a.X = Xraw; a.cap = cap; a.res = res_pinned; a.epoch = epoch;
+    if (first) {
+        static const unsigned init[8] = {~0u, ~0u, ~0u, 0u, 0u, 0u, 0u, 0u};
+        const hipError_t e = hipMemcpyAsync(a.state, init, sizeof init, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_cloud_fused, dim3(a.T), dim3(kFT), kFLds, s, a);
+    return hipGetLastError();
+}
 
 size_t cloud_ws_bytes(int P) {
     const size_t nblk = ((size_t)P + kTile - 1) / kTile;

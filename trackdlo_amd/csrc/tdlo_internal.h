@@ -251,6 +251,12 @@ hipError_t launch_cloud_bbox(const unsigned short *depth, const unsigned char *m
 hipError_t launch_cloud_voxels(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4],
                                const int min_b[3], int mul1, int mul2, float inv_leaf, int nodown, int passes, int n,
                                void *ws, int *total_dev, int cap, double *Xraw, hipStream_t s);
+// the same in ONE launch (k_cloud_fused): up to cloud_fused_max_points() masked pixels, images of up to 4095 tiles of 4096 pixels
+size_t cloud_fused_ws_bytes(int P);
+int cloud_fused_max_points();
+bool cloud_fused_ok(int P);
+hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], float inv_leaf, void *ws, void *fws,
+                              bool first, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s);
 int check_device_image();
 
 }  // namespace tdlo
