@@ -573,3 +573,25 @@ def test_tracking_step_survives_an_abandoned_grid_barrier(nth, ahead):
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a[0], b[0]); assert a[1] == b[1] and a[2] == b[2]
         np.testing.assert_array_equal(a[3], b[3]); np.testing.assert_array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("N,M", [(300, 8), (5000, 45), (30000, 45), (300000, 120), (70000, 1024)])
+def test_visibility_prepass_in_one_launch_equals_the_copy_route(N, M):
+    """tdlo_visibility_prepass (trackdlo_node.cpp:257-277): the nodes read from pinned host memory by the kernel, the minima handed to pinned host memory
+    by the workgroup with the last ticket, which re-arms the minima for the next call -- against two uploads, the kernel, a read-back copy and a
+    stream synchronisation (TDLO_DIRECT_UPLOAD=0).  Same distances bit for bit, call after call, clouds of one and of a thousand workgroups."""
+    from trackdlo_amd import binding as B, synth
+    X, Y0, _ = synth.scene(N, M, config=73, occlude=(0.3, 0.5), outliers=5)
+    coord = synth.geodesic_coord(Y0)
+    new, old = _ctx(B, False, max_points=N, max_nodes=max(64, M)), _ctx(B, True, max_points=N, max_nodes=max(64, M))
+    try:
+        for c in (new, old):
+            c.set_cloud(0, X)
+        for rep in range(3):
+            Y = Y0 + np.array([0.0, 0.002 * rep, 0.0])
+            a = new.visibility_prepass(0, Y, 0.008, 0.06, coord)
+            b = old.visibility_prepass(0, Y, 0.008, 0.06, coord)
+            for u, v in zip(a, b):
+                np.testing.assert_array_equal(u, v)
+    finally:
+        new.close(); old.close()

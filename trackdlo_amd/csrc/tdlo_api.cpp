@@ -171,6 +171,10 @@ struct tdlo_ctx {
     size_t img_pin_cap = 0;
     int img_pin_rows = 0, img_pin_cols = 0;
     bool cloud_fused_on = !(getenv("TDLO_CLOUD_FUSED") && atoi(getenv("TDLO_CLOUD_FUSED")) == 0);
+    // visibility pre-pass in one launch (k_node_min_dist_direct): minima + ticket on the device (kept armed by the kernel), [word | M minima] in pinned host memory
+    unsigned long long *vis_state = nullptr, *vis_res = nullptr;
+    unsigned vis_epoch = 0;
+    bool vis_armed = false;
     long long cloud_route[2] = {0, 0};   // tdlo_debug_route_count 6 / 7: depth -> cloud calls served by the one-launch kernel / sent on to the multi-launch form by it
     size_t pin_doubles = 0;
     std::string err;
@@ -1364,6 +1368,8 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->fd) hipFree(c->fd);
     if (c->cloud_ws) hipFree(c->cloud_ws);
     if (c->cloud_fws) hipFree(c->cloud_fws);
+    if (c->vis_state) hipFree(c->vis_state);
+    if (c->vis_res) hipHostFree(c->vis_res);
     if (c->cloud_res) hipHostFree(c->cloud_res);
     if (c->img_pin) hipHostFree(c->img_pin);
     if (c->reg_ws) hipFree(c->reg_ws);
@@ -2133,15 +2139,56 @@ int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, doubl
     if (rc) return rc;
     NodeCarve nc(M);
     hipStream_t st = c->stream;
-    double *dY = s.nodeblk + nc.Yin;                                  // reuse the node upload area
-    unsigned long long *dbits = (unsigned long long *)(s.nodeblk + nc.dmin);
+    if (c->cloud_pending >= 0 && (rc = flush_pending_cloud(c))) return rc;
     std::memcpy(c->pin, Y, sizeof(double) * 3 * M);
-    for (int m = 0; m < M; ++m) { const unsigned long long inf = 0x7ff0000000000000ull; std::memcpy(c->pin + 3 * M + m, &inf, 8); }
-    HIPCHK(c, hipMemcpyAsync(dY, c->pin, sizeof(double) * 3 * M, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(dbits, c->pin + 3 * M, sizeof(double) * M, hipMemcpyHostToDevice, st));
-    HIPCHK(c, launch_node_min_dist(s.Xraw, s.N0, dY, M, dbits, st));
-    HIPCHK(c, hipMemcpyAsync(c->pin, dbits, sizeof(double) * M, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (c->direct_in && M <= kMaxNodes) {
+        // one launch, no copies: the kernel reads the nodes from the pinned staging block and its last workgroup writes the minima to pinned host
+        // memory (TDLO_DIRECT_UPLOAD=0: the copies + stream synchronisation below, the comparator)
+        if (!c->vis_state) {
+            HIPCHK(c, hipMalloc((void **)&c->vis_state, sizeof(unsigned long long) * (kMaxNodes + 8)));
+            HIPCHK(c, hipHostMalloc((void **)&c->vis_res, sizeof(unsigned long long) * (kMaxNodes + 8), hipHostMallocDefault));
+            std::memset(c->vis_res, 0, sizeof(unsigned long long) * (kMaxNodes + 8));
+            c->vis_armed = false;
+        }
+        if (!c->vis_armed) {
+            std::vector<unsigned long long> init(kMaxNodes + 8, 0x7ff0000000000000ull);
+            for (int i = kMaxNodes; i < kMaxNodes + 8; ++i) init[i] = 0ull;
+            HIPCHK(c, hipMemcpy(c->vis_state, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
+            c->vis_armed = true;
+        }
+        if (++c->vis_epoch == 0) ++c->vis_epoch;
+        HIPCHK(c, launch_node_min_dist_direct(s.Xraw, s.N0, c->pin, M, c->vis_state, c->vis_res, c->vis_epoch, st));
+        auto t_chk = std::chrono::steady_clock::now();
+        for (unsigned spins = 1;; ++spins) {
+            if ((unsigned)__atomic_load_n(c->vis_res, __ATOMIC_ACQUIRE) == c->vis_epoch) break;
+            if ((spins & 255u) == 0) {
+                const auto now = std::chrono::steady_clock::now();
+                if (std::chrono::duration<double, std::micro>(now - t_chk).count() > 500.0) {
+                    t_chk = now;
+                    const hipError_t e = hipStreamQuery(st);
+                    if (e == hipSuccess) {
+                        if ((unsigned)__atomic_load_n(c->vis_res, __ATOMIC_ACQUIRE) == c->vis_epoch) break;
+                        c->vis_armed = false;
+                        return fail(c, TDLO_E_HIP, "the stream drained, but the visibility pre-pass did not report");
+                    }
+                    if (e != hipErrorNotReady) { c->vis_armed = false; return fail(c, TDLO_E_HIP, std::string("stream: ") + hipGetErrorString(e)); }
+                }
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        std::memcpy(c->pin, c->vis_res + 1, sizeof(double) * M);
+    } else {
+        double *dY = s.nodeblk + nc.Yin;                                  // reuse the node upload area
+        unsigned long long *dbits = (unsigned long long *)(s.nodeblk + nc.dmin);
+        for (int m = 0; m < M; ++m) { const unsigned long long inf = 0x7ff0000000000000ull; std::memcpy(c->pin + 3 * M + m, &inf, 8); }
+        HIPCHK(c, hipMemcpyAsync(dY, c->pin, sizeof(double) * 3 * M, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(dbits, c->pin + 3 * M, sizeof(double) * M, hipMemcpyHostToDevice, st));
+        HIPCHK(c, launch_node_min_dist(s.Xraw, s.N0, dY, M, dbits, st));
+        HIPCHK(c, hipMemcpyAsync(c->pin, dbits, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     // thresholding and gap fill on the host (O(M)): trackdlo_node.cpp:316/:326 (distance test only, the OpenCV
     // painter test of :279-343 is out of scope), :345-360
     std::vector<int> vis;

@@ -2009,6 +2009,54 @@ __global__ __launch_bounds__(kBlock) void k_node_min_dist(const double *__restri
     }
 }
 
+// The same in ONE launch and without copies (round 5): the nodes are read from pinned host memory by the kernel, the workgroup that draws the last
+// ticket hands the M minima to pinned host memory, re-arms the minima (+inf) and the ticket for the next call, and raises the word the host waits on.
+// state: [0 .. M) minima as ordered bits (armed: +inf), [kMaxNodes] tickets.  Same arithmetic in the same order as k_node_min_dist.
+__global__ __launch_bounds__(kBlock) void k_node_min_dist_direct(const double *__restrict__ X, int N, const double *__restrict__ Yhost, int M,
+                                                                unsigned long long *__restrict__ state, unsigned long long *__restrict__ res_host, unsigned epoch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Yl = (double *)smem;
+    __shared__ int slast;
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 3 * M; i += kBlock) Yl[i] = Yhost[i];
+    __syncthreads();
+    for (int base = blockIdx.x * kBlock; base < N; base += gridDim.x * kBlock) {
+        const int n = base + t;
+        const bool valid = n < N;
+        double x = 0, y = 0, z = 0;
+        if (valid) { x = X[n]; y = X[(size_t)N + n]; z = X[2 * (size_t)N + n]; }
+        for (int m = 0; m < M; ++m) {
+            const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
+            double d2 = valid ? dx * dx + dy * dy + dz * dz : __builtin_huge_val();
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) d2 = ::fmin(d2, __shfl_xor(d2, o));
+            if (lane == 0) (void)__hip_atomic_fetch_min(state + m, (unsigned long long)__double_as_longlong(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) slast = __hip_atomic_fetch_add(state + kMaxNodes, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(gridDim.x - 1);
+    __syncthreads();
+    if (!slast) return;
+    for (int m = t; m < M; m += kBlock) {
+        res_host[1 + m] = __hip_atomic_load(state + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(state + m, 0x7ff0000000000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t == 0) __hip_atomic_store(state + kMaxNodes, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(res_host, (unsigned long long)epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_node_min_dist_direct(const double *X, int N, const double *Yhost, int M, unsigned long long *state, unsigned long long *res_host, unsigned epoch, hipStream_t s) {
+    int blocks = (N + kBlock - 1) / kBlock;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_node_min_dist_direct, dim3(blocks), dim3(kBlock), sizeof(double) * 3 * M, s, X, N, Yhost, M, state, res_host, epoch);
+    return hipGetLastError();
+}
+
 hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s) {
     int blocks = (N + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;

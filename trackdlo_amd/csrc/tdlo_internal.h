@@ -223,6 +223,7 @@ hipError_t launch_xch_init(const FrameDev *frames_dev, hipStream_t s);          
 hipError_t launch_split_dmin_xch(const FrameDev *frames_dev, const FrameDev *frames_host, double *xch, int import, hipStream_t s);
 hipError_t launch_debug_exp2(const double *x, double *y, int n, hipStream_t s);       // test aid: Num<double>::exp2 on an array
 hipError_t launch_node_min_dist(const double *X, int N, const double *Y, int M, unsigned long long *out_bits, hipStream_t s);
+hipError_t launch_node_min_dist_direct(const double *X, int N, const double *Yhost, int M, unsigned long long *state, unsigned long long *res_host, unsigned epoch, hipStream_t s);
 size_t mstep_lds_bytes(int M);
 // tdlo_mstep_big.hip: M-step for 60 < M <= kMaxNodes without LLE (blocked Gauss-Jordan, tableau in global memory)
 hipError_t launch_mstep_big(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
