@@ -268,7 +268,7 @@ def _compact(full):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     o = {k: full[k] for k in keep if k in full}
     o["config"] = full.get("config")
-    for k in ("timed_region_s", "frames_per_s", "prune_dispatches_per_call", "em_loop_only_iters_per_s", "em_iters_per_s_f64", "us_per_iteration", "gpu_over_cpu"):
+    for k in ("timed_region_s", "frames_per_s", "prune_dispatches_per_call", "em_loop_only_iters_per_s", "em_iters_per_s_f64", "us_per_iteration", "gpu_over_cpu", "ranks_agree", "xch_can_access"):
         if k in full:
             o[k] = full[k]
     o["roofline"] = _compact_roofline(full.get("roofline"))
@@ -926,6 +926,20 @@ def bench_nsplit(args, cfg, env):
         ctx.close()
         return
     n_ranks, ranks = _rank_table(env)
+    # every rank solves the same system from the same reduced sums: the nodes and sigma2 must be the same BITS on all of them (first contact with a
+    # multi-GPU box: scripts/gpu_multi_first_contact.sh reads these)
+    import hashlib
+    import struct
+    y_hash = hashlib.sha1(np.ascontiguousarray(out["Y"], dtype=np.float64).tobytes() + struct.pack("<d", float(out["sigma2"]))).hexdigest()[:16]
+    can_access = [bool(ctx.xch_can_access(d)) if r != rank else True for r, d in enumerate(devices)]
+    if world > 1:
+        hashes, access = [None] * world, [None] * world
+        dist.all_gather_object(hashes, y_hash)
+        dist.all_gather_object(access, can_access)
+    else:
+        hashes, access = [y_hash], [can_access]
+    for r, e in enumerate(ranks):
+        e["y_sha1"] = hashes[r]
     if world > 1:           # what RCCL itself says about the group each rank is in (ncclCommCount of the library's communicator; null: no RCCL in the data path)
         sizes = [None] * world
         dist.all_gather_object(sizes, rccl_size)
@@ -948,6 +962,7 @@ def bench_nsplit(args, cfg, env):
                                          "whole calls (prune + sort + setup + loop + read-back), every call prunes",
                                 parallelism=f"points sharded over {n_ranks} rank(s); per iteration: {form}; identical M-step on every rank"),
                     timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"],
+                    ranks_agree=len(set(hashes)) == 1, xch_can_access=access,
                     roofline=roof, roofline_kernels=roof_all)
         cpu = None
 

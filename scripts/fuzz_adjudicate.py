@@ -1,0 +1,108 @@
+"""What the fuzz harnesses do with a result outside the STATED tolerance (the sweeps used to gate wider than stated and their
+outliers were explained by hand-run scripts).
+
+The stated gates (tests/test_parity_gpu.py): fp32 mode 1e-5 m / 1e-3 relative in sigma2, fp64 mode 1e-9 m / 1e-7.  A result outside
+them is ADJUDICATED -- passed -- only when the oracle itself is measured to be uncertain by that much on this very input (the procedure of
+tests/test_parity_gpu.py::_measured_gate, extended to registrations without an H and to tracker frames):
+  (a) its own rounding error: the faithful QR solve against the quadruple-precision solve of the same double-precision systems
+      (oracle.extended_solver), and
+  (b) its sensitivity to the last bit of the data at the product's working precision: nodes (and H, where one is handed in) perturbed by +-1 ulp per
+      entry -- 2^-52 relative in fp64 mode, 2^-23 in fp32 mode (the product computes its E-step in that precision; the oracle's sensitivity to a
+      perturbation of that size is what a correct fp32 implementation may differ by) --, twice with different signs;
+the gate becomes max(stated, 8 x the larger deviation); a perturbation that moves the oracle's own iteration count (a stopping decision on the
+edge) or makes it fail leaves nothing to compare: adjudicated as `undecided`.  Everything else outside the stated gate is UNEXPLAINED and fails.
+This module is test infrastructure (it drives the CPU oracle); nothing in the product imports it."""
+import numpy as np
+
+STATED = {0: (1e-5, 1e-3), 1: (1e-9, 1e-7)}
+_EPS = {0: 2.0 ** -23, 1: 2.0 ** -52}
+
+
+class Tally:
+    def __init__(self, prec):
+        self.prec = prec
+        self.compared = self.outside = self.adjudicated = self.unexplained = 0
+        self.worst = (0.0, None)
+        self.notes = []
+
+    def summary(self):
+        gy, gs = STATED[self.prec]
+        return (f"{self.compared} compared against the stated gate ({gy:g} m, {gs:g}): outside_stated {self.outside} / adjudicated {self.adjudicated} / "
+                f"unexplained {self.unexplained}; worst |dY| {self.worst[0]:.2e} m at {self.worst[1]}")
+
+    def as_dict(self):
+        return dict(compared=self.compared, outside_stated=self.outside, adjudicated=self.adjudicated, unexplained=self.unexplained, worst=self.worst)
+
+
+def _perturb(a, eps, rng):
+    a = np.asarray(a, dtype=np.float64)
+    return a * (1.0 + eps * rng.choice([-1.0, 1.0], size=a.shape))
+
+
+def cpd_uncertainty(ref_cpu, prec, X, Y0, s2, kw, o, priors=None, visible_nodes=None, H=None):
+    """(dy, ds, undecided) of the oracle's cpd_lle on this input."""
+    def run(Y, Hm):
+        extra = {} if Hm is None else dict(H=Hm)
+        return ref_cpu.cpd_lle(X, Y, s2, priors=priors, visible_nodes=visible_nodes, **extra, **kw)
+    dy = ds = 0.0
+    try:
+        with ref_cpu.extended_solver():
+            e = run(Y0, H)
+        if e["iters"] != o["iters"]:
+            return np.inf, np.inf, True
+        dy = float(np.abs(e["Y"] - o["Y"]).max()); ds = abs(e["sigma2"] - o["sigma2"]) / o["sigma2"]
+        rng = np.random.default_rng(4242)
+        for _ in range(2):
+            p = run(_perturb(Y0, _EPS[prec], rng), None if H is None else _perturb(H, _EPS[prec], rng))
+            if p["iters"] != o["iters"]:
+                return np.inf, np.inf, True
+            dy = max(dy, float(np.abs(p["Y"] - o["Y"]).max())); ds = max(ds, abs(p["sigma2"] - o["sigma2"]) / o["sigma2"])
+    except ValueError:
+        return np.inf, np.inf, True
+    return dy, ds, False
+
+
+def frame_uncertainty(oracle, prec, args, coord, Ypre, s2pre, X, vis, vext, Hpre, ref):
+    """The same for one tracking_step of the oracle's tracker (state before the frame: Ypre, s2pre; `ref` holds the oracle's result of the frame)."""
+    oY, os2, oit = ref.get_tracking_result(), ref.get_sigma2(), (ref.stats_pre.iters, ref.stats_main.iters)
+    oK = ref.get_correspondence_pairs().shape
+
+    def run(Y, Hm):
+        t = oracle.Tracker(*args); t.initialize_nodes(Y); t.initialize_geodesic_coord(coord); t.set_sigma2(s2pre)
+        t.tracking_step(X, vis, vext, H_pre=Hm)
+        return t
+    dy = ds = 0.0
+    try:
+        with oracle.extended_solver():
+            e = run(Ypre, Hpre)
+        cands = [e]
+        rng = np.random.default_rng(4242)
+        for _ in range(2):
+            cands.append(run(_perturb(Ypre, _EPS[prec], rng), _perturb(Hpre, _EPS[prec], rng)))
+        for t in cands:
+            if (t.stats_pre.iters, t.stats_main.iters) != oit or t.get_correspondence_pairs().shape != oK:
+                return np.inf, np.inf, True
+            dy = max(dy, float(np.abs(t.get_tracking_result() - oY).max())); ds = max(ds, abs(t.get_sigma2() - os2) / os2)
+    except ValueError:
+        return np.inf, np.inf, True
+    return dy, ds, False
+
+
+def judge(tally, label, dy, ds, same_counts, uncertainty):
+    """Counts one comparison; `uncertainty` is a callable returning (dy, ds, undecided), evaluated only when the stated gate is exceeded.
+    Returns True when the comparison passes (inside the stated gate, or adjudicated)."""
+    gy, gs = STATED[tally.prec]
+    tally.compared += 1
+    if dy > tally.worst[0] and np.isfinite(dy):
+        tally.worst = (dy, label)
+    if same_counts and dy <= gy and ds <= gs:
+        return True
+    tally.outside += 1
+    udy, uds, undecided = uncertainty()
+    if undecided or (dy <= max(gy, 8.0 * udy) and ds <= max(gs, 8.0 * uds) and same_counts):
+        tally.adjudicated += 1
+        tally.notes.append(f"adjudicated {label}: dY {dy:.2e} ds {ds:.2e}, oracle " + ("undecided (its own iteration count moves with the last bit of the input)" if undecided else f"uncertain by {udy:.2e} m / {uds:.2e}"))
+        return True
+    tally.unexplained += 1
+    tally.notes.append(f"UNEXPLAINED {label}: dY {dy:.2e} ds {ds:.2e} same iteration counts {same_counts}; oracle uncertain by {udy:.2e} m / {uds:.2e}")
+    return False

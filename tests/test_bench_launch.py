@@ -129,3 +129,15 @@ def test_in_run_parity_figure_is_on_the_line_and_fatal():
     r = subprocess.run(cmd, env=_env(TDLO_STUB_COMPUTE="1", TDLO_STUB_WRONG_CLOUD="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "GPU and CPU oracle disagree" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_first_contact_script_dry_run():
+    """scripts/gpu_multi_first_contact.sh -- the one command for the first multi-GPU box -- run here with the stand-in context
+    under gloo: c3 on 2 ranks, c4 on 2 ranks in both exchange forms; every run yields a line, the summary carries the peer-access matrix, the RCCL
+    group sizes and the per-rank hashes of the result, and the script's exit code says whether the ranks agree."""
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "gpu_multi_first_contact.sh"), "2"], env=dict(_env(), TDLO_FIRST_CONTACT_DRYRUN="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    out = r.stdout
+    assert out.count("n_gpus 2") == 3 and "ranks_agree True" in out and "xch_can_access [[True, True], [True, True]]" in out
+    assert "rccl_size [2, 2]" in out and "rccl_size [None, None]" in out and "every run produced a line and the ranks agree" in out
