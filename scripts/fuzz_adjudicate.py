@@ -8,7 +8,9 @@ tests/test_parity_gpu.py::_measured_gate, extended to registrations without an H
       (oracle.extended_solver), and
   (b) its sensitivity to the last bit of the data at the product's working precision: nodes (and H, where one is handed in) perturbed by +-1 ulp per
       entry -- 2^-52 relative in fp64 mode, 2^-23 in fp32 mode (the product computes its E-step in that precision; the oracle's sensitivity to a
-      perturbation of that size is what a correct fp32 implementation may differ by) --, twice with different signs;
+      perturbation of that size is what a correct fp32 implementation may differ by) --, twice with different signs, and
+  (c) its sensitivity to the ORDER of its own sums: the same cloud with its points permuted (mathematically the same registration; every sum over
+      the points is added up in another order, as any parallel implementation's is), twice;
 the gate becomes max(stated, 8 x the larger deviation); a perturbation that moves the oracle's own iteration count (a stopping decision on the
 edge) or makes it fail leaves nothing to compare: adjudicated as `undecided`.  Everything else outside the stated gate is UNEXPLAINED and fails.
 This module is test infrastructure (it drives the CPU oracle); nothing in the product imports it."""
@@ -57,6 +59,14 @@ def cpd_uncertainty(ref_cpu, prec, X, Y0, s2, kw, o, priors=None, visible_nodes=
             if p["iters"] != o["iters"]:
                 return np.inf, np.inf, True
             dy = max(dy, float(np.abs(p["Y"] - o["Y"]).max())); ds = max(ds, abs(p["sigma2"] - o["sigma2"]) / o["sigma2"])
+        Xa = np.asarray(X)
+        for _ in range(2):                                       # (c) the same points in another order: the same sums, added up differently
+            perm = rng.permutation(len(Xa))
+            extra = {} if H is None else dict(H=H)
+            p = ref_cpu.cpd_lle(Xa[perm], Y0, s2, priors=priors, visible_nodes=visible_nodes, **extra, **kw)
+            if p["iters"] != o["iters"]:
+                return np.inf, np.inf, True
+            dy = max(dy, float(np.abs(p["Y"] - o["Y"]).max())); ds = max(ds, abs(p["sigma2"] - o["sigma2"]) / o["sigma2"])
     except ValueError:
         return np.inf, np.inf, True
     return dy, ds, False
@@ -79,6 +89,12 @@ def frame_uncertainty(oracle, prec, args, coord, Ypre, s2pre, X, vis, vext, Hpre
         rng = np.random.default_rng(4242)
         for _ in range(2):
             cands.append(run(_perturb(Ypre, _EPS[prec], rng), _perturb(Hpre, _EPS[prec], rng)))
+        Xa = np.asarray(X)
+        for _ in range(2):                                       # (c) the frame's points in another order
+            perm = rng.permutation(len(Xa))
+            t = oracle.Tracker(*args); t.initialize_nodes(Ypre); t.initialize_geodesic_coord(coord); t.set_sigma2(s2pre)
+            t.tracking_step(Xa[perm], vis, vext, H_pre=Hpre)
+            cands.append(t)
         for t in cands:
             if (t.stats_pre.iters, t.stats_main.iters) != oit or t.get_correspondence_pairs().shape != oK:
                 return np.inf, np.inf, True
