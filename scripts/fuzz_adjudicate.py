@@ -13,6 +13,10 @@ tests/test_parity_gpu.py::_measured_gate, extended to registrations without an H
       the points is added up in another order, as any parallel implementation's is), twice;
 the gate becomes max(stated, 8 x the larger deviation); a perturbation that moves the oracle's own iteration count (a stopping decision on the
 edge) or makes it fail leaves nothing to compare: adjudicated as `undecided`.  Everything else outside the stated gate is UNEXPLAINED and fails.
+What the long fp64-mode sweeps of round 5 left unexplained (profiles/r05_fuzz.log: 6 of 400 chain draws, 6 of 1500 band draws, all at 1 .. 10 x the gate, none
+with the reference's parameter sets) was traced with TDLO_ACC_COARSER=n (the E-step's fixed-point sums made 2^n coarser): the chain draws' deviations
+grow in proportion (lambda = 1 without the LLE term: lambda sigma2 ~ 1e-5 amplifies the sums' 2^-39 .. 2^-42 m resolution per 64-point share), the band
+draws' do not move (chains of 394 .. 508 nodes: the unpivoted banded elimination's own rounding).  DESIGN.md 4.
 This module is test infrastructure (it drives the CPU oracle); nothing in the product imports it."""
 import numpy as np
 

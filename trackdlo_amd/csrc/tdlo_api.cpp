@@ -718,7 +718,8 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         for (int i = 0; i + 1 < M; ++i) { double d2 = 0; for (int d = 0; d < 3; ++d) { const double e = Y[d * M + i + 1] - Y[d * M + i]; d2 += e * e; } len += std::sqrt(d2); }
         int ld = 0; while (std::ldexp(1.0, ld) < 2.0 * (len + 0.2) && ld < 20) ++ld;
         // ... and one wave's share of one 64-point batch below 2^51 (acc_fix): P1 <= 64, |R| <= 64 D, a point's share of Q <= D^2
-        const int shP = std::min(60 - ln, 44);
+        static const int sh_coarser = getenv("TDLO_ACC_COARSER") ? atoi(getenv("TDLO_ACC_COARSER")) : 0;      // experiment: how much of a deviation from the oracle is the sums' resolution (scripts/gpu_acc.py)
+        const int shP = std::min(60 - ln, 44) - sh_coarser;
         f.acc_sh[0] = shP; f.acc_sh[1] = shP - ld; f.acc_sh[2] = shP - 2 * ld;
         // D is a heuristic (nodes can be pulled anywhere by a prior, a diverging registration leaves it): the E-step CHECKS every value it
         // converts against these limits -- the conversion stays exact below 2^51, the sum of all batches' shares (P1, R: one per 64-point
