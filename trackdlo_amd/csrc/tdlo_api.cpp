@@ -721,6 +721,10 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         static const int sh_coarser = getenv("TDLO_ACC_COARSER") ? atoi(getenv("TDLO_ACC_COARSER")) : 0;      // experiment: how much of a deviation from the oracle is the sums' resolution (scripts/gpu_acc.py)
         const int shP = std::min(60 - ln, 44) - sh_coarser;
         f.acc_sh[0] = shP; f.acc_sh[1] = shP - ld; f.acc_sh[2] = shP - 2 * ld;
+        {   // (experiment, with TDLO_ACC_COARSER: only one class of sums coarser)
+            static const int only = getenv("TDLO_ACC_COARSER_ONLY") ? atoi(getenv("TDLO_ACC_COARSER_ONLY")) : -1;
+            if (only >= 0) for (int k = 0; k < 3; ++k) if (k != only) f.acc_sh[k] += sh_coarser;
+        }
         // D is a heuristic (nodes can be pulled anywhere by a prior, a diverging registration leaves it): the E-step CHECKS every value it
         // converts against these limits -- the conversion stays exact below 2^51, the sum of all batches' shares (P1, R: one per 64-point
         // batch and node; Q: one per point) below 2^62 -- and ends the registration with TDLO_E_NUMERIC beyond them, as it does for NaN

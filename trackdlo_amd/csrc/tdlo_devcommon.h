@@ -223,7 +223,12 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
 // The extent is a heuristic: every converted value is therefore CHECKED against FrameDev::acc_lim in the E-step (exact conversion below 2^51,
 // totals below 2^62, NaN fails the comparison) and a violation ends the registration with TDLO_E_NUMERIC -- never a wrapped-around integer.
 __host__ __device__ inline int acc_stride(int M) { return 4 * M + 2; }
-__device__ __forceinline__ int acc_shift(const FrameDev &f, int i) { const int M = f.M; return i < M ? f.acc_sh[0] : (i < 4 * M ? f.acc_sh[1] : f.acc_sh[2]); }
+// (the sums the M-step reads were formed by the E-step in front of it with IterState::sh_boost extra digits for R, twice as many for Q: the word is read
+//  before the M-step's own set_iter_consts replaces it)
+__device__ __forceinline__ int acc_shift(const FrameDev &f, int i) {
+    const int M = f.M, b = TDLO_AS_GLOBAL(IterState, f.st)->sh_boost;
+    return i < M ? f.acc_sh[0] : (i < 4 * M ? f.acc_sh[1] + b : f.acc_sh[2] + 2 * b);
+}
 // double -> fixed point, round to nearest, |v * 2^sh| < 2^51 (checked by the caller against FrameDev::acc_lim): the sum v * 2^sh + 1.5 * 2^52 has unit spacing, so its low mantissa bits ARE the integer -- one FMA and
 // one 64-bit subtraction instead of the ~12 instructions of a double -> int64 conversion
 __device__ __forceinline__ double acc_scale(int sh) { return __hiloint2double((1023 + sh) << 20, 0); }
@@ -272,6 +277,21 @@ __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st
     // the E-step's node window (FrameDev::win_e32): E / |k2| = E 2 ln2 sigma2
     st->rwin32 = f.win_e32 * 1.3862943611198906 * sigma2;
     st->rwin64 = f.win_e64 * 1.3862943611198906 * sigma2;
+    // fp64 mode: the resolution of the fixed-point sums follows sigma.  FrameDev::acc_sh is sized for point-node distances up to twice the chain's
+    // length (a wave's share of R_m = sum p (x - y_m) is bounded by 64 D); but a normalised membership times its distance is at most about
+    // d_nearest + 0.61 sigma (p <= exp(-arc^2 / 2 sigma2), |x - y_m| <= d_nearest + arc), so once sigma is centimetres the shares are a hundredth of that
+    // bound and the sums can carry ld - ld_eff more digits, D_eff = 2 (0.4 m + 2 sigma) -- four times the prune's 0.1 m for nodes that have moved.  The
+    // E-step still CHECKS every share against the (finer) limit.  With lambda sigma2 ~ 1e-5 (lambda = 1 without the LLE term) the coarse resolution, 2^-39 m
+    // per share on a chain of 460 nodes, had put nodes 1e-8 m from the oracle's (profiles/r05_fuzz.log); fp32 mode's tile sums carry 1e-7 relative anyway.
+    int boost = 0;
+    if (f.precision == TDLO_PREC_F64 && sigma2 > 0.0) {
+        const int ld = f.acc_sh[0] - f.acc_sh[1];
+        const double deff = 2.0 * (0.4 + 2.0 * ::sqrt(sigma2));
+        int lde = 0;                                   // (D_eff >= 0.8: 2^0 is the smallest extent there is)
+        while (lde < ld && ::ldexp(1.0, lde) < deff) ++lde;
+        boost = ld - lde;
+    }
+    st->sh_boost = boost;
 }
 
 

@@ -498,7 +498,7 @@ __device__ __forceinline__ void setup_body(const FrameDev &f, int split_mode, co
         if (!reuse && !split_mode) { f.keep[0] = (double)N; f.keep[1] = sS; }
         st->N = N; st->sum_d2 = sS;
         st->it = 0; st->converged = 1; st->crit = 0; st->Np = 0;
-        st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0;
+        st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0; st->sh_boost = 0;
         if (!split_mode) {
             if (N == 0) { st->status = TDLO_E_EMPTY; st->done = 1; st->sigma2 = f.sigma2_in; }
             else {
@@ -537,7 +537,7 @@ __device__ __forceinline__ void fused_iter0(const FrameDev &f, int N, double sS)
     f.keep[0] = (double)N; f.keep[1] = sS;
     st->N = N; st->sum_d2 = sS;
     st->it = 0; st->converged = 1; st->crit = 0; st->Np = 0;
-    st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0;
+    st->status = 0; st->done = 0; st->retries = 0; st->retry_pending = 0; st->sh_boost = 0;
     if (N == 0) { st->status = TDLO_E_EMPTY; st->done = 1; st->sigma2 = f.sigma2_in; }
     else {
         double sigma2 = f.sigma2_in;
@@ -553,7 +553,7 @@ __device__ __forceinline__ void fused_fail(const FrameDev &f) {
     f.keep[0] = 0.0; f.keep[1] = 0.0;
     st->N = 0; st->sum_d2 = 0.0;
     st->it = 0; st->converged = 0; st->crit = 0; st->Np = 0;
-    st->retries = 0; st->retry_pending = 0; st->sigma2 = f.sigma2_in;
+    st->retries = 0; st->retry_pending = 0; st->sh_boost = 0; st->sigma2 = f.sigma2_in;
     st->status = TDLO_E_FUSE; st->done = 1;
 }
 
@@ -1081,10 +1081,11 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 
     // running sums in 64-bit fixed point (acc_fix at the grain of one wave x one batch; integer from there on: tdlo_devcommon.h)
     long long accQ = 0;
-    const double scP = acc_scale(f.acc_sh[0]), scR = acc_scale(f.acc_sh[1]), scQ = acc_scale(f.acc_sh[2]);
+    const int shb = stg->sh_boost;         // (fp64 mode: extra digits for R, twice as many for Q, while sigma is small: set_iter_consts)
+    const double scP = acc_scale(f.acc_sh[0]), scR = acc_scale(f.acc_sh[1] + shb), scQ = acc_scale(f.acc_sh[2] + 2 * shb);
     // every converted value is checked against its limit (FrameDev::acc_lim: exact conversion, no wrap-around of the totals; a NaN fails
     // the comparison too): one compare per conversion into a lane mask, looked at once per wave at the end
-    const double limP = f.acc_lim[0], limR = f.acc_lim[1], limQ = f.acc_lim[2];
+    const double limP = f.acc_lim[0], limR = f.acc_lim[1] * acc_scale(-shb), limQ = f.acc_lim[2] * acc_scale(-2 * shb);
     bool acc_ok = true;
     // NCH == 1 (M <= 64): windowed variant.  The cloud is sorted by nearest node, so the 64 points of a
     // wave sit on a short piece of the chain, and every membership whose exponent is below -151 (fp32;

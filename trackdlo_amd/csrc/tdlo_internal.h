@@ -45,6 +45,8 @@ struct IterState {
     int status;         // 0 or TDLO_E_*
     int retry_pending;  // set by the finishing workgroup of a multi-CU M-step after a timed-out hand-off: the one-workgroup kernel that follows redoes the iteration
     int retries;        // iterations whose multi-CU elimination hit a hand-off time limit and were redone in one workgroup
+    int sh_boost;       // fp64 mode: extra binary digits of the E-step's fixed-point sums R (and twice as many of Q) in the iteration that follows -- set with sigma2
+                        // (set_iter_consts), used by that E-step and by the M-step that reads its sums
 };
 
 // Immutable-after-setup description of one frame's registration.
