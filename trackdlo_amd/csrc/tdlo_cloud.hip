@@ -328,10 +328,15 @@ struct FusedCloud {
 
 __device__ __forceinline__ float ordered_decode(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 
+// inclusive scan over the 64 lanes: four DPP row shifts inside the rows of 16 lanes (lanes without a source read 0), then the totals of the rows in
+// front by three v_readlane -- ~100 clocks where six trips through the LDS crossbar (__shfl_up) took 576 (scripts/ubench/wg1024.hip)
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    return v + (lane >= 16 ? r0 : 0) + (lane >= 32 ? r1 : 0) + (lane >= 48 ? r2 : 0);
 }
 // exclusive scan over the 1024 threads (wtot: 16 ints of LDS, free again on return); *total = sum
 __device__ __forceinline__ int block_excl_scan_i(int v, int *wtot, int t, int *total) {
