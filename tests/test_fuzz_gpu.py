@@ -62,3 +62,12 @@ def test_band_sweep_block_of_60_cases(block):
     r = _harness("gpu_fuzz_band").run(60, 60 * block, verbose=False)
     print(f"band sweep block {block}: outside_stated {r['outside_stated']} / adjudicated {r['adjudicated']} / unexplained {r['unexplained']}")
     assert r["bad"] == 0 and r["unexplained"] == 0 and r["compared"] >= 40, r
+
+
+@pytest.mark.parametrize("seed", [78, 124, 228])
+def test_sums_resolution_follows_sigma_in_fp64_mode(seed):
+    """Three draws of the chain sweep that lay 3e-9 .. 1e-8 m from the oracle before round 5 (lambda = 1 without the LLE term, beta = 0.1 / a 427-point
+    cloud on 435 nodes: lambda sigma2 ~ 1e-5 amplifies the E-step's fixed-point resolution, 2^-39 m per 64-point share on a 460-node chain).  In fp64
+    mode the sums now carry ld - ld_eff more digits once sigma is small (IterState::sh_boost): inside the stated 1e-9 m gate, no adjudication needed."""
+    r = _harness("gpu_fuzz_chain").run(1, seed, 1, verbose=False)
+    assert r["compared"] == 1 and r["outside_stated"] == 0 and r["worst"][0] < 1e-9, r
