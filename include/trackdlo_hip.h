@@ -337,9 +337,10 @@ int tdlo_depth_to_cloud(tdlo_ctx *ctx, int slot, const unsigned short *depth, co
                         double fx, double fy, double cx, double cy, double leaf_size,
                         double *X_out, int x_capacity, int *n_out, int *n_raw_out);
 /* Up to 32 704 masked pixels (a 1280 x 720 frame of the reference's camera, launch/realsense_node.launch:7-12, holds about 30 000 on the rope) the
- * whole step is ONE kernel launch (csrc/tdlo_cloud.hip, k_cloud_fused: compaction, back-projection and bounding box per 4096-pixel tile, then the
- * workgroup that finishes last sorts cell index | pixel rank in LDS, 4 bits a pass, and forms the centroids) whose last workgroup reports the counts through
- * pinned host memory; more masked pixels, a grid whose cell-index bits + rank bits exceed 32, or PCL's pass-through case take the multi-launch
+ * whole step is ONE kernel launch (csrc/tdlo_cloud.hip: compaction, back-projection and bounding box per 4096-pixel tile; then the last eight workgroups
+ * to finish sort cell index | pixel rank as a team -- k_cloud_team: they are running, hence co-resident, every wait between them is bounded and a team
+ * that cannot complete hands the frame to the multi-launch form -- and form the centroids; TDLO_CLOUD_TEAM=0: the ONE workgroup that finishes last does it
+ * alone in LDS, k_cloud_fused) whose last workgroup reports the counts through pinned host memory; more masked pixels, a grid whose cell-index bits + rank bits exceed 32, or PCL's pass-through case take the multi-launch
  * form (bounding box, host round trip, radix sort passes, centroids) -- the same bits either way (TDLO_CLOUD_FUSED=0 forces it; tdlo_debug_route_count
  * 6 / 7 count the calls the one-launch kernel served / passed on).
  *

@@ -1,10 +1,11 @@
-"""Phase split of k_cloud_fused's finishing workgroup (build: bash scripts/build_variant.sh cstamps -DTDLO_CLOUD_STAMPS; run with
+"""Phase split of the one-launch depth -> cloud kernel: team workgroup 0 of k_cloud_team (default) or, with TDLO_CLOUD_TEAM=0, k_cloud_fused's finishing workgroup (build: bash scripts/build_variant.sh cstamps -DTDLO_CLOUD_STAMPS; run with
 TDLO_LIBRARY=scripts/tmp/libtrackdlo_cstamps.so).  s_memtime ticks = shader clocks (about 2.1 GHz)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from trackdlo_amd import binding as B, synth
-names = ["offsets+box", "source map", "gather+keys", "sort", "heads", "centroids"]
+team = os.environ.get("TDLO_CLOUD_TEAM", "1") != "0"
+names = ["offsets+grid", "gather", "sort", "heads", "run end + staging", "centroids"] if team else ["offsets+box", "source map", "gather+keys", "sort", "heads", "centroids"]
 c = B.Context(device=0, timing=False)
 for shape in ((480, 640), (720, 1280)):
     depth, mask, cam, _ = synth.depth_scene(50, config=9, frame=3, rows=shape[0], cols=shape[1])
@@ -20,6 +21,6 @@ for shape in ((480, 640), (720, 1280)):
             extra = np.array([full[8] - full[3], full[9] - full[8], full[10] - full[9], full[11] - full[10], full[16] - full[3], full[17] - full[16], full[8] - full[17]])
             xacc = xacc + extra if k > 8 else extra
     acc /= 32
-    print(f"   sort passes (4 bits each): " + " / ".join(f"{v / 32:.0f}" for v in xacc[:4]) + f" clk   pass 1: words + count {xacc[4] / 32:.0f}  scan {xacc[5] / 32:.0f}  scatter {xacc[6] / 32:.0f} clk")
+    if not team: print(f"   sort passes (4 bits each): " + " / ".join(f"{v / 32:.0f}" for v in xacc[:4]) + f" clk   pass 1: words + count {xacc[4] / 32:.0f}  scan {xacc[5] / 32:.0f}  scatter {xacc[6] / 32:.0f} clk")
     print(f"{shape[1]}x{shape[0]}: " + "  ".join(f"{n} {v:.0f} clk" for n, v in zip(names, acc)) + f"   total {acc.sum() / 2100:.2f} us at 2.1 GHz", flush=True)
 c.close()

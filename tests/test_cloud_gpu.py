@@ -136,3 +136,68 @@ def test_cases_the_one_launch_kernel_passes_on(oracle):
         assert n == 1 and np.array_equal(X, Xo) and ctx.cloud_route_counts() == [3, 3]
     finally:
         ctx.close()
+
+
+def test_one_finishing_workgroup_and_the_team_give_the_same_bits(oracle):
+    """The one-launch kernel in its two forms: phase B by the last EIGHT workgroups as a team (k_cloud_team, the default) and by the one workgroup with
+    the last ticket (k_cloud_fused, TDLO_CLOUD_TEAM=0).  Same words, same stable order, same float sums: the same doubles, at both image sizes and on a
+    speckle mask (every point its own cell: the team's slices end inside runs of length one)."""
+    from trackdlo_amd import binding as B, synth
+    old = os.environ.get("TDLO_CLOUD_TEAM")
+    try:
+        os.environ.pop("TDLO_CLOUD_TEAM", None)
+        team = _ctx(B)
+        os.environ["TDLO_CLOUD_TEAM"] = "0"
+        one = _ctx(B)
+    finally:
+        if old is None:
+            os.environ.pop("TDLO_CLOUD_TEAM", None)
+        else:
+            os.environ["TDLO_CLOUD_TEAM"] = old
+    try:
+        rng = np.random.default_rng(77)
+        for shape, leaf in (((480, 640), 0.008), ((720, 1280), 0.008), ((720, 1280), 0.05), ((90, 100), 0.02)):
+            depth, mask, cam, _ = synth.depth_scene(40, config=9, frame=shape[0], rows=shape[0], cols=shape[1])
+            if shape[0] < 100:
+                mask[:] = (rng.random(shape) < 0.3) * 255
+            for speckle in (False, True):
+                if speckle:
+                    mask = ((rng.random(shape) < 0.02) * 255).astype(np.uint8)
+                    depth = (500 + rng.integers(0, 300, size=shape)).astype(np.uint16)
+                Xo, nraw_o = oracle.depth_to_cloud(depth, mask, *_args(cam), leaf)
+                Xt, nt, nrawt = team.depth_to_cloud(0, depth, mask, *_args(cam), leaf)
+                X1, n1, nraw1 = one.depth_to_cloud(0, depth, mask, *_args(cam), leaf)
+                assert nrawt == nraw1 == nraw_o and nt == n1 == Xo.shape[0]
+                assert np.array_equal(Xt, Xo) and np.array_equal(X1, Xo)
+        assert team.cloud_route_counts()[0] >= 6 and one.cloud_route_counts()[0] >= 6
+    finally:
+        team.close(); one.close()
+
+
+def test_a_team_that_loses_a_member_gives_the_launch_up(oracle):
+    """Every wait inside the team is bounded: with a member that never arrives (TDLO_CLOUD_TEAM_FORCE_TIMEOUT=2: the process's second team launch) the
+    others give the launch up after 2 s, the last one reports that, the host initialises the state words again and runs the multi-launch form -- the
+    caller gets the same cloud, only late; the launches before and after are served by the team."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, os.getcwd())
+        import numpy as np
+        from oracle import ref_cpu
+        from trackdlo_amd import binding as B, synth
+        depth, mask, cam, _ = synth.depth_scene(40, config=9, frame=5)
+        a = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        Xo, _ = ref_cpu.depth_to_cloud(depth, mask, *a, 0.008)
+        ctx = B.Context(device=0)
+        for k in range(4):
+            t0 = time.perf_counter(); X, n, _ = ctx.depth_to_cloud(0, depth, mask, *a, 0.008); dt = time.perf_counter() - t0
+            assert np.array_equal(X, Xo), k
+            assert (dt > 1.9) == (k == 1), (k, dt)
+        assert ctx.cloud_route_counts() == [3, 1], ctx.cloud_route_counts()
+        print("OK")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TDLO_CLOUD_TEAM_FORCE_TIMEOUT="2")
+    env.pop("TDLO_CLOUD_TEAM", None); env.pop("TDLO_CLOUD_FUSED", None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

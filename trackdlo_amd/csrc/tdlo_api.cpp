@@ -171,6 +171,7 @@ struct tdlo_ctx {
     size_t img_pin_cap = 0;
     int img_pin_rows = 0, img_pin_cols = 0;
     bool cloud_fused_on = !(getenv("TDLO_CLOUD_FUSED") && atoi(getenv("TDLO_CLOUD_FUSED")) == 0);
+    bool cloud_team_on = !(getenv("TDLO_CLOUD_TEAM") && atoi(getenv("TDLO_CLOUD_TEAM")) == 0);      // 0: ONE finishing workgroup (k_cloud_fused) instead of the last eight as a team (k_cloud_team)
     // visibility pre-pass in one launch (k_node_min_dist_direct): minima + ticket on the device (kept armed by the kernel), [word | M minima] in pinned host memory
     unsigned long long *vis_state = nullptr, *vis_res = nullptr;
     unsigned vis_epoch = 0;
@@ -2068,7 +2069,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
         }
         if ((rc = ensure_points(c, s, cloud_fused_max_points()))) return rc;      // (an output point per masked pixel at most; sized once)
         if (++c->cloud_epoch == 0) ++c->cloud_epoch;
-        HIPCHK(c, launch_cloud_fused(d_depth, d_mask, P, cols, cam, inv, ws, c->cloud_fws, c->cloud_fused_first, s.Xraw, s.cap_points, c->cloud_res, c->cloud_epoch, st));
+        HIPCHK(c, launch_cloud_fused(d_depth, d_mask, P, cols, cam, inv, ws, c->cloud_fws, c->cloud_fused_first, c->cloud_team_on, s.Xraw, s.cap_points, c->cloud_res, c->cloud_epoch, st));
         c->cloud_fused_first = false;
         const int status = cloud_wait(c, st, c->cloud_epoch);
         if (status < 0) { c->cloud_fused_first = true; return status; }
@@ -2077,6 +2078,7 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
         nraw = (int)(unsigned)(w1 >> 32);
         if (status == 1) { n = (int)(unsigned)w1; ++c->cloud_route[0]; }
         else if (status == 3) return fail(c, TDLO_E_HIP, "voxel grid produced more points than the slot holds");
+        else if (status == 4) { c->cloud_fused_first = true; ++c->cloud_route[1]; }      // the team gave the launch up (a wait of 2 s): state words initialised again, the multi-launch form below
         else ++c->cloud_route[1];                 // not taken (too many masked pixels / cells, pass-through): the multi-launch form below
     }
     if (n < 0) {

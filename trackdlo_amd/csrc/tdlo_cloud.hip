@@ -23,6 +23,7 @@
 #include "tdlo_internal.h"
 #include "tdlo_devcommon.h"
 #include <cstdint>
+#include <cstdlib>
 
 namespace tdlo {
 
@@ -320,10 +321,13 @@ struct FusedCloud {
     float *ex, *ey, *ez;                 // P each: tile b's points at [b * kFPix ...)
     float *cx, *cy, *cz;                 // kFNmax each: the same points compacted (rank = position in pixel order)
     int *tcnt;                           // T
+    unsigned *tw0, *tw1;                 // kFNmax each: the team kernel's sort words, ping and pong
+    int *thist;                          // kTK x 256 digit counts + kTK head counts of the team kernel
     unsigned *state;                     // [0..2] box min, [3..5] box max (order-preserving bits), [6] tickets; re-armed by the last workgroup
     double *X; int cap;                  // the slot's raw cloud and its capacity in points
     unsigned long long *res;             // pinned host: [1] = n_raw << 32 | n, then [0] = epoch << 32 | status (1 done, 2 not taken, 3 capacity)
     unsigned epoch;
+    int hook;                            // test hook (TDLO_CLOUD_TEAM_FORCE_TIMEOUT): the team's last workgroup leaves before its first barrier, the others wait out the limit
 };
 
 __device__ __forceinline__ float ordered_decode(unsigned o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
@@ -365,23 +369,36 @@ __device__ __forceinline__ int next_head(const unsigned long long *H, int from, 
 
 struct FusedGrid { int min_b[3]; int mul1, mul2, rb, kb, take; };
 
-__global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
-    extern __shared__ __attribute__((aligned(16))) char fsm[];
-    unsigned *E = (unsigned *)fsm;                                           // kFNmax sort words (through sw(): bank swizzle)
-    unsigned *cnt32 = (unsigned *)(fsm + kFLdsE);                            // 32 KB: per (digit, thread) counts as bytes, then start offsets as 16-bit words
-    int *toff = (int *)cnt32;                                                // (before the sort) T + 1 tile offsets
-    __shared__ int wtot[kFW];
-    __shared__ unsigned sbox[8];
-    __shared__ int slast;
-    __shared__ FusedGrid sgrid;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, b = blockIdx.x;
-#ifdef TDLO_CLOUD_STAMPS      // phase stamps of the last workgroup (instrumented build only, scripts/gpu_cloud_stamps.py): 64-bit words behind the state words
-#define FSTAMP(i) do { __syncthreads(); if (t == 0) ((unsigned long long *)(a.state + 16))[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FSTAMP(i) do { } while (0)
-#endif
+// pcl/filters/impl/voxel_grid.hpp applyFilter: leaf-size check, min_b / div_b / divb_mul in float arithmetic, from the bounding box (ordered bits) and the
+// point count; g.take = 0 when the in-LDS sort cannot serve the frame (too many points, cell-index bits + rank bits beyond 32, PCL's pass-through)
+__device__ __forceinline__ void cloud_grid(const unsigned *sbox, int n, float inv, FusedGrid &g) {
+    int min_b[3], div_b[3];
+    bool take = n <= kFNmax;
+    long long ddp = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float mn = ordered_decode(sbox[d]), mx = ordered_decode(sbox[3 + d]);
+        const float ext = (mx - mn) * inv;
+        if (!(ext >= 0.0f && ext < 2147483000.0f)) take = false;             // (the host's arithmetic decides what happens out there)
+        const long long dd = (long long)(take ? ext : 0.0f) + 1;
+        ddp = (ddp > 2147483647ll || dd > 2147483647ll) ? 4294967296ll : ddp * dd;
+        const float lo = floorf(mn * inv), hi = floorf(mx * inv);
+        if (!(lo > -2147483000.0f && hi < 2147483000.0f)) take = false;
+        min_b[d] = take ? (int)lo : 0;
+        div_b[d] = take ? (int)hi - min_b[d] + 1 : 1;
+    }
+    if (ddp > 2147483647ll) take = false;                                     // "leaf size too small": the pass-through of the multi-launch form
+    const long long cells = (long long)div_b[0] * div_b[1] * div_b[2];
+    const int rb = bits_for((unsigned long long)n), kb = bits_for((unsigned long long)(cells > 0 ? cells : 1));
+    if (cells <= 0 || cells > 2147483647ll || rb + kb > 32) take = false;
+    g.min_b[0] = min_b[0]; g.min_b[1] = min_b[1]; g.min_b[2] = min_b[2];
+    g.mul1 = div_b[0]; g.mul2 = div_b[0] * div_b[1]; g.rb = rb; g.kb = kb; g.take = take ? 1 : 0;
+}
 
-    // ================= phase A: this tile
+// phase A of the one-launch kernels, every workgroup: its tile of 4096 pixels -- compaction in pixel order, back-projection, the points to the tile's
+// region, count, bounding box -- and a ticket (returned to every thread: 0 .. T - 1 in the order the workgroups finished)
+__device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot, unsigned *sticket) {
+    const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
     {
         const int p0 = b * kFPix + 4 * t;
         unsigned m4 = 0;
@@ -441,10 +458,32 @@ __global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
         if (t == 0) __hip_atomic_store(a.tcnt + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's stores and atomics have been performed
         __syncthreads();
-        if (t == 0) slast = __hip_atomic_fetch_add(a.state + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.T - 1);
+        if (t == 0) *sticket = __hip_atomic_fetch_add(a.state + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (!slast) return;
     }
+    return *sticket;
+}
+
+
+
+__global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    unsigned *E = (unsigned *)fsm;                                           // kFNmax sort words (through sw(): bank swizzle)
+    unsigned *cnt32 = (unsigned *)(fsm + kFLdsE);                            // 32 KB: per (digit, thread) counts as bytes, then start offsets as 16-bit words
+    int *toff = (int *)cnt32;                                                // (before the sort) T + 1 tile offsets
+    __shared__ int wtot[kFW];
+    __shared__ unsigned sbox[8];
+    __shared__ unsigned sticket;
+    __shared__ FusedGrid sgrid;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+#ifdef TDLO_CLOUD_STAMPS      // phase stamps of the last workgroup (instrumented build only, scripts/gpu_cloud_stamps.py): 64-bit words behind the state words
+#define FSTAMP(i) do { __syncthreads(); if (t == 0) ((unsigned long long *)(a.state + 16))[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
+    // ================= phase A: this tile
+    if (cloud_phase_a(a, wtot, &sticket) != (unsigned)(a.T - 1)) return;
 
     // ================= phase B: the workgroup with the last ticket
     FSTAMP(0);
@@ -464,31 +503,9 @@ __global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
         n = carry;
         if (t == 0) toff[a.T] = n;
     }
-    // ---- pcl/filters/impl/voxel_grid.hpp applyFilter: leaf-size check, min_b / div_b / divb_mul in float arithmetic (one thread; the others wait)
+    // ---- pcl's grid from the box (one thread; the others wait)
     const float inv = a.inv_leaf;
-    if (t == 0 && n > 0) {
-        int min_b[3], div_b[3];
-        bool take = n <= kFNmax;
-        long long ddp = 1;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float mn = ordered_decode(sbox[d]), mx = ordered_decode(sbox[3 + d]);
-            const float ext = (mx - mn) * inv;
-            if (!(ext >= 0.0f && ext < 2147483000.0f)) take = false;             // (the host's arithmetic decides what happens out there)
-            const long long dd = (long long)(take ? ext : 0.0f) + 1;
-            ddp = (ddp > 2147483647ll || dd > 2147483647ll) ? 4294967296ll : ddp * dd;
-            const float lo = floorf(mn * inv), hi = floorf(mx * inv);
-            if (!(lo > -2147483000.0f && hi < 2147483000.0f)) take = false;
-            min_b[d] = take ? (int)lo : 0;
-            div_b[d] = take ? (int)hi - min_b[d] + 1 : 1;
-        }
-        if (ddp > 2147483647ll) take = false;                                     // "leaf size too small": the pass-through of the multi-launch form
-        const long long cells = (long long)div_b[0] * div_b[1] * div_b[2];
-        const int rb = bits_for((unsigned long long)n), kb = bits_for((unsigned long long)(cells > 0 ? cells : 1));
-        if (cells <= 0 || cells > 2147483647ll || rb + kb > 32) take = false;
-        sgrid.min_b[0] = min_b[0]; sgrid.min_b[1] = min_b[1]; sgrid.min_b[2] = min_b[2];
-        sgrid.mul1 = div_b[0]; sgrid.mul2 = div_b[0] * div_b[1]; sgrid.rb = rb; sgrid.kb = kb; sgrid.take = take ? 1 : 0;
-    }
+    if (t == 0 && n > 0) cloud_grid(sbox, n, inv, sgrid);
     __syncthreads();
     FSTAMP(1);
     auto finish = [&](unsigned status, int n_out) __attribute__((always_inline)) {
@@ -735,9 +752,357 @@ __global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
 
 }  // namespace
 
+
+// =================================================================================================================================================
+// The same launch with phase B spread over a TEAM of workgroups (round 5, second form).  One compute unit pulls ~10 bytes a clock from memory and pays
+// an LDS round trip or a barrier for every step of a 16-wave workgroup: the single finishing workgroup above takes 48 us at 8 000 points and 123 us at
+// 32 000.  Here the LAST K = min(8, T) workgroups to draw a ticket form a team: they are running, hence co-resident by construction -- the barriers
+// between them cannot deadlock on scheduling, and a workgroup that is not in the team never waits for anything.  The team members wait until all T
+// tickets are drawn, then each takes n / K positions:
+//   gather (tile of a rank by binary search over the tile offsets), cell index, sort word -> registers, compacted points -> memory;
+//   per 8-bit digit pass (LSD, stable): chunks of 64 positions are matched by 8 ballots, (chunk, digit) counts in LDS, the workgroup's digit
+//   histogram published | TEAM BARRIER | every workgroup scans the K histograms itself, scatters its words (agent-scope stores) | TEAM BARRIER |
+//   takes its slice of the result;
+//   heads of its slice, head counts published | TEAM BARRIER | output offsets; the coordinates of its slice (and of the run that crosses its end)
+//   into LDS in sorted order, one lane per head: float sums in input order; the last workgroup to finish re-arms the state and reports to the host.
+// Cross-workgroup data travels by agent-scope stores and loads (the L2 caches of the eight XCDs are not coherent with each other).  Every wait is
+// bounded (2 s): a team that cannot complete abandons the launch, the host re-initialises the state words and runs the multi-launch form.
+// Same words, same stable order, same float sums as k_cloud_fused: bit-exact to it, to the multi-launch form and to the oracle.
+namespace {
+
+constexpr int kTK = 8;                   // team size
+constexpr int kTCh = 64;                 // chunks of 64 positions per team workgroup and pass: 4096 positions
+constexpr int kTVcap = 6144;             // sorted positions whose coordinates a team workgroup stages in LDS (its slice + the run that crosses its end)
+constexpr size_t kTLdsCnt = (size_t)kTCh * 256 * 2, kTLdsV = (size_t)3 * kTVcap * 4;
+constexpr size_t kTLds = kTLdsCnt + 2 * 4 * 256 * 4 + 256 * 4 + kTCh * 8 + kTCh * 4 + kTLdsV;      // 116 KB
+static_assert(kTLdsCnt >= (size_t)(kFTmax + 1) * 4, "the tile offsets live in the counters' area during the gather");
+static_assert(kTK * kTCh * 64 >= kFNmax, "the team covers every point the one-launch form takes");
+
+// all threads of a team workgroup; idx: which of the launch's barriers.  false: the launch was abandoned (by this workgroup after 2 s, or by another)
+__device__ __forceinline__ bool team_barrier(unsigned *state, int idx, int K, int *sflag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        (void)__hip_atomic_fetch_add(state + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (one counter for all barriers of the launch: barrier idx is passed at K (idx + 1))
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while (__hip_atomic_load(state + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(K * (idx + 1))) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 15u) == 0u) {
+                if (__hip_atomic_load(state + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(state + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+            }
+        }
+        *sflag = ok;
+    }
+    __syncthreads();
+    return *sflag != 0;
+}
+
+__global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    unsigned short *cnt = (unsigned short *)fsm;                             // [chunk][digit]: lanes of the chunk with the digit, then their start inside the chunk's quarter
+    int *toff = (int *)fsm;                                                  // (during the gather) T + 1 tile offsets
+    int *qt = (int *)(fsm + kTLdsCnt);                                       // [4][256]: a quarter's (16 chunks') lanes with the digit
+    int *qb = qt + 4 * 256;                                                  // [4][256]: the same, exclusive over the quarters
+    int *gb = qb + 4 * 256;                                                  // [256]: where this workgroup's words with the digit start in the whole array
+    unsigned long long *hm = (unsigned long long *)(gb + 256);               // [chunk]: head bits of the slice
+    int *hp = (int *)(hm + kTCh);                                            // [chunk]: heads in the chunks before
+    float *V = (float *)(hp + kTCh);                                         // 3 x kTVcap coordinates in sorted order
+    __shared__ int wtot[kFW];
+    __shared__ unsigned sbox[8];
+    __shared__ unsigned sticket;
+    __shared__ int sflag, send;
+    __shared__ FusedGrid sgrid;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef TDLO_CLOUD_STAMPS      // phase stamps of team workgroup 0 (instrumented build only, scripts/gpu_cloud_stamps.py)
+#define TSTAMP(i) do { __syncthreads(); if (t == 0 && k == 0) ((unsigned long long *)(a.state + 16))[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+    const unsigned ticket = cloud_phase_a(a, wtot, &sticket);
+    const int K = a.T < kTK ? a.T : kTK;
+    if ((int)ticket < a.T - K) return;                                       // not in the team: done, having waited for nobody
+    const int k = (int)ticket - (a.T - K);                                   // rank in the team
+
+    unsigned status = 1u;
+    int n = 0, ncell = 0;
+    // the last team workgroup to come here re-arms the state words for the next launch and reports to the host
+    auto finish = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                     // every wave's stores to X have been performed
+        if (t == 0) send = __hip_atomic_fetch_add(a.state + 15, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(K - 1);
+        __syncthreads();
+        if (!send) return;
+        if (__hip_atomic_load(a.state + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) status = 4u;      // somebody gave the launch up: whatever this workgroup finished, the cloud is not complete
+        __syncthreads();
+        if (t < 3) __hip_atomic_store(a.state + t, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (t < 16) __hip_atomic_store(a.state + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            __hip_atomic_store(a.res + 1, ((unsigned long long)(unsigned)n << 32) | (unsigned)ncell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.res, ((unsigned long long)a.epoch << 32) | status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    // ---- everybody's ticket
+    if (t == 0) {
+        int ok = 1;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.state + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.T) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 15u) == 0u) {
+                if (__hip_atomic_load(a.state + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(a.state + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+            }
+        }
+        sflag = ok;
+    }
+    __syncthreads();
+    if (!sflag) { status = 4u; finish(); return; }
+    TSTAMP(0);
+    // ---- the tiles' offsets, the count, the box, the grid (every team workgroup for itself: the same numbers)
+    {
+        int carry = 0;
+        for (int b0 = 0; b0 < a.T; b0 += kFT) {
+            const int bb = b0 + t;
+            const int c = bb < a.T ? __hip_atomic_load(a.tcnt + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            if (b0 == 0 && t < 6) sbox[t] = __hip_atomic_load(a.state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int tot;
+            const int ex = block_excl_scan_i(c, wtot, t, &tot);
+            if (bb < a.T) toff[bb] = carry + ex;
+            carry += tot;
+        }
+        n = carry;
+        if (t == 0) toff[a.T] = n;
+    }
+    const float inv = a.inv_leaf;
+    if (t == 0 && n > 0) cloud_grid(sbox, n, inv, sgrid);
+    __syncthreads();
+    if (n == 0) { finish(); return; }
+    if (!sgrid.take) { status = 2u; finish(); return; }
+    const int mb0 = sgrid.min_b[0], mb1 = sgrid.min_b[1], mb2 = sgrid.min_b[2], mul1 = sgrid.mul1, mul2 = sgrid.mul2, rb = sgrid.rb, kb = sgrid.kb;
+    const unsigned rmask = (1u << rb) - 1u;
+    const int per = ((n + K - 1) / K + 63) & ~63;                            // positions per team workgroup: whole chunks, at most 4096
+    const int s0 = k * per < n ? k * per : n, s1 = s0 + per < n ? s0 + per : n;
+    TSTAMP(1);
+    // ---- gather: position p = s0 + 64 (w + 16 r) + lane, r < 4 (a wave's chunk: 64 consecutive positions)
+    unsigned wreg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int g = s0 + 64 * (w + 16 * r) + lane;
+        wreg[r] = 0xffffffffu;
+        if (g < s1) {
+            int lo = 0, hi = a.T;                                            // the tile b with toff[b] <= g < toff[b + 1] (empty tiles have equal offsets)
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (toff[mid] <= g) lo = mid; else hi = mid; }
+            const unsigned src = (unsigned)(lo * kFPix + (g - toff[lo]));
+            const float px = __hip_atomic_load(a.ex + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float py = __hip_atomic_load(a.ey + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float pz = __hip_atomic_load(a.ez + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int i0 = (int)(floorf(px * inv) - (float)mb0);             // voxel_grid.hpp: ijk = floor(p * inv_leaf) - min_b
+            const int i1 = (int)(floorf(py * inv) - (float)mb1);
+            const int i2 = (int)(floorf(pz * inv) - (float)mb2);
+            wreg[r] = ((unsigned)(i0 + i1 * mul1 + i2 * mul2) << rb) | (unsigned)g;
+            __hip_atomic_store(a.cx + g, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.cy + g, py, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.cz + g, pz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();                                                         // (the tile offsets are not needed any more: the counters take their place)
+    TSTAMP(2);
+    // ---- stable LSD radix sort over the team, 8 bits a pass
+    unsigned *win = a.tw0, *wout = a.tw1;
+    int bar = 0;
+    for (int sh = 0; sh < kb; sh += 8) {
+        const int shift = rb + sh;
+        const unsigned dmask = kb - sh >= 8 ? 255u : ((1u << (kb - sh)) - 1u);
+        {
+            uint4 *z = (uint4 *)cnt;
+            z[t] = make_uint4(0u, 0u, 0u, 0u); z[t + kFT] = make_uint4(0u, 0u, 0u, 0u);      // 32 KB
+        }
+        __syncthreads();
+        int rank[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = w + 16 * r, p = s0 + 64 * c + lane;
+            const bool valid = p < s1;
+            const unsigned long long vm = __ballot(valid);
+            rank[r] = 0;
+            if (vm != 0ull) {                                                // (wave-uniform)
+                const unsigned d = (wreg[r] >> shift) & dmask;
+                unsigned long long same = vm;
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) {
+                    const unsigned one = (d >> bit) & 1u;
+                    const unsigned long long bl = __ballot(one != 0u);
+                    same &= bl ^ ((unsigned long long)one - 1ull);           // one ? bl : ~bl
+                }
+                rank[r] = __popcll(same & below);
+                if (valid && rank[r] == 0) cnt[c * 256 + d] = (unsigned short)__popcll(same);
+            }
+        }
+        __syncthreads();
+        {   // thread = (digit, quarter of the chunks): the quarter's count, the chunks' starts inside the quarter
+            const int d = t & 255, qd = t >> 8;
+            int run = 0;
+#pragma unroll 4
+            for (int c = 16 * qd; c < 16 * qd + 16; ++c) { const int v = cnt[c * 256 + d]; cnt[c * 256 + d] = (unsigned short)run; run += v; }
+            qt[qd * 256 + d] = run;
+        }
+        __syncthreads();
+        if (t < 256) {
+            const int q0 = qt[t], q1 = qt[256 + t], q2 = qt[512 + t], q3 = qt[768 + t];
+            qb[t] = 0; qb[256 + t] = q0; qb[512 + t] = q0 + q1; qb[768 + t] = q0 + q1 + q2;
+            __hip_atomic_store(a.thist + k * 256 + t, q0 + q1 + q2 + q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.hook && K > 1 && k == K - 1 && bar == 0) { status = 4u; finish(); return; }      // (test hook: a team member that never arrives)
+        if (!team_barrier(a.state, bar++, K, &sflag)) { status = 4u; finish(); return; }
+        {   // every workgroup: the team's histograms, the digit's start in the whole array + the words of the workgroups in front
+            int tot = 0, before = 0;
+            if (t < 256) {
+                int h[kTK];
+#pragma unroll
+                for (int j = 0; j < kTK; ++j) h[j] = j < K ? __hip_atomic_load(a.thist + j * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+                for (int j = 0; j < kTK; ++j) { tot += h[j]; before += j < k ? h[j] : 0; }
+            }
+            int all;
+            const int ex = block_excl_scan_i(tot, wtot, t, &all);
+            if (t < 256) gb[t] = ex + before;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = w + 16 * r, p = s0 + 64 * c + lane;
+            if (p < s1) {
+                const unsigned d = (wreg[r] >> shift) & dmask;
+                const int dst = gb[d] + qb[(c >> 4) * 256 + d] + (int)cnt[c * 256 + d] + rank[r];
+                __hip_atomic_store(wout + dst, wreg[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!team_barrier(a.state, bar++, K, &sflag)) { status = 4u; finish(); return; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = s0 + 64 * (w + 16 * r) + lane;
+            wreg[r] = p < s1 ? __hip_atomic_load(wout + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        }
+        { unsigned *tmp = win; win = wout; wout = tmp; }
+    }
+    TSTAMP(3);
+    // ---- heads of the slice (win holds the sorted words now); the word in front of a chunk's first lane comes from memory
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = w + 16 * r, p = s0 + 64 * c + lane;
+        unsigned prevw = (unsigned)__shfl_up((int)wreg[r], 1);
+        if (lane == 0) prevw = (p > 0 && p < s1) ? __hip_atomic_load(win + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const unsigned long long m = __ballot(p < s1 && (p == 0 || (prevw >> rb) != (wreg[r] >> rb)));
+        if (lane == 0) hm[c] = m;
+    }
+    __syncthreads();
+    int nh;                                                                  // heads in this slice
+    {
+        const int hc = t < kTCh ? __popcll(hm[t]) : 0;                       // (wave 0: one chunk per lane)
+        const int ex = block_excl_scan_i(hc, wtot, t, &nh);
+        if (t < kTCh) hp[t] = ex;
+        if (t == 0) __hip_atomic_store(a.thist + kTK * 256 + k, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the slice's heads as a list (position inside the slice), so that EVERY lane of the workgroup can take one: a chunk of 64 positions holds about one
+    // head, and a wave walking its four chunks one after the other would leave 60 of its lanes idle through four runs
+    unsigned short *hl = cnt;                                                // (the counters are done with)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = w + 16 * r, p = s0 + 64 * c + lane;
+        if (p < s1 && ((hm[c] >> lane) & 1ull)) hl[hp[c] + __popcll(hm[c] & below)] = (unsigned short)(p - s0);
+    }
+    if (!team_barrier(a.state, bar++, K, &sflag)) { status = 4u; finish(); return; }
+    int out0 = 0;
+    {
+        int h[kTK];
+#pragma unroll
+        for (int j = 0; j < kTK; ++j) h[j] = j < K ? __hip_atomic_load(a.thist + kTK * 256 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+        for (int j = 0; j < kTK; ++j) { ncell += h[j]; out0 += j < k ? h[j] : 0; }
+    }
+    if (ncell > a.cap) { status = 3u; finish(); return; }
+    TSTAMP(4);
+    // ---- where the run that crosses the end of the slice ends (the next head at or behind s1)
+    int e_k = s1;
+    if (s1 > s0 && s1 < n) {
+        const unsigned lastw = __hip_atomic_load(win + s1 - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q0 = s1;; q0 += kFT) {                                      // (uniform trip count: every thread sees the same sflag)
+            const int q = q0 + t;
+            const bool stop = q >= n || (__hip_atomic_load(win + (q < n ? q : n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> rb) != (lastw >> rb);
+            const unsigned long long sm = __ballot(stop);
+            if (lane == 0) wtot[w] = sm ? (int)__builtin_ctzll(sm) : 64;
+            __syncthreads();
+            int first = kFT;
+#pragma unroll
+            for (int i = kFW - 1; i >= 0; --i) if (wtot[i] < 64) first = 64 * i + wtot[i];
+            __syncthreads();
+            if (first < kFT) { e_k = q0 + first; break; }
+        }
+    }
+    // ---- the coordinates of [s0, min(e_k, s0 + kTVcap)) in sorted order into LDS; beyond that (a run of thousands of points) they are read from memory
+    const int vend = e_k < s0 + kTVcap ? e_k : s0 + kTVcap;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                            // the slice itself: its words are in registers
+        const int q = s0 + 64 * (w + 16 * r) + lane;
+        if (q < s1) {
+            const unsigned wq = wreg[r] & rmask;
+            V[q - s0] = __hip_atomic_load(a.cx + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            V[kTVcap + q - s0] = __hip_atomic_load(a.cy + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            V[2 * kTVcap + q - s0] = __hip_atomic_load(a.cz + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    for (int q = s1 + t; q < vend; q += kFT) {                               // the run that crosses its end
+        const unsigned wq = __hip_atomic_load(win + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & rmask;
+        V[q - s0] = __hip_atomic_load(a.cx + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        V[kTVcap + q - s0] = __hip_atomic_load(a.cy + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        V[2 * kTVcap + q - s0] = __hip_atomic_load(a.cz + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    TSTAMP(5);
+    // ---- one lane per head: CentroidPoint's float sums in input order
+    {
+        const size_t ld = (size_t)ncell;
+        for (int i = t; i < nh; i += kFT) {
+            const int p = s0 + (int)hl[i];
+            const int e = i + 1 < nh ? s0 + (int)hl[i + 1] : e_k;             // the next head inside the slice, or where the run that crosses its end stops
+            const int out = out0 + i;
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            int j = p;
+            const int el = e < vend ? e : vend;
+            for (; j + 4 <= el; j += 4) {
+                float vx[4], vy[4], vz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { vx[q] = V[j + q - s0]; vy[q] = V[kTVcap + j + q - s0]; vz[q] = V[2 * kTVcap + j + q - s0]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sx += vx[q]; sy += vy[q]; sz += vz[q]; }
+            }
+            for (; j < el; ++j) { sx += V[j - s0]; sy += V[kTVcap + j - s0]; sz += V[2 * kTVcap + j - s0]; }
+            for (; j < e; ++j) {                                             // (beyond the staged range)
+                const unsigned g = __hip_atomic_load(win + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & rmask;
+                sx += __hip_atomic_load(a.cx + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sy += __hip_atomic_load(a.cy + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sz += __hip_atomic_load(a.cz + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const float cf = (float)(e - p);
+            a.X[out] = (double)__fdiv_rn(sx, cf); a.X[ld + out] = (double)__fdiv_rn(sy, cf); a.X[2 * ld + out] = (double)__fdiv_rn(sz, cf);
+        }
+    }
+    TSTAMP(6);
+    finish();
+#undef TSTAMP
+}
+
+}  // namespace
+
 size_t cloud_fused_ws_bytes(int P) {       // beside the multi-launch form's workspace: state words, compacted points, tile counts
     const size_t T = ((size_t)P + kFPix - 1) / kFPix;
-    return 256 + 3 * (size_t)kFNmax * sizeof(float) + ((T * sizeof(int) + 255) & ~(size_t)255);
+    return 256 + 3 * (size_t)kFNmax * sizeof(float) + 2 * (size_t)kFNmax * sizeof(unsigned) + (kTK * 256 + 64) * sizeof(int) + ((T * sizeof(int) + 255) & ~(size_t)255);
 }
 int cloud_fused_max_points() { return kFNmax; }
 bool cloud_fused_ok(int P) { return ((size_t)P + kFPix - 1) / kFPix <= (size_t)kFTmax; }
@@ -745,10 +1110,11 @@ bool cloud_fused_ok(int P) { return ((size_t)P + kFPix - 1) / kFPix <= (size_t)k
 // ws: the multi-launch form's workspace (three of its four P-word sort buffers serve as the tiles' regions), fws: cloud_fused_ws_bytes(P)
 // bytes kept by the kernels themselves between the launches (first == true: the state words are initialised by a copy in front of the launch)
 hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], float inv_leaf, void *ws, void *fws,
-                              bool first, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s) {
+                              bool first, bool team, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void *)k_cloud_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFLds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_cloud_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFLds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cloud_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTLds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -759,14 +1125,21 @@ hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *
     a.ex = (float *)ws; a.ey = a.ex + P; a.ez = a.ey + P;
     a.state = (unsigned *)fws;                                   // (at a fixed place: another image size finds the words re-armed by the last launch)
     a.cx = (float *)((char *)fws + 256); a.cy = a.cx + kFNmax; a.cz = a.cy + kFNmax;
-    a.tcnt = (int *)(a.cz + kFNmax);
+    a.tw0 = (unsigned *)(a.cz + kFNmax); a.tw1 = a.tw0 + kFNmax;
+    a.thist = (int *)(a.tw1 + kFNmax);
+    a.tcnt = a.thist + kTK * 256 + 64;
     a.X = Xraw; a.cap = cap; a.res = res_pinned; a.epoch = epoch;
+    {   // test hook: the n-th team launch of the process loses a team member (the others give the launch up after 2 s; the host runs the multi-launch form)
+        static int hook_at = getenv("TDLO_CLOUD_TEAM_FORCE_TIMEOUT") ? atoi(getenv("TDLO_CLOUD_TEAM_FORCE_TIMEOUT")) : 0;
+        a.hook = (team && hook_at > 0 && --hook_at == 0) ? 1 : 0;
+    }
     if (first) {
-        static const unsigned init[8] = {~0u, ~0u, ~0u, 0u, 0u, 0u, 0u, 0u};
+        static const unsigned init[16] = {~0u, ~0u, ~0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};      // box, tickets, team: abandon word, barrier counter, finish tickets (word 15)
         const hipError_t e = hipMemcpyAsync(a.state, init, sizeof init, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_cloud_fused, dim3(a.T), dim3(kFT), kFLds, s, a);
+    if (team) hipLaunchKernelGGL(k_cloud_team, dim3(a.T), dim3(kFT), kTLds, s, a);
+    else hipLaunchKernelGGL(k_cloud_fused, dim3(a.T), dim3(kFT), kFLds, s, a);
     return hipGetLastError();
 }
 
