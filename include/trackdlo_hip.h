@@ -86,8 +86,9 @@ typedef struct {
                            * precision: tdlo_set_sort_reuse) and skipped the prune of trackdlo.cpp:177-195 -- identical results; 0: it pruned;
                            * 2 (tdlo_tracker_tracking_step's main registration, every node visible): as 1, and its node-side set-up had been done
                            * by the pre-processing registration's prologue as well -- it started at its first E-step (TDLO_PAIR_SETUP=0: never) */
-    int band_retry;       /* 1: the banded LLE M-step met a non-positive pivot (or a non-finite sigma2) and the call was repeated on the dense
-                           * pivoted eliminations, whose result this is (the reference's solver is a general one, trackdlo.cpp:415) */
+    int band_retry;       /* 1: the banded LLE M-step met a non-positive pivot (or a non-finite sigma2; in fp64 mode also a sigma2 computed from the
+                           * data that is too large for the banded form to hold 1e-9 m, see tdlo_debug_band_retries) and the call was repeated on
+                           * the dense pivoted eliminations, whose result this is (the reference's solver is a general one, trackdlo.cpp:415) */
 } tdlo_stats;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -420,7 +421,11 @@ int tdlo_debug_mstep_lle_dense(int on);
 /* How many calls of this context were repeated on the dense pivoted kernels because the banded L D L^T (which takes no pivots) met a
  * non-positive pivot or produced a non-finite sigma2: an indefinite H_override, or a chain at the edge of the gap test.  The reference's
  * solver is a general one (trackdlo.cpp:415); the caller sees the dense kernels' result, and tdlo_stats.band_retry = 1 on that call
- * (tdlo_cpd_lle*, tdlo_split_run in both forms: the ranks solve the same system and repeat together).  -1 for a null context. */
+ * (tdlo_cpd_lle*, tdlo_split_run in both forms: the ranks solve the same system and repeat together).  fp64 mode adds one more reason: a
+ * sigma2 above 6.25e7 h^3 / beta^4 m2 (h = the chain's mean link length; 0.8 m2 at beta = 5 and 2 cm links, 6e4 m2 at the reference's
+ * beta = 0.35) -- met only when a registration starts from sigma2 = 0 on a chain many metres long -- where the state precision's entries,
+ * rounded to fp64, leave the banded result a few 1e-9 m from the dense system's; a sigma2 GIVEN above the bound takes the dense kernels
+ * without a first attempt (no retry counted).  -1 for a null context. */
 long long tdlo_debug_band_retries(tdlo_ctx *ctx);
 /* Test aid: the 13 diagonals of H = (I - L)^T (I - L) (see tdlo_calc_lle_regulariser) formed by the DEVICE routine that tdlo_tracker_tracking_step's
  * main registration ends with (csrc/tdlo_lle_dev.h; 1 .. 256 nodes): Hb[13 i + u] = H(i, i - 6 + u), the host routine's values bit for bit. */

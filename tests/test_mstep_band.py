@@ -302,3 +302,45 @@ def test_band_mstep_hands_an_indefinite_system_to_the_dense_kernels(oracle):
         assert ctx.band_retries() == 4
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_band_mstep_leaves_a_large_sigma2_to_the_dense_kernels_in_fp64_mode(oracle):
+    """Round 5's band sweep: five of 1 500 draws 1.4 .. 5.5e-9 m from the oracle -- chains of 394 .. 508 nodes (8 .. 10 m), beta = 5, started from sigma2 = 0,
+    i.e. from sigma2 = 3 .. 6 m2.  The state precision's entries (~ 3 beta^4 / h^3), rounded to fp64, do not resolve the mode's 1e-9 m there whatever solves the
+    band (scripts/gpu_band_cond_study.py); the dense system does.  prepare_frame's bound (FrameDev::band_s2_max) hands such a registration over: the
+    M-step that meets a sigma2 above it ends the call like a bad pivot and the call is repeated on the dense kernels; a sigma2 GIVEN above it goes there
+    directly; fp32 mode (1e-5 m) keeps the banded solve."""
+    import importlib.util
+    from trackdlo_amd import binding as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    spec = importlib.util.spec_from_file_location("gpu_fuzz_band", os.path.join(root, "scripts", "gpu_fuzz_band.py"))
+    FB = importlib.util.module_from_spec(spec); spec.loader.exec_module(FB)
+    X, Y0, H, kw, pri, s2 = FB.draw(1425)                      # 404 nodes, beta 5, lambda 10, priors, sigma2 from the data (3.7 m2)
+    assert s2 == 0.0 and len(Y0) == 404 and kw["beta"] == 5.0
+    o = oracle.cpd_lle(X, Y0, 0.0, priors=pri, H=H, **kw)
+    ctx = B.Context(device=0, max_points=1 << 14, max_nodes=512)
+    try:
+        p64 = B.make_params(kw["beta"], kw["lambda_"], kw["lle_weight"], kw["mu"], kw["max_iter"], kw["tol"], True, kw["alpha"], 0.0, kw["visibility_threshold"], 1)
+        p32 = B.make_params(kw["beta"], kw["lambda_"], kw["lle_weight"], kw["mu"], kw["max_iter"], kw["tol"], True, kw["alpha"], 0.0, kw["visibility_threshold"], 0)
+        r0 = ctx.band_retries()
+        g = ctx.cpd_lle(X, Y0, 0.0, p64, priors=pri, H=H)
+        assert ctx.band_retries() == r0 + 1 and g["band_retry"] == 1
+        assert g["rc"] == 0 and g["iters"] == o["iters"]
+        assert np.abs(g["Y"] - o["Y"]).max() <= 1e-9 and abs(g["sigma2"] - o["sigma2"]) <= 1e-7 * o["sigma2"]
+        # a sigma2 given above the bound: the dense kernels without a first attempt
+        g2 = ctx.cpd_lle(X, Y0, 3.0, p64, priors=pri, H=H)
+        o2 = oracle.cpd_lle(X, Y0, 3.0, priors=pri, H=H, **kw)
+        assert ctx.band_retries() == r0 + 1 and ctx.profile_iteration(1)[3] != "k_mstep_band"
+        assert np.abs(g2["Y"] - o2["Y"]).max() <= 1e-9
+        # the reference's own scale of sigma2 on the same chain: the banded solve, inside the gate
+        g3 = ctx.cpd_lle(X, Y0, 1e-4, p64, priors=pri, H=H)
+        o3 = oracle.cpd_lle(X, Y0, 1e-4, priors=pri, H=H, **kw)
+        assert ctx.band_retries() == r0 + 1 and ctx.profile_iteration(1)[3] == "k_mstep_band"
+        assert np.abs(g3["Y"] - o3["Y"]).max() <= 1e-9
+        # fp32 mode: no bound
+        g4 = ctx.cpd_lle(X, Y0, 0.0, p32, priors=pri, H=H)
+        assert ctx.band_retries() == r0 + 1 and g4["rc"] == 0 and np.abs(g4["Y"] - o["Y"]).max() <= 1e-5
+    finally:
+        ctx.close()

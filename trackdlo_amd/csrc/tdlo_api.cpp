@@ -597,6 +597,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         if (prc) return prc;
     }
     bool lle_band = false, h_banded = false, hb_resident = false;
+    double band_s2_max = 1e300;
     if (p->include_lle) {
         double *H = stage + nc.H;
         // The banded L D L^T in the chain's state (tdlo_mstep_band.hip) serves the registration when (i) H is banded like the
@@ -608,10 +609,25 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         if (mstep_band_enabled() && !c->lle_dense_once && !c->lle_batch_dense && p->lambda > 0 && p->beta > 0 && M <= kChainLdsMaxNodes) {      // (the banded solve keeps a record per unknown in LDS: up to 512 nodes)
             lle_band = true;
             const double hmin = 1e-3 * std::cbrt(p->lambda * std::pow(p->beta / 3.0, 4));
+            double hsum = 0;
             for (int i = 0; i + 1 < M && lle_band; ++i) {
                 double d2 = 0;
                 for (int d = 0; d < 3; ++d) { const double e = Y[d * M + i + 1] - Y[d * M + i]; d2 += e * e; }
                 if (!(d2 >= hmin * hmin)) lle_band = false;
+                hsum += std::sqrt(d2);
+            }
+            // (iv) fp64 mode only: K's entries ~ 3 beta^4 / h^3 are rounded to fp64 when the records are formed, and a smooth displacement field
+            // cancels in K x to many digits -- the rounding comes back divided by the data term, ~ eps sigma2 K |x| / P1.  At the reference's scale
+            // (sigma2 <= 1e-2 m2) that is 1e-13 m; a registration started from sigma2 = 0 on a chain of 8 .. 10 m begins at sigma2 = 3 .. 6 m2 and
+            // with beta = 5 the banded form -- ANY fp64 solve of the stored band: scripts/gpu_band_cond_study.py, DESIGN.md 4 -- is 1.4 .. 5.5e-9 m
+            // from the reference's dense system, outside the mode's 1e-9 m.  Measured onset sigma2 beta^4 ~ 1 500 at h = 2 cm; the bound sits a
+            // factor 3 below and scales with K.  A sigma2 given by the caller is checked here, one computed on the device (sigma2 == 0,
+            // trackdlo.cpp:271-273) by the M-step itself (FrameDev::band_s2_max), which ends in the repeat on the dense kernels (run_frames).
+            band_s2_max = 1e300;
+            if (lle_band && p->precision == 1 && M > 1) {
+                const double hm = hsum / (M - 1);
+                band_s2_max = 6.25e7 * hm * hm * hm / std::pow(p->beta, 4);
+                if (sigma2 > band_s2_max) lle_band = false;
             }
             if (H_override) {
                 for (int j = 0; j < M && lle_band; ++j)
@@ -675,6 +691,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     // which M-step: decided here, once per frame (the launchers dispatch on the descriptor, not on the process-wide toggles)
     f.mstep_dense = (mstep_chain_enabled() && p->lambda > 0.0) ? 0 : 1;      // (the chain smoother works in units of 1 / (lambda sigma2))
     f.lle_band = lle_band ? 1 : 0;
+    f.band_s2_max = band_s2_max;
     f.h_banded = h_banded ? 1 : 0;
     f.need_G = ((p->include_lle && !lle_band) || (!p->include_lle && f.mstep_dense)) ? 1 : 0;
     {   // test hook: iteration k of the multi-CU M-steps behaves as if a hand-off had timed out (tests/test_parity_gpu.py)

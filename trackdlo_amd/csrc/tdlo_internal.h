@@ -95,6 +95,8 @@ struct FrameDev {
     int h_banded;           // the dense LLE M-steps: H is zero beyond +-6 nodes (the library's own always is; an H_override is checked by the host): H G and H Y0 are formed from the band
     int lle_band;           // registrations with the LLE term: 1 the banded L D L^T in the chain's state (tdlo_mstep_band.hip), 0 the dense pivoted eliminations
     double *band;           // lle_band: one 16-double column record per unknown of the state-space system (band_record_doubles(M)), written by k_setup
+    double band_s2_max;     // lle_band, fp64 mode: above this sigma2 the banded M-step reports TDLO_E_NUMERIC and the call is repeated on the dense pivoted kernels
+                            // (the state precision's entries, rounded to fp64, no longer hold the mode's 1e-9 m: prepare_frame); fp32 mode: never
     double *sums;           // 4M+2 reduced sums (N-split interface)
     double *Ascr;           // (M x (M+3)) scratch for the M-step when it does not fit LDS
     double *Yout;           // M x 3 uncentred result

@@ -18,6 +18,10 @@
 // 1e6) the banded form stays at 1e-16 .. 1e-13 m where partial-pivot LU of the dense matrix leaves 1e-13 .. 5e-10 m.  The price:
 // K contains Q^-1 ~ 1 / h^3, so nodes closer than about a millimetre make it ill-conditioned (coincident nodes: infinite);
 // such chains, and an H_override that is not banded, keep the dense pivoted kernels (prepare_frame decides, FrameDev::lle_band).
+// The same entries limit the form at the other end of the scale: rounded to fp64 they come back in the solution as ~ eps sigma2 K |x| / P1, 1e-13 m
+// at the reference's sigma2 but 1e-9 .. 1e-8 m at sigma2 = 3 .. 6 m2 with beta = 5 (a registration started from sigma2 = 0 on a chain of 8 .. 10 m) --
+// the fp64 mode's tolerance is 1e-9 m, so there the M-step ends the call like a bad pivot and the host repeats it on the dense kernels
+// (FrameDev::band_s2_max, prepare_frame; scripts/gpu_band_cond_study.py).
 //
 // Everything but D and B is fixed for the whole registration after division by sigma2,
 //     (lambda K + lle_weight H + D / sigma2) x = E^T B / sigma2:
@@ -386,7 +390,9 @@ __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__
         }
         BSTAMP(5);
     }
-    bad_pivot = __syncthreads_or(bad_pivot < 0 ? 1 : 0);
+    // (sigma2 beyond what the stored band resolves to the fp64 mode's tolerance, FrameDev::band_s2_max: the same verdict as a bad pivot -- the host
+    //  repeats the call on the dense kernels.  Not in the one-shot exchange form: chains of more than 64 nodes have no dense kernel there.)
+    bad_pivot = __syncthreads_or((bad_pivot < 0 || (!XCH && sigma2 > f.band_s2_max)) ? 1 : 0);
     BSTAMP(6);
 
     // ---- 4. T = Y0 + V, sigma2 (residual form of :418-422) and the convergence criterion (:424); publish Y and the nodes.  thread = node
