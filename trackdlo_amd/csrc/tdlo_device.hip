@@ -1124,17 +1124,20 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         {
             const T cx = bcast_first(x), cy = bcast_first(y), cz = bcast_first(z);      // all 64 lanes are active here
             T r2 = valid ? (x - cx) * (x - cx) + (y - cy) * (y - cy) + (z - cz) * (z - cz) : T(0);
+            // (the test runs on the SQUARES: D_m^2 <= lim^2 -- one square root per wave after the reduction instead of one per lane and chunk, 5 x ~25
+            //  fp64 instructions per batch at 300 nodes; the margin covers the rounding of the square as it covers that of the distances)
             T Dm[NCH];
             T dmin_w = Num<T>::inf();
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {                  // lane = node 64 c + lane
                 const int m = c * kChunk + lane;
                 Dm[c] = Num<T>::inf();
-                if (m < M) { const V4<T> qn = nodesL[m]; Dm[c] = Num<T>::sqrt_fast((qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz)); }
+                if (m < M) { const V4<T> qn = nodesL[m]; Dm[c] = (qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz); }
                 dmin_w = tmin(dmin_w, Dm[c]);
             }
             wave_max_min_nonneg(r2, dmin_w, r2, dmin_w);          // (both reductions in one folded butterfly)
-            const T lim = (dmin_w + T(2) * Num<T>::sqrt_fast(r2)) * T(1.0001) + T(1e-30);
+            T lim = (Num<T>::sqrt_fast(dmin_w) + T(2) * Num<T>::sqrt_fast(r2)) * T(1.0001) + T(1e-30);
+            lim = lim * lim;
             int first = M, last = -1;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {

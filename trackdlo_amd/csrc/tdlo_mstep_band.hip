@@ -89,6 +89,7 @@ size_t mstep_band_lds_bytes(int M) { return BandPlan(M).lds_doubles(M) * sizeof(
 template <typename T, bool SINGLE, bool XCH>
 __global__ __launch_bounds__(kBB) void k_mstep_band(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
     constexpr int MB = kBB;
+    if (!SINGLE) __builtin_amdgcn_s_setprio(3);      // (a batch: the other stream groups' E-steps share the SIMD -- tdlo_mstep_chain.hip)
     const FrameDev &f = SINGLE ? f0 : frames[blockIdx.x];
     IterState *st = f.st;
     const int M = f.M, t = threadIdx.x, lane = t & 63;

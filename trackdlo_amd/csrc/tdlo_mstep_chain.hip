@@ -152,6 +152,9 @@ struct ChainCarve {
 template <typename T, bool SINGLE, bool XCH, bool TRK = false>
 __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
     constexpr int MB = kCB;
+    // One wave walks a chain of dependent instructions.  In a batch the other stream groups' E-steps fill the same SIMDs with waves that always have
+    // something to issue: at the default priority this wave takes its turn among them (C3: 10.0 us per M-step against 7.4 us with the GPU to itself)
+    if (!SINGLE) __builtin_amdgcn_s_setprio(3);
     const FrameDev &f = SINGLE ? f0 : frames[blockIdx.x];
     IterState *st = f.st;
     const int M = f.M, t = threadIdx.x, lane = t & 63;
@@ -866,6 +869,7 @@ struct ChainLink { double p11, p12, p21, p22, q11, q12, q22; };
 template <typename T, bool SINGLE>
 __global__ __launch_bounds__(kCB) void k_mstep_chain_long(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
     constexpr int MB = kCB;
+    if (!SINGLE) __builtin_amdgcn_s_setprio(3);      // (see k_mstep_chain)
     const FrameDev &f = SINGLE ? f0 : frames[blockIdx.x];
     IterState *st = f.st;
     const int M = f.M, t = threadIdx.x, lane = t & 63;
