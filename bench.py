@@ -268,7 +268,8 @@ def _compact(full):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     o = {k: full[k] for k in keep if k in full}
     o["config"] = full.get("config")
-    for k in ("timed_region_s", "frames_per_s", "prune_dispatches_per_call", "em_loop_only_iters_per_s", "em_iters_per_s_f64", "us_per_iteration", "gpu_over_cpu", "ranks_agree", "xch_can_access"):
+    for k in ("timed_region_s", "frames_per_s", "prune_dispatches_per_call", "em_loop_only_iters_per_s", "em_iters_per_s_f64", "us_per_iteration", "gpu_over_cpu", "ranks_agree", "xch_can_access",
+              "self_exchange_iters_per_s"):
         if k in full:
             o[k] = full[k]
     o["roofline"] = _compact_roofline(full.get("roofline"))
@@ -288,6 +289,8 @@ def _compact(full):
         legs[name] = dict(value=r.get("value"), ms_per_step=r.get("ms_per_step"), dtype=r.get("dtype"), roofline_kernel=rf.get("kernel"), roofline_frac=rf.get("frac"),
                           avg_launch_us=rf.get("avg_launch_us"), traffic=rf.get("traffic"), cpu_value=cb.get("value"),
                           parity_dY_m=(float(f"{cb['parity']['max_abs_dY_m']:.2e}") if cb.get("parity") else None))
+        if "self_exchange_iters_per_s" in r:      # c4 on one rank: the rate with the per-iteration exchange carried out against the own inbox
+            legs[name]["self_exchange_value"] = r["self_exchange_iters_per_s"]
     if legs:
         o["configs"] = legs
     if "sustained" in full:
@@ -960,11 +963,27 @@ def bench_nsplit(args, cfg, env):
                     higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=f"C4: one frame, N={NT} points split over {n_ranks} rank(s) ({hi - lo} per rank), M={M} nodes, {EM_ITERS} EM iterations per cpd_lle call, tol=0, fp32 E-step + fp64 M-step; "
                                          "whole calls (prune + sort + setup + loop + read-back), every call prunes",
-                                parallelism=f"points sharded over {n_ranks} rank(s); per iteration: {form}; identical M-step on every rank"),
+                                parallelism=f"points sharded over {n_ranks} rank(s); per iteration: {form}; identical M-step on every rank"
+                                            + ("; ONE rank: no peer, the per-iteration exchange is skipped (self_exchange_iters_per_s: with it, against the own inbox)" if n_ranks == 1 and comm is None else "")),
                     timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"],
                     ranks_agree=len(set(hashes)) == 1, xch_can_access=access,
                     roofline=roof, roofline_kernels=roof_all)
         cpu = None
+        if n_ranks == 1 and comm is None:
+            # a lone rank skips the per-iteration exchange (nobody to exchange with); what the exchange itself costs on this GPU -- every rank of a
+            # larger group pays it -- is measured against the own inbox (TDLO_XCH_SELF=1, read per call)
+            os.environ["TDLO_XCH_SELF"] = "1"
+            try:
+                nse = max(4, cfg["steps"] // 4)
+                for _ in range(2):
+                    step()
+                ctx.synchronize(); t1 = time.perf_counter()
+                for _ in range(nse):
+                    step()
+                ctx.synchronize()
+                line["self_exchange_iters_per_s"] = round(nse * EM_ITERS / (time.perf_counter() - t1), 2)
+            finally:
+                os.environ.pop("TDLO_XCH_SELF", None)
 
         def gpu_run(iters):
             # the split registration itself on the whole cloud (one rank), staged again: the shard-of-8 figures below leave an eighth of it in the slot
@@ -989,6 +1008,7 @@ def bench_nsplit(args, cfg, env):
                 return n * EM_ITERS / (time.perf_counter() - t1)
             nun = max(10, cfg["steps"] // 4)
             line["unsplit_iters_per_s"] = round(rate(lambda: ctx.cpd_lle_resident(0, Y0, 0.0, params), nun), 2)
+            os.environ["TDLO_XCH_SELF"] = "1"       # (the shard-of-8 figures below are a rank's share of a larger group: with the exchange)
             try:
                 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
                 c1 = ctx.rccl_comm_init(1, 0, B.rccl_unique_id())
@@ -1006,6 +1026,7 @@ def bench_nsplit(args, cfg, env):
             if line.get("rccl_form_iters_per_s"):
                 shard["rccl_form_vis_us_per_iteration"] = round(1e6 / rate(lambda: ctx.split_run(Y0, 0.0, pv, comm=c1, visible_nodes=vext), 60), 2)
             line["shard_of_8"] = shard
+            os.environ.pop("TDLO_XCH_SELF", None)
             if not args.no_cpu_baseline:
                 kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                           include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])

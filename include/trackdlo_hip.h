@@ -210,7 +210,9 @@ int tdlo_split_poll(tdlo_ctx *ctx, int *done, int *iters);   /* synchronises the
  *       only up to 64 nodes); up to 8 ranks.  A rank that is more than 2 s behind its peers (or gone) makes the waiting kernels give up:
  *       TDLO_E_EXCHANGE on the ranks that waited.  A rank whose own shard fails (TDLO_E_NUMERIC from the E-step's range check) raises its
  *       flag with an error mark: its peers leave the same iteration with TDLO_E_NUMERIC instead of waiting out the limit.  Arguments are validated before anything is exchanged; a shard that loses every point
- *       to the prune still takes part (it contributes zeros).
+ *       to the prune still takes part (it contributes zeros).  A group of ONE rank has nobody to exchange with: the per-iteration
+ *       exchange is skipped (the plain call's kernels and bits); TDLO_XCH_SELF=1 (read per call) makes it write to and read from its
+ *       own inbox like a rank of a larger group -- what the exchange itself costs on one GPU (bench.py, tests).
  * The stopping rule is evaluated on the device and read after iterations 1, 2, 4, 8, 12, ... (tol > 0).
  * With the LLE term, a banded solve that meets a non-positive pivot is repeated on the dense pivoted kernels by all ranks together
  * (stats->band_retry), as tdlo_cpd_lle_resident does; in the one-shot form only for chains of up to 64 nodes (longer: TDLO_E_NUMERIC). */

@@ -36,9 +36,10 @@ def _params(P, B, max_iter, tol, vis_on, prec, lle=False):
 
 
 @pytest.mark.parametrize("vis_on,tol,prec", [(False, 0.0, 0), (True, 0.0, 0), (True, 2e-4, 0), (True, 0.0, 1), (False, 2e-4, 1)])
-def test_one_shot_exchange_single_rank_reproduces_the_plain_call(hip_ctx, vis_on, tol, prec):
-    """R = 1: the inbox is written and read by the same GPU; the reduction over one contribution is the identity, so the
-    result is the plain call's, bit for bit."""
+def test_one_shot_exchange_single_rank_reproduces_the_plain_call(hip_ctx, vis_on, tol, prec, monkeypatch):
+    """R = 1, both forms.  TDLO_XCH_SELF=1: the inbox is written and read by the same GPU, the reduction over one contribution is the identity.
+    Default (round 5): a lone rank has nobody to exchange with and the kernels skip the per-iteration exchange (k_dmin's hand-over, the sums inside the
+    M-step).  Either way the result is the plain call's, bit for bit."""
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
     M = 40
@@ -47,10 +48,12 @@ def test_one_shot_exchange_single_rank_reproduces_the_plain_call(hip_ctx, vis_on
     a = hip_ctx.cpd_lle(X, Y0, 0.0, pr, visible_nodes=vext)
     hip_ctx.xch_bind(0, [hip_ctx.xch_create(1, 64)])
     try:
-        for _ in range(2):                              # twice: the epoch of the flags advances per registration
-            b = hip_ctx.split_run(Y0, 0.0, pr, visible_nodes=vext)
-            np.testing.assert_array_equal(a["Y"], b["Y"])
-            assert a["sigma2"] == b["sigma2"] and a["iters"] == b["iters"] and a["converged"] == b["converged"] and a["n_kept"] == b["n_kept"]
+        for self_x in ("1", "0", "1"):
+            monkeypatch.setenv("TDLO_XCH_SELF", self_x)      # (read by tdlo_split_run per call)
+            for _ in range(2):                              # twice: the epoch of the flags advances per registration
+                b = hip_ctx.split_run(Y0, 0.0, pr, visible_nodes=vext)
+                np.testing.assert_array_equal(a["Y"], b["Y"])
+                assert a["sigma2"] == b["sigma2"] and a["iters"] == b["iters"] and a["converged"] == b["converged"] and a["n_kept"] == b["n_kept"]
     finally:
         hip_ctx.lib.tdlo_xch_bind(hip_ctx.h, 0, 0, None)
 

@@ -1826,6 +1826,7 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     if (oneshot) {
         for (int r = 0; r < kMaxXchRanks; ++r) f.xch_inbox[r] = c->xch_peer[r];
         f.xch_rank = c->xch_rank; f.xch_nranks = c->xch_nranks; f.xch_mcap = c->xch_mcap; f.xch_epoch = ++c->xch_calls;
+        { const char *e = getenv("TDLO_XCH_SELF"); f.xch_self = (e && atoi(e)) ? 1 : 0; }      // (read per call: a test switches it between two calls)
         {   // test hook (tests/test_split_native_gpu.py): rank r's E-step refuses every sum as out of range -- an error of ONE shard, which its
             // peers must learn about inside the exchange (kXchErrMark) instead of waiting out the time limit
             static const int fail_rank = getenv("TDLO_TEST_RANGE_FAIL_RANK") ? atoi(getenv("TDLO_TEST_RANGE_FAIL_RANK")) : -1;

@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kBlock) void k_dmin(const FrameDev *__restrict__ fr
     // N-split with the one-shot exchange: the workgroup that finishes last hands the shard's minima to every peer, waits
     // for theirs and leaves the global minimum in dminbits for the E-step (what the MIN all-reduce does in the RCCL form).
     // One workgroup waits, so that shards sharing a GPU (tests) cannot starve each other of CUs.
-    if (f.xch_nranks > 0) {
+    if (f.xch_nranks > 1 || (f.xch_nranks == 1 && f.xch_self)) {      // (a lone rank: its own minima are the global ones, as in the plain call)
         __shared__ int s_last;
         // the atomicMins are device-scope read-modify-writes: once they are acknowledged (vmcnt) they are performed where every
         // CU's device-scope atomics meet, so the ticket needs no cache write-back in front of it (an agent-scope fence per
@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(NW * 64) void k_mstep_fast(const FrameDev *__restri
         if (t == 0) f.sums[nS] = (double)stg->N;
         return;
     }
-    if (XCH && from_sums == 3) {
+    if (XCH && from_sums == 3 && (f.xch_nranks > 1 || f.xch_self)) {      // (a lone rank: its own sums are the total)
         // N-split with the one-shot exchange: the shard's sums go to every peer's inbox (peer stores), the flag follows; then
         // this workgroup waits for the R flags in its own inbox and adds the R contributions in rank order (the same bits
         // on every rank) -- the SUM all-reduce of the RCCL form, inside the M-step, without a launch in between.

@@ -128,6 +128,8 @@ struct FrameDev {
     // pointer valid on THIS device (own inbox included); xch_nranks == 0: no exchange
     unsigned long long *xch_inbox[kMaxXchRanks];
     int xch_rank, xch_nranks, xch_mcap;
+    int xch_self;           // xch_nranks == 1: 0 (default) a lone rank has nobody to exchange with -- the kernels skip the exchange; 1 (TDLO_XCH_SELF=1): it writes to and
+                            // reads from its own inbox like any rank of a larger group (the cost of the exchange proper on one GPU; tests)
     unsigned xch_epoch;     // tag of this registration: flags carry (epoch << 32 | iteration + 1)
     // ---- tracking_step's short cuts (round 4, second step).  At the END of the descriptor: the offsets of everything above are those of the
     //      kernels measured before (with fields inserted in the middle C2 came out 0.8 % slower in an A/B on one box, 13.80 against 13.62 us per iteration; with them here: level)

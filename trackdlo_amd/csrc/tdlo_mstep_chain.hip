@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         if (t == 0) f.sums[nS] = (double)stg->N;
         return;
     }
-    if (XCH && from_sums == 3) {
+    if (XCH && from_sums == 3 && (f.xch_nranks > 1 || f.xch_self)) {      // (a lone rank: its own sums are the total)
         // N-split with the one-shot exchange (see k_mstep_fast): sums to every peer's inbox, flag, wait for the R flags in the
         // own inbox, add the R contributions in rank order
         const int R = f.xch_nranks, me = f.xch_rank, Mc = f.xch_mcap, it = stg->it, par = it & 1;
