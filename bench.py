@@ -237,7 +237,7 @@ def _flush_c_stdio():
 LINE_LIMIT = 4096       # bytes of the final stdout line (the driver keeps 8 KB of stdout; round 3's 25.7 KB line scrolled out of it)
 DETAIL_FILE = "bench_detail.json"
 _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes_per_launch",
-              "algorithmic_flops_per_launch", "share_of_gpu_time", "iteration_us", "valu_issue_frac", "clocks_per_node", "traffic_over_algorithmic")
+              "algorithmic_flops_per_launch", "share_of_gpu_time", "iteration_us", "valu_issue_frac", "clocks_per_node", "clocks_per_node_floor", "traffic_over_algorithmic")
 
 
 def _compact_roofline(r):
@@ -509,6 +509,23 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
             # what one can act on in a one-workgroup M-step: shader clocks of the launch per chain node (the critical wave issues one dependent
             # instruction per ~8 clocks; nominal 2.4 GHz -- the phase split is scripts/gpu_chain_stamps.py / gpu_band_stamps.py, profiles/*_measured.log)
             o["clocks_per_node"] = round(o["avg_launch_us"] * 1e-6 * SHADER_CLOCK_HZ / M, 1)
+            # ... and the floor that number is to be read against, from the phase stamps over chain lengths (profiles/r05_measured.log,
+            # shader clocks; a lone wave's CU runs at ~2.0 GHz, so a shader clock is 1.2 of the nominal ones clocks_per_node is quoted in)
+            if o["kernel"] == "k_mstep_chain":
+                # long chains: forward step 276 clocks (~35 dependent instructions at ~8: 2 x 2 covariance update + gain), backward step 68; a step serves four
+                # nodes (four directions) -> 86 clocks per node; per launch ~7 500 more (sums and records: two memory round trips; gains; T, sigma2, publish)
+                o["clocks_per_node_floor"] = round(1.2 * (276 + 68) / 4.0, 1)
+                o["clocks_per_node_model"] = round(1.2 * ((276 + 68) / 4.0 + (7500.0 + 13 * 140) / M), 1)
+                o["critical_path"] = ("shader clocks: forward step 276 (~35 dependent instructions x ~8) + backward step 68 per FOUR nodes = 86 per node; "
+                                      "~7 500 per launch for two memory round trips (sums, records), gains and publish; the first ~13 steps run ~140 above the steady step")
+            elif o["kernel"] == "k_mstep_band":
+                # per unknown and wave: one 65-clock fp64 MFMA + ~21 serialised instructions = 265 clocks, back substitution ~55; two waves from both ends:
+                # 131 + 27 clocks per unknown of the chain, two unknowns per node; per launch ~9 000 more (sums, records, first window, T + sigma2 + publish)
+                # and the chunk of 13 unknowns both waves finish where they meet
+                o["clocks_per_node_floor"] = round(1.2 * 2 * (131 + 27), 1)
+                o["clocks_per_node_model"] = round(1.2 * (2 * (131 + 27) + (9000.0 + 13 * (265 + 55)) / M), 1)
+                o["critical_path"] = ("shader clocks: per unknown and wave one 65-clock fp64 MFMA + ~21 serialised instructions = 265, back substitution ~55; two waves: "
+                                      "158 per unknown of the chain, 2 unknowns per node; ~9 000 per launch (sums, records, first window, T, publish) + one shared chunk of 13")
     objs.sort(key=lambda o: -o["avg_launch_us"])
     dom = dict(objs[0])
     dom["iteration_us"] = round(iter_us, 3)
