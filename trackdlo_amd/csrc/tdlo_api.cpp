@@ -2526,6 +2526,8 @@ struct tdlo_tracker {
     std::vector<double> geodesic_coord;
     std::vector<double> priors;         // K x 4 row-major
     double visibility_threshold;
+    std::vector<double> trav1, trav2, trav2r;      // scratch of the priors' formation, kept across frames (their growth was a dozen reallocations per frame,
+    std::vector<int> vis_ext;                      // on the host path between the two registrations)
     int last_iters[2] = {0, 0};         // iterations the two registrations of the previous frame took: how many are enqueued before the host looks (tdlo_ctx::iter_hint;
                                         // the larger of the last two frames' counts was tried instead: no difference)
 };
@@ -2685,8 +2687,9 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
         return rc;
     }
 
-    std::vector<int> ve(vis_ext, vis_ext + n_ext);
-    std::vector<double> p1, p2;
+    std::vector<int> &ve = t->vis_ext;
+    ve.assign(vis_ext, vis_ext + n_ext);
+    std::vector<double> &p1 = t->trav1, &p2 = t->trav2;
     const double *guide = t->guide_nodes.data();
     auto trav = [&](int alignment, int anchor, std::vector<double> &out) {
         return traverse_euclidean(t->geodesic_coord, guide, Mg, ve, alignment, anchor, out);
@@ -2699,8 +2702,10 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
         const int n1 = trav(0, -1, p1), n2 = trav(1, -1, p2);
         if (n1 <= 0 || n2 <= 0) return fail(c, TDLO_E_TRAVERSE, oob);
         // p2 runs tail -> head; bring it to ascending order (:942)
-        std::vector<double> r2(p2.size());
+        std::vector<double> &r2 = t->trav2r;
+        r2.resize(p2.size());
         for (int i = 0; i < n2; ++i) std::memcpy(&r2[4 * i], &p2[4 * (n2 - 1 - i)], 4 * sizeof(double));
+        t->priors.reserve(t->priors.size() + 4 * (size_t)M);
         for (int i = 0; i < M; ++i) {
             const long long j2 = (long long)i - ((long long)M - n2);     // unsigned in the reference: negative == huge
             const bool j2_ok = j2 >= 0 && j2 < n2;

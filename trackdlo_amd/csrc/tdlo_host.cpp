@@ -244,18 +244,47 @@ struct Pursuit {
 
     Vec3 row(int i) const { return Vec3{guide[i], guide[Mg + i], guide[2 * Mg + i]}; }
 
+    // dist(p, r) > dist(q, r) as the reference decides it (on the rounded square roots), from the squares: the square root is monotone and correctly
+    // rounded, so squares that differ by more than a few ulps give roots that differ, and s1 <= s2 gives root1 <= root2; only the band between takes
+    // the two square roots (sqrtsd: ~18 cycles of latency each on the path between the two registrations of tracking_step)
+    static bool farther(const Vec3 &p, const Vec3 &q, const Vec3 &r) {
+        const double ax = p.x - r.x, ay = p.y - r.y, az = p.z - r.z, bx = q.x - r.x, by = q.y - r.y, bz = q.z - r.z;
+        const double s1 = ax * ax + ay * ay + az * az, s2 = bx * bx + by * by + bz * bz;      // (the sums dist() forms, in its order)
+        if (s1 > s2 * (1.0 + 0x1p-50)) return true;
+        if (s1 <= s2) return false;
+        return std::sqrt(s1) > std::sqrt(s2);
+    }
+    // dist(p, r) <= dist(q, r), likewise (a NaN anywhere: false, as the comparison of the roots would say)
+    static bool not_farther(const Vec3 &p, const Vec3 &q, const Vec3 &r) {
+        const double ax = p.x - r.x, ay = p.y - r.y, az = p.z - r.z, bx = q.x - r.x, by = q.y - r.y, bz = q.z - r.z;
+        const double s1 = ax * ax + ay * ay + az * az, s2 = bx * bx + by * by + bz * bz;
+        if (s1 <= s2) return true;
+        if (s1 > s2 * (1.0 + 0x1p-50)) return false;
+        return std::sqrt(s1) <= std::sqrt(s2);
+    }
+
     // Scans segments (i, i+dir) from last_found while `more(i)`; accepts the first usable hit.
     template <class More> bool step(int dir, double look, More more, Vec3 &hit) {
+        const double lm = look - 2e-4, lm2 = lm > 0 ? lm * lm : -1.0;
         for (int i = last_found; more(i); i += dir) {
             const int j = i + dir;
             if (i < 0 || i >= Mg || j < 0 || j >= Mg) { oob = true; return false; }
             const Vec3 a = row(i), b = row(j);
+            // A segment with BOTH ends more than 0.2 mm inside the sphere has no usable hit: it lies inside (convexity), the line meets the sphere beyond
+            // its ends, at least look - |end - centre| > 0.2 mm beyond -- and isBetween's slack is 0.1 mm PER AXIS, which a point s beyond an end along the
+            // segment exceeds on its steepest axis once s > 0.174 mm.  line_sphere would return 0 (also for a == b, where the reference's 0 / 0 fails the
+            // box test): skipped without its square root, two divisions and two box tests.  This is the usual fate of the first segment of a step
+            // (the one the previous hit lies on).
+            {
+                const double ax = a.x - centre.x, ay = a.y - centre.y, az = a.z - centre.z, bx = b.x - centre.x, by = b.y - centre.y, bz = b.z - centre.z;
+                if (ax * ax + ay * ay + az * az < lm2 && bx * bx + by * by + bz * bz < lm2) continue;
+            }
             Vec3 cand[2];
             const int n = line_sphere(a, b, centre, look, cand);
             if (n == 0) continue;
-            if (n == 1 && dist(cand[0], b) > dist(centre, b)) continue;      // lone hit behind us
+            if (n == 1 && farther(cand[0], centre, b)) continue;             // lone hit behind us
             last_found = i;
-            hit = (n == 2 && !(dist(cand[0], b) <= dist(cand[1], b))) ? cand[1] : cand[0];
+            hit = (n == 2 && !not_farther(cand[0], cand[1], b)) ? cand[1] : cand[0];
             centre = hit;
             return true;
         }
