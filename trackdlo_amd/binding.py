@@ -542,7 +542,9 @@ class trackdlo:
         if not self.h:
             raise TdloError(TDLO_E_INVALID, "tdlo_tracker_create failed")
         lib.tdlo_tracker_set_precision(self.h, precision)
-        self.last_stats = None
+        self._stats_raw = None      # (the two tdlo_stats of the last tracking_step; turned into dicts when somebody looks: last_stats)
+        self._st = (Stats * 2)()
+        self._st_ptr = C.cast(self._st, C.c_void_p)
 
     def __del__(self):
         try:
@@ -589,6 +591,11 @@ class trackdlo:
         n = self.ctx.lib.tdlo_tracker_get_correspondence_pairs(self.h, _ptr(buf), buf.shape[0])
         return buf[:n].copy()
 
+    @property
+    def last_stats(self):
+        """[pre-processing registration, main registration] of the last tracking_step as dicts (tdlo_stats), None before the first one."""
+        return None if self._stats_raw is None else [s.as_dict() for s in self._stats_raw]
+
     def tracking_step(self, X_orig, visible_nodes, visible_nodes_extended, proj_matrix=None, img_rows=0, img_cols=0, *,
                       H_pre=None):
         """trackdlo::tracking_step (trackdlo.cpp:900-999). proj_matrix/img_rows/img_cols are accepted and ignored, as in
@@ -597,11 +604,12 @@ class trackdlo:
         v = np.ascontiguousarray(visible_nodes, dtype=np.int32)
         ve = np.ascontiguousarray(visible_nodes_extended, dtype=np.int32)
         Hm = _f64(H_pre) if H_pre is not None else None
-        st = (Stats * 2)()
+        st = self._st
         rc = self.ctx.lib.tdlo_tracker_tracking_step(self.h, _ptr(X), X.shape[0] if X is not None else 0, _ptr(v), len(v), _ptr(ve), len(ve), _ptr(Hm),
-                                                     C.cast(st, C.c_void_p))
-        self.last_stats = [s.as_dict() for s in st]
-        self.ctx._chk(rc)
+                                                     self._st_ptr)
+        self._stats_raw = st
+        if rc:
+            self.ctx._chk(rc)
 
 
 def calc_LLE_weights(k, Y):
