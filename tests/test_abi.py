@@ -243,6 +243,43 @@ def test_traverse_euclidean_randomised(oracle):
     assert n_ok > 300
 
 
+def test_traverse_euclidean_is_the_oracles_bit_for_bit(oracle):
+    """Round 5 shortened the host path between tracking_step's two registrations: the pure pursuit skips a segment that lies more than 0.2 mm inside
+    the look-ahead sphere (no usable intersection: isBetween's slack is 0.1 mm per axis) and compares distances on their squares, taking the square
+    roots only inside a band of a few ulps.  Neither may change a single decision: the same rows as the oracle's straight restatement, bit for bit, over
+    stretched and compressed arc lengths, noisy and gappy guides, zero-length segments, all three alignments."""
+    from trackdlo_amd import binding as B, synth
+    rng = np.random.default_rng(777)
+    n_ok = 0
+    for trial in range(3000):
+        M = int(rng.integers(4, 80))
+        Y = synth.nodes(M) + rng.normal(scale=float(rng.choice([0.0, 0.0005, 0.001, 0.005])), size=(M, 3))
+        coord = synth.geodesic_coord(Y) * float(rng.choice([1.0, 0.98, 1.02, 0.7]))
+        keep = rng.random(M) < rng.choice([0.5, 0.8, 1.0, 1.0])
+        if keep.sum() < 2:
+            keep[:2] = True
+        vis = np.nonzero(keep)[0]
+        guide = Y[vis] + rng.normal(scale=float(rng.choice([0.0, 0.0002, 0.002, 0.01])), size=(len(vis), 3))
+        if rng.random() < 0.1 and len(vis) > 3:
+            guide[2] = guide[1]                                    # a zero-length segment (the reference divides 0 by 0 there)
+        alignment = int(rng.integers(0, 3))
+        anchor = int(rng.integers(0, len(vis))) if alignment == 2 else -1
+        try:
+            a = oracle.traverse_euclidean(coord, guide, vis, alignment, anchor)
+        except Exception:
+            a = None
+        try:
+            b = B.traverse_euclidean(coord, guide, vis, alignment, anchor)
+        except Exception:
+            b = None
+        assert (a is None) == (b is None), (trial, M, alignment, anchor)
+        if a is None:
+            continue
+        n_ok += 1
+        assert a.shape == b.shape and np.array_equal(a, b), (trial, M, alignment, anchor, float(np.abs(a - b).max()) if a.shape == b.shape else None)
+    assert n_ok > 2500
+
+
 def test_band_regulariser_is_the_dense_one_bit_for_bit(oracle):
     """The banded LLE M-step receives H = (I - L)^T (I - L) (trackdlo.cpp:236-237) as its 13 diagonals, formed in O(M) on the host
     (lle_regulariser_band); the dense M-steps receive the M x M matrix.  Same weights, same products in the same order: equal BITS, for

@@ -344,3 +344,36 @@ def test_band_mstep_leaves_a_large_sigma2_to_the_dense_kernels_in_fp64_mode(orac
         assert ctx.band_retries() == r0 + 1 and g4["rc"] == 0 and np.abs(g4["Y"] - o["Y"]).max() <= 1e-5
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_band_sigma2_bound_in_a_batch(oracle):
+    """The same hand-over inside a batch (fp64 mode): one frame of three is GIVEN a sigma2 above prepare_frame's bound, so the batch as a whole takes the dense
+    pivoted kernels (a batch runs one M-step kernel); a second batch leaves sigma2 to the device on every frame -- the first banded M-step meets 3.7 m2 and the
+    whole batch is repeated on the dense kernels.  Every frame inside the mode's gate against the oracle either way."""
+    import importlib.util
+    from trackdlo_amd import binding as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    spec = importlib.util.spec_from_file_location("gpu_fuzz_band", os.path.join(root, "scripts", "gpu_fuzz_band.py"))
+    FB = importlib.util.module_from_spec(spec); spec.loader.exec_module(FB)
+    X, Y0, H, kw, pri, _ = FB.draw(1425)
+    kw = dict(kw, alpha=0.0)                              # (a batch shares its priors: none here)
+    M = len(Y0)
+    p64 = B.make_params(kw["beta"], kw["lambda_"], kw["lle_weight"], kw["mu"], kw["max_iter"], kw["tol"], True, 0.0, 0.0, kw["visibility_threshold"], 1)
+    ctx = B.Context(device=0, max_frames=3, max_points=len(X), max_nodes=M)
+    try:
+        for fr in range(3):
+            ctx.set_cloud(fr, X)
+        for s2s in ([1e-4, 3.0, 2e-4], [0.0, 0.0, 0.0]):
+            r0 = ctx.band_retries()
+            out = ctx.cpd_lle_batch([Y0, Y0, Y0], s2s, p64, H=H)
+            assert ctx.profile_iteration(1)[3] != "k_mstep_band"
+            assert ctx.band_retries() == r0 + (1 if s2s[0] == 0.0 else 0)
+            for fr in range(3):
+                o = oracle.cpd_lle(X, Y0, s2s[fr], H=H, **kw)
+                st = out["stats"][fr]
+                assert st["status"] == 0 and st["iters"] == o["iters"]
+                assert np.abs(np.asarray(out["Y"][fr]) - o["Y"]).max() <= 1e-9 and abs(st["sigma2"] - o["sigma2"]) <= 1e-7 * o["sigma2"]
+    finally:
+        ctx.close()
