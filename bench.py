@@ -304,6 +304,7 @@ def _compact(full):
         o["frame_from_depth_ms"] = ffd["640x480"].get("frame_from_depth_ms_pinned")
         o["frame_from_depth_ms_pageable"] = ffd["640x480"].get("frame_from_depth_ms_pageable")
         o["depth_to_cloud_ms"] = ffd["640x480"].get("depth_to_cloud_ms_pinned")
+        o["frame_from_depth_two_calls_ms"] = ffd["640x480"].get("frame_from_depth_two_calls_ms_pinned")
         if "1280x720" in ffd:
             o["frame_from_depth_720p_ms"] = ffd["1280x720"].get("frame_from_depth_ms_pinned")
     o["ranks"] = full.get("ranks")
@@ -674,7 +675,7 @@ def _preproc_leg(ctx, B, synth):
 
 def _frame_from_depth_leg(ctx, B, synth):
     """The whole device-born frame, the span the reference itself logs (trackdlo_node.cpp:195-369, ROS_INFO at :249-252 / :372-375): depth image + mask ->
-    back-projection + voxel grid (tdlo_depth_to_cloud) -> visibility pre-pass -> tracking_step on the resident cloud (X = NULL).  640 x 480 (the synthetic
+    back-projection + voxel grid -> visibility pre-pass (both in one launch: tdlo_depth_to_cloud_visibility) -> tracking_step on the resident cloud (X = NULL).  640 x 480 (the synthetic
     scenes' stream) and the reference camera's 1280 x 720 (launch/realsense_node.launch:7-12); images handed over in pageable host memory (copied) and
     in the context's pinned image buffers (tdlo_image_buffers: read in place by the kernel)."""
     P = synth.LAUNCH_PARAMS
@@ -705,15 +706,24 @@ def _frame_from_depth_leg(ctx, B, synth):
             def cloud():
                 return ctx.depth_to_cloud(0, d_, m_, *a, 0.008, fetch=False)
 
-            def frame():
+            def frame_two_calls():      # round 5's first form: cloud, then the pre-pass as a launch and a hand-over of its own
                 cloud()
                 _, vis, vext = ctx.visibility_prepass(0, trk.get_tracking_result(), P["visibility_threshold"], 0.06, coord)
                 trk.tracking_step(None, vis, vext)
+
+            def frame():                # the pre-pass rides in the depth -> cloud launch (tdlo_depth_to_cloud_visibility): the same numbers
+                _, vis, vext, _, _ = ctx.depth_to_cloud_visibility(0, d_, m_, *a, 0.008, trk.get_tracking_result(), P["visibility_threshold"], 0.06, coord)
+                trk.tracking_step(None, vis, vext)
+            fused = hasattr(ctx, "depth_to_cloud_visibility")
             res[f"depth_to_cloud_ms_{tag}"] = rate(cloud)
-            res[f"frame_from_depth_ms_{tag}"] = rate(frame)
+            res[f"frame_from_depth_ms_{tag}"] = rate(frame if fused else frame_two_calls)
+            if fused:
+                res[f"frame_from_depth_two_calls_ms_{tag}"] = rate(frame_two_calls)
         res["points"] = int(cloud()[1])
         if hasattr(ctx, "cloud_route_counts"):
             res["cloud_routes"] = ctx.cloud_route_counts()      # [served by the one-launch kernel, passed on to the multi-launch form]
+        if hasattr(ctx, "cloud_vis_rides"):
+            res["prepass_rides"] = ctx.cloud_vis_rides()         # frames whose visibility pre-pass rode in the depth -> cloud launch
         out[key] = res
     return out
 

@@ -365,6 +365,19 @@ int tdlo_visibility_prepass(tdlo_ctx *ctx, int slot, const double *Y, int M, dou
                             const double *geodesic_coord, double *node_dist, int *visible_nodes, int *n_vis,
                             int *visible_nodes_extended, int *n_vis_ext);
 
+/* One frame of the ROS node up to tracking_step in one call (trackdlo/src/trackdlo_node.cpp:195-277, :345-360): tdlo_depth_to_cloud followed by
+ * tdlo_visibility_prepass of the tracker's current nodes Y against the cloud it has just made resident in `slot` -- the same outputs as the two
+ * calls, bit for bit.  With up to 64 nodes and the one-launch team kernel the pre-pass rides in the SAME launch (every team member takes the minima
+ * over the centroids it has just formed; the member that finishes last hands cloud size and minima to pinned host memory together): one launch and one
+ * hand-over instead of two of each.  More nodes, TDLO_CLOUD_TEAM=0 / TDLO_CLOUD_FUSED=0 / TDLO_DIRECT_UPLOAD=0, more masked pixels than the one-launch
+ * form takes, a team that gave its launch up: the two steps run one behind the other as before (tdlo_debug_route_count(ctx, 8) counts the frames
+ * whose pre-pass rode along).  n == 0 (no masked pixel): *n_vis = *n_vis_ext = 0, no error. */
+int tdlo_depth_to_cloud_visibility(tdlo_ctx *ctx, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                                   double fx, double fy, double cx, double cy, double leaf_size,
+                                   const double *Y, int M, double visibility_threshold, double d_vis, const double *geodesic_coord,
+                                   double *node_dist, int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext,
+                                   int *n_out, int *n_raw_out);
+
 /* ---- host helpers on the path (exported so the parity tests can address them directly) -------- */
 /* trackdlo::calc_LLE_weights (trackdlo.cpp:119-159), k as passed at :236 (6). L: M x M col-major out. */
 int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L);

@@ -201,3 +201,72 @@ def test_a_team_that_loses_a_member_gives_the_launch_up(oracle):
     env.pop("TDLO_CLOUD_TEAM", None); env.pop("TDLO_CLOUD_FUSED", None)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("shape,M,leaf,rides", [
+    (None, 30, 0.008, True), (None, 45, 0.008, True), (None, 64, 0.005, True), ((720, 1280), 50, 0.008, True), ((120, 161), 30, 0.008, True),
+    (None, 65, 0.008, False),              # more than 64 nodes: the two steps one behind the other
+    (None, 50, 0.0015, False),             # the one-launch kernel passes the frame on (cell-index bits): multi-launch form, then the pre-pass
+])
+def test_frame_cloud_and_visibility_prepass_in_one_launch(oracle, shape, M, leaf, rides):
+    """tdlo_depth_to_cloud_visibility (trackdlo_node.cpp:195-277, :345-360): the visibility pre-pass of the tracker's nodes rides in the depth -> cloud team
+    kernel -- every team member takes the minima over the centroids it has just formed -- and gives the bits of tdlo_depth_to_cloud followed by
+    tdlo_visibility_prepass (which are the oracle's distances to 1e-12 m and its visible sets); the cloud left in the slot is the same one."""
+    from trackdlo_amd import binding as B, synth
+    kw = dict(rows=shape[0], cols=shape[1]) if shape else {}
+    depth, mask, cam, Y0 = synth.depth_scene(M, config=9, frame=M, **kw)
+    if shape and shape[0] < 200:
+        mask[:] = 0; mask[5, ::3] = 255
+    coord = synth.geodesic_coord(Y0)
+    rng = np.random.default_rng(M)
+    a, b = _ctx(B), _ctx(B)
+    try:
+        for rep in range(3):
+            Y = Y0 + rng.normal(0, 0.003, size=Y0.shape) + (np.array([0.0, 0.0, 0.02 * rep]) if rep else 0.0)      # (rep 2: some nodes beyond the threshold)
+            d1, v1, e1, n1, nraw1 = a.depth_to_cloud_visibility(0, depth, mask, *_args(cam), leaf, Y, 0.008, 0.06, coord)
+            _, n2, nraw2 = b.depth_to_cloud(0, depth, mask, *_args(cam), leaf, fetch=False)
+            d2, v2, e2 = b.visibility_prepass(0, Y, 0.008, 0.06, coord)
+            assert n1 == n2 and nraw1 == nraw2
+            assert np.array_equal(d1, d2) and np.array_equal(v1, v2) and np.array_equal(e1, e2)
+            if n1 >= 4:                    # the cloud left in the slot is the same one: a registration on it gives the same bits
+                p = B.make_params(0.35, 50000.0, 10.0, 0.1, 2, 0.0, False)
+                ra = a.cpd_lle_resident(0, Y0[:8], 0.0, p, check=False); rb = b.cpd_lle_resident(0, Y0[:8], 0.0, p, check=False)
+                assert ra["rc"] == rb["rc"] and np.array_equal(ra["Y"], rb["Y"]) and ra["n_kept"] == rb["n_kept"]
+        assert a.cloud_vis_rides() == (3 if rides else 0) and b.cloud_vis_rides() == 0
+        # ... and against the oracle: the cloud bit for bit, the distances to rounding, the sets exactly
+        Xo, _ = oracle.depth_to_cloud(depth, mask, *_args(cam), leaf)
+        do, viso, exto = oracle.visibility_prepass(np.asfortranarray(Xo), Y, 0.008, 0.06, coord)
+        np.testing.assert_allclose(d1, do, rtol=0, atol=1e-12)
+        assert np.array_equal(v1, viso) and np.array_equal(e1, exto)
+        # the ordinary pre-pass on the same context afterwards finds its state armed
+        d3, v3, e3 = a.visibility_prepass(0, Y, 0.008, 0.06, coord)
+        assert np.array_equal(d3, d1)
+    finally:
+        a.close(); b.close()
+
+
+def test_frame_prepass_survives_a_team_that_gives_up(monkeypatch):
+    """The team kernel's launch is abandoned (test hook: a member never arrives): the frame comes back through the multi-launch form and the pre-pass runs
+    behind it -- the same numbers, and the pre-pass's device state is armed again for the next frame, which rides."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np
+        from trackdlo_amd import binding as B, synth
+        depth, mask, cam, Y0 = synth.depth_scene(30, config=9, frame=3)
+        coord = synth.geodesic_coord(Y0)
+        args = (cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        a = B.Context(device=0); b = B.Context(device=0)
+        out = []
+        for rep in range(3):
+            d1, v1, e1, n1, _ = a.depth_to_cloud_visibility(0, depth, mask, *args, 0.008, Y0, 0.008, 0.06, coord)
+            out.append((d1, v1, e1, n1))
+        _, n2, _ = b.depth_to_cloud(0, depth, mask, *args, 0.008, fetch=False)
+        d2, v2, e2 = b.visibility_prepass(0, Y0, 0.008, 0.06, coord)
+        for d1, v1, e1, n1 in out:
+            assert n1 == n2 and np.array_equal(d1, d2) and np.array_equal(v1, v2) and np.array_equal(e1, e2)
+        print("rides", a.cloud_vis_rides(), "routes", a.cloud_route_counts())
+    ''')
+    env = dict(os.environ, TDLO_CLOUD_TEAM_FORCE_TIMEOUT="2", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rides 2 routes [2, 1]" in r.stdout, r.stdout

@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -193,6 +193,7 @@ def load_library(path: str | None = None):
     lib.tdlo_compute_error.restype = cd
     lib.tdlo_compute_error.argtypes = [vp, ci, vp, ci]
     lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
+    lib.tdlo_depth_to_cloud_visibility.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     lib.tdlo_reg.argtypes = [vp, ci, vp, ci, vp, C.POINTER(cd), ci, cd, ci]
     lib.tdlo_depth_to_cloud.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     lib.tdlo_image_buffers.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(vp)]
@@ -446,6 +447,10 @@ class Context:
         """[depth -> cloud calls served by the one-launch kernel, calls it passed on to the multi-launch form] (tdlo_debug_route_count 6 / 7)."""
         return [int(self.lib.tdlo_debug_route_count(self.h, k)) for k in (6, 7)]
 
+    def cloud_vis_rides(self):
+        """Frames whose visibility pre-pass rode in the depth -> cloud launch (tdlo_debug_route_count 8)."""
+        return int(self.lib.tdlo_debug_route_count(self.h, 8))
+
     def band_retries(self):
         """Calls of this context that were repeated on the dense pivoted kernels after the banded LLE solve gave up (tdlo_debug_band_retries)."""
         return int(self.lib.tdlo_debug_band_retries(self.h))
@@ -491,6 +496,24 @@ class Context:
                                                _ptr(buf), cap, C.byref(n), C.byref(nraw)))
         X = buf[:3 * n.value].reshape(3, n.value).T.copy() if fetch else None
         return X, n.value, nraw.value
+
+    def depth_to_cloud_visibility(self, slot, depth, mask, fx, fy, cx, cy, leaf_size, Y, visibility_threshold, d_vis, geodesic_coord):
+        """One frame of the ROS node up to tracking_step (trackdlo_node.cpp:195-277, :345-360): depth_to_cloud (the cloud stays resident in the slot) and
+        the visibility pre-pass of the nodes Y against it, in one launch where the library can (tdlo_depth_to_cloud_visibility).
+        Returns (node_dist, visible_nodes, visible_nodes_extended, n, n_raw)."""
+        depth = np.ascontiguousarray(depth, dtype=np.uint16); mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        if depth.ndim != 2 or depth.shape != mask.shape:
+            raise ValueError("depth and mask must be rows x cols images of the same shape")
+        rows, cols = depth.shape
+        Y = _f64(Y); M = Y.shape[0]
+        coord = np.ascontiguousarray(geodesic_coord, dtype=np.float64)
+        dist = np.zeros(M); vis = np.zeros(M, dtype=np.int32); ext = np.zeros(M, dtype=np.int32)
+        nv = C.c_int(0); ne = C.c_int(0); n = C.c_int(0); nraw = C.c_int(0)
+        self._chk(self.lib.tdlo_depth_to_cloud_visibility(self.h, slot, depth.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p), rows, cols,
+                                                          float(fx), float(fy), float(cx), float(cy), float(leaf_size), _ptr(Y), M,
+                                                          float(visibility_threshold), float(d_vis), _ptr(coord), _ptr(dist), _ptr(vis), C.byref(nv),
+                                                          _ptr(ext), C.byref(ne), C.byref(n), C.byref(nraw)))
+        return dist, vis[:nv.value].copy(), ext[:ne.value].copy(), n.value, nraw.value
 
     def debug_read_cloud(self, max_points, slot=0):
         out = np.zeros((3, max_points)); ctr = np.zeros(3)

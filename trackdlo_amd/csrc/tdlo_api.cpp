@@ -176,6 +176,8 @@ struct tdlo_ctx {
     unsigned long long *vis_state = nullptr, *vis_res = nullptr;
     unsigned vis_epoch = 0;
     bool vis_armed = false;
+    double *vis_nodes_pin = nullptr;     // 3 x 64 doubles in pinned host memory: the nodes of a pre-pass that rides in the depth -> cloud team kernel
+    long long cloud_vis_rides = 0;       // how many frames' pre-passes did (tdlo_debug_route_count 8)
     long long cloud_route[2] = {0, 0};   // tdlo_debug_route_count 6 / 7: depth -> cloud calls served by the one-launch kernel / sent on to the multi-launch form by it
     size_t pin_doubles = 0;
     std::string err;
@@ -1393,6 +1395,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->cloud_fws) hipFree(c->cloud_fws);
     if (c->vis_state) hipFree(c->vis_state);
     if (c->vis_res) hipHostFree(c->vis_res);
+    if (c->vis_nodes_pin) hipHostFree(c->vis_nodes_pin);
     if (c->cloud_res) hipHostFree(c->cloud_res);
     if (c->img_pin) hipHostFree(c->img_pin);
     if (c->reg_ws) hipFree(c->reg_ws);
@@ -2030,9 +2033,28 @@ int tdlo_image_buffers(tdlo_ctx *c, int rows, int cols, unsigned short **depth, 
     return TDLO_OK;
 }
 
-int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
-                        double fx, double fy, double cx, double cy, double leaf_size,
-                        double *X_out, int x_capacity, int *n_out, int *n_raw_out) {
+// the visibility pre-pass's device / pinned words (shared by tdlo_visibility_prepass's one-launch route and the depth -> cloud team kernel's own pre-pass)
+static int ensure_vis_state(tdlo_ctx *c) {
+    if (!c->vis_state) {
+        HIPCHK(c, hipMalloc((void **)&c->vis_state, sizeof(unsigned long long) * (kMaxNodes + 8)));
+        HIPCHK(c, hipHostMalloc((void **)&c->vis_res, sizeof(unsigned long long) * (kMaxNodes + 8), hipHostMallocDefault));
+        std::memset(c->vis_res, 0, sizeof(unsigned long long) * (kMaxNodes + 8));
+        c->vis_armed = false;
+    }
+    if (!c->vis_armed) {
+        std::vector<unsigned long long> init(kMaxNodes + 8, 0x7ff0000000000000ull);
+        for (int i = kMaxNodes; i < kMaxNodes + 8; ++i) init[i] = 0ull;
+        HIPCHK(c, hipMemcpy(c->vis_state, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
+        c->vis_armed = true;
+    }
+    return TDLO_OK;
+}
+
+// vis_Y != nullptr: the caller wants the frame's visibility pre-pass as well; *vis_done = true when the one-launch team kernel has left the M squared
+// minima in c->vis_res[1 ..] (otherwise the caller runs tdlo_visibility_prepass on the resident cloud)
+static int depth_to_cloud_impl(tdlo_ctx *c, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                               double fx, double fy, double cx, double cy, double leaf_size,
+                               double *X_out, int x_capacity, int *n_out, int *n_raw_out, const double *vis_Y, int vis_M, bool *vis_done) {
     if (!c) return TDLO_E_INVALID;
     if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
     if (!depth || !mask || rows <= 0 || cols <= 0 || (long long)rows * cols > (1ll << 26)) return fail(c, TDLO_E_INVALID, "bad image");
@@ -2087,14 +2109,23 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
         }
         if ((rc = ensure_points(c, s, cloud_fused_max_points()))) return rc;      // (an output point per masked pixel at most; sized once)
         if (++c->cloud_epoch == 0) ++c->cloud_epoch;
-        HIPCHK(c, launch_cloud_fused(d_depth, d_mask, P, cols, cam, inv, ws, c->cloud_fws, c->cloud_fused_first, c->cloud_team_on, s.Xraw, s.cap_points, c->cloud_res, c->cloud_epoch, st));
+        // the frame's visibility pre-pass rides along when the team kernel runs (up to 64 nodes): the nodes staged in pinned memory, read by the kernel
+        const bool vis_ride = vis_Y != nullptr && vis_M >= 1 && vis_M <= 64 && c->cloud_team_on && c->direct_in;
+        if (vis_ride) {
+            if ((rc = ensure_vis_state(c))) return rc;
+            if (!c->vis_nodes_pin) HIPCHK(c, hipHostMalloc((void **)&c->vis_nodes_pin, sizeof(double) * 3 * 64, hipHostMallocDefault));
+            std::memcpy(c->vis_nodes_pin, vis_Y, sizeof(double) * 3 * (size_t)vis_M);
+        }
+        HIPCHK(c, launch_cloud_fused(d_depth, d_mask, P, cols, cam, inv, ws, c->cloud_fws, c->cloud_fused_first, c->cloud_team_on, s.Xraw, s.cap_points, c->cloud_res, c->cloud_epoch, st,
+                                     vis_ride ? c->vis_nodes_pin : nullptr, vis_ride ? vis_M : 0, c->vis_state, c->vis_res));
         c->cloud_fused_first = false;
         const int status = cloud_wait(c, st, c->cloud_epoch);
+        if (status != 1 && vis_ride) c->vis_armed = false;      // (whatever the team left in the minima: armed again before their next use)
         if (status < 0) { c->cloud_fused_first = true; return status; }
         if (status == 0) { c->cloud_fused_first = true; return fail(c, TDLO_E_HIP, "the stream drained, but the depth -> cloud kernel did not report"); }
         const unsigned long long w1 = __atomic_load_n(c->cloud_res + 1, __ATOMIC_RELAXED);
         nraw = (int)(unsigned)(w1 >> 32);
-        if (status == 1) { n = (int)(unsigned)w1; ++c->cloud_route[0]; }
+        if (status == 1) { n = (int)(unsigned)w1; ++c->cloud_route[0]; if (vis_ride && vis_done) { *vis_done = true; ++c->cloud_vis_rides; } }
         else if (status == 3) return fail(c, TDLO_E_HIP, "voxel grid produced more points than the slot holds");
         else if (status == 4) { c->cloud_fused_first = true; ++c->cloud_route[1]; }      // the team gave the launch up (a wait of 2 s): state words initialised again, the multi-launch form below
         else ++c->cloud_route[1];                 // not taken (too many masked pixels / cells, pass-through): the multi-launch form below
@@ -2148,7 +2179,16 @@ int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, cons
     return TDLO_OK;
 }
 
+int tdlo_depth_to_cloud(tdlo_ctx *c, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                        double fx, double fy, double cx, double cy, double leaf_size,
+                        double *X_out, int x_capacity, int *n_out, int *n_raw_out) {
+    return depth_to_cloud_impl(c, slot, depth, mask, rows, cols, fx, fy, cx, cy, leaf_size, X_out, x_capacity, n_out, n_raw_out, nullptr, 0, nullptr);
+}
+
 // ---- caller-side visibility pre-pass ------------------------------------------------------------
+static void vis_threshold_and_fill(const double *min_d2, int M, double visibility_threshold, double d_vis, const double *geodesic_coord, double *node_dist,
+                                   int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext);
+
 int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, double visibility_threshold, double d_vis,
                             const double *geodesic_coord, double *node_dist, int *visible_nodes, int *n_vis,
                             int *visible_nodes_extended, int *n_vis_ext) {
@@ -2169,18 +2209,7 @@ int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, doubl
     if (c->direct_in && M <= kMaxNodes) {
         // one launch, no copies: the kernel reads the nodes from the pinned staging block and its last workgroup writes the minima to pinned host
         // memory (TDLO_DIRECT_UPLOAD=0: the copies + stream synchronisation below, the comparator)
-        if (!c->vis_state) {
-            HIPCHK(c, hipMalloc((void **)&c->vis_state, sizeof(unsigned long long) * (kMaxNodes + 8)));
-            HIPCHK(c, hipHostMalloc((void **)&c->vis_res, sizeof(unsigned long long) * (kMaxNodes + 8), hipHostMallocDefault));
-            std::memset(c->vis_res, 0, sizeof(unsigned long long) * (kMaxNodes + 8));
-            c->vis_armed = false;
-        }
-        if (!c->vis_armed) {
-            std::vector<unsigned long long> init(kMaxNodes + 8, 0x7ff0000000000000ull);
-            for (int i = kMaxNodes; i < kMaxNodes + 8; ++i) init[i] = 0ull;
-            HIPCHK(c, hipMemcpy(c->vis_state, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
-            c->vis_armed = true;
-        }
+        if ((rc = ensure_vis_state(c))) return rc;
         if (++c->vis_epoch == 0) ++c->vis_epoch;
         HIPCHK(c, launch_node_min_dist_direct(s.Xraw, s.N0, c->pin, M, c->vis_state, c->vis_res, c->vis_epoch, st));
         auto t_chk = std::chrono::steady_clock::now();
@@ -2214,11 +2243,17 @@ int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, doubl
         HIPCHK(c, hipMemcpyAsync(c->pin, dbits, sizeof(double) * M, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
-    // thresholding and gap fill on the host (O(M)): trackdlo_node.cpp:316/:326 (distance test only, the OpenCV
-    // painter test of :279-343 is out of scope), :345-360
+    vis_threshold_and_fill(c->pin, M, visibility_threshold, d_vis, geodesic_coord, node_dist, visible_nodes, n_vis, visible_nodes_extended, n_vis_ext);
+    return TDLO_OK;      // an empty visible set is reported as n_vis = 0 (the reference underflows at :351)
+}
+
+// thresholding and gap fill on the host (O(M)) from the squared minima: trackdlo_node.cpp:316/:326 (distance test only, the OpenCV
+// painter test of :279-343 is out of scope), :345-360
+static void vis_threshold_and_fill(const double *min_d2, int M, double visibility_threshold, double d_vis, const double *geodesic_coord, double *node_dist,
+                                   int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext) {
     std::vector<int> vis;
     for (int m = 0; m < M; ++m) {
-        const double d = std::sqrt(c->pin[m]);
+        const double d = std::sqrt(min_d2[m]);
         if (node_dist) node_dist[m] = d;
         if (d <= visibility_threshold) vis.push_back(m);
     }
@@ -2235,7 +2270,32 @@ int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, doubl
     }
     if (n_vis_ext) *n_vis_ext = (int)ext.size();
     if (visible_nodes_extended) std::copy(ext.begin(), ext.end(), visible_nodes_extended);
-    return TDLO_OK;      // an empty visible set is reported as n_vis = 0 (the reference underflows at :351)
+}
+
+// One frame of the ROS node up to tracking_step (trackdlo_node.cpp:195-277, :345-360) in one call: depth image -> cloud -> voxel grid, and the visibility
+// pre-pass of the tracker's current nodes against that cloud.  With up to 64 nodes and the one-launch team kernel the pre-pass rides in the same launch
+// (every team member takes the minima over the centroids it has just formed): one launch and one hand-over through pinned memory for both steps.
+// Otherwise -- more nodes, TDLO_CLOUD_TEAM=0, too many masked pixels, a team that gave up -- tdlo_visibility_prepass runs behind it: the same numbers.
+int tdlo_depth_to_cloud_visibility(tdlo_ctx *c, int slot, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                                   double fx, double fy, double cx, double cy, double leaf_size,
+                                   const double *Y, int M, double visibility_threshold, double d_vis, const double *geodesic_coord,
+                                   double *node_dist, int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext,
+                                   int *n_out, int *n_raw_out) {
+    if (!c) return TDLO_E_INVALID;
+    if (!Y || M < 1 || !geodesic_coord) return fail(c, TDLO_E_INVALID, "null Y / geodesic_coord");
+    bool vis_done = false;
+    int n = 0;
+    int rc = depth_to_cloud_impl(c, slot, depth, mask, rows, cols, fx, fy, cx, cy, leaf_size, nullptr, 0, &n, n_raw_out, Y, M, &vis_done);
+    if (n_out) *n_out = n;
+    if (rc) return rc;
+    if (n_vis) *n_vis = 0;
+    if (n_vis_ext) *n_vis_ext = 0;
+    if (n == 0) return TDLO_OK;                  // no cloud, nothing visible (tdlo_visibility_prepass would refuse the empty slot)
+    if (!vis_done) return tdlo_visibility_prepass(c, slot, Y, M, visibility_threshold, d_vis, geodesic_coord, node_dist, visible_nodes, n_vis, visible_nodes_extended, n_vis_ext);
+    if ((rc = ensure_pin(c, (size_t)M + 8))) return rc;
+    std::memcpy(c->pin, c->vis_res + 1, sizeof(double) * M);
+    vis_threshold_and_fill(c->pin, M, visibility_threshold, d_vis, geodesic_coord, node_dist, visible_nodes, n_vis, visible_nodes_extended, n_vis_ext);
+    return TDLO_OK;
 }
 
 // ---- measurement ---------------------------------------------------------------------------------
@@ -2390,7 +2450,8 @@ int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
 long long tdlo_debug_route_count(tdlo_ctx *c, int which) {
-    if (!c || which < 0 || which > 7) return -1;
+    if (!c || which < 0 || which > 8) return -1;
+    if (which == 8) return c->cloud_vis_rides;
     return which < 6 ? c->route_count[which] : c->cloud_route[which - 6];
 }
 

@@ -327,6 +327,10 @@ struct FusedCloud {
     double *X; int cap;                  // the slot's raw cloud and its capacity in points
     unsigned long long *res;             // pinned host: [1] = n_raw << 32 | n, then [0] = epoch << 32 | status (1 done, 2 not taken, 3 capacity)
     unsigned epoch;
+    // the visibility pre-pass of the same frame (trackdlo_node.cpp:257-277) inside the team kernel: visM nodes (<= 64; 0: not asked for) read from pinned host
+    // memory, every team member takes the minima over its own centroids (atomic min on visState, armed with +inf), the member that finishes last hands
+    // them to pinned host memory (visOut[1 + m], the layout of k_node_min_dist_direct) and re-arms
+    const double *visY; int visM; unsigned long long *visState, *visOut;
     int hook;                            // test hook (TDLO_CLOUD_TEAM_FORCE_TIMEOUT): the team's last workgroup leaves before its first barrier, the others wait out the limit
 };
 
@@ -829,6 +833,10 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
 
     unsigned status = 1u;
     int n = 0, ncell = 0;
+    // (pre-pass) lane = node: its coordinates are requested now, from pinned host memory -- a PCIe round trip that the sort hides
+    const int vM = a.visM;
+    double vyx = 0.0, vyy = 0.0, vyz = 0.0;
+    if (vM > 0 && lane < vM) { vyx = a.visY[lane]; vyy = a.visY[vM + lane]; vyz = a.visY[2 * vM + lane]; }
     // the last team workgroup to come here re-arms the state words for the next launch and reports to the host
     auto finish = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -840,6 +848,12 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
         __syncthreads();
         if (t < 3) __hip_atomic_store(a.state + t, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (t < 16) __hip_atomic_store(a.state + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (vM > 0 && t >= 64 && t < 64 + vM) {      // (every member's atomic minima were performed before it drew its finish ticket)
+            const int m = t - 64;
+            const unsigned long long b = __hip_atomic_load(a.visState + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.visOut + 1 + m, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.visState + m, 0x7ff0000000000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) {
@@ -1066,9 +1080,11 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
     __syncthreads();
     TSTAMP(5);
     // ---- one lane per head: CentroidPoint's float sums in input order
+    float ccx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ccy[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ccz[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // this thread's centroids (nh <= 4096 = 4 per thread)
     {
         const size_t ld = (size_t)ncell;
-        for (int i = t; i < nh; i += kFT) {
+        int rr = 0;
+        for (int i = t; i < nh; i += kFT, ++rr) {
             const int p = s0 + (int)hl[i];
             const int e = i + 1 < nh ? s0 + (int)hl[i + 1] : e_k;             // the next head inside the slice, or where the run that crosses its end stops
             const int out = out0 + i;
@@ -1090,10 +1106,34 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
                 sz += __hip_atomic_load(a.cz + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const float cf = (float)(e - p);
-            a.X[out] = (double)__fdiv_rn(sx, cf); a.X[ld + out] = (double)__fdiv_rn(sy, cf); a.X[2 * ld + out] = (double)__fdiv_rn(sz, cf);
+            const float qx = __fdiv_rn(sx, cf), qy = __fdiv_rn(sy, cf), qz = __fdiv_rn(sz, cf);
+            a.X[out] = (double)qx; a.X[ld + out] = (double)qy; a.X[2 * ld + out] = (double)qz;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (q == rr) { ccx[q] = qx; ccy[q] = qy; ccz[q] = qz; }
         }
     }
     TSTAMP(6);
+    if (vM > 0) {
+        // ---- the visibility pre-pass over this member's centroids: they go to LDS (the staged coordinates are done with), then wave = a sixteenth of
+        //      them, lane = node: the distance of k_node_min_dist_direct (node_point_d2 on the centroid as stored: the float widened to double), the
+        //      minimum over the waves through LDS, one atomic minimum per node and member
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = t + q * kFT; if (i < nh) { V[i] = ccx[q]; V[kTVcap + i] = ccy[q]; V[2 * kTVcap + i] = ccz[q]; } }
+        __syncthreads();
+        double mn = __builtin_huge_val();
+        if (lane < vM) {
+            for (int i = w; i < nh; i += kFW) mn = ::fmin(mn, node_point_d2(vyx, vyy, vyz, (double)V[i], (double)V[kTVcap + i], (double)V[2 * kTVcap + i]));
+        }
+        double *red = (double *)qt;                                          // kFW x 64 doubles = 8 KB: the quarter counts qt | qb, done with
+        red[w * 64 + lane] = mn;
+        __syncthreads();
+        if (w == 0 && lane < vM && nh > 0) {
+#pragma unroll
+            for (int j = 1; j < kFW; ++j) mn = ::fmin(mn, red[j * 64 + lane]);
+            (void)__hip_atomic_fetch_min(a.visState + lane, (unsigned long long)__double_as_longlong(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     finish();
 #undef TSTAMP
 }
@@ -1110,7 +1150,8 @@ bool cloud_fused_ok(int P) { return ((size_t)P + kFPix - 1) / kFPix <= (size_t)k
 // ws: the multi-launch form's workspace (three of its four P-word sort buffers serve as the tiles' regions), fws: cloud_fused_ws_bytes(P)
 // bytes kept by the kernels themselves between the launches (first == true: the state words are initialised by a copy in front of the launch)
 hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], float inv_leaf, void *ws, void *fws,
-                              bool first, bool team, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s) {
+                              bool first, bool team, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s,
+                              const double *vis_nodes_pinned, int vis_M, unsigned long long *vis_state, unsigned long long *vis_out_pinned) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_cloud_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFLds);
@@ -1129,6 +1170,7 @@ hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *
     a.thist = (int *)(a.tw1 + kFNmax);
     a.tcnt = a.thist + kTK * 256 + 64;
     a.X = Xraw; a.cap = cap; a.res = res_pinned; a.epoch = epoch;
+    a.visY = vis_nodes_pinned; a.visM = (team && vis_nodes_pinned && vis_M > 0 && vis_M <= 64) ? vis_M : 0; a.visState = vis_state; a.visOut = vis_out_pinned;
     {   // test hook: the n-th team launch of the process loses a team member (the others give the launch up after 2 s; the host runs the multi-launch form)
         static int hook_at = getenv("TDLO_CLOUD_TEAM_FORCE_TIMEOUT") ? atoi(getenv("TDLO_CLOUD_TEAM_FORCE_TIMEOUT")) : 0;
         a.hook = (team && hook_at > 0 && --hook_at == 0) ? 1 : 0;

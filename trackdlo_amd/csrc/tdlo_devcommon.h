@@ -61,6 +61,13 @@ template <> struct Num<double> {
     static __device__ __forceinline__ double from_bits(unsigned long long b) { return __longlong_as_double((long long)b); }
 };
 
+// Squared node-to-point distance of the visibility pre-pass (trackdlo_node.cpp:257-277), written out as the fused operations it is computed in: three
+// kernels form it (k_node_min_dist, k_node_min_dist_direct, the depth -> cloud team kernel's own pre-pass) and must give the same bits.
+__device__ __forceinline__ double node_point_d2(double yx, double yy, double yz, double x, double y, double z) {
+    const double dx = yx - x, dy = yy - y, dz = yz - z;
+    return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+}
+
 // LDS hand-off between lanes of ONE wave: DS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering across the point.
 __device__ __forceinline__ void wave_lds_sync() {

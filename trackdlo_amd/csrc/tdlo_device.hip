@@ -2004,8 +2004,7 @@ __global__ __launch_bounds__(kBlock) void k_node_min_dist(const double *__restri
         double x = 0, y = 0, z = 0;
         if (valid) { x = X[n]; y = X[(size_t)N + n]; z = X[2 * (size_t)N + n]; }
         for (int m = 0; m < M; ++m) {
-            const double dx = Y[m] - x, dy = Y[M + m] - y, dz = Y[2 * M + m] - z;
-            double d2 = valid ? dx * dx + dy * dy + dz * dz : __builtin_huge_val();
+            double d2 = valid ? node_point_d2(Y[m], Y[M + m], Y[2 * M + m], x, y, z) : __builtin_huge_val();
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) d2 = ::fmin(d2, __shfl_xor(d2, o));
             if (lane == 0) atomicMin(&out_bits[m], (unsigned long long)__double_as_longlong(d2));
@@ -2030,8 +2029,7 @@ __global__ __launch_bounds__(kBlock) void k_node_min_dist_direct(const double *_
         double x = 0, y = 0, z = 0;
         if (valid) { x = X[n]; y = X[(size_t)N + n]; z = X[2 * (size_t)N + n]; }
         for (int m = 0; m < M; ++m) {
-            const double dx = Yl[m] - x, dy = Yl[M + m] - y, dz = Yl[2 * M + m] - z;
-            double d2 = valid ? dx * dx + dy * dy + dz * dz : __builtin_huge_val();
+            double d2 = valid ? node_point_d2(Yl[m], Yl[M + m], Yl[2 * M + m], x, y, z) : __builtin_huge_val();
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) d2 = ::fmin(d2, __shfl_xor(d2, o));
             if (lane == 0) (void)__hip_atomic_fetch_min(state + m, (unsigned long long)__double_as_longlong(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -263,7 +263,8 @@ size_t cloud_fused_ws_bytes(int P);
 int cloud_fused_max_points();
 bool cloud_fused_ok(int P);
 hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], float inv_leaf, void *ws, void *fws,
-                              bool first, bool team, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s);
+                              bool first, bool team, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s,
+                              const double *vis_nodes_pinned = nullptr, int vis_M = 0, unsigned long long *vis_state = nullptr, unsigned long long *vis_out_pinned = nullptr);
 int check_device_image();
 
 }  // namespace tdlo
