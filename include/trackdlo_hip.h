@@ -451,7 +451,10 @@ int tdlo_debug_lle_band_device(tdlo_ctx *ctx, const double *Y, int M, double *Hb
  * by the pre-processing registration instead of repeating that E-step (TDLO_PAIR_SUMS=0); 2: ... whose first M-step had been launched ahead of
  * its priors and was released when they were staged (TDLO_SPEC_MSTEP=0); 3: pre-processing registrations whose LLE regulariser had been formed
  * on the device by the M-step that finished the previous frame (TDLO_LLE_NEXT=0); 4: main registrations of frames with hidden nodes whose first
- * iteration had run on the second stream beside the pre-processing registration (TDLO_AHEAD=0).  -1 for a null context or an unknown counter. */
+ * iteration had run on the second stream beside the pre-processing registration (TDLO_AHEAD=0); 5: calls repeated on the three-kernel route because
+ * the fused prologue's grid barrier was abandoned; 6 / 7: tdlo_depth_to_cloud calls served by the one-launch kernel / passed on by it to the
+ * multi-launch form; 8: frames whose visibility pre-pass rode in the depth -> cloud launch (tdlo_depth_to_cloud_visibility).
+ * -1 for a null context or an unknown counter. */
 long long tdlo_debug_route_count(tdlo_ctx *ctx, int which);
 /* Phase stamps (s_memtime) of the last depth -> cloud launch's finishing workgroup; only a -DTDLO_CLOUD_STAMPS build writes them. */
 int tdlo_debug_cloud_stamps(tdlo_ctx *ctx, unsigned long long *out, int n);
