@@ -711,10 +711,9 @@ def _frame_from_depth_leg(ctx, B, synth):
                 _, vis, vext = ctx.visibility_prepass(0, trk.get_tracking_result(), P["visibility_threshold"], 0.06, coord)
                 trk.tracking_step(None, vis, vext)
 
-            def frame():                # the pre-pass rides in the depth -> cloud launch (tdlo_depth_to_cloud_visibility): the same numbers
-                _, vis, vext, _, _ = ctx.depth_to_cloud_visibility(0, d_, m_, *a, 0.008, trk.get_tracking_result(), P["visibility_threshold"], 0.06, coord)
-                trk.tracking_step(None, vis, vext)
-            fused = hasattr(ctx, "depth_to_cloud_visibility")
+            def frame():                # the pre-pass rides in the depth -> cloud launch, the callback is one call (tdlo_tracker_frame_from_depth): the same numbers
+                trk.frame_from_depth(d_, m_, *a, 0.008, 0.06)
+            fused = hasattr(trk, "frame_from_depth")
             res[f"depth_to_cloud_ms_{tag}"] = rate(cloud)
             res[f"frame_from_depth_ms_{tag}"] = rate(frame if fused else frame_two_calls)
             if fused:

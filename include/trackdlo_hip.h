@@ -378,6 +378,17 @@ int tdlo_depth_to_cloud_visibility(tdlo_ctx *ctx, int slot, const unsigned short
                                    double *node_dist, int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext,
                                    int *n_out, int *n_raw_out);
 
+/* The ROS node's callback from the images to the nodes in one call (trackdlo/src/trackdlo_node.cpp:195-369): tdlo_depth_to_cloud_visibility with the
+ * tracker's own nodes, visibility threshold and geodesic coordinates, then tdlo_tracker_tracking_step on the cloud left in the tracker's slot
+ * (X == NULL, no H_pre).  The visible sets of the frame are returned as well (arrays of M ints, may be NULL); stats: the two tdlo_stats of
+ * tracking_step.  The result is read with tdlo_tracker_get_tracking_result.  A frame whose mask selects no pixel, or none of whose nodes lies
+ * within the visibility threshold of the cloud, is TDLO_E_EMPTY (the reference's callback indexes visible_nodes[size() - 1] there, :351-361);
+ * the tracker's state is untouched then. */
+int tdlo_tracker_frame_from_depth(tdlo_tracker *t, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                                  double fx, double fy, double cx, double cy, double leaf_size, double d_vis,
+                                  int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext,
+                                  int *n_out, int *n_raw_out, tdlo_stats *stats);
+
 /* ---- host helpers on the path (exported so the parity tests can address them directly) -------- */
 /* trackdlo::calc_LLE_weights (trackdlo.cpp:119-159), k as passed at :236 (6). L: M x M col-major out. */
 int tdlo_calc_lle_weights(int k, const double *Y, int M, double *L);

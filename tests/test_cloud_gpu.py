@@ -270,3 +270,47 @@ def test_frame_prepass_survives_a_team_that_gives_up(monkeypatch):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rides 2 routes [2, 1]" in r.stdout, r.stdout
+
+
+def test_the_callback_in_one_call_equals_its_three_steps():
+    """tdlo_tracker_frame_from_depth (trackdlo_node.cpp:195-369): images in, nodes out -- the bits of tdlo_depth_to_cloud, tdlo_visibility_prepass and
+    tdlo_tracker_tracking_step(X = NULL) called one after the other, over a short sequence (the rope drifts, one frame hides a stretch of it); a frame
+    whose mask is empty, or that leaves no node visible, is TDLO_E_EMPTY and leaves the tracker as it was."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    M = 30
+    a, b = _ctx(B), _ctx(B)
+    try:
+        depth0, mask0, cam, Y0 = synth.depth_scene(M, config=9, frame=0)
+        coord = synth.geodesic_coord(Y0)
+        targs = (M, P["visibility_threshold"], P["beta"], P["lambda_"], P["alpha"], P["k_vis"], P["mu"], 30, P["tol"], P["beta_pre_proc"], P["lambda_pre_proc"], P["lle_weight"])
+        ta, tb = B.trackdlo(*targs, ctx=a), B.trackdlo(*targs, ctx=b)
+        for t in (ta, tb):
+            t.initialize_nodes(Y0); t.initialize_geodesic_coord(coord)
+        da, ma = a.image_buffers(*depth0.shape)
+        for fr in range(5):
+            depth, mask, _, _ = synth.depth_scene(M, config=9, frame=fr)
+            if fr == 3:
+                mask = mask.copy(); mask[:, 300:340] = 0                 # a stretch of the rope hidden: some nodes beyond the threshold
+            da[:] = depth; ma[:] = mask
+            va, ea, na, nra = ta.frame_from_depth(da, ma, *_args(cam), 0.008, 0.06)
+            _, nb, nrb = b.depth_to_cloud(0, depth, mask, *_args(cam), 0.008, fetch=False)
+            _, vb, eb = b.visibility_prepass(0, tb.get_tracking_result(), P["visibility_threshold"], 0.06, coord)
+            tb.tracking_step(None, vb, eb)
+            assert na == nb and nra == nrb and np.array_equal(va, vb) and np.array_equal(ea, eb)
+            assert np.array_equal(ta.get_tracking_result(), tb.get_tracking_result()) and ta.get_sigma2() == tb.get_sigma2()
+            assert [s["iters"] for s in ta.last_stats] == [s["iters"] for s in tb.last_stats]
+            if fr == 3:
+                assert len(va) < M
+        assert a.cloud_vis_rides() == 5
+        Yk, sk = ta.get_tracking_result().copy(), ta.get_sigma2()
+        with pytest.raises(B.TdloError) as e1:
+            ta.frame_from_depth(depth0, np.zeros_like(mask0), *_args(cam), 0.008, 0.06)
+        assert e1.value.code == B.TDLO_E_EMPTY
+        far = depth0.copy(); far[mask0 > 0] += 400                          # the rope 0.4 m further away: a cloud, but no node near it
+        with pytest.raises(B.TdloError) as e2:
+            ta.frame_from_depth(far, mask0, *_args(cam), 0.008, 0.06)
+        assert e2.value.code == B.TDLO_E_EMPTY
+        assert np.array_equal(ta.get_tracking_result(), Yk) and ta.get_sigma2() == sk
+    finally:
+        a.close(); b.close()

@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_tracker_frame_from_depth", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg",
 ]
 
@@ -193,6 +193,7 @@ def load_library(path: str | None = None):
     lib.tdlo_compute_error.restype = cd
     lib.tdlo_compute_error.argtypes = [vp, ci, vp, ci]
     lib.tdlo_visibility_prepass.argtypes = [vp, ci, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci)]
+    lib.tdlo_tracker_frame_from_depth.argtypes = [vp, vp, vp, ci, ci, cd, cd, cd, cd, cd, cd, vp, C.POINTER(ci), vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), vp]
     lib.tdlo_depth_to_cloud_visibility.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, cd, cd, vp, vp, vp, C.POINTER(ci), vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     lib.tdlo_reg.argtypes = [vp, ci, vp, ci, vp, C.POINTER(cd), ci, cd, ci]
     lib.tdlo_depth_to_cloud.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, C.POINTER(ci), C.POINTER(ci)]
@@ -567,6 +568,7 @@ class trackdlo:
         lib.tdlo_tracker_set_precision(self.h, precision)
         self._stats_raw = None      # (the two tdlo_stats of the last tracking_step; turned into dicts when somebody looks: last_stats)
         self._st = (Stats * 2)()
+        self._fv = None
         self._st_ptr = C.cast(self._st, C.c_void_p)
 
     def __del__(self):
@@ -618,6 +620,23 @@ class trackdlo:
     def last_stats(self):
         """[pre-processing registration, main registration] of the last tracking_step as dicts (tdlo_stats), None before the first one."""
         return None if self._stats_raw is None else [s.as_dict() for s in self._stats_raw]
+
+    def frame_from_depth(self, depth, mask, fx, fy, cx, cy, leaf_size=0.008, d_vis=0.06):
+        """The ROS node's callback from the images to the nodes (trackdlo_node.cpp:195-369) in one call: cloud + voxel grid + visibility pre-pass (one
+        launch), tracking_step on the resident cloud.  depth / mask: rows x cols uint16 / uint8 arrays (the context's image buffers are read in place).
+        Returns (visible_nodes, visible_nodes_extended, n, n_raw); the nodes: get_tracking_result()."""
+        if depth.dtype != np.uint16 or mask.dtype != np.uint8 or not depth.flags.c_contiguous or not mask.flags.c_contiguous:
+            depth = np.ascontiguousarray(depth, dtype=np.uint16); mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        rows, cols = depth.shape
+        if self._fv is None:
+            self._fv = (np.zeros(self.M, dtype=np.int32), np.zeros(self.M, dtype=np.int32), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0))
+        v, e, nv, ne, n, nraw = self._fv
+        rc = self.ctx.lib.tdlo_tracker_frame_from_depth(self.h, depth.ctypes.data, mask.ctypes.data, rows, cols, fx, fy, cx, cy, leaf_size, d_vis,
+                                                        v.ctypes.data, C.byref(nv), e.ctypes.data, C.byref(ne), C.byref(n), C.byref(nraw), self._st_ptr)
+        self._stats_raw = self._st
+        if rc:
+            self.ctx._chk(rc)
+        return v[:nv.value].copy(), e[:ne.value].copy(), n.value, nraw.value
 
     def tracking_step(self, X_orig, visible_nodes, visible_nodes_extended, proj_matrix=None, img_rows=0, img_cols=0, *,
                       H_pre=None):

@@ -2589,6 +2589,7 @@ struct tdlo_tracker {
     double visibility_threshold;
     std::vector<double> trav1, trav2, trav2r;      // scratch of the priors' formation, kept across frames (their growth was a dozen reallocations per frame,
     std::vector<int> vis_ext;                      // on the host path between the two registrations)
+    std::vector<int> frame_vis, frame_vis_ext;     // tdlo_tracker_frame_from_depth: the frame's visible sets
     int last_iters[2] = {0, 0};         // iterations the two registrations of the previous frame took: how many are enqueued before the host looks (tdlo_ctx::iter_hint;
                                         // the larger of the last two frames' counts was tried instead: no difference)
 };
@@ -2824,6 +2825,33 @@ int tdlo_tracker_tracking_step(tdlo_tracker *t, const double *X, int N, const in
     if (c->cloud_pending >= 0) { const int frc = flush_pending_cloud(c); if (!rc) rc = frc; }
     if (stats) stats[1] = st_main;
     return rc;
+}
+
+// One frame of the ROS node's callback, images in, nodes out (trackdlo_node.cpp:195-369): depth image + mask -> cloud -> voxel grid and the visibility
+// pre-pass of the tracker's nodes (tdlo_depth_to_cloud_visibility: one launch), then tracking_step on the cloud resident in the tracker's slot.
+int tdlo_tracker_frame_from_depth(tdlo_tracker *t, const unsigned short *depth, const unsigned char *mask, int rows, int cols,
+                                  double fx, double fy, double cx, double cy, double leaf_size, double d_vis,
+                                  int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext,
+                                  int *n_out, int *n_raw_out, tdlo_stats *stats) {
+    if (!t) return TDLO_E_INVALID;
+    tdlo_ctx *c = t->ctx;
+    const int M = t->M;
+    if (t->geodesic_coord.size() != (size_t)M) return fail(c, TDLO_E_INVALID, "the tracker has no nodes / geodesic coordinates yet (tdlo_tracker_initialize_*)");
+    std::vector<int> &ve = t->frame_vis_ext, &v = t->frame_vis;
+    v.resize(M); ve.resize(M);
+    int nv = 0, ne = 0, n = 0;
+    int rc = tdlo_depth_to_cloud_visibility(c, t->slot, depth, mask, rows, cols, fx, fy, cx, cy, leaf_size, t->Y.data(), M, t->visibility_threshold, d_vis,
+                                            t->geodesic_coord.data(), nullptr, v.data(), &nv, ve.data(), &ne, &n, n_raw_out);
+    if (n_out) *n_out = n;
+    if (n_vis) *n_vis = nv;
+    if (n_vis_ext) *n_vis_ext = ne;
+    if (visible_nodes) std::copy(v.begin(), v.begin() + nv, visible_nodes);
+    if (visible_nodes_extended) std::copy(ve.begin(), ve.begin() + ne, visible_nodes_extended);
+    if (rc) return rc;
+    // (the reference's callback indexes visible_nodes[size() - 1] without a test, trackdlo_node.cpp:351-361: a frame without a cloud or without a visible node is an error here)
+    if (n == 0) return fail(c, TDLO_E_EMPTY, "the mask selects no pixel: no cloud for this frame");
+    if (ne == 0) return fail(c, TDLO_E_EMPTY, "no node within the visibility threshold of the cloud (the reference's callback is undefined here, trackdlo_node.cpp:351)");
+    return tdlo_tracker_tracking_step(t, nullptr, 0, v.data(), nv, ve.data(), ne, nullptr, stats);
 }
 
 }  // extern "C"
