@@ -31,7 +31,9 @@ The default run (--gpus 1, config c2) also carries, after the headline measureme
                     split driver), c5 (M = 300, fp64) -- each {value, ms_per_step, roofline, roofline_kernels, cpu_baseline}
   sustained         >= 3 s of back-to-back C2 calls (sustained_iters_per_s): the same quantity as `value` over a span a GPU-activity sampler sees
   frame_from_depth  the whole device-born frame (trackdlo_node.cpp:195-369): depth image -> cloud -> visibility pre-pass -> tracking_step, ms per frame at
-                    640 x 480 and 1280 x 720, images copied from pageable memory / read in place from the context's pinned buffers
+                    640 x 480 and 1280 x 720, images copied from pageable memory / read in place from the context's pinned buffers; as ONE call
+                    (tdlo_tracker_frame_from_depth: the pre-pass rides in the cloud's launch) and, beside it, as the three calls of round 5's first form
+                    (frame_from_depth_two_calls_ms: two launches + hand-overs in front of tracking_step)
   preproc           the pre-processing registration of tracking_step (include_lle: trackdlo.cpp:925-927) at production size (N = 5 000, M = 45):
                     its per-iteration kernels (the banded LLE M-step k_mstep_band among them) and tracking_step's ms per frame
 (--no-legs switches them off.)
