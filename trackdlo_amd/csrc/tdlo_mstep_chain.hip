@@ -207,7 +207,8 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     };
     // ---- 1. everything that comes from memory is requested up front: this thread's step slot (its link, its node), the E-step's sums
     struct SlotQ { dbl2 l[4]; double y[3], y0[3], yp[3], ay[3], aj, w; int node, li; bool obs; };
-    auto load_slot = [&](int sl) __attribute__((always_inline)) {
+    // (an M-step launched ahead of its priors requests everything BUT the priors before it waits for them: with_pri == false, filled in behind the wait)
+    auto load_slot = [&](int sl, bool with_pri) __attribute__((always_inline)) {
         SlotQ q;
         slot_info(sl < nSl ? sl : 0, q.node, q.li, q.obs);
         const int lc = q.li > 0 ? q.li : 1, mc = q.node;
@@ -217,43 +218,14 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         //  for every load in flight -- the sums included -- before the node's loads below are requested)
         q.y[0] = (double)ndg[mc].x; q.y[1] = (double)ndg[mc].y; q.y[2] = (double)ndg[mc].z; q.w = (double)ndg[mc].w;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { q.y0[d] = Y0g[d * M + mc]; q.yp[d] = Yg[d * M + mc]; q.ay[d] = pri ? aYg[d * M + mc] : 0.0; }
-        q.aj = pri ? aJg[mc] : 0.0;
+        for (int d = 0; d < 3; ++d) { q.y0[d] = Y0g[d * M + mc]; q.yp[d] = Yg[d * M + mc]; q.ay[d] = (pri && with_pri) ? aYg[d * M + mc] : 0.0; }
+        q.aj = (pri && with_pri) ? aJg[mc] : 0.0;
         return q;
     };
     // the E-step's sums: kAccRows replica rows of fixed-point accumulators; both iteration parities are fetched so that no load waits
     // for the iteration counter (M <= 512: at most 9 elements per thread).  Requested before the slot: its index arithmetic
     // runs while these are in flight.
-    if (TRK && f.spec_flag != nullptr) {      // launched ahead of its priors (FrameDev::spec_flag)
-        if (f.spec_prev != nullptr) {             // (nullptr: launched on a stream of its own beside that registration -- the host's word alone decides)
-            const auto pv = TDLO_AS_GLOBAL(IterState, f.spec_prev);
-            if (!(pv->done != 0 && pv->status == 0)) return;
-        }
-        if (t == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
-            int go = 0;
-            for (;;) {
-                const unsigned long long v = __hip_atomic_load(f.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned)(v >> 32) == f.spec_epoch && (v & 3ull) != 0ull) {
-                    go = (v & 3ull) == 1ull;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // the priors staged before the word was released (system scope, as xch_wait does)
-                    break;
-                }
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            red[31] = go ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        const bool go = red[31] != 0.0;
-        __syncthreads();
-        if (!go) {
-            // sent away with this registration's own first E-step already behind it (FrameDev::late_mstep): the sums nobody takes are cleared, so
-            // that the registration can start over the ordinary way (its first E-step adds to parity 0 again)
-            if (f.late_mstep != 0 && from_sums == 0) acc_clear_other<MB>(f, 1, t);
-            return;
-        }
-    }
+    const bool spec_wait = TRK && f.spec_flag != nullptr;      // launched ahead of its priors (FrameDev::spec_flag): the wait sits behind the requests below
     const int itn = stg->it;
     double sq[9];
     // (the first element without a branch -- index clamped, the accumulators exist in every mode: inside a conditional block the compiler sums the
@@ -263,7 +235,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     for (int u = 1; u < 9; ++u) sq[u] = 0.0;
     SlotQ q0;
     if (nS <= MB) {             // up to 63 nodes: the slot's loads follow the sums' in the same basic block (nothing is waited for in between)
-        q0 = load_slot(t);
+        q0 = load_slot(t, !spec_wait);
     } else {                    // longer chains: the further elements first (with the slot's forty registers live the compiler requests their
         // rows one by one, a round trip each).  Straight-line code per element count -- indices clamped instead of branched, this iteration's
         // parity only: inside `if (i < nS)` blocks every element's eight rows were waited for before the next element's were requested
@@ -299,7 +271,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
                     break;
             }
         }
-        q0 = load_slot(t);
+        q0 = load_slot(t, !spec_wait);
     }
     // given sums (from_sums == 1: the N-split's reduced sums; tracking_step's paired registration): the first five elements per thread -- chains
     // of up to 256 nodes -- requested with everything else
@@ -308,6 +280,41 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         const auto sums = TDLO_AS_GLOBAL(double, f.sums);
 #pragma unroll
         for (int u = 0; u < 5; ++u) { const int i = t + u * MB; ss[u] = sums[i < nS ? i : nS - 1]; }
+    }
+    if (spec_wait) {      // everything above is on its way (it does not depend on the priors): now the wait for the host's word
+        if (f.spec_prev != nullptr) {             // (nullptr: launched on a stream of its own beside that registration -- the host's word alone decides)
+            const auto pv = TDLO_AS_GLOBAL(IterState, f.spec_prev);
+            if (!(pv->done != 0 && pv->status == 0)) return;
+        }
+        if (t == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+            int go = 0;
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(f.spec_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned)(v >> 32) == f.spec_epoch && (v & 3ull) != 0ull) {
+                    go = (v & 3ull) == 1ull;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // the priors staged before the word was released (system scope, as xch_wait does)
+                    break;
+                }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            red[31] = go ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        const bool go = red[31] != 0.0;
+        __syncthreads();
+        if (!go) {
+            // sent away with this registration's own first E-step already behind it (FrameDev::late_mstep): the sums nobody takes are cleared, so
+            // that the registration can start over the ordinary way (its first E-step adds to parity 0 again)
+            if (f.late_mstep != 0 && from_sums == 0) acc_clear_other<MB>(f, 1, t);
+            return;
+        }
+    }
+    if (spec_wait && pri) {       // ... and this thread's slot takes its priors (staged by the host before it released the word)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q0.ay[d] = aYg[d * M + q0.node];
+        q0.aj = aJg[q0.node];
     }
     double kq[4] = {0.0, 0.0, 0.0, 0.0};              // late priors, element t + u MB of [alpha J | alpha (Y_ext - Y0)]: likewise
     if (late_src && pri) {
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     //         (the E-step delivers R = PX - P1 y, y = the nodes as it saw them)
     for (int sl = t, r = 0; sl < nSl; sl += MB, ++r) {
         dbl2 *o = (dbl2 *)(slots + (size_t)kSlot * sl);
-        const SlotQ q = r == 0 ? q0 : load_slot(sl);
+        const SlotQ q = r == 0 ? q0 : load_slot(sl, true);
         const double p1 = q.obs ? S[q.node] : 0.0;
         const bool idl = q.li == 0;     // identity link: a direction's first step, dummy steps
         o[0] = dbl2{idl ? 1.0 : q.l[0].x, idl ? 0.0 : q.l[0].y}; o[1] = dbl2{idl ? 0.0 : q.l[1].x, idl ? 1.0 : q.l[1].y};
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     V4<T> *nodes_w = (V4<T> *)f.nodes;
     double s_np = 0, s_dr = 0, s_pd = 0, s_cr = 0;
     for (int sl = t, r = 0; sl < nSl; sl += MB, ++r) {
-        const SlotQ q = r == 0 ? q0 : load_slot(sl);
+        const SlotQ q = r == 0 ? q0 : load_slot(sl, true);
         if (!q.obs) continue;
         const int m = q.node;
         const double *o = slots + (size_t)kSlot * sl;
