@@ -401,7 +401,7 @@ __device__ __forceinline__ void cloud_grid(const unsigned *sbox, int n, float in
 
 // phase A of the one-launch kernels, every workgroup: its tile of 4096 pixels -- compaction in pixel order, back-projection, the points to the tile's
 // region, count, bounding box -- and a ticket (returned to every thread: 0 .. T - 1 in the order the workgroups finished)
-__device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot, unsigned *sticket) {
+__device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot, unsigned *sticket, unsigned *sbx /* kFW x 6 words of LDS nobody uses yet */) {
     const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
     {
         const int p0 = b * kFPix + 4 * t;
@@ -442,22 +442,25 @@ __device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot
                 if (++j == a.cols) { j = 0; ++i; }
             }
         }
-        if (__ballot(c != 0) != 0ull) {                                       // (wave-uniform)
+        // the tile's box: every wave's six values by DPP (six trips each through the LDS crossbar before), the sixteen waves' through LDS, then SIX atomics
+        // per tile -- one per wave with a masked pixel had been ~6 000 read-modify-writes on six words per 640 x 480 image, serialised where
+        // the device's atomics meet: most of this phase's 23 us (scripts/gpu_cloud_stamps.py)
+        {
+            const bool any = __ballot(c != 0) != 0ull;                        // (wave-uniform)
+            unsigned r6[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
+            if (any) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const unsigned u = __shfl_xor(mn[d], o), v = __shfl_xor(mx[d], o);
-                    mn[d] = u < mn[d] ? u : mn[d]; mx[d] = v > mx[d] ? v : mx[d];
-                }
+                for (int d = 0; d < 3; ++d) { r6[d] = wave_minmax_u32<false>(mn[d]); r6[3 + d] = wave_minmax_u32<true>(mx[d]); }
             }
-            if (lane == 0) {
+            if (lane < 6) sbx[6 * (t >> 6) + lane] = lane == 0 ? r6[0] : (lane == 1 ? r6[1] : (lane == 2 ? r6[2] : (lane == 3 ? r6[3] : (lane == 4 ? r6[4] : r6[5]))));
+        }
+        __syncthreads();
+        if (t < 6 && total > 0) {
+            unsigned v = sbx[t];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    (void)__hip_atomic_fetch_min(a.state + d, mn[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    (void)__hip_atomic_fetch_max(a.state + 3 + d, mx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            for (int i = 1; i < kFW; ++i) { const unsigned u = sbx[6 * i + t]; v = t < 3 ? (u < v ? u : v) : (u > v ? u : v); }
+            if (t < 3) (void)__hip_atomic_fetch_min(a.state + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else (void)__hip_atomic_fetch_max(a.state + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (t == 0) __hip_atomic_store(a.tcnt + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's stores and atomics have been performed
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
 #endif
 
     // ================= phase A: this tile
-    if (cloud_phase_a(a, wtot, &sticket) != (unsigned)(a.T - 1)) return;
+    if (cloud_phase_a(a, wtot, &sticket, (unsigned *)fsm) != (unsigned)(a.T - 1)) return;
 
     // ================= phase B: the workgroup with the last ticket
     FSTAMP(0);
@@ -826,10 +829,16 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
-    const unsigned ticket = cloud_phase_a(a, wtot, &sticket);
+#ifdef TDLO_CLOUD_STAMPS
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();    // (100 MHz) this workgroup's start
+#endif
+    const unsigned ticket = cloud_phase_a(a, wtot, &sticket, (unsigned *)fsm);
     const int K = a.T < kTK ? a.T : kTK;
     if ((int)ticket < a.T - K) return;                                       // not in the team: done, having waited for nobody
     const int k = (int)ticket - (a.T - K);                                   // rank in the team
+#ifdef TDLO_CLOUD_STAMPS
+    if (t == 0 && k == 0) { unsigned long long *sw = (unsigned long long *)(a.state + 16); sw[20] = rt_begin; sw[21] = __builtin_amdgcn_s_memrealtime(); }      // start, ticket drawn
+#endif
 
     unsigned status = 1u;
     int n = 0, ncell = 0;
@@ -878,6 +887,9 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
     __syncthreads();
     if (!sflag) { status = 4u; finish(); return; }
     TSTAMP(0);
+#ifdef TDLO_CLOUD_STAMPS
+    if (t == 0 && k == 0) ((unsigned long long *)(a.state + 16))[22] = __builtin_amdgcn_s_memrealtime();      // every ticket drawn: the team begins
+#endif
     // ---- the tiles' offsets, the count, the box, the grid (every team workgroup for itself: the same numbers)
     {
         int carry = 0;
@@ -1134,6 +1146,9 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
             (void)__hip_atomic_fetch_min(a.visState + lane, (unsigned long long)__double_as_longlong(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef TDLO_CLOUD_STAMPS
+    if (t == 0 && k == 0) ((unsigned long long *)(a.state + 16))[23] = __builtin_amdgcn_s_memrealtime();
+#endif
     finish();
 #undef TSTAMP
 }
