@@ -75,14 +75,24 @@ __global__ __launch_bounds__(kCB) void k_cloud_bbox(const unsigned short *__rest
         }
         cnt += __shfl_xor(cnt, o);
     }
-    if ((threadIdx.x & 63) == 0 && cnt > 0) {
+    // (the four waves' boxes meet in LDS: seven atomics per tile, not per wave -- the same words are the target of every tile of the image, see cloud_phase_a)
+    __shared__ unsigned wb[4][6];
+    if ((threadIdx.x & 63) == 0) {
+        wc[threadIdx.x >> 6] = cnt;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { atomicMin(&bbox[d], mn[d]); atomicMax(&bbox[3 + d], mx[d]); }
-        atomicAdd(&bbox[6], (unsigned)cnt);
+        for (int d = 0; d < 3; ++d) { wb[threadIdx.x >> 6][d] = mn[d]; wb[threadIdx.x >> 6][3 + d] = mx[d]; }
     }
-    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) blkcnt[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];     // masked pixels of this 1024-pixel tile
+    const int tot = wc[0] + wc[1] + wc[2] + wc[3];
+    if (threadIdx.x < 6 && tot > 0) {
+        const int d = threadIdx.x;
+        unsigned v = wb[0][d];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) { const unsigned u = wb[i][d]; v = d < 3 ? (u < v ? u : v) : (u > v ? u : v); }
+        if (d < 3) atomicMin(&bbox[d], v); else atomicMax(&bbox[d], v);
+    }
+    if (threadIdx.x == 6 && tot > 0) atomicAdd(&bbox[6], (unsigned)tot);
+    if (threadIdx.x == 0) blkcnt[blockIdx.x] = tot;     // masked pixels of this 1024-pixel tile
 }
 
 struct Grid { int min_b[3]; int mul1, mul2; float inv; int nodown; };
