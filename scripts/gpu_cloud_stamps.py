@@ -21,6 +21,9 @@ for shape in ((480, 640), (720, 1280)):
             extra = np.array([full[8] - full[3], full[9] - full[8], full[10] - full[9], full[11] - full[10], full[16] - full[3], full[17] - full[16], full[8] - full[17]])
             xacc = xacc + extra if k > 8 else extra
     acc /= 32
+    if team:
+        pa = np.diff(full[12:19]) / 100
+        print("   phase A of the middle tile, last launch (us): mask arrives %.2f  depth arrives %.2f  scan %.2f  back-projection + stores %.2f  box + stores performed %.2f  ticket %.2f" % tuple(pa))
     if team:        # wall-clock split of team member 0 (100 MHz real-time counter): its own phase A, its wait for the other tiles' tickets, the team's work
         print(f"   member 0, last launch: own phase A {(full[21] - full[20]) / 100:.2f} us, wait for every ticket {(full[22] - full[21]) / 100:.2f} us, team phase {(full[23] - full[22]) / 100:.2f} us")
     if not team: print(f"   sort passes (4 bits each): " + " / ".join(f"{v / 32:.0f}" for v in xacc[:4]) + f" clk   pass 1: words + count {xacc[4] / 32:.0f}  scan {xacc[5] / 32:.0f}  scatter {xacc[6] / 32:.0f} clk")

@@ -413,10 +413,17 @@ __device__ __forceinline__ void cloud_grid(const unsigned *sbox, int n, float in
 // region, count, bounding box -- and a ticket (returned to every thread: 0 .. T - 1 in the order the workgroups finished)
 __device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot, unsigned *sticket, unsigned *sbx /* kFW x 6 words of LDS nobody uses yet */) {
     const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
+#ifdef TDLO_CLOUD_STAMPS      // wall-clock (100 MHz) split of phase A in the middle tile: words 12 .. 18 behind the state words (scripts/gpu_cloud_stamps.py)
+#define ASTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (t == 0 && b == a.T / 2) ((unsigned long long *)(a.state + 16))[12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+    ASTAMP(0);
     {
         const int p0 = b * kFPix + 4 * t;
         unsigned m4 = 0;
         if (p0 < a.P) m4 = *(const unsigned *)(a.mask + p0);
+        ASTAMP(1);
         if (p0 + 4 > a.P) {                                                   // (the last word of the image: bytes beyond it do not count)
             const int keep = a.P - p0;
             m4 = keep <= 0 ? 0u : (m4 & (0xffffffffu >> (8 * (4 - keep))));
@@ -425,8 +432,10 @@ __device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot
         const int c = k0 + k1 + k2 + k3;
         uint2 d4 = make_uint2(0u, 0u);
         if (c) d4 = *(const uint2 *)(a.depth + p0);
+        ASTAMP(2);
         int total;
         int rnk = block_excl_scan_i(c, wtot, t, &total);
+        ASTAMP(3);
         unsigned mn[3] = {~0u, ~0u, ~0u}, mx[3] = {0u, 0u, 0u};
         if (c) {
             int i = p0 / a.cols, j = p0 - i * a.cols;
@@ -452,6 +461,7 @@ __device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot
                 if (++j == a.cols) { j = 0; ++i; }
             }
         }
+        ASTAMP(4);
         // the tile's box: every wave's six values by DPP (six trips each through the LDS crossbar before), the sixteen waves' through LDS, then SIX atomics
         // per tile -- one per wave with a masked pixel had been ~6 000 read-modify-writes on six words per 640 x 480 image, serialised where
         // the device's atomics meet: most of this phase's 23 us (scripts/gpu_cloud_stamps.py)
@@ -475,9 +485,12 @@ __device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot
         if (t == 0) __hip_atomic_store(a.tcnt + b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this wave's stores and atomics have been performed
         __syncthreads();
+        ASTAMP(5);
         if (t == 0) *sticket = __hip_atomic_fetch_add(a.state + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        ASTAMP(6);
     }
+#undef ASTAMP
     return *sticket;
 }
 
