@@ -1077,6 +1077,17 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
     }
     if (ncell > a.cap) { status = 3u; finish(); return; }
     TSTAMP(4);
+    // ---- the slice's own coordinates are requested now (its words are in registers; they do not depend on where the crossing run ends): the round trip
+    //      runs beside the search below instead of behind it
+    float gx[4], gy[4], gz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = s0 + 64 * (w + 16 * r) + lane;
+        const unsigned wq = q < s1 ? (wreg[r] & rmask) : 0u;
+        gx[r] = __hip_atomic_load(a.cx + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gy[r] = __hip_atomic_load(a.cy + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gz[r] = __hip_atomic_load(a.cz + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- where the run that crosses the end of the slice ends (the next head at or behind s1)
     int e_k = s1;
     if (s1 > s0 && s1 < n) {
@@ -1097,14 +1108,9 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
     // ---- the coordinates of [s0, min(e_k, s0 + kTVcap)) in sorted order into LDS; beyond that (a run of thousands of points) they are read from memory
     const int vend = e_k < s0 + kTVcap ? e_k : s0 + kTVcap;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {                                            // the slice itself: its words are in registers
+    for (int r = 0; r < 4; ++r) {                                            // the slice itself
         const int q = s0 + 64 * (w + 16 * r) + lane;
-        if (q < s1) {
-            const unsigned wq = wreg[r] & rmask;
-            V[q - s0] = __hip_atomic_load(a.cx + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            V[kTVcap + q - s0] = __hip_atomic_load(a.cy + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            V[2 * kTVcap + q - s0] = __hip_atomic_load(a.cz + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (q < s1) { V[q - s0] = gx[r]; V[kTVcap + q - s0] = gy[r]; V[2 * kTVcap + q - s0] = gz[r]; }
     }
     for (int q = s1 + t; q < vend; q += kFT) {                               // the run that crosses its end
         const unsigned wq = __hip_atomic_load(win + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & rmask;
