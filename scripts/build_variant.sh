@@ -11,6 +11,7 @@ mkdir -p $B
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value -Wno-unused-result $*"
 cd $S
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -c tdlo_device.hip -o $B/tdlo_device.o &
+/opt/rocm/bin/hipcc $F -c tdlo_estep2.hip -o $B/tdlo_estep2.o &
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -c tdlo_mstep_big.hip -o $B/tdlo_mstep_big.o &
 /opt/rocm/bin/hipcc $F -c tdlo_mstep_chain.hip -o $B/tdlo_mstep_chain.o &
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form -c tdlo_mstep_band.hip -o $B/tdlo_mstep_band.o &

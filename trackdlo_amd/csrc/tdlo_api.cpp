@@ -253,6 +253,11 @@ struct tdlo_ctx {
     bool spec_force_timeout = getenv("TDLO_SPEC_FORCE_TIMEOUT") && atoi(getenv("TDLO_SPEC_FORCE_TIMEOUT")) != 0;   // test hook, see run_frames
     bool spec_on = !(getenv("TDLO_SPEC_MSTEP") && atoi(getenv("TDLO_SPEC_MSTEP")) == 0);        // 0: the paired registration's first M-step is launched when its priors exist (comparator)
     bool pair_sums_on = !(getenv("TDLO_PAIR_SUMS") && atoi(getenv("TDLO_PAIR_SUMS")) == 0);     // 0: the paired registration still runs its own first E-step (comparator)
+    // the E-step with two points per lane (k_estep2, tdlo_estep2.hip) for clouds and batches that fill the GPU.  TDLO_ESTEP2=0: never (comparator: k_estep
+    // everywhere), 1: wherever it is eligible, whatever the size (tests); unset: by size.  TDLO_ESTEP2_ROWS=8|16: rows of its membership tile.
+    int estep2_mode = getenv("TDLO_ESTEP2") ? atoi(getenv("TDLO_ESTEP2")) : -1;
+    int estep2_rows = (getenv("TDLO_ESTEP2_ROWS") && atoi(getenv("TDLO_ESTEP2_ROWS")) == 8) ? 8 : 16;
+    int estep2_blocks = getenv("TDLO_ESTEP2_BLOCKS") ? atoi(getenv("TDLO_ESTEP2_BLOCKS")) : 0;
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
     // split-mode scratch
@@ -584,6 +589,28 @@ int stage_priors(tdlo_ctx *c, double *aJ, double *aYd, const double *Y, int M, c
 }
 
 // Fills the host-side upload block [Yin | aJ | aYd | H] for one frame and its FrameDev.
+// k_estep2 (two points per lane) can serve this frame: fp32 mode, chains of 8 .. 64 nodes
+static bool estep2_eligible(const tdlo_ctx *c, const FrameDev &f) {
+    return c->estep2_mode != 0 && f.precision == TDLO_PREC_F32 && f.M >= 8 && f.M <= kChunk;
+}
+// ... and does: the launch geometry of a frame whose E-step is k_estep2.  `share`: the frame is one of a batch (the batch fills the GPU, every
+// wave takes two 128-point batches so that a workgroup's prologue and epilogue are paid half as often -- as k_estep's batches do).
+static void estep2_geometry(const tdlo_ctx *c, FrameDev &f, bool share) {
+    if (!f.estep2) {
+        // the fixed point's grain is one wave x one 128-point batch here: a node's P1 share can reach 128 (prepare_frame sized the exponents for
+        // 64), and Q is converted per PAIR of points -- one binary digit less keeps every conversion exact (|v 2^sh| < 2^51); the totals' bound
+        // (2^62) only gains from it
+        for (int k = 0; k < 3; ++k) { f.acc_sh[k] -= 1; f.acc_lim[k] *= 2.0; }
+    }
+    f.estep2 = c->estep2_rows;
+    f.wide_tile = 0; f.eb = 256;
+    const int nb128 = (f.N0 + 127) / 128;
+    int nblk = (nb128 + 3) / 4;
+    if (share && nblk >= 32) nblk = (nblk + 1) / 2;
+    const int cap = c->estep2_blocks > 0 ? c->estep2_blocks : (c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : 1024);
+    f.nblkE = std::max(1, std::min(nblk, std::min(cap, kMaxEstepBlocks)));
+}
+
 int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, const tdlo_params *p,
                   const double *priors, int K, const int *vis, int n_vis, const double *H_override,
                   double *stage, FrameDev &f, bool second_block = false, bool hb_may_stay = true) {      // hb_may_stay: f.Hb may point at Slot::hb_next (a batch moves every frame's Hb into its transfer buffer instead)
@@ -751,6 +778,8 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         const int lshare = std::min(51, 67 - std::max(ln, 6)), lpoint = std::min(51, 61 - ln);
         f.acc_lim[0] = std::ldexp(1.0, lshare - f.acc_sh[0]); f.acc_lim[1] = std::ldexp(1.0, lshare - f.acc_sh[1]); f.acc_lim[2] = std::ldexp(1.0, lpoint - f.acc_sh[2]);
     }
+    // one frame whose cloud fills the GPU alone (where k_estep leaves the 64-row tile: 4096 waves of 64 points): two points per lane
+    if (estep2_eligible(c, f) && (c->estep2_mode == 1 || nbatch >= 4096)) estep2_geometry(c, f, false);
     f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
     f.sync = s.sync;
     f.st = (IterState *)(blk + nc.st);
@@ -905,6 +934,15 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             if (p->include_lle) { f.Hb = bu + nc.Hb; f.H = bu + nc.H; }
             f.Yout = br; f.st = (IterState *)(br + (nc.st - nc.Yout));
         }
+    }
+    if (merged) {
+        // a batch whose frames together fill the GPU takes the E-step with two points per lane (one choice for the whole launch)
+        long long waves = 0;
+        bool elig = true;
+        for (int i = 0; i < F; ++i) { waves += (c->fh[i].N0 + 63) / 64; elig = elig && estep2_eligible(c, c->fh[i]); }
+        const bool two = elig && (c->estep2_mode == 1 || waves >= 4096);
+        for (int i = 0; i < F; ++i) if (two) estep2_geometry(c, c->fh[i], true);      // (a frame prepare_frame had given to k_estep2 on its own size keeps it only if the whole batch does:
+        if (!two) for (int i = 0; i < F; ++i) if (c->fh[i].estep2) return fail(c, TDLO_E_INVALID, "internal: a batch's frames disagree about the E-step kernel");   //  same M, precision and mode -- they cannot)
     }
     if (!p->include_lle) break;
     bool all_band = true;

@@ -801,18 +801,6 @@ __global__ void k_xch_init(const FrameDev *__restrict__ frames) {
     }
 }
 
-// four consecutive nodes {x, y, z, coord} by ONE scalar load (s_load_dwordx16; two of them in fp64)
-template <typename T> struct Node4 { T v[16]; };
-template <typename T> __device__ __forceinline__ Node4<T> load_node4(const void *nodes, int m0) {
-    typedef T vec16 __attribute__((ext_vector_type(16)));
-    typedef vec16 __attribute__((aligned(16))) vec16a;
-    const vec16 r = *(const __attribute__((address_space(4))) vec16a *)((uintptr_t)nodes + (size_t)m0 * 4 * sizeof(T));
-    Node4<T> o;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o.v[i] = r[i];
-    return o;
-}
-
 // ------------------------------------------------------------------------------------------------
 // per-node shortest distance to the cloud, trackdlo.cpp:278-296 (only consumed by :358-372)
 // ------------------------------------------------------------------------------------------------
@@ -925,56 +913,6 @@ __global__ __launch_bounds__(kBlock) void k_dmin(const FrameDev *__restrict__ fr
 // ------------------------------------------------------------------------------------------------
 // E-step, trackdlo.cpp:278-389
 // ------------------------------------------------------------------------------------------------
-// Geodesic membership of node m for a point whose nearest pair is (lo, hi):
-//   m <= lo : (coord_lo - coord_m + |x - y_lo|)^2      m >= hi : (coord_m - coord_hi + |x - y_hi|)^2
-//   lo < m < hi (only when hi - lo == 2, the reference's end-node quirk): 0            (:332-350)
-template <typename T>
-__device__ __forceinline__ T geo_arg(int m, int lo, int hi, T cm, T c_lo, T d_lo, T c_hi, T d_hi) {
-    const T t_lo = (c_lo - cm) + d_lo;
-    const T t_hi = (cm - c_hi) + d_hi;
-    T t = (m <= lo) ? t_lo : T(0);
-    t = (m >= hi) ? t_hi : t;
-    return t * t;
-}
-
-// The same value when hi == lo + 1 (every point but the rare end-node case of :313-321, where the node between lo and
-// hi keeps the zero of :305): coord is non-decreasing, so c_lo - cm = |cm - c_lo| for m <= lo and cm - c_hi = |cm - c_hi|
-// for m > lo -- one compare, two selects, |a - b| + d instead of both branches and two compare/select pairs.
-template <typename T>
-__device__ __forceinline__ T geo_arg_adj(int m, int lo, T cm, T c_lo, T d_lo, T c_hi, T d_hi) {
-    const bool s = m <= lo;
-    const T c = s ? c_lo : c_hi, d = s ? d_lo : d_hi;
-    const T t = tabs(cm - c) + d;
-    return t * t;
-}
-
-// wave-wide sum of a 64-bit integer without the LDS crossbar: v_permlane32_swap / v_permlane16_swap put the two halves (row pairs) of the
-// value side by side, four DPP rotations finish inside the rows; every lane returns the total (integer addition: any order)
-template <int CTRL> __device__ __forceinline__ long long dpp_i64(long long v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xf, 0xf, false);
-    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-    const unsigned lo = (unsigned)v, hi = (unsigned)((unsigned long long)v >> 32);
-    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    long long z = (long long)(((unsigned long long)h32[0] << 32) | l32[0]) + (long long)(((unsigned long long)h32[1] << 32) | l32[1]);       // lanes l and l ^ 32
-    const unsigned zl = (unsigned)z, zh = (unsigned)((unsigned long long)z >> 32);
-    const auto l16 = __builtin_amdgcn_permlane16_swap(zl, zl, false, false), h16 = __builtin_amdgcn_permlane16_swap(zh, zh, false, false);
-    z = (long long)(((unsigned long long)h16[0] << 32) | l16[0]) + (long long)(((unsigned long long)h16[1] << 32) | l16[1]);                 // rows r and r ^ 1
-    z += dpp_i64<0x128>(z);      // row_ror:8
-    z += dpp_i64<0x124>(z);      // row_ror:4
-    z += dpp_i64<0x122>(z);      // row_ror:2
-    z += dpp_i64<0x121>(z);      // row_ror:1
-    return z;
-}
-
-// the value of the lane 8 away in the same row of 16 (DPP row_ror:8)
-__device__ __forceinline__ float row_ror8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true)); }
-__device__ __forceinline__ double row_ror8(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x128, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x128, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
 // EB = threads per workgroup (256 or 512); SINGLE: the frame descriptor arrives by value in the
 // kernarg segment (no dependent loads before the first useful one).
 template <typename T, int NCH, bool VIS, int EB, bool SINGLE>
@@ -2124,6 +2062,9 @@ template <typename T, int EB> static hipError_t launch_estep_TE(const FrameDev *
 }
 
 template <typename T> static hipError_t launch_estep_T(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+    if (sizeof(T) == 4 && fh[0].estep2) {            // two points per lane (tdlo_estep2.hip): clouds and batches that fill the GPU
+        return launch_estep2(fd, fh, F, s, g_estep_ev[0], g_estep_ev[1]);
+    }
     if (fh[0].eb == 512) return launch_estep_TE<T, 512>(fd, fh, F, s);
     return launch_estep_TE<T, 256>(fd, fh, F, s);
 }

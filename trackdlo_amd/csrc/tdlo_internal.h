@@ -158,6 +158,9 @@ struct FrameDev {
     // them: 1 = the chain smoother reads late_aJ / late_aYd itself although it starts from the accumulators (from_sums == 0) and keeps them in
     // aJ / aYd for the iterations that follow; the E-step leaves them alone
     int late_mstep;
+    // 0: k_estep (one point per lane, tdlo_device.hip); 8 / 16: k_estep2 (two points per lane, tdlo_estep2.hip) with that many tile rows -- clouds
+    // and batches that fill the GPU, fp32 mode, chains of 8 .. 64 nodes (prepare_frame / run_frames; the same value in every frame of a launch)
+    int estep2;
 };
 
 // Inbox layout in 64-bit words (R ranks, node capacity Mc); rank r writes the [r] entries of every peer's inbox:
@@ -219,6 +222,9 @@ hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_h
 hipError_t launch_iteration_timed(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
                                   hipEvent_t m_start, hipEvent_t m_stop);
 const char *mstep_kernel_name(const FrameDev *frames_host, int F);
+// tdlo_estep2.hip: the E-step with two points per lane (FrameDev::estep2)
+hipError_t launch_estep2(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+size_t estep2_lds_bytes(int M, int tile_rows);
 hipError_t launch_estep_only(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int kind, hipStream_t s);
 hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames_host, hipStream_t s);
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
