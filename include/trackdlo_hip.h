@@ -464,7 +464,12 @@ int tdlo_debug_lle_band_device(tdlo_ctx *ctx, const double *Y, int M, double *Hb
  * on the device by the M-step that finished the previous frame (TDLO_LLE_NEXT=0); 4: main registrations of frames with hidden nodes whose first
  * iteration had run on the second stream beside the pre-processing registration (TDLO_AHEAD=0); 5: calls repeated on the three-kernel route because
  * the fused prologue's grid barrier was abandoned; 6 / 7: tdlo_depth_to_cloud calls served by the one-launch kernel / passed on by it to the
- * multi-launch form; 8: frames whose visibility pre-pass rode in the depth -> cloud launch (tdlo_depth_to_cloud_visibility).
+ * multi-launch form; 8: frames whose visibility pre-pass rode in the depth -> cloud launch (tdlo_depth_to_cloud_visibility); 9: registrations whose
+ * E-step was k_estep2 -- two points per lane, csrc/tdlo_estep2.hip: fp32 mode, chains of 8 .. 64 nodes, a cloud or a batch of at least 4096 x 64
+ * points, i.e. one that fills the GPU (TDLO_ESTEP2=0: k_estep everywhere, the comparator; =1: wherever eligible, whatever the size).  The two
+ * E-step kernels differ in the grain of their fp32 tile sums (one wave x 64 points / x 128 points): each is repeatable bit for bit and held to
+ * the reference at the mode's tolerance, but a frame registered alone (k_estep) and the same frame inside a GPU-filling batch (k_estep2) agree
+ * to about 1e-8 m, not to the bit.
  * -1 for a null context or an unknown counter. */
 long long tdlo_debug_route_count(tdlo_ctx *ctx, int which);
 /* Phase stamps (s_memtime) of the last depth -> cloud launch's finishing workgroup; only a -DTDLO_CLOUD_STAMPS build writes them. */

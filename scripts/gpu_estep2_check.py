@@ -59,3 +59,21 @@ if "time" in what:
             e, m, it, name = ctx.profile_iteration(200)
             print(f"[estep2={mode}] N={N} F={F}: loop {lm:.3f} ms ({lm/50*1e3:.2f} us/iter)  in-situ estep {e:.2f} us mstep {m:.2f} us iter {it:.2f} us  b2b estep {ctx.profile_kernel(0, 200):.2f} us", flush=True)
             ctx.close()
+
+if "time1" in what:      # the environment's own setting (TDLO_ESTEP2 / _ROWS / _BLOCKS), C4 and one C3 batch: scripts/gpu_estep2_sweep.sh
+    pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], 50, 0.0, False)
+    for N, F in ((2000000, 1), (50000, 32)):
+        ctx = B.Context(max_frames=F, max_points=N, max_nodes=50)
+        Ys = []
+        for fr in range(F):
+            X, Y0, _ = synth.scene(N, 50, config=2 if N == 50000 else 4, frame=fr)
+            ctx.set_cloud(fr, X); Ys.append(Y0)
+        if F == 1:
+            g = ctx.cpd_lle_resident(0, Ys[0], 0.0, pr); g = ctx.cpd_lle_resident(0, Ys[0], 0.0, pr)
+            lm = g['loop_ms']
+        else:
+            g = ctx.cpd_lle_batch(Ys, [0.0] * F, pr); g = ctx.cpd_lle_batch(Ys, [0.0] * F, pr)
+            lm = g['stats'][0]['loop_ms']
+        e, m, it, name = ctx.profile_iteration(200)
+        print(f"[{os.environ.get('TDLO_ESTEP2')} rows {os.environ.get('TDLO_ESTEP2_ROWS')} blocks {os.environ.get('TDLO_ESTEP2_BLOCKS')}] N={N} F={F}: loop {lm/50*1e3:.2f} us/iter  in-situ estep {e:.2f} us  b2b estep {ctx.profile_kernel(0, 200):.2f} us", flush=True)
+        ctx.close()

@@ -452,6 +452,10 @@ class Context:
         """Frames whose visibility pre-pass rode in the depth -> cloud launch (tdlo_debug_route_count 8)."""
         return int(self.lib.tdlo_debug_route_count(self.h, 8))
 
+    def estep2_frames(self):
+        """Registrations whose E-step was k_estep2 -- two points per lane: clouds and batches that fill the GPU (tdlo_debug_route_count 9)."""
+        return int(self.lib.tdlo_debug_route_count(self.h, 9))
+
     def band_retries(self):
         """Calls of this context that were repeated on the dense pivoted kernels after the banded LLE solve gave up (tdlo_debug_band_retries)."""
         return int(self.lib.tdlo_debug_band_retries(self.h))

@@ -256,8 +256,9 @@ struct tdlo_ctx {
     // the E-step with two points per lane (k_estep2, tdlo_estep2.hip) for clouds and batches that fill the GPU.  TDLO_ESTEP2=0: never (comparator: k_estep
     // everywhere), 1: wherever it is eligible, whatever the size (tests); unset: by size.  TDLO_ESTEP2_ROWS=8|16: rows of its membership tile.
     int estep2_mode = getenv("TDLO_ESTEP2") ? atoi(getenv("TDLO_ESTEP2")) : -1;
-    int estep2_rows = (getenv("TDLO_ESTEP2_ROWS") && atoi(getenv("TDLO_ESTEP2_ROWS")) == 8) ? 8 : 16;
+    int estep2_rows = (getenv("TDLO_ESTEP2_ROWS") && atoi(getenv("TDLO_ESTEP2_ROWS")) == 16) ? 16 : 8;
     int estep2_blocks = getenv("TDLO_ESTEP2_BLOCKS") ? atoi(getenv("TDLO_ESTEP2_BLOCKS")) : 0;
+    long long estep2_frames = 0;          // registrations whose E-step was k_estep2 (tdlo_debug_route_count 9)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
     // split-mode scratch
@@ -595,8 +596,9 @@ static bool estep2_eligible(const tdlo_ctx *c, const FrameDev &f) {
 }
 // ... and does: the launch geometry of a frame whose E-step is k_estep2.  `share`: the frame is one of a batch (the batch fills the GPU, every
 // wave takes two 128-point batches so that a workgroup's prologue and epilogue are paid half as often -- as k_estep's batches do).
-static void estep2_geometry(const tdlo_ctx *c, FrameDev &f, bool share) {
+static void estep2_geometry(tdlo_ctx *c, FrameDev &f, bool share) {
     if (!f.estep2) {
+        ++c->estep2_frames;
         // the fixed point's grain is one wave x one 128-point batch here: a node's P1 share can reach 128 (prepare_frame sized the exponents for
         // 64), and Q is converted per PAIR of points -- one binary digit less keeps every conversion exact (|v 2^sh| < 2^51); the totals' bound
         // (2^62) only gains from it
@@ -2488,7 +2490,8 @@ int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
 long long tdlo_debug_route_count(tdlo_ctx *c, int which) {
-    if (!c || which < 0 || which > 8) return -1;
+    if (!c || which < 0 || which > 9) return -1;
+    if (which == 9) return c->estep2_frames;
     if (which == 8) return c->cloud_vis_rides;
     return which < 6 ? c->route_count[which] : c->cloud_route[which - 6];
 }

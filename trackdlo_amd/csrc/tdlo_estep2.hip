@@ -66,13 +66,19 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
     const float cn = (float)stg->c_norm;
     const int bstride = f.nblkE * NWE;
     int batch = blockIdx.x * NWE + wave;
-    // the first batch's points (N <= N0: in bounds), the nodes for the LDS copy, and this lane's own node (lane = node in the range searches)
-    f2 X = {0.f, 0.f}, Y = {0.f, 0.f}, Z = {0.f, 0.f};
-    {
-        const int n0 = batch * kE2Points + lane, n1 = n0 + 64;
-        if (n0 < f.N0) { X.x = xs[n0]; Y.x = xs[ld + n0]; Z.x = xs[2 * ld + n0]; }
-        if (n1 < f.N0) { X.y = xs[n1]; Y.y = xs[ld + n1]; Z.y = xs[2 * ld + n1]; }
-    }
+    // the first batch's points, the nodes for the LDS copy, and this lane's own node (lane = node in the range searches).  A batch's loads are
+    // six dword loads off three uniform bases with ONE 32-bit byte offset per lane, clamped to the cloud's last point (lanes behind it are
+    // given a copy of lane 0's point below): no 64-bit address arithmetic and no divergent branch per batch.
+    typedef const __attribute__((address_space(1))) char gbytes;
+    gbytes *bx = (gbytes *)xs, *by = (gbytes *)(xs + ld), *bz = (gbytes *)(xs + 2 * ld);
+    auto load2 = [&](int b, int last, f2 &X_, f2 &Y_, f2 &Z_) {
+        const int n0 = b * kE2Points + lane, n1 = n0 + 64;
+        const unsigned o0 = (unsigned)(n0 < last ? n0 : last) * 4u, o1 = (unsigned)(n1 < last ? n1 : last) * 4u;
+        X_.x = *(const __attribute__((address_space(1))) float *)(bx + o0); Y_.x = *(const __attribute__((address_space(1))) float *)(by + o0); Z_.x = *(const __attribute__((address_space(1))) float *)(bz + o0);
+        X_.y = *(const __attribute__((address_space(1))) float *)(bx + o1); Y_.y = *(const __attribute__((address_space(1))) float *)(by + o1); Z_.y = *(const __attribute__((address_space(1))) float *)(bz + o1);
+    };
+    f2 X, Y, Z;
+    load2(batch, f.N0 - 1, X, Y, Z);                 // (N <= N0: in bounds, whatever the prune kept)
     const auto qg = TDLO_AS_GLOBAL(V4<float>, f.nodes);
     for (int m = tid; m < M; m += EB) { V4<float> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
     V4<float> qn; qn.x = 1e18f; qn.y = 1e18f; qn.z = 1e18f; qn.w = 3e38f;      // lanes behind the chain's end: a node nothing is near to, whose coordinate no window holds
@@ -122,12 +128,8 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
     const int nbatch = (N + kE2Points - 1) >> 7;
     for (; batch < nbatch; batch += bstride) {
         // ---- the next batch's points are requested now and waited for at the end of this one
-        f2 Xn = {0.f, 0.f}, Yn = {0.f, 0.f}, Zn = {0.f, 0.f};
-        {
-            const int n0 = (batch + bstride) * kE2Points + lane, n1 = n0 + 64;
-            if (n0 < N) { Xn.x = xs[n0]; Yn.x = xs[ld + n0]; Zn.x = xs[2 * ld + n0]; }
-            if (n1 < N) { Xn.y = xs[n1]; Yn.y = xs[ld + n1]; Zn.y = xs[2 * ld + n1]; }
-        }
+        f2 Xn, Yn, Zn;
+        load2(batch + bstride, N - 1, Xn, Yn, Zn);
         const int base = batch * kE2Points;
         const bool full = base + kE2Points <= N;                       // wave-uniform
         const float cx = bcast_first(X.x), cy = bcast_first(Y.x), cz = bcast_first(Z.x);       // lane 0's first point: always one of the cloud
@@ -141,9 +143,9 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
         E2PHASE(1);
         // ---- nearest node: argmin of d2, first index (:298-310), over the exact candidate range of k_estep -- ONE range for the 128 points
         const f2 ex = X - sp(cx), ey = Y - sp(cy), ez = Z - sp(cz);       // (kept: the residual coordinates of the column sums)
+        const f2 r2v = fma2(ez, ez, fma2(ey, ey, ex * ex));                // |x - o|^2: the candidate range's radius, and the points' own term of Q
         int plo = 0, phi = M - 1;
         {
-            const f2 r2v = fma2(ez, ez, fma2(ey, ey, ex * ex));
             const float r2 = fmaxf(r2v.x, r2v.y);
             const float ddx = qn.x - cx, ddy = qn.y - cy, ddz = qn.z - cz;
             const float Dm = ddx * ddx + ddy * ddy + ddz * ddz;               // lane = node
@@ -224,15 +226,23 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
             const float bmx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)z, 31));
             max_hi = __builtin_amdgcn_readlane((int)z, 47);
             adj = __builtin_amdgcn_readlane((int)z, 63) == 0;
-            const float amin = nodesL[min_lo].w, amax = nodesL[max_hi].w;
+            // (lane = node holds every node's coordinate: a v_readlane is the broadcast -- no scalar load, no LDS round trip in the batch's dependency chain)
+            const float amin = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(qn.w), min_lo));
+            const float amax = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(qn.w), max_hi));
             const float Rwin = Num<float>::sqrt_fast(bmx + R2win);
             const unsigned long long inw = __ballot(qn.w > amin - Rwin && qn.w < amax + Rwin);
             if (inw) { wlo = (int)__builtin_ctzll(inw); whi = 63 - (int)__builtin_clzll(inw); }
             wlo = __builtin_amdgcn_readfirstlane(wlo); whi = __builtin_amdgcn_readfirstlane(whi);
         }
         E2PHASE(3);
-        // ---- unnormalised memberships, their sum over the nodes, Q (:354-383); the first TR nodes of the window go to the tile
-        f2 sum = {0.f, 0.f}, qs = {0.f, 0.f};
+        // ---- unnormalised memberships and their sum over the nodes (:354-383); the first TR nodes of the window go to the tile.
+        // Q = sum_n sum_m P_mn |x_n - y_m|^2 is NOT accumulated pair by pair (k_estep does: a squared distance and a multiply-add per pair): with the
+        // wave's origin o, |x - y|^2 = |x - o|^2 + 2 (o - y).(x - o) + |o - y|^2, so the batch's share is
+        //     sum_n Pt1_n |x_n - o|^2  +  sum_m sum_k d_mk (s_mk + R_mk),     d = o - y_m,  s = sum_n P_mn (x_n - o),  R = s + d P1_m
+        // -- the first term per point from what is at hand anyway, the second in the column sums' fixed-point tail (fp64) from the very sums it
+        // converts.  The three parts are of the size of Q itself (a batch's points and its window's nodes lie within centimetres of o, like sigma):
+        // no cancellation to speak of.
+        f2 sum = {0.f, 0.f};
         // t of a node for both points; MODE 0: every point has the node at or below its lower pair node (m <= min lo), 1: at or above its
         // upper one (m >= max hi), 2: per point (adjacent pairs), 3: per point, a pair with the end-node gap in the wave (:332-350)
         auto geo_t = [&](float qw, int m, auto MODE) -> f2 {
@@ -254,37 +264,30 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
             }
             return t;
         };
-        auto member = [&](float qx, float qy, float qz, float qw, int m, auto MODE, auto STORE) {
-            const f2 t = geo_t(qw, m, MODE);
+        // (adjacent pairs: the nodes up to the wave's smallest lo and from its largest hi on need no per-point decision -- wave-uniform branches)
+        auto geo_any = [&](float qw, int m) -> f2 {
+            if (!adj) return geo_t(qw, m, std::integral_constant<int, 3>());
+            if (m <= min_lo) return geo_t(qw, m, std::integral_constant<int, 0>());
+            if (m >= max_hi) return geo_t(qw, m, std::integral_constant<int, 1>());
+            return geo_t(qw, m, std::integral_constant<int, 2>());
+        };
+        auto member = [&](float qw, int m, auto STORE) {
+            const f2 t = geo_any(qw, m);
             f2 e = (t * t) * sp(k2);
             if (VIS) e += sp(lvL[m]);
             f2 p; p.x = Num<float>::exp2(e.x); p.y = Num<float>::exp2(e.y);
-            const f2 dx = X - sp(qx), dy = Y - sp(qy), dz = Z - sp(qz);
-            const f2 d2 = fma2(dz, dz, fma2(dy, dy, dx * dx));
             sum += p;
-            qs = fma2(p, d2, qs);
             if (decltype(STORE)::value) { float *row = pb + (m - wlo) * kP2Stride + lane; row[0] = p.x; row[64] = p.y; }
         };
-        // [from, to] in groups of 4 nodes by one scalar load each; evaluations beyond `to` skipped wave-uniformly
-        auto span = [&](int from, int to, auto MODE, auto STORE) {
-            int m0 = from;
-            for (; m0 + 3 <= to; m0 += 4) {
-                const Node4<float> q4 = load_node4<float>(f.nodes, m0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) member(q4.v[4 * k], q4.v[4 * k + 1], q4.v[4 * k + 2], q4.v[4 * k + 3], m0 + k, MODE, STORE);
-            }
-            if (m0 <= to) {
-                const Node4<float> q4 = load_node4<float>(f.nodes, m0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (m0 + k <= to) member(q4.v[4 * k], q4.v[4 * k + 1], q4.v[4 * k + 2], q4.v[4 * k + 3], m0 + k, MODE, STORE);
-            }
+        // [from, to]: a node's coordinate is broadcast from its lane (qn.w) -- one v_readlane per node and nothing to wait for
+        auto span = [&](int from, int to, auto STORE) {
+            for (int m = from; m <= to; ++m)
+                member(__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(qn.w), m)), m, STORE);
         };
         {
             const int wst = (wlo + TR - 1) < whi ? (wlo + TR - 1) : whi;              // last node whose membership is stored
-            typedef std::integral_constant<int, 2> PerPoint;
-            typedef std::integral_constant<int, 3> Gap;
-            if (adj) { span(wlo, wst, PerPoint(), std::true_type()); span(wst + 1, whi, PerPoint(), std::false_type()); }
-            else { span(wlo, wst, Gap(), std::true_type()); span(wst + 1, whi, Gap(), std::false_type()); }
+            span(wlo, wst, std::true_type());
+            span(wst + 1, whi, std::false_type());
         }
         E2PHASE(4);
         f2 inv;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
             const f2 den = sum + sp(cn);
             inv.x = Num<float>::rcp_fast(den.x); inv.y = Num<float>::rcp_fast(den.y);
             if (!full) { inv.x = vA ? inv.x : 0.f; inv.y = vB ? inv.y : 0.f; }
-            const f2 qvv = inv * qs;
+            const f2 qvv = (inv * sum) * r2v;                                   // Pt1_n |x_n - o|^2
             const double qv = (double)(qvv.x + qvv.y);
             acc_ok &= __builtin_fabs(qv) < limQ; accQ += acc_fix(qv, scQ);
             // the normalised points relative to the wave's origin (lane 0's first point), four arrays of 128: column = point
@@ -308,10 +311,9 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
                 const int Wn = (Wtot - c0) < TR ? (Wtot - c0) : TR;
                 const int wlo_c = wlo + c0;
                 if (c0 > 0) {
-                    const auto nodes = TDLO_AS_CONST(V4<float>, f.nodes);
                     for (int m = wlo_c; m < wlo_c + Wn; ++m) {
-                        const float qw = nodes[m].w;
-                        const f2 t = adj ? geo_t(qw, m, std::integral_constant<int, 2>()) : geo_t(qw, m, std::integral_constant<int, 3>());
+                        const float qw = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(qn.w), m));
+                        const f2 t = geo_any(qw, m);
                         f2 e = (t * t) * sp(k2);
                         if (VIS) e += sp(lvL[m]);
                         float *row = pb + (m - wlo_c) * kP2Stride + lane;
@@ -365,6 +367,10 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
                     const double val = ::fma(d, w0, a);
                     acc_ok &= !mine || __builtin_fabs(val) < (gp ? limP : limR);
                     if (mine) __hip_atomic_fetch_add(acn + k, acc_fix(val, gp ? scP : scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    {   // the nodes' part of Q: d (s + R) per (node, coordinate) -- the P1 lanes have d = 1, a = 0 and add nothing of it
+                        const double dq = (mine && !gp) ? d * (a + val) : 0.0;
+                        acc_ok &= __builtin_fabs(dq) < limQ; accQ += acc_fix(dq, scQ);
+                    }
                     wave_lds_sync();
                 }
             }
