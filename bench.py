@@ -38,6 +38,18 @@ The default run (--gpus 1, config c2) also carries, after the headline measureme
                     its per-iteration kernels (the banded LLE M-step k_mstep_band among them) and tracking_step's ms per frame
 (--no-legs switches them off.)
 
+--gpus N > 1 (the driver's scaling run), config c2: behind the frame-sharded headline the SAME process group runs, outside the headline's timed region,
+  configs.c3        BASELINE configs[2] as written: 32 frames per GPU in one tdlo_cpd_lle_batch call per rank (weak; no data-path collective)
+  configs.c4        BASELINE configs[3]: ONE frame of 2 000 000 points split over the N ranks (strong) with the ONE-SHOT EXCHANGE -- value, us_per_iteration,
+                    form, ranks_agree (every rank's nodes and sigma2 hash to the same bits), y_sha1, xch_can_access (peer-access matrix), rccl_size per rank
+  configs.c4_rccl   the same split with the library's RCCL all-reduces (TDLO_BENCH_FORCE_RCCL=1): the collective path of north_star, measured beside it
+so that a scaling run exercises the N-split's exchange over xGMI and not only N independent frames.
+
+Clocks: a background thread (outside the timed path: it only reads sysfs) samples the GPU's shader clock, memory clock, socket power and busy percentage
+from /sys/class/drm/card*/device (hwmon freq1_input / power1_input / power1_cap, pp_dpm_mclk, gpu_busy_percent) during every timed region; the line carries
+sclk_mhz_mean / sclk_mhz_min / power_w_mean / power_cap_w for the headline and under configs.* for the legs -- a slow box and a regression are then
+told apart by what the line itself says.
+
 Extra objects on the JSON line:
   roofline          the per-iteration kernel with the LARGER share of GPU time in this run; roofline_kernels holds both
                     (E-step: algorithmic bytes 3 * s * N per launch against 8 TB/s HBM; `algorithmic_valu_ratio` = SURVEY.md 8(d)'s flop
@@ -98,6 +110,97 @@ LANE_ISSUE_PEAK = FP32_VECTOR_TFLOPS * 1e12 / 2.0      # lane-instructions per s
 # wave): v_fma_f32 53 T lane-instructions/s -- the clock falls from 2.4 to ~1.87 GHz under that load --, compares / selects / conversions /
 # DPP / min / max 35-37 T, v_exp / v_rcp / v_sqrt 19 T, and a scalar instruction between two vector ones of a wave costs as much as a vector one
 LANE_ISSUE_SUSTAINED = 53.0e12
+
+
+class _ClockSampler:
+    """Shader clock / memory clock / socket power / busy percentage of one GPU, sampled from sysfs by a background thread while a timed region runs.
+    Nothing of it is on the timed path (the thread reads files; the registrations run in C with the GIL released).  No sysfs node: every figure None."""
+    def __init__(self, dev_index, period=0.02):
+        import glob
+        import threading
+        self.period, self.samples, self.dev = period, [], None
+        cards = []
+        for c in glob.glob("/sys/class/drm/card[0-9]*/device"):
+            hw = glob.glob(os.path.join(c, "hwmon", "hwmon*", "freq1_input"))
+            if hw:
+                cards.append((os.path.realpath(c), os.path.dirname(hw[0]), c))
+        cards.sort()            # PCI address order = HIP's device order unless the visible set was permuted (the path is recorded in the detail file)
+        if cards:
+            self.dev = cards[dev_index if dev_index < len(cards) else 0]
+        self._stop = threading.Event()
+        self._th = None
+
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().split()[0])
+        except Exception:
+            return None
+
+    def _mclk(self):
+        try:
+            with open(os.path.join(self.dev[2], "pp_dpm_mclk")) as fh:
+                for ln in fh:
+                    if "*" in ln:
+                        return float(ln.split(":")[1].strip().split("M")[0])
+        except Exception:
+            pass
+        return None
+
+    def sample(self):
+        if not self.dev:
+            return None
+        hw, c = self.dev[1], self.dev[2]
+        f, pw = self._num(os.path.join(hw, "freq1_input")), self._num(os.path.join(hw, "power1_input"))
+        if pw is None:
+            pw = self._num(os.path.join(hw, "power1_average"))
+        return (None if f is None else f / 1e6, None if pw is None else pw / 1e6, self._num(os.path.join(c, "gpu_busy_percent")))
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self.sample()
+            if v:
+                self.samples.append(v)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self.idle = self.sample()
+        if self.dev:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        if not self.dev:
+            return dict(sclk_mhz_mean=None, power_w_mean=None, source=None)
+        def col(i):
+            v = [s[i] for s in self.samples if s[i] is not None]
+            return v
+        sc, pw, bz = col(0), col(1), col(2)
+        cap = self._num(os.path.join(self.dev[1], "power1_cap"))
+        return dict(sclk_mhz_mean=round(sum(sc) / len(sc), 1) if sc else None, sclk_mhz_min=round(min(sc), 1) if sc else None,
+                    sclk_mhz_idle=None if not self.idle or self.idle[0] is None else round(self.idle[0], 1), mclk_mhz=self._mclk(),
+                    power_w_mean=round(sum(pw) / len(pw), 1) if pw else None, power_cap_w=None if cap is None else round(cap / 1e6, 1),
+                    gpu_busy_pct_mean=round(sum(bz) / len(bz), 1) if bz else None, samples=len(self.samples), period_s=self.period, source=self.dev[2])
+
+
+def _stub_mark(line):
+    """A line made with the stand-in context (TDLO_BENCH_STUB: tests of the launch / rank / JSON logic on a box without a GPU) says so where nobody can
+    miss it: data = "stub", the workload text starts with STUB, and `stub` names the stand-in.  No measurement can be read out of such a line."""
+    stub = os.environ.get("TDLO_BENCH_STUB")
+    if stub and line is not None:
+        line["data"] = "stub"
+        line["stub"] = stub
+        if isinstance(line.get("config"), dict) and "workload" in line["config"]:
+            line["config"]["workload"] = "STUB (stand-in context, nothing was computed): " + line["config"]["workload"]
+    return line
 
 
 def _self_launch(args):
@@ -274,6 +377,10 @@ def _compact(full):
               "self_exchange_iters_per_s"):
         if k in full:
             o[k] = full[k]
+    for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_cap_w"):      # the GPU's clocks and power while the timed region ran (_ClockSampler)
+        o[k] = (full.get("clocks") or {}).get(k)
+    if full.get("stub"):
+        o["stub"] = full["stub"]
     o["roofline"] = _compact_roofline(full.get("roofline"))
     if full.get("roofline_kernels"):
         o["roofline_kernels"] = [{k: r[k] for k in ("kernel", "bound", "frac", "avg_launch_us", "traffic") if k in r} for r in full["roofline_kernels"]]
@@ -293,6 +400,17 @@ def _compact(full):
                           parity_dY_m=(float(f"{cb['parity']['max_abs_dY_m']:.2e}") if cb.get("parity") else None))
         if "self_exchange_iters_per_s" in r:      # c4 on one rank: the rate with the per-iteration exchange carried out against the own inbox
             legs[name]["self_exchange_value"] = r["self_exchange_iters_per_s"]
+        ck = r.get("clocks") or {}
+        legs[name]["sclk_mhz_mean"], legs[name]["power_w_mean"] = ck.get("sclk_mhz_mean"), ck.get("power_w_mean")
+        if name.startswith("c4") and r.get("n_gpus", 1) > 1:      # the N-split over several GPUs: which exchange ran, and whether the ranks hold the same bits
+            legs[name].update(us_per_iteration=r.get("us_per_iteration"), form=(r.get("form") or "")[:24], ranks_agree=r.get("ranks_agree"), y_sha1=r.get("y_sha1"),
+                              rccl_size=[e.get("rccl_size") for e in (r.get("ranks") or [])],
+                              xch_can_access=["".join("1" if a else "0" for a in row) for row in (r.get("xch_can_access") or [])])
+        if r.get("n_gpus", 1) > 1:
+            legs[name]["n_gpus"] = r["n_gpus"]
+            for drop in ("roofline_kernel", "roofline_frac", "traffic", "cpu_value", "parity_dY_m"):      # (one rank's kernel figures: on the N = 1 line)
+                if legs[name].get(drop) is None:
+                    legs[name].pop(drop, None)
     if legs:
         o["configs"] = legs
     if "sustained" in full:
@@ -312,7 +430,7 @@ def _compact(full):
     o["ranks"] = full.get("ranks")
     o["detail"] = DETAIL_FILE
     # the line must stay under the limit whatever a future leg adds: optional parts go first
-    for drop in ("roofline_kernels", "ranks", "configs", "em_loop_only_iters_per_s", "frames_per_s"):
+    for drop in ("roofline_kernels", "em_loop_only_iters_per_s", "frames_per_s", "ranks", "configs"):
         if len(json.dumps(o)) < LINE_LIMIT:
             break
         o.pop(drop, None)
@@ -428,6 +546,35 @@ def main():
                 raise
             except Exception as e:          # a leg must not take the headline down
                 res["configs"][name] = dict(error=f"{type(e).__name__}: {e}")
+    if world > 1 and args.config == "c2" and not args.frames and not args.no_legs and args.pmc != "child":
+        # the scaling run (the driver's --gpus N): behind the frame-sharded headline the same process group registers BASELINE configs[2] (32 frames per
+        # GPU) and configs[3] (ONE 2 000 000-point frame split over the ranks) -- the latter with the one-shot exchange and again with the library's RCCL
+        # all-reduces --, so that the run exercises the N-split's exchange over xGMI.  Every rank walks the same legs in the same
+        # order (they are collective); a leg that fails on one rank fails on all of them or the group would hang: no per-rank try / except here.
+        import copy
+        legs = {}
+        for name, cname, force_rccl in (("c3", "c3", False), ("c4", "c4", False), ("c4_rccl", "c4", True)):
+            a = copy.copy(args)
+            a.config, a.frames = cname, None
+            lcfg = dict(CONFIGS[cname], leg=True, **LEGS[cname])
+            if force_rccl:
+                os.environ["TDLO_BENCH_FORCE_RCCL"] = "1"
+            try:
+                t0 = time.perf_counter()
+                r = bench_nsplit(a, lcfg, env) if cname == "c4" else bench_frames(a, lcfg, env)
+            finally:
+                if force_rccl:
+                    os.environ.pop("TDLO_BENCH_FORCE_RCCL", None)
+            if r is not None:
+                legs[name] = dict({k: r[k] for k in ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "scaling", "config",
+                                                     "us_per_iteration", "form", "ranks_agree", "y_sha1", "xch_can_access", "roofline", "roofline_kernels", "clocks") if k in r},
+                                  leg_seconds=round(time.perf_counter() - t0, 1))
+        if res is not None:
+            res["configs"] = legs
+    if res is not None:
+        _stub_mark(res)
+        for leg in (res.get("configs") or {}).values():
+            _stub_mark(leg)
     if dist is not None:
         _flush_c_stdio()            # every rank: whatever RCCL has printed so far leaves the buffers before rank 0's line
         dist.barrier()
@@ -775,11 +922,13 @@ def bench_frames(args, cfg, env):
         step()
     barrier()
     timed = []
-    t0 = time.perf_counter()
-    for _ in range(cfg["steps"]):
-        timed.append(step())
-    barrier()
-    dt = _max_over_ranks(env, time.perf_counter() - t0)
+    with _ClockSampler(dev_index) as clk:       # (a thread that reads sysfs beside the timed region, nothing on its path)
+        t0 = time.perf_counter()
+        for _ in range(cfg["steps"]):
+            timed.append(step())
+        barrier()
+        dt_local = time.perf_counter() - t0
+    dt = _max_over_ranks(env, dt_local)
     if args.pmc == "child":     # a PMC pass of _pmc_traffic_live: the calls above are all it is for
         ctx.close()
         return
@@ -820,7 +969,7 @@ def bench_frames(args, cfg, env):
                    timed_region_s=round(dt, 3), frames_per_s=round(cfg["steps"] * F * n_ranks / dt, 2),
                    prune_dispatches_per_call=round(pruned / max(1, cfg["steps"]), 3),
                    em_loop_only_iters_per_s=round(loop_steps * F * EM_ITERS / (loop_ms * 1e-3), 2),
-                   roofline=roof, roofline_kernels=roof_all)
+                   roofline=roof, roofline_kernels=roof_all, clocks=clk.summary())
         if args.config == "c2" and F == 1 and not cfg.get("leg"):
             # the reference's arithmetic is fp64 throughout: the same workload with TDLO_PREC_F64 (not the headline: BASELINE C2 names fp32)
             p64 = mk_params(B.PREC_F64)
@@ -948,11 +1097,13 @@ def bench_nsplit(args, cfg, env):
     for _ in range(cfg["warmup"]):
         step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(cfg["steps"]):
-        out = step()
-    barrier()
-    dt = _max_over_ranks(env, time.perf_counter() - t0)
+    with _ClockSampler(dev_index) as clk:
+        t0 = time.perf_counter()
+        for _ in range(cfg["steps"]):
+            out = step()
+        barrier()
+        dt_local = time.perf_counter() - t0
+    dt = _max_over_ranks(env, dt_local)
     if args.pmc == "child":     # a PMC pass of _pmc_traffic_live: the calls above are all it is for
         ctx.close()
         return
@@ -994,8 +1145,8 @@ def bench_nsplit(args, cfg, env):
                                 parallelism=f"points sharded over {n_ranks} rank(s); per iteration: {form}; identical M-step on every rank"
                                             + ("; ONE rank: no peer, the per-iteration exchange is skipped (self_exchange_iters_per_s: with it, against the own inbox)" if n_ranks == 1 and comm is None else "")),
                     timed_region_s=round(dt, 3), us_per_iteration=round(dt * 1e6 / (cfg["steps"] * EM_ITERS), 2), iters=out["iters"],
-                    ranks_agree=len(set(hashes)) == 1, xch_can_access=access,
-                    roofline=roof, roofline_kernels=roof_all)
+                    ranks_agree=len(set(hashes)) == 1, xch_can_access=access, form=form, y_sha1=hashes[0],
+                    roofline=roof, roofline_kernels=roof_all, clocks=clk.summary())
         cpu = None
         if n_ranks == 1 and comm is None:
             # a lone rank skips the per-iteration exchange (nobody to exchange with); what the exchange itself costs on this GPU -- every rank of a

@@ -378,9 +378,18 @@ int tdlo_depth_to_cloud_visibility(tdlo_ctx *ctx, int slot, const unsigned short
                                    double *node_dist, int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext,
                                    int *n_out, int *n_raw_out);
 
-/* The ROS node's callback from the images to the nodes in one call (trackdlo/src/trackdlo_node.cpp:195-369): tdlo_depth_to_cloud_visibility with the
- * tracker's own nodes, visibility threshold and geodesic coordinates, then tdlo_tracker_tracking_step on the cloud left in the tracker's slot
- * (X == NULL, no H_pre).  The visible sets of the frame are returned as well (arrays of M ints, may be NULL); stats: the two tdlo_stats of
+/* The ROS node's callback from the images to the nodes in one call (trackdlo/src/trackdlo_node.cpp:195-277 and :345-369): tdlo_depth_to_cloud_visibility
+ * with the tracker's own nodes, visibility threshold and geodesic coordinates, then tdlo_tracker_tracking_step on the cloud left in the tracker's slot
+ * (X == NULL, no H_pre).
+ * NOT in this call: the callback's self-occlusion test, trackdlo_node.cpp:279-343 (edges sorted by their distance from the camera and drawn with
+ * cv::line of dlo_pixel_width into an image; a node whose projected pixel lies under an edge drawn before its own is left out of visible_nodes).
+ * It needs the projection matrix and OpenCV's rasteriser: BY DEFAULT it is the caller's, and for a rope that crosses itself in the image the visible
+ * sets this call forms (distance threshold + gap fill only: every node within visibility_threshold of the cloud) are larger than the reference
+ * callback's.  Two ways to the callback's sets: (a) the caller runs its own :279-343 (or tdlo_self_occlusion_visible + tdlo_extend_visible_nodes below) on
+ * the node distances of tdlo_depth_to_cloud_visibility / tdlo_visibility_prepass and hands visible_nodes / visible_nodes_extended to
+ * tdlo_tracker_tracking_step itself; (b) tdlo_tracker_set_self_occlusion(t, proj, dlo_pixel_width) -- this call then applies the library's geometric
+ * restatement of the test (parity against OpenCV's rasteriser unpinned, hence off by default).
+ * tests/test_cloud_gpu.py::test_a_rope_that_crosses_itself shows the default sets, both ways, and that they agree with each other.  The visible sets of the frame are returned as well (arrays of M ints, may be NULL); stats: the two tdlo_stats of
  * tracking_step.  The result is read with tdlo_tracker_get_tracking_result.  A frame whose mask selects no pixel, or none of whose nodes lies
  * within the visibility threshold of the cloud, is TDLO_E_EMPTY (the reference's callback indexes visible_nodes[size() - 1] there, :351-361);
  * the tracker's state is untouched then. */
@@ -388,6 +397,24 @@ int tdlo_tracker_frame_from_depth(tdlo_tracker *t, const unsigned short *depth, 
                                   double fx, double fy, double cx, double cy, double leaf_size, double d_vis,
                                   int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext,
                                   int *n_out, int *n_raw_out, tdlo_stats *stats);
+
+/* The callback's self-occlusion ("painter") test, trackdlo/src/trackdlo_node.cpp:279-343: the edges between consecutive nodes are taken nearest the camera
+ * first (:279-290, by the camera distance of their mid-points) and each is drawn as a line of dlo_pixel_width pixels (:337-341) after its two end nodes
+ * were looked up in what had been drawn before (:304-334): a node whose projected pixel (proj: 3 x 4 row-major, the reference's proj_matrix; pixel
+ * coordinates truncated as by static_cast<int>) lies under an edge nearer than its own is left out; the others are visible when they are within
+ * visibility_threshold of the cloud (node_dist[M]: what tdlo_visibility_prepass / tdlo_depth_to_cloud_visibility return, :257-277).  visible_nodes
+ * receives the ascending indices (room for M ints), *n_vis their number.  Host code, O(M^2) integer tests, no device work.
+ * PARITY UNPINNED against OpenCV: "under an edge" is the geometric content of cv::line with a thickness -- within dlo_pixel_width / 2 of the segment
+ * between the end pixels --, not OpenCV's own fixed-point rasteriser (absent from the build image); boundary pixels may differ.  tests: the oracle's
+ * literal restatement of the callback's loop (oracle/ref_cpu.c, ref_self_occlusion) gives the same index sets on random self-crossing ropes. */
+int tdlo_self_occlusion_visible(const double *Y, int M, const double proj[12], int dlo_pixel_width, const double *node_dist, double visibility_threshold,
+                                int *visible_nodes, int *n_vis);
+/* trackdlo_node.cpp:345-360: visible_nodes sorted, occluded runs shorter than d_vis (in geodesic_coord) filled in.  Room for the chain's node count. */
+int tdlo_extend_visible_nodes(const int *visible_nodes, int n_vis, const double *geodesic_coord, double d_vis, int *visible_nodes_extended, int *n_vis_ext);
+/* tdlo_tracker_frame_from_depth applies the self-occlusion test above between its distance pre-pass and the gap fill (the reference callback's order)
+ * once the tracker has been given the projection matrix and the rope's width in pixels; proj == NULL switches it off again.  OFF by default (see the
+ * parity note above). */
+int tdlo_tracker_set_self_occlusion(tdlo_tracker *t, const double *proj, int dlo_pixel_width);
 
 /* ---- host helpers on the path (exported so the parity tests can address them directly) -------- */
 /* trackdlo::calc_LLE_weights (trackdlo.cpp:119-159), k as passed at :236 (6). L: M x M col-major out. */

@@ -34,7 +34,7 @@ template <class Matrix>
 class trackdlo_t {
 public:
     trackdlo_t() {}                                                        // trackdlo.cpp:8
-    explicit trackdlo_t(int num_of_nodes) { init(num_of_nodes, nullptr); } // trackdlo.cpp:10-28
+    trackdlo_t(int num_of_nodes) { init(num_of_nodes, nullptr); }          // trackdlo.cpp:10-28 (not explicit: trackdlo.h:58 is not either)
     trackdlo_t(int num_of_nodes, double visibility_threshold, double beta, double lambda, double alpha, double k_vis,
                double mu, int max_iter, double tol, double beta_pre_proc, double lambda_pre_proc, double lle_weight) {
         const double p[11] = {visibility_threshold, beta, lambda, alpha, k_vis, mu, (double)max_iter, tol, beta_pre_proc,

@@ -915,6 +915,61 @@ int ref_visibility_prepass(const double *X, int N, const double *Y, int M, doubl
     return nv;
 }
 
+/* ---------------------------------------------------------------- trackdlo_node.cpp:279-343: the callback's self-occlusion ("painter") test.
+ * PARITY UNPINNED against OpenCV: the reference draws every edge with cv::line(..., thickness = dlo_pixel_width) into an 8-bit image and
+ * looks the nodes' pixels up in it; OpenCV is absent from this image, so the thick line is restated as its geometric content -- a pixel is
+ * covered when its distance from the segment between the two (integer) end pixels is at most dlo_pixel_width / 2 (OpenCV draws the
+ * rectangle of that half-width around the segment plus round caps at both ends; pixels on the boundary may differ by its fixed-point
+ * rounding).  Everything else follows the reference line by line: the edges' averaged camera distances (:279-284), the sort (:286-290;
+ * std::sort's order of EQUAL distances is unspecified -- ascending index here), the truncating projection (:304-309), the two look-ups per
+ * edge with their std::find guards (:312-334), the line drawn AFTER the look-ups (:337-341).  proj: 3 x 4 row-major.  Returns n_vis
+ * (ascending, :345-346); vis needs room for M ints. */
+static int px_covered(long long px, long long py, long long ax, long long ay, long long bx, long long by, long long w) {
+    const long long abx = bx - ax, aby = by - ay, apx = px - ax, apy = py - ay;
+    const long long ab2 = abx * abx + aby * aby, dot = apx * abx + apy * aby;
+    if (ab2 == 0 || dot <= 0) return 4 * (apx * apx + apy * apy) <= w * w;
+    if (dot >= ab2) { const long long bpx = px - bx, bpy = py - by; return 4 * (bpx * bpx + bpy * bpy) <= w * w; }
+    const long long cr = apx * aby - apy * abx;                 /* |AP x AB|^2 / |AB|^2 = squared distance from the line */
+    return 4 * cr * cr <= w * w * ab2;
+}
+
+int ref_self_occlusion(const double *Y, int M, const double *proj, int dlo_pixel_width, const double *node_dist, double visibility_threshold, int *vis) {
+    int nE = M - 1, nv = 0, nd = 0;
+    if (M < 2) { if (M == 1 && node_dist[0] <= visibility_threshold) vis[nv++] = 0; return nv; }
+    double *avg = (double *)malloc(sizeof(double) * nE);
+    int *order = (int *)malloc(sizeof(int) * nE), *drawn = (int *)malloc(sizeof(int) * nE), *col = (int *)malloc(sizeof(int) * M), *row = (int *)malloc(sizeof(int) * M);
+    char *isvis = (char *)calloc(M, 1);
+    for (int i = 0; i < nE; i++) {                                /* :281-284 */
+        double mx = (Y[i] + Y[i + 1]) / 2, my = (Y[M + i] + Y[M + i + 1]) / 2, mz = (Y[2 * M + i] + Y[2 * M + i + 1]) / 2;
+        avg[i] = sqrt(mx * mx + my * my + mz * mz); order[i] = i;
+    }
+    for (int i = 1; i < nE; i++) {                                /* :286-290 (insertion sort: stable) */
+        int k = order[i], j = i - 1;
+        while (j >= 0 && avg[order[j]] > avg[k]) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = k;
+    }
+    for (int m = 0; m < M; m++) {                                 /* :294-297, :304-309 */
+        const double h[4] = {Y[m], Y[M + m], Y[2 * M + m], 1.0};
+        double u = 0, v = 0, w = 0;
+        for (int k = 0; k < 4; k++) { u += proj[k] * h[k]; v += proj[4 + k] * h[k]; w += proj[8 + k] * h[k]; }
+        col[m] = (int)(u / w); row[m] = (int)(v / w);
+    }
+    for (int e = 0; e < nE; e++) {                                /* :303-342: edges closest to the camera first */
+        const int idx = order[e];
+        for (int side = 0; side < 2; side++) {
+            const int node = idx + side;
+            int covered = 0;
+            for (int d = 0; d < nd && !covered; d++)              /* projected_edges.at<uchar>(row, col) != 0 */
+                covered = px_covered(col[node], row[node], col[drawn[d]], row[drawn[d]], col[drawn[d] + 1], row[drawn[d] + 1], dlo_pixel_width);
+            if (!covered && node_dist[node] <= visibility_threshold) isvis[node] = 1;        /* :312-317 / :323-328 */
+        }
+        drawn[nd++] = idx;                                        /* :336-341 */
+    }
+    for (int m = 0; m < M; m++) if (isvis[m]) vis[nv++] = m;      /* :345-346 */
+    free(avg); free(order); free(drawn); free(col); free(row); free(isvis);
+    return nv;
+}
+
 /* ---------------------------------------------------------------- evaluator.cpp:233-283, :333-341 */
 
 static double calc_min_distance(const double A[3], const double B[3], const double E[3]) {

@@ -130,6 +130,11 @@ int ref_tracking_step(ref_tracker *t, const double *X, int N, const int *vis, in
 int ref_visibility_prepass(const double *X, int N, const double *Y, int M, double visibility_threshold, double d_vis,
                            const double *coord, double *node_dist, int *vis, int *vis_ext, int *n_ext);
 
+/* The callback's self-occlusion ("painter") test, trackdlo/src/trackdlo_node.cpp:279-343: which nodes are visible when edges nearer the camera hide the
+ * ones behind them.  PARITY UNPINNED against OpenCV's rasteriser (cv::line with thickness; OpenCV is absent here): the thick line is restated as
+ * "within dlo_pixel_width / 2 of the segment".  proj: 3 x 4 row-major; node_dist: per-node shortest distance to the cloud (:257-277).  Returns n_vis. */
+int ref_self_occlusion(const double *Y, int M, const double *proj, int dlo_pixel_width, const double *node_dist, double visibility_threshold, int *vis);
+
 /* evaluator::get_piecewise_error / compute_error, trackdlo/src/evaluator.cpp:233-283, :333-341 (with
  * cross_product / dot_product of utils.cpp:477-489).  Chains n x 3 column-major. */
 double ref_piecewise_error(const double *Y_track, int n1, const double *Y_true, int n2);

@@ -216,6 +216,18 @@ def visibility_prepass(X, Y, visibility_threshold, d_vis, coord):
     return dist, vis[:nv].copy(), ext[:ne.value].copy()
 
 
+def self_occlusion(Y, proj, dlo_pixel_width, node_dist, visibility_threshold):
+    """trackdlo_node.cpp:279-343 (parity unpinned against OpenCV's cv::line: see ref_cpu.c).  Returns the visible node indices."""
+    Y = _f(Y); M = Y.shape[0]
+    proj = np.ascontiguousarray(proj, dtype=np.float64).reshape(12)
+    nd = np.ascontiguousarray(node_dist, dtype=np.float64)
+    vis = np.zeros(max(M, 1), dtype=np.int32)
+    f = lib().ref_self_occlusion
+    f.restype = C.c_int
+    nv = f(_dp(Y), C.c_int(M), _dp(proj), C.c_int(int(dlo_pixel_width)), _dp(nd), C.c_double(visibility_threshold), _dp(vis))
+    return vis[:nv].copy()
+
+
 def piecewise_error(Y_track, Y_true):
     a = _f(Y_track); b = _f(Y_true)
     return lib().ref_piecewise_error(_dp(a), C.c_int(a.shape[0]), _dp(b), C.c_int(b.shape[0]))

@@ -5,6 +5,7 @@
 # What it runs, each step logged under gpurun_out/first_contact/ and summarised at the end:
 #   1. the C++ N-split driver (tests/cpp/split_run_test): two ranks on devices 0 / 1 -- the one-shot exchange's peer stores cross xGMI
 #   2. bench.py --config c3 (frames sharded, barrier only) on 2, 4, 8 GPUs
+#      (the driver's own scaling command, `bench.py --gpus N` with the default config, runs c3 and both c4 forms as legs behind its headline as well: configs.c3 / c4 / c4_rccl)
 #   3. bench.py --config c4 (N = 2 000 000 split; per iteration the 4M+2 sums exchanged) on 2, 4, 8 GPUs in BOTH exchange forms:
 #      default (one-shot exchange: peer-written inboxes, IPC handles) and TDLO_BENCH_FORCE_RCCL=1 (the library's ncclAllReduce calls)
 #   From every line: n_gpus, value, us_per_iteration, the form that ran, ranks[].rccl_size, xch_can_access (rank x rank peer-mapping matrix),
@@ -46,7 +47,7 @@ lines = [l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")]
 if rc != 0 or not lines:
     print(f"   FAILED rc={rc}: no JSON line (see the .err file)"); sys.exit(3)
 d = json.loads(lines[-1])
-out = f"   n_gpus {d['n_gpus']}  value {d['value']} {d['unit']}  ms_per_step {d['ms_per_step']}"
+out = f"   {'STUB (stand-in context, NOT a measurement)  ' if d.get('data') == 'stub' else ''}n_gpus {d['n_gpus']}  value {d['value']} {d['unit']}  ms_per_step {d['ms_per_step']}"
 if "us_per_iteration" in d:
     out += f"  us_per_iteration {d['us_per_iteration']}  form: {d['config']['parallelism'].split('per iteration: ')[-1][:60]}"
     out += f"\n   rccl_size {[r.get('rccl_size') for r in d['ranks']]}  xch_can_access {d.get('xch_can_access')}"

@@ -317,3 +317,39 @@ def test_device_lle_routine_compiled_for_the_host_matches_the_host_routine(tmp_p
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "600 chains, 0 with a differing bit" in r.stdout
+
+
+def test_self_occlusion_test_against_the_oracles_literal_restatement(oracle):
+    """trackdlo_node.cpp:279-343, the callback's painter test (VERDICT r05 item 7; parity against OpenCV's cv::line unpinned -- both sides take the
+    thick line's geometric content): the library's O(M^2) form (per node: the edges painted before the nearer of its incident edges) against the
+    oracle's line-by-line restatement of the callback's loop (edges sorted by camera distance, two look-ups with their std::find guards per edge,
+    the edge painted after them), on ropes that cross themselves in the image -- equal index sets; and :345-360's gap fill."""
+    from trackdlo_amd import binding as B, synth
+    rng = np.random.default_rng(11)
+    K = np.array([[615.0, 0, 320, 0], [0, 615.0, 240, 0], [0, 0, 1, 0]])
+    hidden_cases = 0
+    for trial in range(1500):
+        M = int(rng.integers(2, 60))
+        t = np.linspace(0, 1, M); a = rng.uniform(0.5, 3, 3); ph = rng.uniform(0, 2 * np.pi, 3)
+        Y = np.stack([0.25 * np.sin(2 * np.pi * a[0] * t + ph[0]), 0.2 * np.sin(2 * np.pi * a[1] * t + ph[1]), 0.6 + 0.15 * np.sin(2 * np.pi * a[2] * t + ph[2])], axis=1)
+        nd = rng.uniform(0, 0.016, M); w = int(rng.integers(1, 40))
+        vo = oracle.self_occlusion(np.asfortranarray(Y), K, w, nd, 0.008)
+        vp = B.self_occlusion_visible(Y, K, w, nd, 0.008)
+        assert np.array_equal(vo, vp), (trial, M, w)
+        assert set(vp) <= set(np.nonzero(nd <= 0.008)[0])               # the test only ever takes nodes away from the distance test's set
+        hidden_cases += len(vp) < int((nd <= 0.008).sum())
+        coord = synth.geodesic_coord(Y)
+        if len(vp):
+            ext = B.extend_visible_nodes(vp[::-1], coord, 0.06, M)      # (unsorted on purpose: :346 sorts)
+            ref = []
+            for i in range(len(vp) - 1):
+                ref.append(vp[i])
+                if abs(coord[vp[i + 1]] - coord[vp[i]]) <= 0.06:
+                    ref.extend(range(vp[i] + 1, vp[i + 1]))
+            ref.append(vp[-1])
+            assert list(ext) == ref
+    assert hidden_cases > 300
+    # one node / two nodes / a rope that does not cross itself: nothing is hidden
+    assert list(B.self_occlusion_visible(np.array([[0.0, 0.0, 0.5]]), K, 10, [0.001], 0.008)) == [0]
+    Ys = synth.nodes(30)
+    assert list(B.self_occlusion_visible(Ys, K, 10, np.zeros(30), 0.008)) == list(range(30))

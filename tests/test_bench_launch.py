@@ -52,6 +52,25 @@ def test_gpus_2_self_launches_two_ranks(config, frames):
     assert line["prune_dispatches_per_call"] == 1.0 and "reuse OFF" in line["config"]["workload"]
     d = _detail()
     assert d["value"] == line["value"] and "note" in d["roofline"] and len(d["roofline_kernels"]) == 2
+    # a line made with the stand-in context says so: nobody can read it as a measurement
+    assert line["data"] == "stub" and line["stub"] == "bench_stub:StubContext" and line["config"]["workload"].startswith("STUB")
+    if config == "c2":
+        # the scaling run's legs: behind the frame-sharded headline the same two ranks register configs[2] (32 frames per GPU) and
+        # configs[3] (the 2 000 000-point frame split over the ranks) -- one-shot exchange, then the library's RCCL all-reduces
+        legs = line["configs"]
+        assert set(legs) == {"c3", "c4", "c4_rccl"}
+        assert legs["c3"]["n_gpus"] == 2 and legs["c3"]["value"] > 0
+        for name, rccl in (("c4", [None, None]), ("c4_rccl", [2, 2])):
+            leg = legs[name]
+            assert leg["n_gpus"] == 2 and leg["value"] > 0 and leg["us_per_iteration"] > 0 and leg["ranks_agree"] is True and len(leg["y_sha1"]) == 16
+            assert leg["rccl_size"] == rccl and leg["xch_can_access"] == ["11", "11"]
+            assert leg["form"].startswith("RCCL all-reduce" if name == "c4_rccl" else "one-shot exchange")
+        assert "sclk_mhz_mean" in legs["c4"] and "sclk_mhz_mean" in line
+        dl = d["configs"]
+        assert dl["c4"]["scaling"] == "strong" and "2000000 points split over 2 rank(s)" in dl["c4"]["config"]["workload"] and dl["c4"]["data" if "data" in dl["c4"] else "config"]
+        assert dl["c4_rccl"]["config"]["parallelism"].count("RCCL all-reduce") == 1 and dl["c3"]["config"]["frames_per_gpu"] == 32
+    else:
+        assert "configs" not in line
 
 
 def test_driver_style_launch_and_world_size_mismatch():

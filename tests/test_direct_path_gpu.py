@@ -553,6 +553,33 @@ def test_an_abandoned_grid_barrier_sends_the_call_to_the_three_kernel_route(prec
         hit.close(); ref.close()
 
 
+def test_an_abandoned_grid_barrier_under_the_batch_entry_point_with_one_frame():
+    """tdlo_cpd_lle_batch with F == 1 takes the fused prologue like a single call, but returned run_frames' result as it was -- an
+    abandoned grid barrier reached the caller as the internal code -100 with a stale error text, the arrivals / barrier word were never reset and every
+    later fused launch on that slot could wait 2 s again.  Now the batch entry repeats the call once on the three-kernel route like the others."""
+    import time
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 5000, 45
+    X, Y0, _ = synth.scene(N, M, config=72, outliers=7)
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 20, 0.0, False)
+    hit, ref = _fuse_ctx(B, 1, max_points=N, max_nodes=64), _fuse_ctx(B, 0, classic=True, max_points=N, max_nodes=64)
+    try:
+        for c in (hit, ref):
+            c.set_sort_reuse(False)
+            c.set_cloud(0, X)
+        for k in range(3):
+            t0 = time.perf_counter()
+            a = hit.cpd_lle_batch([Y0], [0.0], pr)
+            dt = time.perf_counter() - t0
+            b = ref.cpd_lle_batch([Y0], [0.0], pr)
+            np.testing.assert_array_equal(np.asarray(a["Y"][0]), np.asarray(b["Y"][0])); assert a["sigma2"][0] == b["sigma2"][0]
+            assert a["stats"][0]["iters"] == 20 and a["stats"][0]["status"] == 0
+            assert hit.route_counts()[5] == 1 and (dt > 1.9) == (k == 0), (k, dt)        # the first call waited the barrier out and was repeated; no later call waits
+    finally:
+        hit.close(); ref.close()
+
+
 @pytest.mark.parametrize("nth,ahead", [(1, True), (3, True), (4, True), (4, False)],
                          ids=["paired prologue", "pre-processing prologue of a frame with hidden nodes", "prologue launched ahead in the twin slot", "main registration's own prologue"])
 def test_tracking_step_survives_an_abandoned_grid_barrier(nth, ahead):

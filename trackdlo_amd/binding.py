@@ -57,7 +57,7 @@ SYMBOLS = [
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
     "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_tracker_frame_from_depth", "tdlo_piecewise_error", "tdlo_compute_error",
-    "tdlo_depth_to_cloud", "tdlo_reg",
+    "tdlo_depth_to_cloud", "tdlo_reg", "tdlo_self_occlusion_visible", "tdlo_extend_visible_nodes", "tdlo_tracker_set_self_occlusion",
 ]
 
 _lib = None
@@ -199,6 +199,9 @@ def load_library(path: str | None = None):
     lib.tdlo_depth_to_cloud.argtypes = [vp, ci, vp, vp, ci, ci, cd, cd, cd, cd, cd, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     lib.tdlo_image_buffers.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(vp)]
     lib.tdlo_debug_cloud_stamps.argtypes = [vp, vp, ci]
+    lib.tdlo_self_occlusion_visible.argtypes = [vp, ci, vp, ci, vp, cd, vp, C.POINTER(ci)]
+    lib.tdlo_extend_visible_nodes.argtypes = [vp, ci, vp, cd, vp, C.POINTER(ci)]
+    lib.tdlo_tracker_set_self_occlusion.argtypes = [vp, vp, ci]
     if path is None:
         _lib = lib
     return lib
@@ -625,6 +628,11 @@ class trackdlo:
         """[pre-processing registration, main registration] of the last tracking_step as dicts (tdlo_stats), None before the first one."""
         return None if self._stats_raw is None else [s.as_dict() for s in self._stats_raw]
 
+    def set_self_occlusion(self, proj, dlo_pixel_width=0):
+        """frame_from_depth applies the callback's self-occlusion test (trackdlo_node.cpp:279-343) with this 3 x 4 projection matrix; None: off (default)."""
+        pj = None if proj is None else np.ascontiguousarray(proj, dtype=np.float64).reshape(12)
+        self.ctx._chk(self.ctx.lib.tdlo_tracker_set_self_occlusion(self.h, _ptr(pj), int(dlo_pixel_width)))
+
     def frame_from_depth(self, depth, mask, fx, fy, cx, cy, leaf_size=0.008, d_vis=0.06):
         """The ROS node's callback from the images to the nodes (trackdlo_node.cpp:195-369) in one call: cloud + voxel grid + visibility pre-pass (one
         launch), tracking_step on the resident cloud.  depth / mask: rows x cols uint16 / uint8 arrays (the context's image buffers are read in place).
@@ -705,6 +713,29 @@ def get_piecewise_error(Y_track, Y_true):
     lib = load_library()
     a = _f64(Y_track); b = _f64(Y_true)
     return lib.tdlo_piecewise_error(_ptr(a), a.shape[0], _ptr(b), b.shape[0])
+
+
+def self_occlusion_visible(Y, proj, dlo_pixel_width, node_dist, visibility_threshold):
+    """The callback's self-occlusion test (trackdlo_node.cpp:279-343; parity against OpenCV's cv::line unpinned): indices of the visible nodes."""
+    lib = load_library()
+    Y = _f64(Y); M = Y.shape[0]
+    pj = np.ascontiguousarray(proj, dtype=np.float64).reshape(12); nd = np.ascontiguousarray(node_dist, dtype=np.float64)
+    v = np.zeros(M, dtype=np.int32); nv = C.c_int(0)
+    rc = lib.tdlo_self_occlusion_visible(_ptr(Y), M, _ptr(pj), int(dlo_pixel_width), _ptr(nd), float(visibility_threshold), _ptr(v), C.byref(nv))
+    if rc:
+        raise TdloError(rc, "tdlo_self_occlusion_visible")
+    return v[:nv.value].copy()
+
+
+def extend_visible_nodes(visible_nodes, geodesic_coord, d_vis, M):
+    """trackdlo_node.cpp:345-360: sort + gap fill."""
+    lib = load_library()
+    v = np.ascontiguousarray(visible_nodes, dtype=np.int32); co = np.ascontiguousarray(geodesic_coord, dtype=np.float64)
+    e = np.zeros(M, dtype=np.int32); ne = C.c_int(0)
+    rc = lib.tdlo_extend_visible_nodes(_ptr(v), len(v), _ptr(co), float(d_vis), _ptr(e), C.byref(ne))
+    if rc:
+        raise TdloError(rc, "tdlo_extend_visible_nodes")
+    return e[:ne.value].copy()
 
 
 def compute_error(Y_track, Y_true):

@@ -1484,6 +1484,21 @@ static int set_cloud_impl(tdlo_ctx *c, int slot, const double *X, int N, bool sy
 
 int tdlo_set_cloud(tdlo_ctx *c, int slot, const double *X, int N) { return set_cloud_impl(c, slot, X, N, true); }
 
+// run_frames for the entry points that register caller-supplied nodes (tdlo_cpd_lle_resident, tdlo_cpd_lle_batch): a registration whose fused
+// prologue was abandoned at its grid barrier (TDLO_E_FUSE: internal, no caller ever sees the code) has touched neither Y, sigma2 nor the slots'
+// clouds -- the context is taken off the fused prologue (fuse_fallback: arrivals and barrier word reset, fuse_on = false) and the call repeated
+// ONCE on the copy + three-kernel route.  (tracking_step's main registration does the same around its own call: it forms its priors again.)
+static int run_frames_checked(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *sigma2, const tdlo_params *p,
+                              const double *priors, int K, const int *vis, int n_vis, const double *H_override, tdlo_stats *stats) {
+    int rc = run_frames(c, F, slots, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+    if (rc == TDLO_E_FUSE) {
+        fuse_fallback(c);
+        rc = run_frames(c, F, slots, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+        if (rc == TDLO_E_FUSE) rc = fail(c, TDLO_E_HIP, "the fused prologue reported a time-out on the route that does not use it");
+    }
+    return rc;
+}
+
 int tdlo_cpd_lle_resident(tdlo_ctx *c, int slot, double *Y, int M, double *sigma2, const tdlo_params *p,
                           const double *priors, int K, const int *vis, int n_vis, const double *H_override,
                           tdlo_stats *stats) {
@@ -1491,13 +1506,7 @@ int tdlo_cpd_lle_resident(tdlo_ctx *c, int slot, double *Y, int M, double *sigma
     if (slot < 0 || slot >= (int)c->slots.size()) return fail(c, TDLO_E_INVALID, "bad slot");
     if (!Y || !sigma2) return fail(c, TDLO_E_INVALID, "null Y / sigma2");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = run_frames(c, 1, &slot, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
-    if (rc == TDLO_E_FUSE) {          // Y, sigma2 and the slot's cloud are untouched: once more, without the fused prologue
-        fuse_fallback(c);
-        rc = run_frames(c, 1, &slot, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
-        if (rc == TDLO_E_FUSE) rc = fail(c, TDLO_E_HIP, "the fused prologue reported a time-out on the route that does not use it");
-    }
-    return rc;
+    return run_frames_checked(c, 1, &slot, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
 }
 
 int tdlo_cpd_lle(tdlo_ctx *c, const double *X, int N, double *Y, int M, double *sigma2, const tdlo_params *p,
@@ -1516,7 +1525,7 @@ int tdlo_cpd_lle_batch(tdlo_ctx *c, int F, double *Y, int M, double *sigma2, con
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<int> slots(F);
     for (int i = 0; i < F; ++i) slots[i] = i;
-    return run_frames(c, F, slots.data(), Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);
+    return run_frames_checked(c, F, slots.data(), Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats);      // (F == 1 takes the fused prologue like a single call)
 }
 
 // ---- N-split -------------------------------------------------------------------------------------
@@ -2287,8 +2296,20 @@ int tdlo_visibility_prepass(tdlo_ctx *c, int slot, const double *Y, int M, doubl
     return TDLO_OK;      // an empty visible set is reported as n_vis = 0 (the reference underflows at :351)
 }
 
-// thresholding and gap fill on the host (O(M)) from the squared minima: trackdlo_node.cpp:316/:326 (distance test only, the OpenCV
-// painter test of :279-343 is out of scope), :345-360
+// trackdlo_node.cpp:348-360: occluded runs shorter than d_vis (in the geodesic coordinate) between two visible nodes are filled in
+static void fill_visible_gaps(const std::vector<int> &vis, const double *geodesic_coord, double d_vis, std::vector<int> &ext) {
+    ext.clear();
+    if (vis.empty()) return;
+    for (size_t i = 0; i + 1 < vis.size(); ++i) {
+        ext.push_back(vis[i]);
+        if (std::fabs(geodesic_coord[vis[i + 1]] - geodesic_coord[vis[i]]) <= d_vis)
+            for (int j = 1; j < vis[i + 1] - vis[i]; ++j) ext.push_back(vis[i] + j);
+    }
+    ext.push_back(vis.back());
+}
+
+// thresholding and gap fill on the host (O(M)) from the squared minima: trackdlo_node.cpp:316/:326 (distance test only; the painter test of
+// :279-343 is tdlo_self_occlusion_visible, applied by the caller or by a tracker it was switched on for), :345-360
 static void vis_threshold_and_fill(const double *min_d2, int M, double visibility_threshold, double d_vis, const double *geodesic_coord, double *node_dist,
                                    int *visible_nodes, int *n_vis, int *visible_nodes_extended, int *n_vis_ext) {
     std::vector<int> vis;
@@ -2300,14 +2321,7 @@ static void vis_threshold_and_fill(const double *min_d2, int M, double visibilit
     if (n_vis) *n_vis = (int)vis.size();
     if (visible_nodes) std::copy(vis.begin(), vis.end(), visible_nodes);
     std::vector<int> ext;
-    if (!vis.empty()) {
-        for (size_t i = 0; i + 1 < vis.size(); ++i) {
-            ext.push_back(vis[i]);
-            if (std::fabs(geodesic_coord[vis[i + 1]] - geodesic_coord[vis[i]]) <= d_vis)
-                for (int j = 1; j < vis[i + 1] - vis[i]; ++j) ext.push_back(vis[i] + j);
-        }
-        ext.push_back(vis.back());
-    }
+    fill_visible_gaps(vis, geodesic_coord, d_vis, ext);
     if (n_vis_ext) *n_vis_ext = (int)ext.size();
     if (visible_nodes_extended) std::copy(ext.begin(), ext.end(), visible_nodes_extended);
 }
@@ -2631,6 +2645,10 @@ struct tdlo_tracker {
     std::vector<double> trav1, trav2, trav2r;      // scratch of the priors' formation, kept across frames (their growth was a dozen reallocations per frame,
     std::vector<int> vis_ext;                      // on the host path between the two registrations)
     std::vector<int> frame_vis, frame_vis_ext;     // tdlo_tracker_frame_from_depth: the frame's visible sets
+    std::vector<double> frame_dist;                // ... and the nodes' distances to the frame's cloud
+    bool painter_on = false;                       // tdlo_tracker_set_self_occlusion: frame_from_depth applies trackdlo_node.cpp:279-343 (off by default)
+    double painter_proj[12] = {0};
+    int painter_width = 0;
     int last_iters[2] = {0, 0};         // iterations the two registrations of the previous frame took: how many are enqueued before the host looks (tdlo_ctx::iter_hint;
                                         // the larger of the last two frames' counts was tried instead: no difference)
 };
@@ -2881,8 +2899,18 @@ int tdlo_tracker_frame_from_depth(tdlo_tracker *t, const unsigned short *depth, 
     std::vector<int> &ve = t->frame_vis_ext, &v = t->frame_vis;
     v.resize(M); ve.resize(M);
     int nv = 0, ne = 0, n = 0;
+    t->frame_dist.resize(M);
     int rc = tdlo_depth_to_cloud_visibility(c, t->slot, depth, mask, rows, cols, fx, fy, cx, cy, leaf_size, t->Y.data(), M, t->visibility_threshold, d_vis,
-                                            t->geodesic_coord.data(), nullptr, v.data(), &nv, ve.data(), &ne, &n, n_raw_out);
+                                            t->geodesic_coord.data(), t->frame_dist.data(), v.data(), &nv, ve.data(), &ne, &n, n_raw_out);
+    if (!rc && t->painter_on && n > 0) {
+        // the callback's self-occlusion test (trackdlo_node.cpp:279-343) between the distance pre-pass and the gap fill, when the tracker was given a
+        // projection matrix for it (tdlo_tracker_set_self_occlusion; off by default: parity against OpenCV's rasteriser is unpinned)
+        std::vector<int> pv, pe;
+        self_occlusion_visible(t->Y.data(), M, t->painter_proj, t->painter_width, t->frame_dist.data(), t->visibility_threshold, pv);
+        fill_visible_gaps(pv, t->geodesic_coord.data(), d_vis, pe);
+        nv = (int)pv.size(); ne = (int)pe.size();
+        std::copy(pv.begin(), pv.end(), v.begin()); std::copy(pe.begin(), pe.end(), ve.begin());
+    }
     if (n_out) *n_out = n;
     if (n_vis) *n_vis = nv;
     if (n_vis_ext) *n_vis_ext = ne;
@@ -2893,6 +2921,37 @@ int tdlo_tracker_frame_from_depth(tdlo_tracker *t, const unsigned short *depth, 
     if (n == 0) return fail(c, TDLO_E_EMPTY, "the mask selects no pixel: no cloud for this frame");
     if (ne == 0) return fail(c, TDLO_E_EMPTY, "no node within the visibility threshold of the cloud (the reference's callback is undefined here, trackdlo_node.cpp:351)");
     return tdlo_tracker_tracking_step(t, nullptr, 0, v.data(), nv, ve.data(), ne, nullptr, stats);
+}
+
+// trackdlo_node.cpp:279-343 on the host (tdlo_host.cpp, self_occlusion_visible): O(M^2) integer tests, no kernel warranted
+int tdlo_self_occlusion_visible(const double *Y, int M, const double proj[12], int dlo_pixel_width, const double *node_dist, double visibility_threshold,
+                                int *visible_nodes, int *n_vis) {
+    if (!Y || !proj || !node_dist || !visible_nodes || !n_vis || M < 1 || dlo_pixel_width < 1) return TDLO_E_INVALID;
+    std::vector<int> v;
+    self_occlusion_visible(Y, M, proj, dlo_pixel_width, node_dist, visibility_threshold, v);
+    *n_vis = (int)v.size();
+    std::copy(v.begin(), v.end(), visible_nodes);
+    return TDLO_OK;
+}
+
+// trackdlo_node.cpp:345-360
+int tdlo_extend_visible_nodes(const int *visible_nodes, int n_vis, const double *geodesic_coord, double d_vis, int *visible_nodes_extended, int *n_vis_ext) {
+    if (n_vis < 0 || (n_vis > 0 && (!visible_nodes || !geodesic_coord)) || !visible_nodes_extended || !n_vis_ext) return TDLO_E_INVALID;
+    std::vector<int> v(visible_nodes, visible_nodes + n_vis), e;
+    std::sort(v.begin(), v.end());                                  // :346
+    fill_visible_gaps(v, geodesic_coord, d_vis, e);
+    *n_vis_ext = (int)e.size();
+    std::copy(e.begin(), e.end(), visible_nodes_extended);
+    return TDLO_OK;
+}
+
+int tdlo_tracker_set_self_occlusion(tdlo_tracker *t, const double *proj, int dlo_pixel_width) {
+    if (!t) return TDLO_E_INVALID;
+    if (!proj) { t->painter_on = false; return TDLO_OK; }
+    if (dlo_pixel_width < 1) return fail(t->ctx, TDLO_E_INVALID, "tdlo_tracker_set_self_occlusion: dlo_pixel_width >= 1");
+    std::copy(proj, proj + 12, t->painter_proj);
+    t->painter_width = dlo_pixel_width; t->painter_on = true;
+    return TDLO_OK;
 }
 
 }  // extern "C"

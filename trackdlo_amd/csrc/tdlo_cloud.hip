@@ -1210,12 +1210,12 @@ bool cloud_fused_ok(int P) { return ((size_t)P + kFPix - 1) / kFPix <= (size_t)k
 hipError_t launch_cloud_fused(const unsigned short *depth, const unsigned char *mask, int P, int cols, const double cam[4], float inv_leaf, void *ws, void *fws,
                               bool first, bool team, double *Xraw, int cap, unsigned long long *res_pinned, unsigned epoch, hipStream_t s,
                               const double *vis_nodes_pinned, int vis_M, unsigned long long *vis_state, unsigned long long *vis_out_pinned) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_cloud_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFLds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cloud_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTLds);
+    {   // on every launch, for the CURRENT device, like every other launcher of the library: HIP keeps the attribute per device function, so a
+        // process-wide "done once" flag would leave a second context on another GPU (the exchange tests, a one-process multi-GPU caller) launching
+        // 116 / 160 KB of dynamic LDS without it; the call is a table look-up
+        hipError_t e = team ? hipFuncSetAttribute((const void *)k_cloud_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTLds)
+                            : hipFuncSetAttribute((const void *)k_cloud_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFLds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     FusedCloud a;
     a.depth = depth; a.mask = mask; a.P = P; a.cols = cols; a.T = (P + kFPix - 1) / kFPix;

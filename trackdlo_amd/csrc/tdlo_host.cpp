@@ -412,4 +412,52 @@ double piecewise_error(const double *Ytrack, int n1, const double *Ytrue, int n2
     return total / n1;
 }
 
+// ---- trackdlo_node.cpp:279-343: which nodes does the rope itself hide from the camera? ------------------------------------------------------------
+// The reference paints the edges into an image nearest first (cv::line, thickness dlo_pixel_width) and looks every node's pixel up just before an edge
+// it ends is painted.  A node is looked up twice at most -- once per incident edge -- and the second look-up always finds its first incident edge
+// painted over its own pixel: what decides is the FIRST look-up, against the edges painted before the nearer of the node's incident edges.  So, per
+// node: rank of its nearer incident edge in the painting order, then "does any edge of smaller rank cover my pixel" -- O(M^2) integer tests on the
+// host, no image.  Coverage is the geometric content of the thick line (within width / 2 of the segment between the end pixels, in exact integer
+// arithmetic); OpenCV's own rasteriser is not available here to pin its boundary pixels against.
+namespace {
+struct Px { long long c, r; };
+inline bool within_half_width(const Px &p, const Px &a, const Px &b, long long w) {
+    const long long ex = b.c - a.c, ey = b.r - a.r, fx = p.c - a.c, fy = p.r - a.r;
+    const long long len2 = ex * ex + ey * ey, along = fx * ex + fy * ey;
+    if (along <= 0 || len2 == 0) return 4 * (fx * fx + fy * fy) <= w * w;                 // in front of the first end pixel (or a zero-length edge): its cap
+    if (along >= len2) { const long long gx = p.c - b.c, gy = p.r - b.r; return 4 * (gx * gx + gy * gy) <= w * w; }
+    const long long area = fx * ey - fy * ex;                                               // twice the triangle's area: distance = |area| / len
+    return 4 * area * area <= w * w * len2;
+}
+}  // namespace
+
+void self_occlusion_visible(const double *Y, int M, const double proj[12], int dlo_pixel_width, const double *node_dist, double visibility_threshold, std::vector<int> &vis) {
+    vis.clear();
+    if (M < 1) return;
+    if (M == 1) { if (node_dist[0] <= visibility_threshold) vis.push_back(0); return; }
+    const int nE = M - 1;
+    std::vector<Px> px(M);
+    for (int m = 0; m < M; ++m) {                                   // :294-297, :304-309: homogeneous projection, truncated like static_cast<int>
+        const double x = Y[m], y = Y[M + m], z = Y[2 * (size_t)M + m];
+        const double u = ((proj[0] * x + proj[1] * y) + proj[2] * z) + proj[3] * 1.0, v = ((proj[4] * x + proj[5] * y) + proj[6] * z) + proj[7] * 1.0,
+                     w = ((proj[8] * x + proj[9] * y) + proj[10] * z) + proj[11] * 1.0;
+        px[m].c = (long long)(int)(u / w); px[m].r = (long long)(int)(v / w);
+    }
+    std::vector<std::pair<double, int>> key(nE);
+    for (int i = 0; i < nE; ++i) {                                  // :281-284
+        const double mx = (Y[i] + Y[i + 1]) / 2, my = (Y[M + i] + Y[M + i + 1]) / 2, mz = (Y[2 * (size_t)M + i] + Y[2 * (size_t)M + i + 1]) / 2;
+        key[i] = {std::sqrt(mx * mx + my * my + mz * mz), i};
+    }
+    std::sort(key.begin(), key.end());                              // :286-290 (equal distances: ascending index)
+    std::vector<int> rank(nE);
+    for (int r = 0; r < nE; ++r) rank[key[r].second] = r;
+    for (int m = 0; m < M; ++m) {
+        if (!(node_dist[m] <= visibility_threshold)) continue;      // :313 / :324
+        const int first = (m == 0) ? rank[0] : (m == M - 1 ? rank[nE - 1] : std::min(rank[m - 1], rank[m]));
+        bool hidden = false;
+        for (int r = 0; r < first && !hidden; ++r) { const int e = key[r].second; hidden = within_half_width(px[m], px[e], px[e + 1], dlo_pixel_width); }
+        if (!hidden) vis.push_back(m);
+    }
+}
+
 }  // namespace tdlo

@@ -19,6 +19,10 @@ int line_sphere(const Vec3 &A, const Vec3 &B, const Vec3 &C, double radius, Vec3
 int traverse_euclidean(const std::vector<double> &coord, const double *guide, int Mg,
                        const std::vector<int> &vis, int alignment, int anchor, std::vector<double> &out);
 
+// The callback's self-occlusion test (trackdlo_node.cpp:279-343): indices of the nodes that are within visibility_threshold of the cloud AND whose
+// projected pixel is not under an edge nearer the camera (edges = thick lines of dlo_pixel_width pixels).  proj: 3 x 4 row-major.  Ascending.
+void self_occlusion_visible(const double *Y, int M, const double proj[12], int dlo_pixel_width, const double *node_dist, double visibility_threshold, std::vector<int> &vis);
+
 // evaluator::get_piecewise_error (evaluator.cpp:258-283); chains are n x 3 column-major.
 double piecewise_error(const double *Ytrack, int n1, const double *Ytrue, int n2);
 
