@@ -1150,8 +1150,8 @@ def bench_nsplit(args, cfg, env):
         cpu = None
         if n_ranks == 1 and comm is None:
             # a lone rank skips the per-iteration exchange (nobody to exchange with); what the exchange itself costs on this GPU -- every rank of a
-            # larger group pays it -- is measured against the own inbox (TDLO_XCH_SELF=1, read per call)
-            os.environ["TDLO_XCH_SELF"] = "1"
+            # larger group pays it -- is measured against the own inbox (tdlo_set_xch_self)
+            ctx.set_xch_self(True)
             try:
                 nse = max(4, cfg["steps"] // 4)
                 for _ in range(2):
@@ -1162,7 +1162,7 @@ def bench_nsplit(args, cfg, env):
                 ctx.synchronize()
                 line["self_exchange_iters_per_s"] = round(nse * EM_ITERS / (time.perf_counter() - t1), 2)
             finally:
-                os.environ.pop("TDLO_XCH_SELF", None)
+                ctx.set_xch_self(False)
 
         def gpu_run(iters):
             # the split registration itself on the whole cloud (one rank), staged again: the shard-of-8 figures below leave an eighth of it in the slot
@@ -1187,7 +1187,7 @@ def bench_nsplit(args, cfg, env):
                 return n * EM_ITERS / (time.perf_counter() - t1)
             nun = max(10, cfg["steps"] // 4)
             line["unsplit_iters_per_s"] = round(rate(lambda: ctx.cpd_lle_resident(0, Y0, 0.0, params), nun), 2)
-            os.environ["TDLO_XCH_SELF"] = "1"       # (the shard-of-8 figures below are a rank's share of a larger group: with the exchange)
+            ctx.set_xch_self(True)                  # (the shard-of-8 figures below are a rank's share of a larger group: with the exchange)
             try:
                 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
                 c1 = ctx.rccl_comm_init(1, 0, B.rccl_unique_id())
@@ -1205,7 +1205,7 @@ def bench_nsplit(args, cfg, env):
             if line.get("rccl_form_iters_per_s"):
                 shard["rccl_form_vis_us_per_iteration"] = round(1e6 / rate(lambda: ctx.split_run(Y0, 0.0, pv, comm=c1, visible_nodes=vext), 60), 2)
             line["shard_of_8"] = shard
-            os.environ.pop("TDLO_XCH_SELF", None)
+            ctx.set_xch_self(False)
             if not args.no_cpu_baseline:
                 kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=EM_ITERS, tol=0.0,
                           include_lle=False, alpha=0.0, k_vis=0.0, visibility_threshold=P["visibility_threshold"])

@@ -496,7 +496,8 @@ int tdlo_debug_lle_band_device(tdlo_ctx *ctx, const double *Y, int M, double *Hb
  * points, i.e. one that fills the GPU (TDLO_ESTEP2=0: k_estep everywhere, the comparator; =1: wherever eligible, whatever the size).  The two
  * E-step kernels differ in the grain of their fp32 tile sums (one wave x 64 points / x 128 points): each is repeatable bit for bit and held to
  * the reference at the mode's tolerance, but a frame registered alone (k_estep) and the same frame inside a GPU-filling batch (k_estep2) agree
- * to about 1e-8 m, not to the bit.
+ * to about 1e-8 m, not to the bit.  10: fp64-mode calls repeated without the sigma-following resolution of the E-step's sums because a share was
+ * refused under its finer range limits (the repeat runs under the coarse limits of every other mode; only its verdict is reported).
  * -1 for a null context or an unknown counter. */
 long long tdlo_debug_route_count(tdlo_ctx *ctx, int which);
 /* Phase stamps (s_memtime) of the last depth -> cloud launch's finishing workgroup; only a -DTDLO_CLOUD_STAMPS build writes them. */
@@ -514,6 +515,11 @@ int tdlo_set_timing(tdlo_ctx *ctx, int on);
  * wants every call to pay for that -- a benchmark that registers the same frame again and again -- turns it off.  Returns the
  * previous setting (or TDLO_E_INVALID). */
 int tdlo_set_sort_reuse(tdlo_ctx *ctx, int on);
+/* The one-shot exchange of tdlo_split_run with ONE rank bound (tdlo_xch_bind, nranks == 1): by default a lone rank has nobody to exchange with and the
+ * kernels skip the per-iteration exchange; on != 0: it stores to, flags and reads back its own inbox like any rank of a larger group (what the exchange
+ * itself costs on one GPU -- bench.py's self_exchange_iters_per_s; tests).  The same results either way, bit for bit.  Initial value: TDLO_XCH_SELF
+ * when the context was made.  Returns the previous setting. */
+int tdlo_set_xch_self(tdlo_ctx *ctx, int on);
 /* Development aid: copies the pruned, centred, node-sorted cloud of the last call (N x 3 column-major, widened to
  * double) and the centring offset; returns N. */
 int tdlo_debug_read_cloud(tdlo_ctx *ctx, int slot, double *out, int max_points, double *ctr);

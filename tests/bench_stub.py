@@ -23,6 +23,9 @@ class StubContext:
             self.clouds[slot] = (X, getattr(self, "version", 0))
             self.version = getattr(self, "version", 0) + 1
 
+    def set_xch_self(self, on):
+        return False
+
     def set_timing(self, on):
         return True
 

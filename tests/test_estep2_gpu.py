@@ -85,7 +85,7 @@ def test_estep2_committed_golden_cases(name):
 
 
 def test_estep2_is_chosen_by_size_and_never_for_what_it_does_not_take():
-    """Default selection (TDLO_ESTEP2 unset): k_estep2 for a cloud of at least 4096 x 64 points or a batch of that many in total, fp32 mode, chains of
+    """Default selection (TDLO_ESTEP2 unset): k_estep2 for a cloud of at least 2048 x 64 points or a batch of that many in total, fp32 mode, chains of
     8 .. 64 nodes; k_estep for everything else -- one 50 000-point frame (C2), fp64 mode, chains beyond 64 nodes."""
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
@@ -96,16 +96,16 @@ def test_estep2_is_chosen_by_size_and_never_for_what_it_does_not_take():
         try:
             X, Y0, _ = synth.scene(50000, 50, config=2)
             ctx.cpd_lle(X, Y0, 0.0, pr()); assert ctx.estep2_frames() == 0                                # C2: one frame that cannot fill the GPU
-            Xb, Yb, _ = synth.scene(262144, 50, config=4)
-            ctx.cpd_lle(Xb, Yb, 0.0, pr()); assert ctx.estep2_frames() == 1                               # 4096 waves of 64 points
+            Xb, Yb, _ = synth.scene(131072, 50, config=4)
+            ctx.cpd_lle(Xb, Yb, 0.0, pr()); assert ctx.estep2_frames() == 1                               # 2048 waves of 64 points: two per SIMD
             ctx.cpd_lle(Xb, Yb, 0.0, pr(precision=B.PREC_F64)); assert ctx.estep2_frames() == 1           # fp64 mode: k_estep
-            Xl, Yl, _ = synth.scene(262144, 80, config=4)
+            Xl, Yl, _ = synth.scene(131072, 80, config=4)
             ctx.cpd_lle(Xl, Yl, 0.0, pr()); assert ctx.estep2_frames() == 1                               # 80 nodes: k_estep
             for f in range(8):
                 ctx.set_cloud(f, synth.scene(40000, 50, config=3, frame=f)[0])
             Ys = [synth.scene(40000, 50, config=3, frame=f)[1] for f in range(8)]
             ctx.cpd_lle_batch(Ys, [0.0] * 8, pr()); assert ctx.estep2_frames() == 1 + 8                   # 8 x 625 = 5000 waves: the batch fills the GPU
-            ctx.cpd_lle_batch(Ys[:4], [0.0] * 4, pr()); assert ctx.estep2_frames() == 9                   # 2500 waves: it does not
+            ctx.cpd_lle_batch(Ys[:3], [0.0] * 3, pr()); assert ctx.estep2_frames() == 9                   # 1875 waves: it does not
         finally:
             ctx.close()
     finally:

@@ -31,7 +31,7 @@ def test_tracker_fuzz_block_of_25_sequences(block, prec):
     perturbation of nodes and H); `unexplained` must be 0.  An error on one side only (oracle / product) counts as a mismatch."""
     r = _harness("gpu_fuzz_tracker").run(25, 25 * block, prec, verbose=False)
     print(f"tracker fuzz block {block} prec {prec}: outside_stated {r['outside_stated']} / adjudicated {r['adjudicated']} / unexplained {r['unexplained']}")
-    assert r["bad"] == 0 and r["unexplained"] == 0, r
+    assert r["bad"] == 0 and r["unexplained"] == 0 and r.get("undecided", 0) <= max(2, r.get("compared", 0) // 50), r      # (an undecided oracle excuses nothing gross, and not often)
     assert r["frames"] >= 40, r            # (the sequences really ran: most of the 150 frames are compared)
 
 

@@ -1489,3 +1489,68 @@ def test_chains_beyond_512_nodes(oracle):
         np.testing.assert_array_equal(g["Y"], p["Y"])
     finally:
         ctx.close()
+
+
+def test_fp64_mode_repeats_without_the_boost_when_a_share_is_refused(oracle):
+    """ADVICE r05 (low): in fp64 mode the E-step's range check runs against limits that follow sigma (IterState::sh_boost); a share beyond them ended the
+    registration with TDLO_E_NUMERIC although the coarse limits of every other mode would have served it.  Now run_frames repeats such a call once
+    without the boost.  TDLO_TEST_BOOST_FAIL=1 treats every fp64-mode call's first attempt as such a refusal: the repeat (coarse limits) must hold the
+    fp64 gate against the oracle, count one retry per call, and leave fp32-mode calls alone."""
+    import os
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    X, Y0, v = synth.scene(6000, 45, config=81, occlude=(0.4, 0.6), outliers=5)
+    vext = synth.extend_visible(v, 45, synth.geodesic_coord(Y0))
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=25, tol=0.0, include_lle=False, alpha=0.0,
+              k_vis=P["k_vis"], visibility_threshold=P["visibility_threshold"])
+    o = oracle.cpd_lle(X, Y0, 0.0, visible_nodes=vext, **kw)
+    os.environ["TDLO_TEST_BOOST_FAIL"] = "1"
+    try:
+        ctx = B.Context(device=0)
+    finally:
+        os.environ.pop("TDLO_TEST_BOOST_FAIL", None)
+    try:
+        g = ctx.cpd_lle(X, Y0, 0.0, _params(kw, 1), visible_nodes=vext)
+        _check(g, o, 1)
+        assert int(ctx.lib.tdlo_debug_route_count(ctx.h, 10)) == 1
+        g32 = ctx.cpd_lle(X, Y0, 0.0, _params(kw, 0), visible_nodes=vext)
+        _check(g32, o, 0)
+        assert int(ctx.lib.tdlo_debug_route_count(ctx.h, 10)) == 1
+    finally:
+        ctx.close()
+
+
+def test_spin_ahead_loop_gives_the_ordinary_loops_bits(oracle):
+    """VERDICT r05 item 3, the experiment (TDLO_SPIN_AHEAD=1, off by default -- measured 45 % SLOWER than the dependent dispatches it replaces,
+    profiles/r06_spin_ahead_ab.txt): one frame's fixed-length loop with the E-steps on a second stream and every kernel parked on a device word until the
+    kernel it depends on has reported.  It must give the ordinary loop's bits (and therefore the oracle's nodes at the gate), call after call on two slots,
+    and leave calls it does not take (early exit, fp64 mode, the LLE term) to the ordinary loop."""
+    import os
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    N, M = 20000, 50
+    pairs = [synth.scene(N, M, config=2, frame=f)[:2] for f in range(2)]
+    kw = dict(beta=P["beta"], lambda_=P["lambda_"], lle_weight=P["lle_weight"], mu=P["mu"], max_iter=30, tol=0.0, include_lle=False, alpha=0.0, k_vis=0.0,
+              visibility_threshold=P["visibility_threshold"])
+    outs = {}
+    for mode in ("0", "1"):
+        os.environ["TDLO_SPIN_AHEAD"] = mode
+        try:
+            ctx = B.Context(device=0, max_frames=2, max_points=N, max_nodes=64, timing=False)
+        finally:
+            os.environ.pop("TDLO_SPIN_AHEAD", None)
+        try:
+            ctx.set_sort_reuse(False)
+            for k in (0, 1):
+                ctx.set_cloud(k, pairs[k][0])
+            outs[mode] = [ctx.cpd_lle_resident(k, pairs[k][1], 0.0, _params(kw, 0)) for k in (0, 1, 0, 1, 0)]
+            spins = int(ctx.lib.tdlo_debug_route_count(ctx.h, 11))
+            assert spins == (5 if mode == "1" else 0)
+            early = ctx.cpd_lle_resident(0, pairs[0][1], 0.0, _params(dict(kw, max_iter=50, tol=P["tol"]), 0))        # early exit: the ordinary loop
+            f64 = ctx.cpd_lle_resident(0, pairs[0][1], 0.0, _params(kw, 1))                                             # fp64 mode: the ordinary loop
+            assert int(ctx.lib.tdlo_debug_route_count(ctx.h, 11)) == spins and early["rc"] == 0 and f64["rc"] == 0
+        finally:
+            ctx.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a["Y"], b["Y"]) and a["sigma2"] == b["sigma2"] and a["iters"] == b["iters"] == 30
+    _check(outs["1"][0], oracle.cpd_lle(pairs[0][0], pairs[0][1], 0.0, **kw), 0)

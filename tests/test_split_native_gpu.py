@@ -49,12 +49,13 @@ def test_one_shot_exchange_single_rank_reproduces_the_plain_call(hip_ctx, vis_on
     hip_ctx.xch_bind(0, [hip_ctx.xch_create(1, 64)])
     try:
         for self_x in ("1", "0", "1"):
-            monkeypatch.setenv("TDLO_XCH_SELF", self_x)      # (read by tdlo_split_run per call)
+            hip_ctx.set_xch_self(self_x == "1")              # (a context setting: tdlo_set_xch_self)
             for _ in range(2):                              # twice: the epoch of the flags advances per registration
                 b = hip_ctx.split_run(Y0, 0.0, pr, visible_nodes=vext)
                 np.testing.assert_array_equal(a["Y"], b["Y"])
                 assert a["sigma2"] == b["sigma2"] and a["iters"] == b["iters"] and a["converged"] == b["converged"] and a["n_kept"] == b["n_kept"]
     finally:
+        hip_ctx.set_xch_self(False)
         hip_ctx.lib.tdlo_xch_bind(hip_ctx.h, 0, 0, None)
 
 

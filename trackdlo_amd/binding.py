@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_tracker_frame_from_depth", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_set_xch_self", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_tracker_frame_from_depth", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg", "tdlo_self_occlusion_visible", "tdlo_extend_visible_nodes", "tdlo_tracker_set_self_occlusion",
 ]
 
@@ -187,6 +187,8 @@ def load_library(path: str | None = None):
     lib.tdlo_set_timing.restype = ci
     lib.tdlo_set_sort_reuse.argtypes = [vp, ci]
     lib.tdlo_set_sort_reuse.restype = ci
+    lib.tdlo_set_xch_self.argtypes = [vp, ci]
+    lib.tdlo_set_xch_self.restype = ci
     lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
     lib.tdlo_piecewise_error.restype = cd
     lib.tdlo_piecewise_error.argtypes = [vp, ci, vp, ci]
@@ -287,6 +289,10 @@ class Context:
             raise TdloError(err.value, "tdlo_create failed (no usable gfx950 device? there is no CPU fallback)")
         self.max_frames = max_frames
         self.set_timing(timing)
+
+    def set_xch_self(self, on):
+        """A lone rank of the one-shot exchange exchanges with its own inbox instead of skipping the exchange (tdlo_set_xch_self); returns the previous setting."""
+        return bool(self.lib.tdlo_set_xch_self(self.h, 1 if on else 0))
 
     def set_timing(self, on):
         return bool(self.lib.tdlo_set_timing(self.h, 1 if on else 0))

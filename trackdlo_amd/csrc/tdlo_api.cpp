@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 using namespace tdlo;
@@ -28,10 +29,12 @@ namespace {
 constexpr int kMaxEstepBlocks = 4096;      // (upper bound of TDLO_ESTEP_BLOCKS / tdlo_config.estep_blocks; the defaults are 512 and 1024)
 constexpr int kBatchStreams = 4;       // streams a batch of frames is spread over (run_frames); more than 4 lose (measured: 6 or 8 fall below one stream)
 constexpr int kIterHintMax = 8;        // tdlo_ctx::iter_hint: at most this many iterations go out before the host first looks
+constexpr int kEstep2MinWaves = 2048;   // 64-point batches of a cloud (or of a batch's frames together) from which the E-step is k_estep2 (two points per lane): two waves per SIMD
 constexpr int kChunkIters = 4;          // EM iterations per early-exit polling chunk; the first chunks are shorter (1, 1, 2):
                                         // a tracker in steady state converges in one or two iterations
 
 struct Slot {
+    unsigned spin_ecount = 0, spin_mtag = 0;      // the spin-ahead loop's running counts (FrameDev::spin_wait / spin_signal): E-step workgroups reported, M-steps tagged
     // cloud-sized
     int cap_points = 0;
     int N0 = 0;
@@ -149,6 +152,17 @@ struct tdlo_ctx {
     size_t xfer_doubles = 0;
     hipStream_t stream2[kBatchStreams - 1] = {};   // further groups of a batch: their E-steps overlap another group's one-workgroup-per-frame M-step
     hipEvent_t evx[kBatchStreams] = {}, evj[kBatchStreams] = {};   // fork / join of the batch groups
+    // chained E-steps of a batch's stream groups (run_frames): group g's E-step of iteration k goes out behind group g-1's (an event per group and
+    // iteration, a ring of kChainRing): the groups' E-steps then run ONE AFTER THE OTHER, each with the GPU to itself, beside the other groups' M-steps.
+    // Left to themselves the groups lock into whatever phase the first iteration gave them -- E-steps on top of each other, then a stretch with
+    // nothing but M-steps (scripts/gpu_c3_timeline.sh).  Round 6 experiment, TDLO_BATCH_CHAIN=1 switches it on: the events and the host threads waiting for
+    // each other cost more than the phase is worth.
+    static constexpr int kChainRing = 8;
+    hipEvent_t evc[kBatchStreams][kChainRing] = {};
+    // 0 (default): never.  1: every iteration -- measured SLOWER, 0.90 - 0.96 M against 1.21 - 1.24 M it/s at C3: the events and the enqueueing threads waiting
+    // for each other cost more than the phase is worth.  2: only at four iterations of the call (two groups of equal work that overlap slow each other down
+    // equally, so a phase once set should persist) -- 1.18 - 1.21 M against 1.23 M: no gain either (profiles/r06_measured.log).  Kept as comparators.
+    int batch_chain = getenv("TDLO_BATCH_CHAIN") ? atoi(getenv("TDLO_BATCH_CHAIN")) : 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0..3 timing, 4..5 early-exit polling
     tdlo_config cfg{};
     std::vector<Slot> slots;
@@ -258,6 +272,14 @@ struct tdlo_ctx {
     int estep2_mode = getenv("TDLO_ESTEP2") ? atoi(getenv("TDLO_ESTEP2")) : -1;
     int estep2_rows = (getenv("TDLO_ESTEP2_ROWS") && atoi(getenv("TDLO_ESTEP2_ROWS")) == 16) ? 16 : 8;
     int estep2_blocks = getenv("TDLO_ESTEP2_BLOCKS") ? atoi(getenv("TDLO_ESTEP2_BLOCKS")) : 0;
+    bool xch_self = getenv("TDLO_XCH_SELF") && atoi(getenv("TDLO_XCH_SELF")) != 0;      // a lone rank of the one-shot exchange exchanges with its own inbox (tdlo_set_xch_self)
+    bool boost_off_once = false;          // run_frames' retry: an fp64-mode E-step refused a share under the sigma-following (finer) limits -- this call repeats with the coarse ones
+    long long boost_retries = 0;          // how often that happened (tdlo_debug_route_count 10)
+    bool test_boost_fail = getenv("TDLO_TEST_BOOST_FAIL") && atoi(getenv("TDLO_TEST_BOOST_FAIL")) != 0;   // test hook: every fp64-mode call's first attempt is treated as such a refusal
+    // Round 6 experiment, OFF by default: one frame's fixed-length loop as a spin-ahead loop -- E-steps on the second stream, M-steps on
+    // the first, the kernels parked on device words instead of the streams' dependent dispatches (FrameDev::spin_on).  TDLO_SPIN_AHEAD=1 switches it on.
+    bool spin_ahead_on = getenv("TDLO_SPIN_AHEAD") && atoi(getenv("TDLO_SPIN_AHEAD")) != 0;
+    long long spin_calls = 0;             // registrations run that way (tdlo_debug_route_count 11)
     long long estep2_frames = 0;          // registrations whose E-step was k_estep2 (tdlo_debug_route_count 9)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
@@ -780,8 +802,10 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         const int lshare = std::min(51, 67 - std::max(ln, 6)), lpoint = std::min(51, 61 - ln);
         f.acc_lim[0] = std::ldexp(1.0, lshare - f.acc_sh[0]); f.acc_lim[1] = std::ldexp(1.0, lshare - f.acc_sh[1]); f.acc_lim[2] = std::ldexp(1.0, lpoint - f.acc_sh[2]);
     }
-    // one frame whose cloud fills the GPU alone (where k_estep leaves the 64-row tile: 4096 waves of 64 points): two points per lane
-    if (estep2_eligible(c, f) && (c->estep2_mode == 1 || nbatch >= 4096)) estep2_geometry(c, f, false);
+    f.acc_boost_off = c->boost_off_once ? 1 : 0;
+    // one frame whose cloud fills the GPU alone (2048 waves of 64 points: from there on two points per lane win, scripts/gpu_estep2_check.py /
+    // profiles/r06_measured.log -- 131 072 points 4.8 against 5.3 us per E-step, 250 000 points (a shard of C4 on eight ranks) 5.5 against 7.3 us)
+    if (estep2_eligible(c, f) && (c->estep2_mode == 1 || nbatch >= kEstep2MinWaves)) estep2_geometry(c, f, false);
     f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
     f.sync = s.sync;
     f.st = (IterState *)(blk + nc.st);
@@ -942,7 +966,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         long long waves = 0;
         bool elig = true;
         for (int i = 0; i < F; ++i) { waves += (c->fh[i].N0 + 63) / 64; elig = elig && estep2_eligible(c, c->fh[i]); }
-        const bool two = elig && (c->estep2_mode == 1 || waves >= 4096);
+        const bool two = elig && (c->estep2_mode == 1 || waves >= kEstep2MinWaves);
         for (int i = 0; i < F; ++i) if (two) estep2_geometry(c, c->fh[i], true);      // (a frame prepare_frame had given to k_estep2 on its own size keeps it only if the whole batch does:
         if (!two) for (int i = 0; i < F; ++i) if (c->fh[i].estep2) return fail(c, TDLO_E_INVALID, "internal: a batch's frames disagree about the E-step kernel");   //  same M, precision and mode -- they cannot)
     }
@@ -1088,9 +1112,24 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
     int enqueued = 0;                                  // iterations this call has put on the stream (or released)
     // test hook: the M-step launched ahead is told to leave instead of being released, as if it had given up waiting (2 s without the host)
     const bool spec_force_timeout = c->spec_force_timeout;
+    // the spin-ahead loop (experiment): ONE frame, fixed iteration count, fp32 mode, the chain smoother on up to 63 nodes, no visibility term, results through the mailbox
+    const bool spin_mode = c->spin_ahead_on && !merged && F == 1 && !paired && !ahead && late == nullptr && use_mbox && !timing && p->precision == TDLO_PREC_F32 &&
+                           !p->include_lle && !c->fh[0].mstep_dense && !c->fh[0].vis_branch && c->fh[0].wide_tile != 0 && c->fh[0].estep2 == 0 && 4 * M + 1 <= 256 &&
+                           (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) && p->max_iter > 0;
+    if (spin_mode) {
+        if (!c->stream2[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2[0], hipStreamNonBlocking));
+        HIPCHK(c, hipEventRecord(c->evx[0], s));                       // the first E-step behind the prologue; every later one behind its M-step's tag
+        HIPCHK(c, hipStreamWaitEvent(c->stream2[0], c->evx[0], 0));
+        ++c->spin_calls;
+    }
     auto iterate = [&](int n) -> hipError_t {
         for (int it = 0; it < n; ++it) {
             ++enqueued;
+            if (spin_mode) {
+                Slot &sl = c->slots[slots[0]];
+                TDLO_RET(launch_iteration_spin(fdp, c->fh.data(), c->stream2[0], s, enqueued == 1, &sl.spin_ecount, &sl.spin_mtag));
+                continue;
+            }
             if (sums_first || ahead_first) {
                 const bool from_given = sums_first;
                 sums_first = false; ahead_first = false;
@@ -1169,11 +1208,45 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             HIPCHK(c, iterate(1));
             if (!c->pool) { c->pool = new EnqueuePool; c->pool->start(kBatchStreams - 1, c->device); }
             const int rest = p->max_iter - 1;
+            const bool chain = c->batch_chain != 0 && !c->fh[0].vis_branch;
+            const bool chain_all = c->batch_chain == 1;
+            auto chain_at = [&](int it) { return chain_all || it == 4 || it == 10 || it == 22 || it == 34; };      // (iterations of the enqueueing loop: the call's iteration it + 1)
+            if (chain)
+                for (int g = 0; g < NS; ++g) for (int r = 0; r < tdlo_ctx::kChainRing; ++r)
+                    if (!c->evc[g][r]) HIPCHK(c, hipEventCreateWithFlags(&c->evc[g][r], hipEventDisableTiming));
+            // (chain) how far every group's enqueueing thread has come: recorded[g] = iterations whose E-step event group g has recorded, waited[g] =
+            // iterations whose event of group g-1 group g has put a wait on -- a thread records event it % ring only when the group behind it has
+            // put its wait on the record of iteration it - ring, and waits on an event only when it has been recorded for this iteration
+            std::atomic<int> recorded[kBatchStreams], waited[kBatchStreams];
+            std::atomic<bool> broken{false};
+            for (int g = 0; g < kBatchStreams; ++g) { recorded[g].store(0); waited[g].store(0); }
             const int prc = c->pool->run([&](int g) -> int {
                 if (g >= NS) return 0;
                 const FrameDev *fdg = fdp + goff[g], *fhg = c->fh.data() + goff[g];
                 const int Fg = goff[g + 1] - goff[g];
-                for (int it = 0; it < rest; ++it) { const hipError_t e = launch_iteration(fdg, fhg, Fg, gs[g]); if (e != hipSuccess) return (int)e; }
+                if (!chain) {
+                    for (int it = 0; it < rest; ++it) { const hipError_t e = launch_iteration(fdg, fhg, Fg, gs[g]); if (e != hipSuccess) return (int)e; }
+                    return 0;
+                }
+                auto bail = [&](hipError_t e) { broken.store(true); return (int)e; };
+                for (int it = 0; it < rest; ++it) {
+                    hipError_t e;
+                    if (!chain_at(it)) { if ((e = launch_iteration(fdg, fhg, Fg, gs[g])) != hipSuccess) return bail(e); continue; }
+                    // (the event of a chained iteration: every iteration -> a ring with the hazard check below; the four phase-setting iterations -> one event each)
+                    const int slot = chain_all ? it % tdlo_ctx::kChainRing : (it == 4 ? 0 : (it == 10 ? 1 : (it == 22 ? 2 : 3)));
+                    if (g > 0) {            // behind the E-step of the group in front, same iteration
+                        while (recorded[g - 1].load(std::memory_order_acquire) <= it) { if (broken.load()) return 0; std::this_thread::yield(); }
+                        if ((e = hipStreamWaitEvent(gs[g], c->evc[g - 1][slot], 0)) != hipSuccess) return bail(e);
+                        waited[g].store(it + 1, std::memory_order_release);
+                    }
+                    if ((e = launch_estep_only(fdg, fhg, Fg, 0, gs[g])) != hipSuccess) return bail(e);
+                    if (g + 1 < NS) {
+                        while (chain_all && waited[g + 1].load(std::memory_order_acquire) < it + 1 - tdlo_ctx::kChainRing) { if (broken.load()) return 0; std::this_thread::yield(); }
+                        if ((e = hipEventRecord(c->evc[g][slot], gs[g])) != hipSuccess) return bail(e);
+                        recorded[g].store(it + 1, std::memory_order_release);
+                    }
+                    if ((e = launch_estep_only(fdg, fhg, Fg, 2, gs[g])) != hipSuccess) return bail(e);
+                }
                 return 0;
             });
             if (prc) return fail(c, TDLO_E_HIP, std::string("batch enqueue: ") + hipGetErrorString((hipError_t)prc));
@@ -1320,6 +1393,28 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             return rr;
         }
     }
+    // fp64 mode: the E-step's range check runs against limits that follow sigma (IterState::sh_boost: finer sums while sigma is small).  The extent
+    // behind them is a heuristic (D_eff = 2 (0.4 m + 2 sigma)): a registration whose shares exceed it -- nodes dragged far by priors while sigma is
+    // small -- would have passed under the coarse limits.  It is not failed for the boost: the call is repeated ONCE without it (inputs, Y, sigma2
+    // untouched so far), and only that verdict is reported.
+    if (p->precision == TDLO_PREC_F64 && !c->boost_off_once && p->max_iter > 0) {
+        bool numeric = c->test_boost_fail;
+        for (int i = 0; i < F && !numeric; ++i) {
+            IterState is;
+            std::memcpy(&is, c->pin + (size_t)i * rstride + (nc.st - nc.Yout), sizeof is);
+            numeric = is.status == TDLO_E_NUMERIC;
+        }
+        if (numeric) {
+            if (c->pair.ahead) { spec_abort(c); c->pair.state = 0; c->pair.ahead = false; }
+            else c->pair.spec = 0;
+            c->boost_off_once = true;
+            ++c->boost_retries;
+            for (int i = 0; i < F; ++i) c->slots[slots[i]].sorted_valid = false;
+            const int rr = run_frames(c, F, slots, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats, late);      // (late priors: formed again from the same guide nodes)
+            c->boost_off_once = false;
+            return rr;
+        }
+    }
     float loop_ms = 0, total_ms = 0;
     if (timing) { hipEventElapsedTime(&loop_ms, c->ev[1], c->ev[2]); hipEventElapsedTime(&total_ms, c->ev[0], c->ev[3]); }
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
@@ -1452,6 +1547,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     if (c->own_comm) { const RcclApi *r = rccl_api(nullptr, nullptr); if (r) r->CommDestroy(c->own_comm); }
     for (auto &e : c->evx) if (e) hipEventDestroy(e);
     for (auto &e : c->evj) if (e) hipEventDestroy(e);
+    for (auto &row : c->evc) for (auto &e : row) if (e) hipEventDestroy(e);
     for (auto &q : c->stream2) if (q) hipStreamDestroy(q);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1878,7 +1974,7 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     if (oneshot) {
         for (int r = 0; r < kMaxXchRanks; ++r) f.xch_inbox[r] = c->xch_peer[r];
         f.xch_rank = c->xch_rank; f.xch_nranks = c->xch_nranks; f.xch_mcap = c->xch_mcap; f.xch_epoch = ++c->xch_calls;
-        { const char *e = getenv("TDLO_XCH_SELF"); f.xch_self = (e && atoi(e)) ? 1 : 0; }      // (read per call: a test switches it between two calls)
+        f.xch_self = c->xch_self ? 1 : 0;          // a context setting (tdlo_set_xch_self; TDLO_XCH_SELF gives its initial value when the context is made)
         {   // test hook (tests/test_split_native_gpu.py): rank r's E-step refuses every sum as out of range -- an error of ONE shard, which its
             // peers must learn about inside the exchange (kXchErrMark) instead of waiting out the time limit
             static const int fail_rank = getenv("TDLO_TEST_RANGE_FAIL_RANK") ? atoi(getenv("TDLO_TEST_RANGE_FAIL_RANK")) : -1;
@@ -2504,7 +2600,9 @@ int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
 long long tdlo_debug_route_count(tdlo_ctx *c, int which) {
-    if (!c || which < 0 || which > 9) return -1;
+    if (!c || which < 0 || which > 11) return -1;
+    if (which == 11) return c->spin_calls;
+    if (which == 10) return c->boost_retries;
     if (which == 9) return c->estep2_frames;
     if (which == 8) return c->cloud_vis_rides;
     return which < 6 ? c->route_count[which] : c->cloud_route[which - 6];
@@ -2529,6 +2627,13 @@ int tdlo_debug_fail_hip(tdlo_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(nullptr, nullptr, 16, hipMemcpyDeviceToDevice));      // hipErrorInvalidValue
     return TDLO_OK;
+}
+
+int tdlo_set_xch_self(tdlo_ctx *c, int on) {
+    if (!c) return TDLO_E_INVALID;
+    const int prev = c->xch_self ? 1 : 0;
+    c->xch_self = on != 0;
+    return prev;
 }
 
 int tdlo_set_sort_reuse(tdlo_ctx *c, int on) {

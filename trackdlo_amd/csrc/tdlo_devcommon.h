@@ -291,7 +291,7 @@ __device__ __forceinline__ void set_iter_consts(const FrameDev &f, IterState *st
     // E-step still CHECKS every share against the (finer) limit.  With lambda sigma2 ~ 1e-5 (lambda = 1 without the LLE term) the coarse resolution, 2^-39 m
     // per share on a chain of 460 nodes, had put nodes 1e-8 m from the oracle's (profiles/r05_fuzz.log); fp32 mode's tile sums carry 1e-7 relative anyway.
     int boost = 0;
-    if (f.precision == TDLO_PREC_F64 && sigma2 > 0.0) {
+    if (f.precision == TDLO_PREC_F64 && !f.acc_boost_off && sigma2 > 0.0) {
         const int ld = f.acc_sh[0] - f.acc_sh[1];
         const double deff = 2.0 * (0.4 + 2.0 * ::sqrt(sigma2));
         int lde = 0;                                   // (D_eff >= 0.8: 2^0 is the smallest extent there is)
@@ -432,6 +432,16 @@ __device__ __forceinline__ void host_publish(const FrameDev &f, IterState *st, i
     if (lane == 0)
         __hip_atomic_store(f.host_prog, ((unsigned long long)f.host_epoch << 32) | ((unsigned long long)(done ? 1u : 0u) << 31) | (unsigned)(it & 0x7fffffff),
                            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- spin-ahead loop (FrameDev::spin_on): bounded wait of ONE thread for a word of `sync` to take a value (agent scope); false: 2 s passed
+__device__ __forceinline__ bool spin_wait_word(const unsigned *word, unsigned want) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) return false;
+    }
+    return true;
 }
 
 // ---- one-shot exchange of the N-split: peer-written inboxes (xGMI peer stores on a multi-GPU node), system scope ---------

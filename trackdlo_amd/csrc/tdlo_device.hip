@@ -964,7 +964,41 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const auto nodes = TDLO_AS_CONST(V4<T>, f.nodes);
     const auto xs = TDLO_AS_GLOBAL(T, f.Xs);
     const size_t ld = f.ldx;
-    // first wave of loads: iteration state, this wave's first points, nodes for the LDS copy
+    // first wave of loads: this wave's first points, iteration state, nodes for the LDS copy
+    const int batch0 = blockIdx.x * NWE + wave;
+    T x = 0, y = 0, z = 0;
+    {
+        const int n = batch0 * 64 + lane;
+        if (n < f.N0) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }     // N <= N0: always in bounds
+    }
+    // spin-ahead loop (FrameDev::spin_on; one frame, fp32, up to 64 nodes, no visibility term): this launch was dispatched while the M-step in front of
+    // it still runs -- the points above are on their way, everything the M-step writes (state, nodes) is read behind the wait
+    constexpr bool SPINNABLE = SINGLE && NCH == 1 && sizeof(T) == 4 && !VIS;
+    const bool spin = SPINNABLE && f.spin_on != 0;
+    bool spin_lost = false;
+    if (spin) {
+        if (!f.spin_first) {
+            int *okl = (int *)scratch;
+            if (tid == 0) *okl = spin_wait_word(f.sync + kSpinWordM, f.spin_wait) ? 1 : 0;
+            __syncthreads();
+            spin_lost = *okl == 0;
+            __syncthreads();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_dcache_inv();          // the nodes come through scalar loads: lines of the previous iteration's nodes may sit in the scalar cache
+    }
+    // every workgroup of a spin-ahead launch reports itself when it is through, whatever way it leaves (the M-step behind it counts them)
+    auto spin_report = [&]() {
+        if (!spin) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // this thread's atomics on the accumulators have been performed
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(f.sync + kSpinWordE, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (spin_lost) {      // the M-step in front never reported (2 s): the registration ends with an error; the count still goes up so that nothing behind waits in turn
+        if (tid == 0) { IterState *sw = f.st; sw->status = TDLO_E_EXCHANGE; sw->converged = 0; sw->done = 1; }
+        spin_report();
+        return;
+    }
     const int done = stg->done;
     if (SINGLE && f.late_aJ != nullptr && f.late_mstep == 0 && blockIdx.x == 0 && stg->it == 0) {
         // (tracking_step's second registration) the priors the host formed while the set-up kernel ran: to their place in the node block, for the
@@ -976,14 +1010,8 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const int N = stg->N;
     const T k2 = (T)stg->k2;
     const T cn = (T)stg->c_norm;
-    const int batch0 = blockIdx.x * NWE + wave;
-    T x = 0, y = 0, z = 0;
-    {
-        const int n = batch0 * 64 + lane;
-        if (n < f.N0) { x = xs[n]; y = xs[ld + n]; z = xs[2 * ld + n]; }     // N <= N0: always in bounds
-    }
     for (int m = tid; m < M; m += EB) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
-    if (done) return;
+    if (done) { spin_report(); return; }
     double lv_span = 0;      // VIS: the largest -log2 v_m + log2 v_m' over the nodes -- how far the visibility weights can lower a nearest node's membership against another's
     if (VIS) {
         // P_vis rows, :362-372: v_m = exp(-k_vis * dmin_m) / sum, folded into the exponent as log2 v_m
@@ -1024,6 +1052,8 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     // every converted value is checked against its limit (FrameDev::acc_lim: exact conversion, no wrap-around of the totals; a NaN fails
     // the comparison too): one compare per conversion into a lane mask, looked at once per wave at the end
     const double limP = f.acc_lim[0], limR = f.acc_lim[1] * acc_scale(-shb), limQ = f.acc_lim[2] * acc_scale(-2 * shb);
+    // (a node's share of Q -- the column sums' tail -- is one conversion for up to a batch's points: held to the conversion's own exactness bound, 2^51 units)
+    const double limQn = acc_scale(51 - (f.acc_sh[2] + 2 * shb));
     bool acc_ok = true;
     // NCH == 1 (M <= 64): windowed variant.  The cloud is sorted by nearest node, so the 64 points of a
     // wave sit on a short piece of the chain, and every membership whose exponent is below -151 (fp32;
@@ -1153,9 +1183,23 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 
         // ---- node window of this wave
         int wlo = 0, whi = M - 1;
+        // fp64 (round 6): the range of the nearest pairs' INDICES and "some point has the end-node gap" go through one folded butterfly of 32-bit keys
+        // (the coordinates of the range's ends are looked up: coord is non-decreasing) instead of two more fp64 wave reductions, and they let the
+        // membership loop take the nodes below every point's lo / above every point's hi without a per-point decision (k_estep2's scheme)
+        int min_lo = 0, max_hi = M - 1;
+        bool gap_any = true;
         {
             T amin, amax, bmx;                                                                                          // coord >= 0
-            wave_min_max_max_nonneg(valid ? c_lo : Num<T>::inf(), valid ? c_hi : T(0), valid ? best : T(0), amin, amax, bmx);   // (three reductions, one folded butterfly)
+            if constexpr (sizeof(T) == 8) {
+                const unsigned klo = valid ? (unsigned)(kMaxNodes - lo) : 0u, khi = valid ? (unsigned)hi : 0u, kgap = (valid && hi - lo != 1) ? 1u : 0u;
+                const unsigned zz = rows_max_u32(fold16_max(fold32_max(klo, khi), fold32_max(kgap, kgap)));
+                min_lo = kMaxNodes - __builtin_amdgcn_readlane((int)zz, 15); max_hi = __builtin_amdgcn_readlane((int)zz, 47);
+                gap_any = __builtin_amdgcn_readlane((int)zz, 31) != 0;
+                bmx = wave_max_nonneg(valid ? best : T(0));
+                amin = nodesL[min_lo].w; amax = nodesL[max_hi].w;
+            } else {
+                wave_min_max_max_nonneg(valid ? c_lo : Num<T>::inf(), valid ? c_hi : T(0), valid ? best : T(0), amin, amax, bmx);   // (three reductions, one folded butterfly)
+            }
             const T Rwin = Num<T>::sqrt_fast(bmx + R2win);
             int first = M, last = -1;
 #pragma unroll
@@ -1176,9 +1220,29 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         EPHASE(3);
         // ---- unnormalised membership, column sum, Q (:354-383)
         // adj: no point of this wave has the end-node gap (hi == lo + 2), the cheaper form of the exponent applies
-        const bool adj = __ballot(valid && hi - lo != 1) == 0;
+        const bool adj = sizeof(T) == 8 ? !gap_any : __ballot(valid && hi - lo != 1) == 0;
         T sum = 0, qs = 0;
+        // fp64: the argument of the exponent without a per-point decision for the nodes at or below every point's lo (m <= min_lo) and at or above
+        // every point's hi (m >= max_hi) -- wave-uniform branches; the per-point form in between (and everywhere when a pair has the end-node gap)
+        auto geo64 = [&](int m, T cm) -> T {
+            if (adj) {
+                if (m <= min_lo) { const T t = (c_lo - cm) + d_lo; return t * t; }
+                if (m >= max_hi) { const T t = (cm - c_hi) + d_hi; return t * t; }
+                return geo_arg_adj<T>(m, lo, cm, c_lo, d_lo, c_hi, d_hi);
+            }
+            return geo_arg<T>(m, lo, hi, cm, c_lo, d_lo, c_hi, d_hi);
+        };
         auto member = [&](const V4<T> &q, int m, auto ADJ, auto STORE) {
+            if constexpr (sizeof(T) == 8) {
+                // (fp64, round 6) Q is not accumulated pair by pair: with the wave's origin o, sum_m P_mn |x_n - y_m|^2 = Pt1_n |x_n - o|^2 + the nodes' part
+                // sum_mk d_mk (s_mk + R_mk), d = o - y_m, formed in the column sums' fixed-point tail from the very sums it converts (k_estep2 has the algebra;
+                // in fp64 the three parts' cancellation costs nothing that matters at the mode's 1e-7)
+                T e = geo64(m, q.w) * k2;
+                if (VIS) e += lvL[m];
+                const T p = Num<T>::exp2(e);
+                sum += p;
+                if (decltype(STORE)::value) pb[(m - wlo) * kPStride + lane] = p;
+            } else {
             T e = (decltype(ADJ)::value ? geo_arg_adj<T>(m, lo, q.w, c_lo, d_lo, c_hi, d_hi) : geo_arg<T>(m, lo, hi, q.w, c_lo, d_lo, c_hi, d_hi)) * k2;
             if (VIS) e += lvL[m];
             const T p = Num<T>::exp2(e);
@@ -1187,6 +1251,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             sum += p;
             qs += p * d2;
             if (decltype(STORE)::value) pb[(m - wlo) * kPStride + lane] = p;          // the chunks of the window that fit the tile
+            }
         };
         // [from, to] in groups of 4 nodes: scalar loads first (clamped index), evaluations beyond `to` skipped wave-uniformly
         auto span = [&](int from, int to, auto ADJ, auto STORE) {
@@ -1218,11 +1283,12 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         ESTAMP(4);
         EPHASE(4);
         const T inv = valid ? Num<T>::rcp_fast(sum + cn) : T(0);
-        { const double qv = (double)(inv * qs); acc_ok &= __builtin_fabs(qv) < limQ; accQ += acc_fix(qv, scQ); }
         // column sums are taken relative to a wave-local origin (lane 0's point; the sorted cloud keeps a
         // wave's points within centimetres) and leave as the residual R_m = sum_n P_mn (x_n - y_m):
         // small numbers, so fp32 tile sums lose nothing that matters (everything after a tile's sums is 64-bit fixed point)
         const T ox = bcast_first(x), oy = bcast_first(y), oz = bcast_first(z);
+        if constexpr (sizeof(T) == 8) { const T ux = x - ox, uy = y - oy, uz = z - oz; qs = sum * (ux * ux + uy * uy + uz * uz); }      // Pt1_n |x_n - o|^2 (Pt1 = inv * sum)
+        { const double qv = (double)(inv * qs); acc_ok &= __builtin_fabs(qv) < limQ; accQ += acc_fix(qv, scQ); }
         V4<T> pw; pw.x = inv; pw.y = inv * (x - ox); pw.z = inv * (y - oy); pw.w = inv * (z - oz);     // (s0, sx) and (sy, sz) pair up for v_pk_fma
         // one entry of padding after every 16 points: the column sums below read 16-point slices with all lanes of a slice on one
         // address (broadcast), and a ds_read_b128 serves 16 lanes that straddle two slices at a time -- 256 bytes apart they fall
@@ -1246,7 +1312,9 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 #pragma unroll 4
                 for (int m = wlo_c; m < wlo_c + Wn; ++m) {
                     const T cm = nodes[m].w;
-                    T e = (adj ? geo_arg_adj<T>(m, lo, cm, c_lo, d_lo, c_hi, d_hi) : geo_arg<T>(m, lo, hi, cm, c_lo, d_lo, c_hi, d_hi)) * k2;
+                    T e;
+                    if constexpr (sizeof(T) == 8) e = geo64(m, cm) * k2;
+                    else e = (adj ? geo_arg_adj<T>(m, lo, cm, c_lo, d_lo, c_hi, d_hi) : geo_arg<T>(m, lo, hi, cm, c_lo, d_lo, c_hi, d_hi)) * k2;
                     if (VIS) e += lvL[m];
                     pb[(m - wlo_c) * kPStride + lane] = Num<T>::exp2(e);
                 }
@@ -1364,6 +1432,10 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
                     acc_ok &= !mine || __builtin_fabs(val) < (gp ? limP : limR);
                     // (ds_add_u64 without return: one LDS instruction per value instead of read, 64-bit add, write)
                     if (mine) __hip_atomic_fetch_add(acn + k, acc_fix(val, gp ? scP : scR), __ATOMIC_RELAXED, NCH == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (sizeof(T) == 8) {      // the nodes' part of Q: d (s + R) per (node, coordinate); the P1 lanes add nothing of it
+                        const double dq = (mine && !gp) ? d * (a + val) : 0.0;
+                        acc_ok &= __builtin_fabs(dq) < limQn; accQ += acc_fix(dq, scQ);
+                    }
                 }
                 wave_lds_sync();
             }
@@ -1409,6 +1481,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         for (int w = 0; w < NWE; ++w) q += iscr[w];
         acc_add(arow, 4 * M, q);
     }
+    spin_report();
     ESTAMP(7);
     EPHASE(7);
 #ifdef TDLO_TIMELINE
@@ -2200,6 +2273,18 @@ hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipSt
     if (fh[0].vis_branch) TDLO_TRY(f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s));
+    return hipSuccess;
+}
+
+hipError_t launch_iteration_spin(const FrameDev *fd, FrameDev *fh, hipStream_t s_e, hipStream_t s_m, bool first, unsigned *ecount, unsigned *mtag) {
+    FrameDev &f = fh[0];
+    f.spin_on = 1;
+    f.spin_first = first ? 1 : 0; f.spin_wait = *mtag; f.spin_signal = 0;             // E-step: behind the M-step that stored the tag in front of it
+    TDLO_TRY(launch_estep_T<float>(fd, fh, 1, s_e));
+    *ecount += (unsigned)f.nblkE;
+    f.spin_first = 0; f.spin_wait = *ecount; f.spin_signal = ++*mtag;                  // M-step: behind every workgroup of that E-step
+    TDLO_TRY(launch_mstep_chain(fd, fh, 1, 0, false, s_m));
+    f.spin_on = 0;
     return hipSuccess;
 }
 

@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
     const int shb = stg->sh_boost;
     const double scP = acc_scale(f.acc_sh[0]), scR = acc_scale(f.acc_sh[1] + shb), scQ = acc_scale(f.acc_sh[2] + 2 * shb);
     const double limP = f.acc_lim[0], limR = f.acc_lim[1] * acc_scale(-shb), limQ = f.acc_lim[2] * acc_scale(-2 * shb);
+    // (a node's share of Q -- the column sums' tail -- is one conversion for up to a batch's points: held to the conversion's own exactness bound, 2^51 units)
+    const double limQn = acc_scale(51 - (f.acc_sh[2] + 2 * shb));
     bool acc_ok = true;
     // node window (k_estep: E / |k2|, widened by what the visibility weights can take from a nearest node's membership)
     const float R2win = (float)(stg->rwin32 * (1.0 + (VIS ? lv_span / f.win_e32 : 0.0)));
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
                     if (mine) __hip_atomic_fetch_add(acn + k, acc_fix(val, gp ? scP : scR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     {   // the nodes' part of Q: d (s + R) per (node, coordinate) -- the P1 lanes have d = 1, a = 0 and add nothing of it
                         const double dq = (mine && !gp) ? d * (a + val) : 0.0;
-                        acc_ok &= __builtin_fabs(dq) < limQ; accQ += acc_fix(dq, scQ);
+                        acc_ok &= __builtin_fabs(dq) < limQn; accQ += acc_fix(dq, scQ);
                     }
                     wave_lds_sync();
                 }

@@ -161,7 +161,20 @@ struct FrameDev {
     // 0: k_estep (one point per lane, tdlo_device.hip); 8 / 16: k_estep2 (two points per lane, tdlo_estep2.hip) with that many tile rows -- clouds
     // and batches that fill the GPU, fp32 mode, chains of 8 .. 64 nodes (prepare_frame / run_frames; the same value in every frame of a launch)
     int estep2;
+    // fp64 mode: 1 = the sums' resolution does NOT follow sigma (IterState::sh_boost stays 0): the call is the repeat of one whose E-step refused a share
+    // under the finer limits (run_frames: a registration that the coarse limits of rounds 1-4 would have served must not fail on the boost)
+    int acc_boost_off;
+    // The spin-ahead loop of ONE frame (round 6 experiment, TDLO_SPIN_AHEAD=1; run_frames): the E-steps go to a second stream, the M-steps stay on the
+    // first, everything is enqueued up front, and the kernels order themselves through two words of `sync` -- E-step k+1 is dispatched while M-step k still
+    // runs, requests its first points and parks on word 110 until that M-step stores its tag there; M-step k+1 is dispatched behind M-step k, requests
+    // everything that does not come from the E-step and parks on word 111 until the E-step's workgroups have all added themselves to it.  The tags are
+    // the host's running counts (unsigned, compared for equality: no reset between registrations).  Every wait is bounded (2 s -> TDLO_E_EXCHANGE).
+    // spin_on: 0 off; 1 this launch takes part.  E-step: waits for word 110 == spin_wait unless spin_first; adds 1 per workgroup to word 111.
+    // M-step: waits for word 111 == spin_wait; stores spin_signal to word 110.
+    int spin_on, spin_first;
+    unsigned spin_wait, spin_signal;
 };
+constexpr int kSpinWordM = 110, kSpinWordE = 111;
 
 // Inbox layout in 64-bit words (R ranks, node capacity Mc); rank r writes the [r] entries of every peer's inbox:
 //   flags: init [R] | dmin [2][R] | sums [2][R]      (parity = iteration & 1)
@@ -219,6 +232,9 @@ bool prologue_pair_ok(const FrameDev &f);      // the fused form itself (not the
 hipError_t launch_prologue_direct(const FrameDev *fh, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s,
                                   const FrameDev *f2 = nullptr, const double *host_up2 = nullptr, double *dev_up2 = nullptr, int up_doubles2 = 0);
 hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
+// one iteration of the spin-ahead loop (FrameDev::spin_on): the E-step on s_e, the M-step on s_m; fh[0]'s spin fields are set per launch (the one-frame kernels take
+// the descriptor by value).  ecount / mtag: the slot's running counts behind the tags.
+hipError_t launch_iteration_spin(const FrameDev *frames_dev, FrameDev *frames_host, hipStream_t s_e, hipStream_t s_m, bool first, unsigned *ecount, unsigned *mtag);
 hipError_t launch_iteration_timed(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
                                   hipEvent_t m_start, hipEvent_t m_stop);
 const char *mstep_kernel_name(const FrameDev *frames_host, int F);

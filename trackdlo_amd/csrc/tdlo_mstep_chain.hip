@@ -149,7 +149,9 @@ struct ChainCarve {
 // TRK: the extras of tracking_step's main registration (one frame, no exchange) -- late priors read from pinned host memory when no E-step has
 // run yet, the launch ahead of its priors (FrameDev::spec_flag), the next frame's LLE regulariser at the end (FrameDev::lle_next).  The plain
 // instantiation is the kernel of the registrations proper, unchanged.
-template <typename T, bool SINGLE, bool XCH, bool TRK = false>
+// SPIN (round 6 experiment, FrameDev::spin_on): the launch was dispatched behind the M-step of the iteration before while THIS iteration's E-step still
+// runs on another stream -- everything but the sums is requested, then the kernel waits for the E-step's workgroups to have counted themselves in.
+template <typename T, bool SINGLE, bool XCH, bool TRK = false, bool SPIN = false>
 __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
     constexpr int MB = kCB;
     // One wave walks a chain of dependent instructions.  In a batch the other stream groups' E-steps fill the same SIMDs with waves that always have
@@ -228,13 +230,40 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
     const bool spec_wait = TRK && f.spec_flag != nullptr;      // launched ahead of its priors (FrameDev::spec_flag): the wait sits behind the requests below
     const int itn = stg->it;
     double sq[9];
+    SlotQ q0;
+    bool spin_lost = false;
+    if (SPIN) {
+        // (up to 63 nodes: one element per thread.)  The slot -- links, the node, Y0, Y -- is requested first: nothing of it comes from this iteration's
+        // E-step; then the wait for that E-step's workgroups, then the sums
+        q0 = load_slot(t, true);
+        if (t == 0) red[29] = spin_wait_word(f.sync + kSpinWordE, f.spin_wait) ? 1.0 : 0.0;
+        __syncthreads();
+        spin_lost = red[29] == 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        sq[0] = acc_read_both(f, t < nS ? t : nS - 1, itn);
+#pragma unroll
+        for (int u = 1; u < 9; ++u) sq[u] = 0.0;
+    } else {
     // (the first element without a branch -- index clamped, the accumulators exist in every mode: inside a conditional block the compiler sums the
     //  16 rows on the spot, i.e. waits for them BEFORE it requests the slot below: two memory round trips in a row instead of one)
     sq[0] = acc_read_both(f, t < nS ? t : nS - 1, itn);
 #pragma unroll
     for (int u = 1; u < 9; ++u) sq[u] = 0.0;
-    SlotQ q0;
-    if (nS <= MB) {             // up to 63 nodes: the slot's loads follow the sums' in the same basic block (nothing is waited for in between)
+    }
+    // spin-ahead: this M-step's tag goes out when it is through, whatever way it leaves (the next E-step is parked on it)
+    auto spin_report = [&]() __attribute__((always_inline)) {
+        if (!SPIN) return;
+        __syncthreads();                                           // (every thread's stores to the nodes and to Y have been performed: workgroup-scope release)
+        if (t == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __hip_atomic_store(f.sync + kSpinWordM, f.spin_signal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    };
+    if (SPIN && spin_lost) {      // the E-step never completed (2 s): the registration ends with an error, the tag still goes out
+        if (t == 0) { st->status = TDLO_E_EXCHANGE; st->done = 1; st->converged = 0; }
+        spin_report();
+        if (t < 64) host_publish(f, st, lane, false);
+        return;
+    }
+    if (SPIN) {
+    } else if (nS <= MB) {             // up to 63 nodes: the slot's loads follow the sums' in the same basic block (nothing is waited for in between)
         q0 = load_slot(t, !spec_wait);
     } else {                    // longer chains: the further elements first (with the slot's forty registers live the compiler requests their
         // rows one by one, a round trip each).  Straight-line code per element count -- indices clamped instead of branched, this iteration's
@@ -333,6 +362,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
 #endif
     if (done) {
         if (XCH && from_sums == 3) xch_post_error(f, st, t);
+        spin_report();
         if (!XCH && t < 64 && stg->status != 0) host_publish(f, st, lane, false);      // a registration that ended on an error somewhere else (E-step, setup)
         return;
     }
@@ -843,6 +873,7 @@ __global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict_
         if (itn >= 20 && itn < 28) f.dbg[4 * (itn - 20) + 3] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
+    spin_report();
     if (!XCH && t < 64 && __builtin_amdgcn_readfirstlane(pub)) host_publish(f, st, lane, true);      // progress (and, from the M-step that finishes the registration, the results) into pinned host memory
     if (TRK && f.lle_next != nullptr) {
         // the M-step that finishes the registration without an error goes on (the host has its results already) to form the LLE regulariser
@@ -1061,6 +1092,11 @@ template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd,
         if ((e = set_lds_c(k_mstep_chain<T, true, false, true>, lds)) != hipSuccess) return e;
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false, true>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
         else hipLaunchKernelGGL((k_mstep_chain<T, true, false, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
+    } else if (F == 1 && fh[0].spin_on != 0) {          // the spin-ahead loop's M-step (63 nodes at most: launch_iteration_spin's caller has checked)
+        if (4 * fh[0].M + 1 > kCB) return hipErrorInvalidValue;
+        if ((e = set_lds_c(k_mstep_chain<T, true, false, false, true>, lds)) != hipSuccess) return e;
+        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false, false, true>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
+        else hipLaunchKernelGGL((k_mstep_chain<T, true, false, false, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
     } else if (F == 1) {
         if ((e = set_lds_c(k_mstep_chain<T, true, false>, lds)) != hipSuccess) return e;
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
