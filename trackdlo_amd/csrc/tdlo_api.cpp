@@ -631,7 +631,11 @@ static void estep2_geometry(tdlo_ctx *c, FrameDev &f, bool share) {
     const int nb128 = (f.N0 + 127) / 128;
     int nblk = (nb128 + 3) / 4;
     if (share && nblk >= 32) nblk = (nblk + 1) / 2;
-    const int cap = c->estep2_blocks > 0 ? c->estep2_blocks : (c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : 1024);
+    // One frame: every workgroup resident at once (five of 28 KB and 86 VGPRs per CU: 1280 on 256 CUs) and every wave the SAME number of batches -- first
+    // the batches per wave that fits the cloud into the resident waves, then the workgroups that many batches need.  (N = 2 000 000: 15 625 batches, 4 per
+    // wave, 977 workgroups.  1280 workgroups gave waves of 3 and of 4 batches -- 19.0 us per E-step against 16.9 with 1024 or 1536, scripts/gpu_estep2_sweep.sh.)
+    const int cap = c->estep2_blocks > 0 ? c->estep2_blocks : (c->cfg.estep_blocks > 0 ? c->cfg.estep_blocks : 1280);
+    if (nblk > cap) { const int per_wave = (nb128 + 4 * cap - 1) / (4 * cap); nblk = (nb128 + 4 * per_wave - 1) / (4 * per_wave); }
     f.nblkE = std::max(1, std::min(nblk, std::min(cap, kMaxEstepBlocks)));
 }
 

@@ -32,8 +32,10 @@ __device__ __forceinline__ unsigned rows4_max(unsigned a, unsigned b, unsigned c
     return rows_max_u32(fold16_max(fold32_max(a, b), fold32_max(c, d)));
 }
 
+// (TR: rows of the membership tile.  8 rows: 28 KB of LDS per workgroup and -- told so -- 86 VGPRs: FIVE workgroups per CU, five waves per SIMD; the
+//  compiler's own choice was 110 VGPRs = four.  16 rows: four workgroups of 45 KB, 96 VGPRs with a handful of spills -- the comparator.)
 template <bool VIS, int TR>
-__global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ frames) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_estep2(const FrameDev *__restrict__ frames) {
     constexpr int NWE = 4, EB = 256;
     const FrameDev &f = frames[blockIdx.y];
     if ((int)blockIdx.x >= f.nblkE) return;
@@ -161,7 +163,34 @@ __global__ __launch_bounds__(256) void k_estep2(const FrameDev *__restrict__ fra
         }
         f2 best = sp(Num<float>::inf());
         int aA = plo, aB = plo;
-        {
+        if (phi - plo < 16) {
+            // up to 16 candidates (the rule): the argmin through ONE unsigned minimum per point and node -- a squared distance is a non-negative float, its bits
+            // order like an unsigned integer, and the candidate's offset in the range rides in the four lowest mantissa bits (v_and_or_b32 with the offset as
+            // an inline constant, v_min_u32) instead of a compare and two selects.  First index on ties, as before; the distance that comes out has lost four
+            // bits (1e-6 relative: 5e-9 m on the pair's centimetres -- the coordinates themselves resolve 3e-8 m).
+            unsigned kA = 0xffffffffu, kB = 0xffffffffu;
+            auto cand1 = [&](float qx, float qy, float qz, auto OFF) {
+                const f2 dx = X - sp(qx), dy = Y - sp(qy), dz = Z - sp(qz);
+                const f2 d2 = fma2(dz, dz, fma2(dy, dy, dx * dx));
+                const unsigned ka = (__float_as_uint(d2.x) & 0xfffffff0u) | (unsigned)decltype(OFF)::value, kb = (__float_as_uint(d2.y) & 0xfffffff0u) | (unsigned)decltype(OFF)::value;
+                kA = ka < kA ? ka : kA; kB = kb < kB ? kb : kB;
+            };
+            auto group = [&](auto G) {                  // candidates plo + 4 G .. plo + 4 G + 3: one scalar load, evaluations beyond phi skipped wave-uniformly
+                constexpr int g = decltype(G)::value;
+                const int m0 = plo + 4 * g;
+                const Node4<float> q4 = load_node4<float>(f.nodes, m0);
+                cand1(q4.v[0], q4.v[1], q4.v[2], std::integral_constant<int, 4 * g>());
+                if (m0 + 1 <= phi) cand1(q4.v[4], q4.v[5], q4.v[6], std::integral_constant<int, 4 * g + 1>());
+                if (m0 + 2 <= phi) cand1(q4.v[8], q4.v[9], q4.v[10], std::integral_constant<int, 4 * g + 2>());
+                if (m0 + 3 <= phi) cand1(q4.v[12], q4.v[13], q4.v[14], std::integral_constant<int, 4 * g + 3>());
+            };
+            group(std::integral_constant<int, 0>());
+            if (plo + 4 <= phi) { group(std::integral_constant<int, 1>());
+                if (plo + 8 <= phi) { group(std::integral_constant<int, 2>());
+                    if (plo + 12 <= phi) group(std::integral_constant<int, 3>()); } }
+            aA = plo + (int)(kA & 15u); aB = plo + (int)(kB & 15u);
+            best.x = __uint_as_float(kA & 0xfffffff0u); best.y = __uint_as_float(kB & 0xfffffff0u);
+        } else {
             auto cand1 = [&](float qx, float qy, float qz, int m) {
                 const f2 dx = X - sp(qx), dy = Y - sp(qy), dz = Z - sp(qz);
                 const f2 d2 = fma2(dz, dz, fma2(dy, dy, dx * dx));
