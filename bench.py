@@ -115,18 +115,20 @@ LANE_ISSUE_SUSTAINED = 53.0e12
 class _ClockSampler:
     """Shader clock / memory clock / socket power / busy percentage of one GPU, sampled from sysfs by a background thread while a timed region runs.
     Nothing of it is on the timed path (the thread reads files; the registrations run in C with the GIL released).  No sysfs node: every figure None."""
-    def __init__(self, dev_index, period=0.02):
+    def __init__(self, ctx, period=0.02):
         import glob
         import threading
         self.period, self.samples, self.dev = period, [], None
-        cards = []
-        for c in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        # the GPU's own sysfs node by its PCI bus id (tdlo_pci_bus_id): a container's /sys/class/drm lists every card of the HOST, and the first one with a
+        # hwmon directory is somebody else's idle GPU (95 MHz, 0 % busy while this one runs flat out: the first version of this sampler read that)
+        try:
+            bus = ctx.pci_bus_id()
+            c = os.path.join("/sys/bus/pci/devices", bus)
             hw = glob.glob(os.path.join(c, "hwmon", "hwmon*", "freq1_input"))
             if hw:
-                cards.append((os.path.realpath(c), os.path.dirname(hw[0]), c))
-        cards.sort()            # PCI address order = HIP's device order unless the visible set was permuted (the path is recorded in the detail file)
-        if cards:
-            self.dev = cards[dev_index if dev_index < len(cards) else 0]
+                self.dev = (bus, os.path.dirname(hw[0]), c)
+        except Exception:
+            self.dev = None
         self._stop = threading.Event()
         self._th = None
 
@@ -922,7 +924,7 @@ def bench_frames(args, cfg, env):
         step()
     barrier()
     timed = []
-    with _ClockSampler(dev_index) as clk:       # (a thread that reads sysfs beside the timed region, nothing on its path)
+    with _ClockSampler(ctx) as clk:       # (a thread that reads sysfs beside the timed region, nothing on its path)
         t0 = time.perf_counter()
         for _ in range(cfg["steps"]):
             timed.append(step())
@@ -1097,7 +1099,7 @@ def bench_nsplit(args, cfg, env):
     for _ in range(cfg["warmup"]):
         step()
     barrier()
-    with _ClockSampler(dev_index) as clk:
+    with _ClockSampler(ctx) as clk:
         t0 = time.perf_counter()
         for _ in range(cfg["steps"]):
             out = step()

@@ -520,6 +520,9 @@ int tdlo_set_sort_reuse(tdlo_ctx *ctx, int on);
  * itself costs on one GPU -- bench.py's self_exchange_iters_per_s; tests).  The same results either way, bit for bit.  Initial value: TDLO_XCH_SELF
  * when the context was made.  Returns the previous setting. */
 int tdlo_set_xch_self(tdlo_ctx *ctx, int on);
+/* The PCI bus id of the context's GPU ("0000:c1:00.0"; out needs >= 16 bytes): which /sys/bus/pci/devices/<id> node -- clocks, power, busy percentage --
+ * belongs to it (bench.py's clock sampler: the container's /sys/class/drm lists every card of the host, not only the visible one). */
+int tdlo_pci_bus_id(tdlo_ctx *ctx, char *out, int len);
 /* Development aid: copies the pruned, centred, node-sorted cloud of the last call (N x 3 column-major, widened to
  * double) and the centring offset; returns N. */
 int tdlo_debug_read_cloud(tdlo_ctx *ctx, int slot, double *out, int max_points, double *ctr);

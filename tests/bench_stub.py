@@ -26,6 +26,10 @@ class StubContext:
     def set_xch_self(self, on):
         return False
 
+    def pci_bus_id(self):
+        return "0000:00:00.0"
+
+
     def set_timing(self, on):
         return True
 

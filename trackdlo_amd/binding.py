@@ -56,7 +56,7 @@ SYMBOLS = [
     "tdlo_tracker_initialize_nodes", "tdlo_tracker_initialize_geodesic_coord", "tdlo_tracker_copy_state", "tdlo_tracker_get_sigma2",
     "tdlo_tracker_set_sigma2", "tdlo_tracker_get_tracking_result", "tdlo_tracker_get_guide_nodes",
     "tdlo_tracker_get_correspondence_pairs", "tdlo_tracker_tracking_step", "tdlo_calc_lle_weights", "tdlo_calc_lle_regulariser",
-    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_set_xch_self", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_tracker_frame_from_depth", "tdlo_piecewise_error", "tdlo_compute_error",
+    "tdlo_line_sphere_intersection", "tdlo_traverse_euclidean", "tdlo_profile_kernel", "tdlo_profile_iteration", "tdlo_debug_stamps", "tdlo_debug_exp2", "tdlo_debug_mstep_dense", "tdlo_debug_mstep_lle_dense", "tdlo_debug_band_retries", "tdlo_debug_lle_band_device", "tdlo_debug_route_count", "tdlo_debug_fail_hip", "tdlo_set_timing", "tdlo_set_sort_reuse", "tdlo_set_xch_self", "tdlo_pci_bus_id", "tdlo_debug_read_cloud", "tdlo_image_buffers", "tdlo_debug_cloud_stamps", "tdlo_visibility_prepass", "tdlo_depth_to_cloud_visibility", "tdlo_tracker_frame_from_depth", "tdlo_piecewise_error", "tdlo_compute_error",
     "tdlo_depth_to_cloud", "tdlo_reg", "tdlo_self_occlusion_visible", "tdlo_extend_visible_nodes", "tdlo_tracker_set_self_occlusion",
 ]
 
@@ -187,6 +187,7 @@ def load_library(path: str | None = None):
     lib.tdlo_set_timing.restype = ci
     lib.tdlo_set_sort_reuse.argtypes = [vp, ci]
     lib.tdlo_set_sort_reuse.restype = ci
+    lib.tdlo_pci_bus_id.argtypes = [vp, vp, ci]
     lib.tdlo_set_xch_self.argtypes = [vp, ci]
     lib.tdlo_set_xch_self.restype = ci
     lib.tdlo_debug_read_cloud.argtypes = [vp, ci, vp, ci, vp]
@@ -289,6 +290,12 @@ class Context:
             raise TdloError(err.value, "tdlo_create failed (no usable gfx950 device? there is no CPU fallback)")
         self.max_frames = max_frames
         self.set_timing(timing)
+
+    def pci_bus_id(self):
+        """PCI bus id of the context's GPU, e.g. '0000:c1:00.0' (tdlo_pci_bus_id)."""
+        buf = C.create_string_buffer(32)
+        self._chk(self.lib.tdlo_pci_bus_id(self.h, buf, 32))
+        return buf.value.decode().lower()
 
     def set_xch_self(self, on):
         """A lone rank of the one-shot exchange exchanges with its own inbox instead of skipping the exchange (tdlo_set_xch_self); returns the previous setting."""

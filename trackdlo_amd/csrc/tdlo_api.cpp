@@ -2633,6 +2633,12 @@ int tdlo_debug_fail_hip(tdlo_ctx *c) {
     return TDLO_OK;
 }
 
+int tdlo_pci_bus_id(tdlo_ctx *c, char *out, int len) {
+    if (!c || !out || len < 16) return TDLO_E_INVALID;
+    HIPCHK(c, hipDeviceGetPCIBusId(out, len, c->device));
+    return TDLO_OK;
+}
+
 int tdlo_set_xch_self(tdlo_ctx *c, int on) {
     if (!c) return TDLO_E_INVALID;
     const int prev = c->xch_self ? 1 : 0;
