@@ -308,7 +308,9 @@ def _pmc_traffic_live(args, cfg, mstep_name):
         tname = "float" if cfg["prec"] == "f32" else "double"
 
         def pick(prefix):
-            ks = [k for k in F if prefix in k and k in W]
+            # (the E-step is k_estep<T, ...> or, for clouds / batches that fill the GPU in fp32 mode, k_estep2<...>: whichever was dispatched most)
+            pre = (prefix, "k_estep2<") if prefix.startswith("k_estep<") else (prefix,)
+            ks = [k for k in F if any(q in k for q in pre) and k in W]
             return max(ks, key=lambda k: F[k][1]) if ks else None
 
         res = dict(fetch_calibration_factor=round(cal, 4), fetch_calibration_measured=round(cal_raw, 4), fetch_calibration_in_range=cal_ok,
@@ -542,7 +544,7 @@ def main():
                 t0 = time.perf_counter()
                 r = bench_nsplit(a, lcfg, env) if name == "c4" else bench_frames(a, lcfg, env)
                 res["configs"][name] = dict({k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "scaling", "config",
-                                                                 "roofline", "roofline_kernels", "cpu_baseline", "gpu_over_cpu") if k in r},
+                                                                 "roofline", "roofline_kernels", "cpu_baseline", "gpu_over_cpu", "clocks", "self_exchange_iters_per_s") if k in r},
                                             leg_seconds=round(time.perf_counter() - t0, 1))
             except ParityError:             # ... except when it shows the GPU path to be WRONG: then nothing of this run is a result
                 raise
@@ -607,7 +609,7 @@ def _max_over_ranks(env, dt):
     return float(t.item())
 
 
-def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b2b_us=None):
+def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b2b_us=None, estep_name="k_estep"):
     """Both per-iteration kernels against their rooflines; the one with the larger share of GPU time first."""
     alg_bytes = 3 * esize * N * F                                   # one read of the cloud (SURVEY.md 8(d)); Pt1 is never materialised
     e_flops = 24.0 * M * N * F                                      # FMA-class flops of the E-step as SURVEY.md 8(d) counts them
@@ -615,7 +617,8 @@ def _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mstep_name, est_b
     bw = alg_bytes / (est_us * 1e-6) / 1e9
     traffic, tsrc = _traffic_from_profiles(F) if (N == 50000 and M == 50) else (None, None)
     vpeak = FP32_VECTOR_TFLOPS if esize == 4 else FP64_TFLOPS
-    est = dict(bound="hbm", kernel=f"k_estep<{'float' if esize == 4 else 'double'}>", achieved=round(bw, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+    est = dict(bound="hbm", kernel=(f"{estep_name}<{'float' if esize == 4 else 'double'}>" if estep_name == "k_estep" else "k_estep2<two points per lane, float>"),
+               achieved=round(bw, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                frac=round(bw / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc, avg_launch_us=round(est_us, 3),
                algorithmic_bytes_per_launch=alg_bytes, algorithmic_flops_per_launch=e_flops,
                algorithmic_valu_tflops=round(e_flops / (est_us * 1e-6) / 1e12, 3), valu_peak_tflops=vpeak,
@@ -953,7 +956,8 @@ def bench_frames(args, cfg, env):
         est_us, mst_us, iter_us, mname = ctx.profile_iteration(200)
         est_b2b_us = ctx.profile_kernel(0, 300)     # the E-step launched back to back (hot caches): lower bound, reported beside it
         esize = 4 if cfg["prec"] == "f32" else 8
-        roof, roof_all = _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mname, est_b2b_us)
+        ename = "k_estep2" if getattr(ctx, "estep2_frames", lambda: 0)() > 0 else "k_estep"      # which E-step kernel served this workload (tdlo_debug_route_count 9)
+        roof, roof_all = _roofline_objects(N, M, F, esize, est_us, mst_us, iter_us, mname, est_b2b_us, estep_name=ename)
         # iteration_us as profiled carries the cost of the event-carrying dispatches (two signals per kernel); what one iteration of the
         # timed loop takes is the stream time between the loop's own events
         roof["iteration_us_profiled"] = roof.pop("iteration_us")
@@ -1135,7 +1139,8 @@ def bench_nsplit(args, cfg, env):
         est_us = ctx.profile_kernel(0, 50)
         mst_us = ctx.profile_kernel(2, 50)
         mname = ctx.profile_iteration(1)[3]
-        roof, roof_all = _roofline_objects(hi - lo, M, 1, 4, est_us, mst_us, dt * 1e6 / (cfg["steps"] * EM_ITERS), mname)
+        ename = "k_estep2" if getattr(ctx, "estep2_frames", lambda: 0)() > 0 else "k_estep"
+        roof, roof_all = _roofline_objects(hi - lo, M, 1, 4, est_us, mst_us, dt * 1e6 / (cfg["steps"] * EM_ITERS), mname, estep_name=ename)
         live = _pmc_traffic_live(args, dict(cfg, N=hi - lo, frames=1), mname) if n_ranks == 1 else None
         _apply_live_traffic(live, roof, roof_all)
         roof["note_durations"] = "back-to-back launches on the shard's state (in the split loop the M-step kernel also waits for the peers' sums, so its in-situ duration is not a kernel cost)"

@@ -7,7 +7,7 @@ for c in default c2 c3 c4 c5; do
   [ -s $O/bench_detail_$c.json ] && cp $O/bench_detail_$c.json profiles/${pre}_bench_detail_$c.json
 done
 for f in kernel_stats_c2.csv kernel_stats_c3.csv kernel_stats_c4.csv kernel_stats_c5.csv kernel_stats_lle_M30_to_512.csv kernel_stats_tracking_step.csv kernel_stats_depth_to_cloud.csv \
-         pmc_hbm.json estep_sq_counters_c4.txt measured.log tracking_step_timeline.txt tracking_step_timeline_copy_route.txt \
+         pmc_hbm.json estep_sq_counters_c4.txt estep_sq_counters_c4_k_estep.txt measured.log c3_timeline.txt tracking_step_timeline.txt tracking_step_timeline_copy_route.txt \
          tracking_step_timeline_hidden_nodes.txt tracking_step_timeline_hidden_nodes_ahead_off.txt; do
   [ -s $O/$f ] && cp $O/$f profiles/${pre}_$f
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5's sweeps at the STATED tolerances, outliers adjudicated in place (scripts/fuzz_adjudicate.py): three counts per sweep.   usage: bash scripts/gpu_r05_fuzz.sh <tag> [scale]
+# Round 5's sweeps at the STATED tolerances, outliers adjudicated in place (scripts/fuzz_adjudicate.py): three counts per sweep.   usage: bash scripts/gpu_fuzz_sweeps.sh <tag> [scale]
 tag=${1:-r05fuzz}; scale=${2:-10}
 O=gpurun_out/$tag; mkdir -p $O
 {
