@@ -630,6 +630,7 @@ static void estep2_geometry(tdlo_ctx *c, FrameDev &f, bool share) {
     f.wide_tile = 0; f.eb = 256;
     const int nb128 = (f.N0 + 127) / 128;
     int nblk = (nb128 + 3) / 4;
+    { static const int share_env = getenv("TDLO_ESTEP2_SHARE") ? atoi(getenv("TDLO_ESTEP2_SHARE")) : 1; if (!share_env) share = false; }      // (experiment: a batch's frames keep one batch per wave)
     if (share && nblk >= 32) nblk = (nblk + 1) / 2;
     // One frame: every workgroup resident at once (five of 28 KB and 86 VGPRs per CU: 1280 on 256 CUs) and every wave the SAME number of batches -- first
     // the batches per wave that fits the cloud into the resident waves, then the workgroups that many batches need.  (N = 2 000 000: 15 625 batches, 4 per

@@ -1011,6 +1011,20 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const T k2 = (T)stg->k2;
     const T cn = (T)stg->c_norm;
     for (int m = tid; m < M; m += EB) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
+    // One frame that cannot fill the GPU, chains of up to 64 nodes (round 6): the kernel is a chain of latencies there (one wave per SIMD: 8 500 clocks per batch, of
+    // which the scalar node loads of the two node loops and the LDS reads of the range tests are round trips nothing overlaps).  Lane l keeps node l in registers for the
+    // whole kernel and a node's values reach the wave by v_readlane -- the same values in the same operand positions (an SGPR either way): the same bits, no round trip.
+#ifdef TDLO_NO_LANE_NODES          // (scripts/build_variant.sh nolane -DTDLO_NO_LANE_NODES: the comparator of scripts/gpu_ab.sh)
+    constexpr bool LANE_NODES = false;
+#else
+    constexpr bool LANE_NODES = SINGLE && NCH == 1;
+#endif
+    V4<T> qn; qn.x = 0; qn.y = 0; qn.z = 0; qn.w = 0;
+    if (LANE_NODES && lane < M) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); qn.x = qg[lane].x; qn.y = qg[lane].y; qn.z = qg[lane].z; qn.w = qg[lane].w; }
+    auto lane_val = [&](T v, int src) -> T {          // v of lane src (wave-uniform), as a wave-uniform operand
+        if constexpr (sizeof(T) == 4) return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src));
+        else return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
     if (done) { spin_report(); return; }
     double lv_span = 0;      // VIS: the largest -log2 v_m + log2 v_m' over the nodes -- how far the visibility weights can lower a nearest node's membership against another's
     if (VIS) {
@@ -1100,7 +1114,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
             for (int c = 0; c < NCH; ++c) {                  // lane = node 64 c + lane
                 const int m = c * kChunk + lane;
                 Dm[c] = Num<T>::inf();
-                if (m < M) { const V4<T> qn = nodesL[m]; Dm[c] = (qn.x - cx) * (qn.x - cx) + (qn.y - cy) * (qn.y - cy) + (qn.z - cz) * (qn.z - cz); }
+                if (m < M) { const V4<T> qq = LANE_NODES ? qn : nodesL[m]; Dm[c] = (qq.x - cx) * (qq.x - cx) + (qq.y - cy) * (qq.y - cy) + (qq.z - cz) * (qq.z - cz); }
                 dmin_w = tmin(dmin_w, Dm[c]);
             }
             wave_max_min_nonneg(r2, dmin_w, r2, dmin_w);          // (both reductions in one folded butterfly)
@@ -1123,7 +1137,13 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         int a = plo;
         // candidates in groups of 4: the group's scalar loads are issued together (index clamped to phi), the evaluations
         // beyond phi are skipped by wave-uniform branches -- one scalar-memory latency per group instead of one per node
-        {
+        if constexpr (LANE_NODES) {
+            for (int m = plo; m <= phi; ++m) {           // (the candidate's coordinates from its lane: nothing to wait for)
+                const T dx = x - lane_val(qn.x, m), dy = y - lane_val(qn.y, m), dz = z - lane_val(qn.z, m);
+                const T d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < best) { best = d2; a = m; }
+            }
+        } else {
             int m0 = plo;
             for (; m0 + 3 <= phi; m0 += 4) {             // whole groups: ONE scalar load of four nodes, no per-node index clamp or test
                 const Node4<T> q4 = load_node4<T>(f.nodes, m0);
@@ -1205,7 +1225,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int m = c * kChunk + lane;
-                const T cm = (m < M) ? nodesL[m].w : Num<T>::inf();
+                const T cm = (m < M) ? (LANE_NODES ? qn.w : nodesL[m].w) : Num<T>::inf();
                 const unsigned long long inw = __ballot(m < M && cm > amin - Rwin && cm < amax + Rwin);
                 if (inw) {
                     const int lo_c = c * kChunk + (int)__builtin_ctzll(inw), hi_c = c * kChunk + 63 - (int)__builtin_clzll(inw);
@@ -1255,6 +1275,13 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         };
         // [from, to] in groups of 4 nodes: scalar loads first (clamped index), evaluations beyond `to` skipped wave-uniformly
         auto span = [&](int from, int to, auto ADJ, auto STORE) {
+            if constexpr (LANE_NODES) {                  // (a node's four values from its lane: no scalar load in the loop)
+                for (int m = from; m <= to; ++m) {
+                    V4<T> q; q.x = lane_val(qn.x, m); q.y = lane_val(qn.y, m); q.z = lane_val(qn.z, m); q.w = lane_val(qn.w, m);
+                    member(q, m, ADJ, STORE);
+                }
+                return;
+            }
             int m0 = from;
             for (; m0 + 3 <= to; m0 += 4) {              // whole groups: one scalar load of four nodes (the scalar unit is shared by the
                 const Node4<T> q4 = load_node4<T>(f.nodes, m0);          // CU's four SIMDs: index clamps, address arithmetic and a
