@@ -110,3 +110,39 @@ def test_estep2_is_chosen_by_size_and_never_for_what_it_does_not_take():
             ctx.close()
     finally:
         if old is not None: os.environ["TDLO_ESTEP2"] = old
+
+
+def test_batch_loop_in_one_launch_gives_the_launch_per_step_loops_bits():
+    """The round-6 experiment k_batch_loop (TDLO_BATCH_PERSIST=1, off by default -- measured four times SLOWER at C3): a batch's whole
+    fixed-length loop as one launch, tickets (iteration, frame, chunk) dealt to resident workgroups, the workgroup that completes a frame's E-step runs its
+    M-step, per-frame progress counters in device memory.  It must give the bits of the launch-per-step loop on stream groups, report itself in
+    tdlo_debug_route_count 12 with no fall-back (13), and leave batches it does not take (early exit, too small for k_estep2) to the ordinary loop."""
+    from trackdlo_amd import binding as B, synth
+    P = synth.LAUNCH_PARAMS
+    F, N, M = 6, 44000, 50                      # 6 x 688 = 4128 waves of 64 points: the batch fills the GPU, k_estep2
+    scenes = [synth.scene(N, M, config=3, frame=f)[:2] for f in range(F)]
+    Ys = [y for _, y in scenes]
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 12, 0.0, False)
+    pr_tol = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 50, P["tol"], False)
+    outs = {}
+    for mode in ("0", "1"):
+        os.environ["TDLO_BATCH_PERSIST"] = mode
+        try:
+            ctx = B.Context(device=0, max_frames=F, max_points=N, max_nodes=M, timing=False)
+        finally:
+            os.environ.pop("TDLO_BATCH_PERSIST", None)
+        try:
+            ctx.set_sort_reuse(False)
+            for f, (X, _) in enumerate(scenes):
+                ctx.set_cloud(f, X)
+            outs[mode] = [ctx.cpd_lle_batch(Ys, [0.0] * F, pr) for _ in range(2)]
+            calls, fb = int(ctx.lib.tdlo_debug_route_count(ctx.h, 12)), int(ctx.lib.tdlo_debug_route_count(ctx.h, 13))
+            assert (calls, fb) == ((2, 0) if mode == "1" else (0, 0)), (mode, calls, fb)
+            early = ctx.cpd_lle_batch(Ys, [0.0] * F, pr_tol)                     # early exit: the ordinary loop
+            small = ctx.cpd_lle_batch(Ys[:2], [0.0] * 2, pr)                     # 1376 waves: k_estep, the ordinary loop
+            assert int(ctx.lib.tdlo_debug_route_count(ctx.h, 12)) == calls and all(s["status"] == 0 for s in list(early["stats"]) + list(small["stats"]))
+        finally:
+            ctx.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(np.asarray(a["Y"]), np.asarray(b["Y"])) and np.array_equal(a["sigma2"], b["sigma2"])
+        assert [s["iters"] for s in a["stats"]] == [s["iters"] for s in b["stats"]] == [12] * F

@@ -280,6 +280,14 @@ struct tdlo_ctx {
     // the first, the kernels parked on device words instead of the streams' dependent dispatches (FrameDev::spin_on).  TDLO_SPIN_AHEAD=1 switches it on.
     bool spin_ahead_on = getenv("TDLO_SPIN_AHEAD") && atoi(getenv("TDLO_SPIN_AHEAD")) != 0;
     long long spin_calls = 0;             // registrations run that way (tdlo_debug_route_count 11)
+    // A batch's whole fixed-length loop in ONE launch (k_batch_loop, tdlo_estep2.hip): tickets (iteration, frame, chunk) drawn by resident workgroups, the workgroup
+    // that completes a frame's E-step runs its M-step.  Round 6 EXPERIMENT, OFF by default (TDLO_BATCH_PERSIST=1 switches it on): the same bits, but 5.1 ms
+    // against 1.27 ms per C3 call.  A call whose loop kernel gives a wait up is repeated on the launch-per-step loop.
+    bool batch_persist_on = getenv("TDLO_BATCH_PERSIST") && atoi(getenv("TDLO_BATCH_PERSIST")) != 0;
+    unsigned *batch_ctl = nullptr;        // device: ticket, abort, per-frame progress counters (batch_loop_ctl_words)
+    size_t batch_ctl_words = 0;
+    long long batch_loop_calls = 0, batch_loop_fallbacks = 0;      // tdlo_debug_route_count 12 / 13
+    bool batch_persist_off_once = false;  // run_frames' repeat of a call whose loop kernel gave a wait up
     long long estep2_frames = 0;          // registrations whose E-step was k_estep2 (tdlo_debug_route_count 9)
     bool timing = false;                  // tdlo_set_timing: record the four events behind tdlo_stats.loop_ms / total_ms (~15 us per call)
     EnqueuePool *pool = nullptr;          // made by the first batch that runs on several streams
@@ -630,7 +638,6 @@ static void estep2_geometry(tdlo_ctx *c, FrameDev &f, bool share) {
     f.wide_tile = 0; f.eb = 256;
     const int nb128 = (f.N0 + 127) / 128;
     int nblk = (nb128 + 3) / 4;
-    { static const int share_env = getenv("TDLO_ESTEP2_SHARE") ? atoi(getenv("TDLO_ESTEP2_SHARE")) : 1; if (!share_env) share = false; }      // (experiment: a batch's frames keep one batch per wave)
     if (share && nblk >= 32) nblk = (nblk + 1) / 2;
     // One frame: every workgroup resident at once (five of 28 KB and 86 VGPRs per CU: 1280 on 256 CUs) and every wave the SAME number of batches -- first
     // the batches per wave that fits the cloud into the resident waves, then the workgroups that many batches need.  (N = 2 000 000: 15 625 batches, 4 per
@@ -1206,6 +1213,23 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         }
         return 0;
     };
+    // a batch whose frames all take k_estep2 and the chain smoother, fixed iteration count: the whole loop as one launch (k_batch_loop)
+    bool persist = merged && c->batch_persist_on && !c->batch_persist_off_once && (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) && p->max_iter > 0 &&
+                   p->precision == TDLO_PREC_F32 && !p->include_lle && M <= 63;
+    for (int i = 0; i < F && persist; ++i) persist = c->fh[i].estep2 != 0 && !c->fh[i].vis_branch && !c->fh[i].mstep_dense;
+    if (persist) {
+        const size_t words = batch_loop_ctl_words(F);
+        if (words > c->batch_ctl_words) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->batch_ctl) (void)hipFree(c->batch_ctl);
+            c->batch_ctl = nullptr; c->batch_ctl_words = 0;
+            HIPCHK(c, hipMalloc((void **)&c->batch_ctl, words * sizeof(unsigned)));
+            c->batch_ctl_words = words;
+        }
+        HIPCHK(c, hipMemsetAsync(c->batch_ctl, 0, words * sizeof(unsigned), s));
+        HIPCHK(c, launch_batch_loop(fdp, c->fh.data(), F, p->max_iter, c->batch_ctl, s));
+        ++c->batch_loop_calls;
+    } else
     if (p->tol <= 0.0 || p->max_iter <= 2 * kChunkIters) {
         // fixed iteration count: enqueue everything, no host involvement.  Several stream groups and enough iterations: the first
         // iteration (which releases the groups one after the other) from this thread, the rest of every group from a thread of its own.
@@ -1398,6 +1422,24 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
             return rr;
         }
     }
+    // the loop kernel gave a wait up (2 s; a frame ended with TDLO_E_EXCHANGE): the call is repeated once on the launch-per-step loop -- inputs, Y and sigma2 are untouched so far
+    if (persist) {
+        bool gave_up = false;
+        for (int i = 0; i < F && !gave_up; ++i) {
+            IterState is;
+            std::memcpy(&is, c->pin + (size_t)i * rstride + (nc.st - nc.Yout), sizeof is);
+            gave_up = is.status == TDLO_E_EXCHANGE;
+        }
+        if (gave_up) {
+            ++c->batch_loop_fallbacks;
+            std::fprintf(stderr, "trackdlo_hip: a wait inside the batch loop kernel gave up after 2 s (device %d); the call is repeated with a launch per step\n", c->device);
+            for (int i = 0; i < F; ++i) c->slots[slots[i]].sorted_valid = false;
+            c->batch_persist_off_once = true;
+            const int rr = run_frames(c, F, slots, Y, M, sigma2, p, priors, K, vis, n_vis, H_override, stats, late);
+            c->batch_persist_off_once = false;
+            return rr;
+        }
+    }
     // fp64 mode: the E-step's range check runs against limits that follow sigma (IterState::sh_boost: finer sums while sigma is small).  The extent
     // behind them is a heuristic (D_eff = 2 (0.4 m + 2 sigma)): a registration whose shares exceed it -- nodes dragged far by priors while sigma is
     // small -- would have passed under the coarse limits.  It is not failed for the boost: the call is repeated ONCE without it (inputs, Y, sigma2
@@ -1553,6 +1595,7 @@ void tdlo_destroy(tdlo_ctx *c) {
     for (auto &e : c->evx) if (e) hipEventDestroy(e);
     for (auto &e : c->evj) if (e) hipEventDestroy(e);
     for (auto &row : c->evc) for (auto &e : row) if (e) hipEventDestroy(e);
+    if (c->batch_ctl) (void)hipFree(c->batch_ctl);
     for (auto &q : c->stream2) if (q) hipStreamDestroy(q);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -2605,7 +2648,9 @@ int tdlo_debug_mstep_lle_dense(int on) { return mstep_set_lle_dense(on); }
 long long tdlo_debug_band_retries(tdlo_ctx *c) { return c ? c->band_retries : -1; }
 
 long long tdlo_debug_route_count(tdlo_ctx *c, int which) {
-    if (!c || which < 0 || which > 11) return -1;
+    if (!c || which < 0 || which > 13) return -1;
+    if (which == 13) return c->batch_loop_fallbacks;
+    if (which == 12) return c->batch_loop_calls;
     if (which == 11) return c->spin_calls;
     if (which == 10) return c->boost_retries;
     if (which == 9) return c->estep2_frames;

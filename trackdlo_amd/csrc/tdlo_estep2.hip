@@ -14,6 +14,8 @@
 // fp32 mode, chains of 8 .. 64 nodes; everything else stays with k_estep (launch_estep_T, FrameDev::estep2).
 #include "tdlo_devcommon.h"
 #include "tdlo_mstep_generic.h"
+#include "tdlo_mstep_chain_body.h"
+#include <algorithm>
 #include <hip/hip_ext.h>
 #include <type_traits>
 
@@ -34,11 +36,11 @@ __device__ __forceinline__ unsigned rows4_max(unsigned a, unsigned b, unsigned c
 
 // (TR: rows of the membership tile.  8 rows: 28 KB of LDS per workgroup and -- told so -- 86 VGPRs: FIVE workgroups per CU, five waves per SIMD; the
 //  compiler's own choice was 110 VGPRs = four.  16 rows: four workgroups of 45 KB, 96 VGPRs with a handful of spills -- the comparator.)
+// The kernel's body as a device function of (frame, chunk): chunk = what blockIdx.x is to k_estep2 -- the workgroup's place among the frame's nblkE workgroups.
+// Shared by k_estep2 and by the batches' persistent loop (k_batch_loop below).
 template <bool VIS, int TR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_estep2(const FrameDev *__restrict__ frames) {
+__device__ __forceinline__ void estep2_chunk(const FrameDev &f, const int chunk, char *smem) {
     constexpr int NWE = 4, EB = 256;
-    const FrameDev &f = frames[blockIdx.y];
-    if ((int)blockIdx.x >= f.nblkE) return;
 #ifdef TDLO_ESTEP_PHASES
     unsigned long long ph_prev = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define E2PHASE(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[i] += t_ - ph_prev; ph_prev = t_; } while (0)
@@ -46,7 +48,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #define E2PHASE(i) do { } while (0)
 #endif
     const auto stg = TDLO_AS_GLOBAL(IterState, f.st);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = f.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const float k2 = (float)stg->k2;
     const float cn = (float)stg->c_norm;
     const int bstride = f.nblkE * NWE;
-    int batch = blockIdx.x * NWE + wave;
+    int batch = chunk * NWE + wave;
     // the first batch's points, the nodes for the LDS copy, and this lane's own node (lane = node in the range searches).  A batch's loads are
     // six dword loads off three uniform bases with ONE 32-bit byte offset per lane, clamped to the cloud's last point (lanes behind it are
     // given a copy of lane 0's point below): no 64-bit address arithmetic and no divergent branch per batch.
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         sw->status = TDLO_E_NUMERIC; sw->converged = 0; sw->done = 1;
     }
     __syncthreads();
-    long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (blockIdx.x % kAccRows)) * acc_stride(M);
+    long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (chunk % kAccRows)) * acc_stride(M);
     for (int i = tid; i < 4 * M; i += EB) acc_add(arow, (i & 3) * M + (i >> 2), accL[i]);
     if (tid == 0) {
         long long q = 0;
@@ -433,8 +434,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
     E2PHASE(7);
 #ifdef TDLO_ESTEP_PHASES
-    if (tid == 0 && (int)blockIdx.x == f.nblkE / 2) { for (int i = 0; i < 10; ++i) f.dbg[48 + i] = ph_acc[i]; }
+    if (tid == 0 && chunk == f.nblkE / 2) { for (int i = 0; i < 10; ++i) f.dbg[48 + i] = ph_acc[i]; }
 #endif
+}
+
+template <bool VIS, int TR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_estep2(const FrameDev *__restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FrameDev &f = frames[blockIdx.y];
+    if ((int)blockIdx.x >= f.nblkE) return;
+    estep2_chunk<VIS, TR>(f, (int)blockIdx.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// A batch's whole EM loop in ONE launch (round 6 EXPERIMENT, off by default: TDLO_BATCH_PERSIST=1; measured 5.1 ms against 1.27 ms per C3 call -- DESIGN.md 3.2c
+// says why: a frame's own chain chunk -> M-step -> chunk is longer than an iteration of all frames' E-steps, the M-step's body as a called function spills, and
+// every hand-over is an agent-scope atomic plus a cache invalidate / write-back).  With a launch per E-step and per M-step a batch's stream groups leave the GPU without an E-step for a
+// third of the time: a frame's M-step is one wave for 8 us, and whatever the host enqueues, kernels of one stream wait for each other as
+// wholes.  Here the dependency is per FRAME: the loop's work is the sequence of tickets (iteration, frame, chunk) -- chunk = one workgroup's share of the
+// frame's E-step --, the resident workgroups draw them in order; the workgroup that completes the last chunk of (iteration, frame) runs that frame's M-step
+// (the chain smoother's body, tdlo_mstep_chain_body.h) and raises mdone[frame]; a workgroup that draws a chunk of iteration k + 1 first makes sure the
+// frame's M-step k is through (it nearly always is: a frame's chunks come round once per iteration, its M-step takes half of one).  So other frames'
+// E-steps fill the GPU while a frame's M-step runs, with no host in the loop and no kernel boundary between iterations.
+// Deadlock-free: a ticket's holder waits only for the M-step of an EARLIER ticket's frame, whose runner holds an earlier ticket and is running.  Every
+// wait is bounded (2 s): a workgroup that gives up marks its frame TDLO_E_EXCHANGE and raises `abort`, everybody leaves at their next ticket, and the host
+// repeats the call on the launch-per-step loop (run_frames).  What the kernels compute is what k_estep2 and k_mstep_chain compute, in the same order per
+// frame: the same bits (tests/test_estep2_gpu.py).
+// ctl: [1] abort; then per frame a 4 KB block with mdone (M-steps completed), then per frame a 4 KB block with edone (chunks reported); zeroed per call.
+constexpr int kBatchCtlStride = 1024;      // words between two frames' counters (4 KB)
+// (the two bodies as functions of their own: inlined side by side the register allocator held both bodies' values at once -- 128 VGPRs and a hundred spills.
+//  Each refers to the launch's dynamic LDS by its own declaration, so that its accesses stay LDS accesses.)
+template <int TR>
+__device__ __noinline__ void batch_estep(const FrameDev *f, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    estep2_chunk<false, TR>(*f, chunk, smem);
+}
+__device__ __noinline__ void batch_mstep(const FrameDev *f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    mstep_chain_run<float, false, false, false, false>(*f, 0, smem);
+}
+template <int TR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_batch_loop(const FrameDev *__restrict__ frames, unsigned *__restrict__ ctl, int F, int nblk, int iters, int edone_off) {
+    __shared__ unsigned s_tk[4];          // [0] this round's ticket, [1] the frame's mdone as prefetched, [2] abort as seen, [3] answers of thread 0
+    const int tid = threadIdx.x;
+    const unsigned per_it = (unsigned)F * (unsigned)nblk, total = per_it * (unsigned)iters;
+    // (a frame's two counters in 4 KB blocks of their own: agent-scope atomics are performed where the XCDs meet, ~100 ns each and one after the other per memory
+    //  channel -- with all frames' counters in one cache line the 78 400 chunk reports of a call took 5.5 ms)
+    unsigned *mdone = ctl + kBatchCtlStride, *edone = ctl + edone_off;
+    // (tickets are dealt round-robin, workgroup w takes w, w + G, w + 2 G, ...: drawn from ONE counter they cost 100 ns each -- agent-scope atomics on a single
+    //  address are serialised where the XCDs meet -- 8 ms for a call's 78 400.  Every workgroup still takes its tickets in increasing order, which is all the
+    //  deadlock argument needs.)
+    unsigned nx_ticket = blockIdx.x, nx_md = 0;
+    if (tid == 0 && nx_ticket < total) nx_md = __hip_atomic_load(mdone + (size_t)((nx_ticket % per_it) / (unsigned)nblk) * kBatchCtlStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (tid == 0) { s_tk[0] = nx_ticket; s_tk[1] = nx_md; s_tk[2] = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __syncthreads();
+        const unsigned ticket = s_tk[0];
+        const bool stop = s_tk[2] != 0u;
+        unsigned md = s_tk[1];
+        __syncthreads();
+        if (ticket >= total || stop) break;
+        const unsigned it = ticket / per_it, r = ticket - it * per_it;
+        const int fi = (int)(r / (unsigned)nblk), c = (int)(r - (unsigned)fi * (unsigned)nblk);
+        const FrameDev &f = frames[fi];
+        // the next ticket and its frame's progress are requested now and looked at when this chunk is done
+        nx_ticket = ticket + gridDim.x;
+        if (tid == 0) nx_md = nx_ticket < total ? __hip_atomic_load(mdone + (size_t)((nx_ticket % per_it) / (unsigned)nblk) * kBatchCtlStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        // the frame's M-step of the iteration before must be through (its nodes, its state, the cleared accumulator rows)
+        if (md < it) {
+            if (tid == 0) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned v;
+                while ((v = __hip_atomic_load(mdone + (size_t)fi * kBatchCtlStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < it) {
+                    if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;       // 2 s of the 100 MHz clock
+                }
+                s_tk[3] = v;
+            }
+            __syncthreads();
+            md = s_tk[3];
+            __syncthreads();
+            if (md < it) {          // gave up (or told to): the frame's registration ends with an error, everybody leaves at their next ticket
+                if (tid == 0) {
+                    IterState *sw = f.st; sw->status = TDLO_E_EXCHANGE; sw->converged = 0; sw->done = 1;
+                    __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
+        }
+        // (cache maintenance by ONE wave per workgroup: an agent-scope acquire / release is an invalidate / write-back of the XCD's whole L2 -- issued by every wave of
+        //  every ticket they took 20 ms per call where the loop's work is 1; the CU's vector cache and the scalar cache are shared by the workgroup's waves, and
+        //  the other waves' own stores have reached the L2 when their workgroup-scope release -- a wait for their memory counters -- is through)
+        if (tid < 64) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __builtin_amdgcn_s_dcache_inv(); }      // (the nodes come through scalar loads)
+        __syncthreads();
+        if (c < f.nblkE) batch_estep<TR>(&f, c);
+        // report the chunk; the workgroup that completes the frame's E-step runs its M-step
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's atomics on the accumulators have been performed
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            s_tk[3] = __hip_atomic_fetch_add(edone + (size_t)fi * kBatchCtlStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (it + 1u) * (unsigned)nblk ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool last = s_tk[3] != 0u;
+        __syncthreads();
+        if (last) {
+            if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every workgroup's sums
+            __syncthreads();
+            __builtin_amdgcn_s_setprio(3);
+            batch_mstep(&f);
+            __builtin_amdgcn_s_setprio(0);
+            __syncthreads();                                    // every thread's stores to the nodes, Y and the state have been performed
+            if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __hip_atomic_store(mdone + (size_t)fi * kBatchCtlStride, it + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+    }
 }
 
 size_t estep2_lds_bytes(int M, int tr) {
@@ -457,6 +571,29 @@ hipError_t launch_estep2(const FrameDev *fd, const FrameDev *fh, int F, hipStrea
     if (tr == 8) { if (vis) TDLO_E2L(true, 8); else TDLO_E2L(false, 8); }
     else { if (vis) TDLO_E2L(true, 16); else TDLO_E2L(false, 16); }
 #undef TDLO_E2L
+    return hipGetLastError();
+}
+
+size_t batch_loop_ctl_words(int F) { return (size_t)kBatchCtlStride * (1 + 2 * (size_t)F); }
+
+// the whole loop of a batch in one launch (k_batch_loop); ctl: batch_loop_ctl_words(F) zeroed words on the device
+hipError_t launch_batch_loop(const FrameDev *fd, const FrameDev *fh, int F, int iters, unsigned *ctl, hipStream_t s) {
+    const int M = fh[0].M, tr = fh[0].estep2;
+    int nblk = 0;
+    for (int i = 0; i < F; ++i) nblk = fh[i].nblkE > nblk ? fh[i].nblkE : nblk;
+    const size_t lds = std::max(estep2_lds_bytes(M, tr), sizeof(double) * ChainCarve(M).total);
+    const int edone_off = kBatchCtlStride * (1 + F);
+    // four workgroups of 128 VGPRs per CU (the M-step's body needs them): every workgroup of the launch resident, or the tickets' order would not protect from deadlock
+    int cus = 256;
+    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    const long long want = (long long)F * nblk;
+    const int grid = (int)std::min<long long>(want, 4LL * cus);
+    hipError_t e;
+#define TDLO_BL(TR) do { \
+        if (lds > 64 * 1024) { e = hipFuncSetAttribute((const void *)k_batch_loop<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL((k_batch_loop<TR>), dim3(grid), dim3(256), lds, s, fd, ctl, F, nblk, iters, edone_off); } while (0)
+    if (tr == 8) TDLO_BL(8); else TDLO_BL(16);
+#undef TDLO_BL
     return hipGetLastError();
 }
 

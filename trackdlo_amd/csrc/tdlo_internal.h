@@ -241,6 +241,9 @@ const char *mstep_kernel_name(const FrameDev *frames_host, int F);
 // tdlo_estep2.hip: the E-step with two points per lane (FrameDev::estep2)
 hipError_t launch_estep2(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 size_t estep2_lds_bytes(int M, int tile_rows);
+// tdlo_estep2.hip: a batch's whole loop in one launch (k_batch_loop): tickets (iteration, frame, chunk), per-frame dependency counters in `ctl`
+size_t batch_loop_ctl_words(int F);
+hipError_t launch_batch_loop(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int iters, unsigned *ctl, hipStream_t s);
 hipError_t launch_estep_only(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int kind, hipStream_t s);
 hipError_t launch_split_setup(const FrameDev *frames_dev, const FrameDev *frames_host, hipStream_t s);
 hipError_t launch_split_set_global(const FrameDev *frames_dev, double Nglob, double Sglob, hipStream_t s);
