@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trackdlo_amd import binding as B, synth
 P = synth.LAUNCH_PARAMS
-for N, M, prec in ((200000, 300, B.PREC_F64), (200000, 300, B.PREC_F32), (50000, 100, B.PREC_F32), (50000, 64, B.PREC_F32), (50000, 128, B.PREC_F64)):
+CASES = ((200000, 300, B.PREC_F64), (200000, 300, B.PREC_F32), (50000, 100, B.PREC_F32), (50000, 64, B.PREC_F32), (50000, 128, B.PREC_F64))
+for N, M, prec in CASES[:int(os.environ.get("CASES", "5"))]:
     ctx = B.Context(max_points=N, max_nodes=M)
     X, Y0, _ = synth.scene(N, M, config=5)
     pr = B.make_params(P['beta'], P['lambda_'], P['lle_weight'], P['mu'], int(os.environ.get('ITERS', '5')), 0.0, False, precision=prec)

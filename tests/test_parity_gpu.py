@@ -1395,10 +1395,11 @@ def test_results_do_not_depend_on_the_estep_launch_geometry(prec):
     """The E-step's sums are converted to 64-bit fixed point at the grain of one wave x one 64-point batch and are integers from there
     on (csrc/tdlo_devcommon.h: acc_fix): however the batches are dealt out to waves and workgroups -- 196 workgroups of one batch per
     wave, 7 workgroups of 28 -- and in whatever order the workgroups' atomics arrive, every bit of the result is the same.  With
-    visibility weighting, priors, and a chain of 130 nodes (the register-accumulator variant of the E-step) as well."""
+    visibility weighting, priors, and chains of 130 and 300 nodes (fp64: their first iterations' batches take the lane = node form, tdlo_estep_wide.h, whose
+    grain is the same one batch) as well."""
     from trackdlo_amd import binding as B, synth
     P = synth.LAUNCH_PARAMS
-    for N, M, occ in ((50000, 50, None), (20000, 45, (0.3, 0.5)), (30000, 130, None)):
+    for N, M, occ in ((50000, 50, None), (20000, 45, (0.3, 0.5)), (30000, 130, None), (20000, 300, (0.3, 0.5))):
         X, Y0, vis = synth.scene(N, M, config=410 + M, occlude=occ)
         pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 12, 0.0, False, P["alpha"], P["k_vis"] if occ else 0.0,
                            P["visibility_threshold"], prec)

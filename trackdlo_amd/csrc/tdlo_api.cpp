@@ -29,6 +29,7 @@ namespace {
 constexpr int kMaxEstepBlocks = 4096;      // (upper bound of TDLO_ESTEP_BLOCKS / tdlo_config.estep_blocks; the defaults are 512 and 1024)
 constexpr int kBatchStreams = 4;       // streams a batch of frames is spread over (run_frames); more than 4 lose (measured: 6 or 8 fall below one stream)
 constexpr int kIterHintMax = 8;        // tdlo_ctx::iter_hint: at most this many iterations go out before the host first looks
+constexpr int kEstepWideMin = 129;          // (measured: scripts/gpu_estep_wide_ab.py)
 constexpr int kEstep2MinWaves = 2048;   // 64-point batches of a cloud (or of a batch's frames together) from which the E-step is k_estep2 (two points per lane): two waves per SIMD
 constexpr int kChunkIters = 4;          // EM iterations per early-exit polling chunk; the first chunks are shorter (1, 1, 2):
                                         // a tracker in steady state converges in one or two iterations
@@ -279,6 +280,8 @@ struct tdlo_ctx {
     // Round 6 experiment, OFF by default: one frame's fixed-length loop as a spin-ahead loop -- E-steps on the second stream, M-steps on
     // the first, the kernels parked on device words instead of the streams' dependent dispatches (FrameDev::spin_on).  TDLO_SPIN_AHEAD=1 switches it on.
     bool spin_ahead_on = getenv("TDLO_SPIN_AHEAD") && atoi(getenv("TDLO_SPIN_AHEAD")) != 0;
+    // fp64 E-step of chains beyond 64 nodes: batches whose node window is wide go lane = node (tdlo_estep_wide.h); TDLO_ESTEP_WIDE=0: thread = point throughout (comparator)
+    int estep_wide_min = getenv("TDLO_ESTEP_WIDE") ? (atoi(getenv("TDLO_ESTEP_WIDE")) > 0 ? atoi(getenv("TDLO_ESTEP_WIDE")) : (1 << 30)) : kEstepWideMin;
     long long spin_calls = 0;             // registrations run that way (tdlo_debug_route_count 11)
     // A batch's whole fixed-length loop in ONE launch (k_batch_loop, tdlo_estep2.hip): tickets (iteration, frame, chunk) drawn by resident workgroups, the workgroup
     // that completes a frame's E-step runs its M-step.  Round 6 EXPERIMENT, OFF by default (TDLO_BATCH_PERSIST=1 switches it on): the same bits, but 5.1 ms
@@ -815,6 +818,7 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
         f.acc_lim[0] = std::ldexp(1.0, lshare - f.acc_sh[0]); f.acc_lim[1] = std::ldexp(1.0, lshare - f.acc_sh[1]); f.acc_lim[2] = std::ldexp(1.0, lpoint - f.acc_sh[2]);
     }
     f.acc_boost_off = c->boost_off_once ? 1 : 0;
+    f.estep_wide_min = c->estep_wide_min;
     // one frame whose cloud fills the GPU alone (2048 waves of 64 points: from there on two points per lane win, scripts/gpu_estep2_check.py /
     // profiles/r06_measured.log -- 131 072 points 4.8 against 5.3 us per E-step, 250 000 points (a shard of C4 on eight ranks) 5.5 against 7.3 us)
     if (estep2_eligible(c, f) && (c->estep2_mode == 1 || nbatch >= kEstep2MinWaves)) estep2_geometry(c, f, false);

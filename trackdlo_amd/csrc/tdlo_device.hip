@@ -22,6 +22,7 @@
 //   Q = sum_mn P_mn |x_n - y_m|^2,  R_m = PX_m - P1_m y_m (accumulated directly by the E-step),  d_m = T_m - y_m
 // instead of :418-422's difference of three large traces, which would cancel catastrophically in fp32.
 #include "tdlo_devcommon.h"
+#include "tdlo_estep_wide.h"
 #include "tdlo_mstep_generic.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
@@ -1241,6 +1242,16 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         // ---- unnormalised membership, column sum, Q (:354-383)
         // adj: no point of this wave has the end-node gap (hi == lo + 2), the cheaper form of the exponent applies
         const bool adj = sizeof(T) == 8 ? !gap_any : __ballot(valid && hi - lo != 1) == 0;
+        // fp64, chains beyond 64 nodes, a window too wide for the tile (C5's first iterations: the whole chain): lane = node for this batch (tdlo_estep_wide.h)
+        if constexpr (sizeof(T) == 8 && NCH > 1) {
+            constexpr int WCH = NCH < 5 ? NCH : 5;
+            if (whi - wlo + 1 >= f.estep_wide_min && whi - wlo + 1 <= 64 * WCH) {
+                estep_wide_batch<WCH, VIS>(lane, wlo, whi, batch * 64, N, adj, min_lo, max_hi, x, y, z, lo, hi, c_lo, d_lo, c_hi, d_hi, k2, cn, nodesL, lvL, (double *)pb, accL,
+                                           scP, scR, scQ, limP, limR, limQ, limQn, accQ, acc_ok);
+                EPHASE(5);
+                continue;
+            }
+        }
         T sum = 0, qs = 0;
         // fp64: the argument of the exponent without a per-point decision for the nodes at or below every point's lo (m <= min_lo) and at or above
         // every point's hi (m >= max_hi) -- wave-uniform branches; the per-point form in between (and everywhere when a pair has the end-node gap)

@@ -173,6 +173,9 @@ struct FrameDev {
     // M-step: waits for word 111 == spin_wait; stores spin_signal to word 110.
     int spin_on, spin_first;
     unsigned spin_wait, spin_signal;
+    // fp64 E-step, chains beyond 64 nodes: a batch whose node window holds at least this many nodes (and at most 320) goes lane = node (tdlo_estep_wide.h;
+    // TDLO_ESTEP_WIDE=0: never -- the comparator; =n: from n nodes on)
+    int estep_wide_min;
 };
 constexpr int kSpinWordM = 110, kSpinWordE = 111;
 
