@@ -1011,6 +1011,13 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     const int N = stg->N;
     const T k2 = (T)stg->k2;
     const T cn = (T)stg->c_norm;
+    // (everything this kernel reads of the iteration state is requested HERE, in one memory round trip with the points: read where they are used -- behind the
+    //  barrier -- the boost, the window and the parity each cost a round trip of their own, 1 600 clocks of a 8 000-clock workgroup at C2: scripts/archive/gpu_estamps.py)
+    //  (fp32 only: the fp64 instantiations, two waves per SIMD with their registers full, measured 0.4 % slower with the three values held across the kernel)
+    constexpr bool EARLY = sizeof(T) == 4;
+    const int shb_e = EARLY ? stg->sh_boost : 0;
+    const double rwin_e = EARLY ? stg->rwin32 : 0.0;
+    const int par_e = EARLY ? (stg->it & 1) : 0;
     for (int m = tid; m < M; m += EB) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
     // One frame that cannot fill the GPU, chains of up to 64 nodes (round 6): the kernel is a chain of latencies there (one wave per SIMD: 8 500 clocks per batch, of
     // which the scalar node loads of the two node loops and the LDS reads of the range tests are round trips nothing overlaps).  Lane l keeps node l in registers for the
@@ -1062,7 +1069,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
 
     // running sums in 64-bit fixed point (acc_fix at the grain of one wave x one batch; integer from there on: tdlo_devcommon.h)
     long long accQ = 0;
-    const int shb = stg->sh_boost;         // (fp64 mode: extra digits for R, twice as many for Q, while sigma is small: set_iter_consts)
+    const int shb = EARLY ? shb_e : stg->sh_boost;         // (fp64 mode: extra digits for R, twice as many for Q, while sigma is small: set_iter_consts)
     const double scP = acc_scale(f.acc_sh[0]), scR = acc_scale(f.acc_sh[1] + shb), scQ = acc_scale(f.acc_sh[2] + 2 * shb);
     // every converted value is checked against its limit (FrameDev::acc_lim: exact conversion, no wrap-around of the totals; a NaN fails
     // the comparison too): one compare per conversion into a lane mask, looked at once per wave at the end
@@ -1087,7 +1094,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     // Node window: E / |k2| (a squared arc length, left by the M-step; E bits: FrameDev::win_e32 / win_e64), widened by what the visibility
     // weights can take from a nearest node's membership.  A wave leaves node m out when (coord distance to the wave's nearest pairs)^2 exceeds
     // (largest nearest-node distance of the wave)^2 + this: every point's membership of m is then below 2^-E of its largest one
-    const T R2win = (T)((sizeof(T) == 4 ? stg->rwin32 : stg->rwin64) * (1.0 + (VIS ? lv_span / (sizeof(T) == 4 ? f.win_e32 : f.win_e64) : 0.0)));
+    const T R2win = (T)((EARLY ? rwin_e : stg->rwin64) * (1.0 + (VIS ? lv_span / (sizeof(T) == 4 ? f.win_e32 : f.win_e64) : 0.0)));
 
     const int nbatch = (N + 63) >> 6;
     for (int batch = batch0; batch < nbatch; batch += f.nblkE * NWE) {
@@ -1498,7 +1505,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     __syncthreads();
     ESTAMP(6);
-    long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (blockIdx.x % kAccRows)) * acc_stride(M);
+    long long *arow = f.acc + ((size_t)(EARLY ? par_e : (TDLO_AS_GLOBAL(IterState, f.st)->it & 1)) * kAccRows + (blockIdx.x % kAccRows)) * acc_stride(M);
     {
         const long long *accAll = (const long long *)(scratch + 16);
         for (int i = tid; i < 4 * M; i += EB) {
