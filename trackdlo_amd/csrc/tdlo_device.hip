@@ -1000,25 +1000,23 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
         spin_report();
         return;
     }
-    const int done = stg->done;
-    if (SINGLE && f.late_aJ != nullptr && f.late_mstep == 0 && blockIdx.x == 0 && stg->it == 0) {
-        // (tracking_step's second registration) the priors the host formed while the set-up kernel ran: to their place in the node block, for the
-        // M-step of this and every later iteration
-        double *dj = (double *)f.aJ, *dy = (double *)f.aYd;
-        for (int i = threadIdx.x; i < f.M; i += EB) dj[i] = f.late_aJ[i];
-        for (int i = threadIdx.x; i < 3 * f.M; i += EB) dy[i] = f.late_aYd[i];
-    }
-    const int N = stg->N;
-    const T k2 = (T)stg->k2;
-    const T cn = (T)stg->c_norm;
-    // (everything this kernel reads of the iteration state is requested HERE, in one memory round trip with the points: read where they are used -- behind the
-    //  barrier -- the boost, the window and the parity each cost a round trip of their own, 1 600 clocks of a 8 000-clock workgroup at C2: scripts/archive/gpu_estamps.py)
-    //  (fp32 only: the fp64 instantiations, two waves per SIMD with their registers full, measured 0.4 % slower with the three values held across the kernel)
+    // ---- EVERYTHING this kernel reads from memory before its first barrier is requested here, back to back, in ONE round trip with the points above: the
+    // iteration state, this thread's node for the LDS copy, this lane's node.  (Until round 6 the state's `done` was waited for on its own -- the branch below
+    // needs it -- then N, k2, c_norm were requested, waited for, then the nodes: three round trips in a row, and the boost, the window radius and the parity
+    // one more each behind the barrier: 3 500 clocks of a 8 000-clock workgroup at C2 spent waiting for memory, scripts/archive/gpu_estamps.py + the ISA.)
+    // (fp32 only: the fp64 instantiations -- two waves per SIMD, registers full, chains of hundreds of nodes -- measured 0.4 % ... 4 % SLOWER with the requests up
+    //  front and their values held across the kernel; they keep the order of before)
     constexpr bool EARLY = sizeof(T) == 4;
+    const int done = stg->done;
+    const int it0 = EARLY ? stg->it : 0;
+    int N; T k2, cn;
+    if constexpr (EARLY) { N = stg->N; k2 = (T)stg->k2; cn = (T)stg->c_norm; }
     const int shb_e = EARLY ? stg->sh_boost : 0;
     const double rwin_e = EARLY ? stg->rwin32 : 0.0;
-    const int par_e = EARLY ? (stg->it & 1) : 0;
-    for (int m = tid; m < M; m += EB) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
+    const int par_e = it0 & 1;
+    const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes);
+    V4<T> nd0; nd0.x = 0; nd0.y = 0; nd0.z = 0; nd0.w = 0;
+    if (EARLY && tid < M) { nd0.x = qg[tid].x; nd0.y = qg[tid].y; nd0.z = qg[tid].z; nd0.w = qg[tid].w; }
     // One frame that cannot fill the GPU, chains of up to 64 nodes (round 6): the kernel is a chain of latencies there (one wave per SIMD: 8 500 clocks per batch, of
     // which the scalar node loads of the two node loops and the LDS reads of the range tests are round trips nothing overlaps).  Lane l keeps node l in registers for the
     // whole kernel and a node's values reach the wave by v_readlane -- the same values in the same operand positions (an SGPR either way): the same bits, no round trip.
@@ -1028,7 +1026,21 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     constexpr bool LANE_NODES = SINGLE && NCH == 1;
 #endif
     V4<T> qn; qn.x = 0; qn.y = 0; qn.z = 0; qn.w = 0;
-    if (LANE_NODES && lane < M) { const auto qg = TDLO_AS_GLOBAL(V4<T>, f.nodes); qn.x = qg[lane].x; qn.y = qg[lane].y; qn.z = qg[lane].z; qn.w = qg[lane].w; }
+    if (LANE_NODES && lane < M) { qn.x = qg[lane].x; qn.y = qg[lane].y; qn.z = qg[lane].z; qn.w = qg[lane].w; }
+    if (SINGLE && f.late_aJ != nullptr && f.late_mstep == 0 && blockIdx.x == 0 && (EARLY ? it0 : stg->it) == 0) {
+        // (tracking_step's second registration) the priors the host formed while the set-up kernel ran: to their place in the node block, for the
+        // M-step of this and every later iteration
+        double *dj = (double *)f.aJ, *dy = (double *)f.aYd;
+        for (int i = threadIdx.x; i < f.M; i += EB) dj[i] = f.late_aJ[i];
+        for (int i = threadIdx.x; i < 3 * f.M; i += EB) dy[i] = f.late_aYd[i];
+    }
+    if constexpr (EARLY) {
+        if (tid < M) nodesL[tid] = nd0;
+        for (int m = tid + EB; m < M; m += EB) { V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
+    } else {
+        N = stg->N; k2 = (T)stg->k2; cn = (T)stg->c_norm;
+        for (int m = tid; m < M; m += EB) { V4<T> o; o.x = qg[m].x; o.y = qg[m].y; o.z = qg[m].z; o.w = qg[m].w; nodesL[m] = o; }
+    }
     auto lane_val = [&](T v, int src) -> T {          // v of lane src (wave-uniform), as a wave-uniform operand
         if constexpr (sizeof(T) == 4) return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src));
         else return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
