@@ -81,6 +81,12 @@ sec() { echo "== $1"; shift; "$@" 2>&1 | grep -v amdgpu.ids; local rc=${PIPESTAT
   sec "E-step phases at C5 (N = 200 000, M = 300, fp64) over the iterations" timeout 300 python scripts/gpu_ephases.py 200000 300 1 5
   sec "c5_5it" env ITERS=5 timeout 200 python scripts/gpu_c5.py
   sec "pcie" timeout 200 python scripts/gpu_pcie.py
+  sec "fp64 E-step of long chains: wide windows lane = node (default) against thread = point (TDLO_ESTEP_WIDE=0), C5" env MODES=0,129 timeout 400 python scripts/gpu_estep_wide_ab.py 200000 300 3
+  sec "the same, per-iteration E-step durations of one call (rocprofv3 kernel trace)" env ITERS=50 CASES=1 timeout 400 bash scripts/gpu_estep_wide_trace.sh gpurun_out/$tag/wide_trace
+  sec "a batch's loop as one launch (TDLO_BATCH_PERSIST=1, experiment) against the launch-per-step loop, C3" timeout 300 python scripts/gpu_batch_loop_ab.py 32 50000 2 50
+  sec "loop timeline under the profiler: C2" bash scripts/gpu_loop_timeline.sh 50000 50 0
+  sec "loop timeline under the profiler: C4" bash scripts/gpu_loop_timeline.sh 2000000 50 0
+  sec "loop timeline under the profiler: C5" bash scripts/gpu_loop_timeline.sh 200000 300 1
 } > $O/measured.log 2>&1
 ls -la $O
 head -12 $O/pmc_summary.log
