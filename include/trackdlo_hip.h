@@ -492,12 +492,14 @@ int tdlo_debug_lle_band_device(tdlo_ctx *ctx, const double *Y, int M, double *Hb
  * iteration had run on the second stream beside the pre-processing registration (TDLO_AHEAD=0); 5: calls repeated on the three-kernel route because
  * the fused prologue's grid barrier was abandoned; 6 / 7: tdlo_depth_to_cloud calls served by the one-launch kernel / passed on by it to the
  * multi-launch form; 8: frames whose visibility pre-pass rode in the depth -> cloud launch (tdlo_depth_to_cloud_visibility); 9: registrations whose
- * E-step was k_estep2 -- two points per lane, csrc/tdlo_estep2.hip: fp32 mode, chains of 8 .. 64 nodes, a cloud or a batch of at least 4096 x 64
+ * E-step was k_estep2 -- two points per lane, csrc/tdlo_estep2.hip: fp32 mode, chains of 8 .. 64 nodes, a cloud or a batch of at least 2048 x 64
  * points, i.e. one that fills the GPU (TDLO_ESTEP2=0: k_estep everywhere, the comparator; =1: wherever eligible, whatever the size).  The two
  * E-step kernels differ in the grain of their fp32 tile sums (one wave x 64 points / x 128 points): each is repeatable bit for bit and held to
  * the reference at the mode's tolerance, but a frame registered alone (k_estep) and the same frame inside a GPU-filling batch (k_estep2) agree
  * to about 1e-8 m, not to the bit.  10: fp64-mode calls repeated without the sigma-following resolution of the E-step's sums because a share was
  * refused under its finer range limits (the repeat runs under the coarse limits of every other mode; only its verdict is reported).
+ * 11: calls served by the spin-ahead loop (TDLO_SPIN_AHEAD=1, a round-6 experiment, off by default); 12 / 13: batches whose whole loop ran as one launch
+ * (TDLO_BATCH_PERSIST=1, a round-6 experiment, off by default) / such calls repeated on the launch-per-step loop because a wait inside the launch gave up.
  * -1 for a null context or an unknown counter. */
 long long tdlo_debug_route_count(tdlo_ctx *ctx, int which);
 /* Phase stamps (s_memtime) of the last depth -> cloud launch's finishing workgroup; only a -DTDLO_CLOUD_STAMPS build writes them. */
