@@ -228,7 +228,7 @@ def _context_class():
 
 
 def _traffic_from_profiles(F):
-    """HBM bytes per E-step launch from the newest committed rocprofv3 PMC summary (separate --pmc passes; scripts/gpu_profile.sh):
+    """HBM bytes per E-step launch from the newest committed rocprofv3 PMC summary (separate --pmc passes; scripts/gpu_r06_round_end.sh):
     NOT measured by this run, hence labelled with its source."""
     try:
         import glob

@@ -3,7 +3,7 @@ quadruple-precision solve of the same double-precision system, the banded L D L^
 usage: python scripts/gpu_fuzz_band_adjudicate.py seed [seed ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from trackdlo_amd import binding as B
 from oracle import ref_cpu

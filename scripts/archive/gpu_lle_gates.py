@@ -2,7 +2,7 @@
 error (QR vs quadruple-precision solve, oracle.extended_solver) beside the device's distance to the oracle in both precisions."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import ref_cpu as oracle
 from trackdlo_amd import binding as B, synth
 

@@ -2,7 +2,7 @@
 node workgroup (k_setup's body): 0 start | 1 (scan: skipped) | 2 | 3 | 4 nodes from host, centroid, coord | 5 nodes, accumulators cleared, chain links | 6 LLE records, H Y0 | 7 end (the counts are summed by point workgroup 0 since the end of round 4)
 point workgroup 0: 0 start | 1 nodes (host) + points loaded | 2 pruned, nearest node, block sum | 3 counts published, ticket | 4 grid barrier passed | 5 offsets | 6 scattered"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from trackdlo_amd import binding as B, synth
 _v = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tmp", "libtrackdlo_stamps.so")

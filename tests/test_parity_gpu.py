@@ -32,7 +32,7 @@ def _measured_gate(oracle, prec, run, H, o):
     measured to be uncertain by on this very input -- 8 x the larger of (a) its own rounding error: the faithful QR solve
     against the quadruple-precision solve of the same systems, (b) its sensitivity to the last bit of the data: H perturbed
     by +-1 ulp per entry (the reference forms H, H G and the sums in another order than any re-implementation can).
-    On all but the pathological draws both are ~1e-12 m and the stated tolerance stands (scripts/gpu_lle_gates.py)."""
+    On all but the pathological draws both are ~1e-12 m and the stated tolerance stands (scripts/archive/gpu_lle_gates.py)."""
     ty, ts = TOL[prec]
     with oracle.extended_solver():
         e = run(H)

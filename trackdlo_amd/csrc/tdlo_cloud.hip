@@ -413,7 +413,7 @@ __device__ __forceinline__ void cloud_grid(const unsigned *sbox, int n, float in
 // region, count, bounding box -- and a ticket (returned to every thread: 0 .. T - 1 in the order the workgroups finished)
 __device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot, unsigned *sticket, unsigned *sbx /* kFW x 6 words of LDS nobody uses yet */) {
     const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
-#ifdef TDLO_CLOUD_STAMPS      // wall-clock (100 MHz) split of phase A in the middle tile: words 12 .. 18 behind the state words (scripts/gpu_cloud_stamps.py)
+#ifdef TDLO_CLOUD_STAMPS      // wall-clock (100 MHz) split of phase A in the middle tile: words 12 .. 18 behind the state words (scripts/archive/gpu_cloud_stamps.py)
 #define ASTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (t == 0 && b == a.T / 2) ((unsigned long long *)(a.state + 16))[12 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ASTAMP(i) do { } while (0)
@@ -464,7 +464,7 @@ __device__ __forceinline__ unsigned cloud_phase_a(const FusedCloud &a, int *wtot
         ASTAMP(4);
         // the tile's box: every wave's six values by DPP (six trips each through the LDS crossbar before), the sixteen waves' through LDS, then SIX atomics
         // per tile -- one per wave with a masked pixel had been ~6 000 read-modify-writes on six words per 640 x 480 image, serialised where
-        // the device's atomics meet: most of this phase's 23 us (scripts/gpu_cloud_stamps.py)
+        // the device's atomics meet: most of this phase's 23 us (scripts/archive/gpu_cloud_stamps.py)
         {
             const bool any = __ballot(c != 0) != 0ull;                        // (wave-uniform)
             unsigned r6[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kFT) void k_cloud_fused(const FusedCloud a) {
     __shared__ unsigned sticket;
     __shared__ FusedGrid sgrid;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-#ifdef TDLO_CLOUD_STAMPS      // phase stamps of the last workgroup (instrumented build only, scripts/gpu_cloud_stamps.py): 64-bit words behind the state words
+#ifdef TDLO_CLOUD_STAMPS      // phase stamps of the last workgroup (instrumented build only, scripts/archive/gpu_cloud_stamps.py): 64-bit words behind the state words
 #define FSTAMP(i) do { __syncthreads(); if (t == 0) ((unsigned long long *)(a.state + 16))[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kFT) void k_cloud_team(const FusedCloud a) {
     __shared__ FusedGrid sgrid;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-#ifdef TDLO_CLOUD_STAMPS      // phase stamps of team workgroup 0 (instrumented build only, scripts/gpu_cloud_stamps.py)
+#ifdef TDLO_CLOUD_STAMPS      // phase stamps of team workgroup 0 (instrumented build only, scripts/archive/gpu_cloud_stamps.py)
 #define TSTAMP(i) do { __syncthreads(); if (t == 0 && k == 0) ((unsigned long long *)(a.state + 16))[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TSTAMP(i) do { } while (0)
