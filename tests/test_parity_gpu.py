@@ -1555,3 +1555,45 @@ def test_spin_ahead_loop_gives_the_ordinary_loops_bits(oracle):
     for a, b in zip(outs["0"], outs["1"]):
         assert np.array_equal(a["Y"], b["Y"]) and a["sigma2"] == b["sigma2"] and a["iters"] == b["iters"] == 30
     _check(outs["1"][0], oracle.cpd_lle(pairs[0][0], pairs[0][1], 0.0, **kw), 0)
+
+
+@pytest.mark.gpu
+def test_mstep_told_the_wrong_parity_reads_its_sums_again(oracle):
+    """The host counts the iterations it enqueues and tells every plain chain M-step its iteration's parity, so that the kernel requests that parity's
+    accumulator rows alone (half the lines of the round trip every iteration waits for) without waiting for the device's counter; the kernel compares the word
+    with the counter and, if they disagree, reads the sums again the ordinary way.  TDLO_TEST_PARITY_FLIP=1 makes every hint wrong: the same bits, one frame
+    (two row counts: fp32 at 50 nodes, fp64 at 130) and a batch; TDLO_ACC_ROWS=2|4|8 (how many replica rows the E-step spreads over): the same bits as well."""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+from trackdlo_amd import binding as B, synth
+P = synth.LAUNCH_PARAMS
+out = {}
+for name, N, M, prec in (("f32", 30000, 50, 0), ("f64", 20000, 130, 1)):
+    X, Y0, _ = synth.scene(N, M, config=900 + M)
+    pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 9, 0.0, False, precision=prec)
+    c = B.Context(max_points=N, max_nodes=M, timing=False)
+    g = c.cpd_lle(X, Y0, 0.0, pr); c.close()
+    out[name] = [hashlib.sha1(np.ascontiguousarray(g["Y"]).tobytes()).hexdigest(), float(g["sigma2"]), int(g["iters"])]
+F, N, M = 3, 20000, 50
+scenes = [synth.scene(N, M, config=910, frame=f)[:2] for f in range(F)]
+c = B.Context(max_frames=F, max_points=N, max_nodes=M, timing=False)
+for f, (X, _) in enumerate(scenes): c.set_cloud(f, X)
+pr = B.make_params(P["beta"], P["lambda_"], P["lle_weight"], P["mu"], 9, 0.0, False)
+g = c.cpd_lle_batch([y for _, y in scenes], [0.0] * F, pr); c.close()
+out["batch"] = [hashlib.sha1(np.ascontiguousarray(np.asarray(g["Y"])).tobytes()).hexdigest(), [float(v) for v in g["sigma2"]]]
+print("RESULT " + json.dumps(out))
+''' % root
+    res = {}
+    for tag, env in (("plain", {}), ("flip", {"TDLO_TEST_PARITY_FLIP": "1"}), ("rows2", {"TDLO_ACC_ROWS": "2"}), ("rows4", {"TDLO_ACC_ROWS": "4"}),
+                     ("rows8flip", {"TDLO_ACC_ROWS": "8", "TDLO_TEST_PARITY_FLIP": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and line, (tag, r.stdout[-2000:], r.stderr[-2000:])
+        res[tag] = json.loads(line[0][7:])
+    for tag in res:
+        assert res[tag] == res["plain"], (tag, res[tag], res["plain"])
+    assert res["plain"]["f32"][2] == 9 and res["plain"]["f64"][2] == 9

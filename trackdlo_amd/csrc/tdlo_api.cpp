@@ -624,6 +624,23 @@ int stage_priors(tdlo_ctx *c, double *aJ, double *aYd, const double *Y, int M, c
 
 // Fills the host-side upload block [Yin | aJ | aYd | H] for one frame and its FrameDev.
 // k_estep2 (two points per lane) can serve this frame: fp32 mode, chains of 8 .. 64 nodes
+// How many replica rows of the accumulators a frame's E-step workgroups spread their atomics over (FrameDev::acc_rows).  More rows: fewer atomics per address;
+// fewer rows: less for the one-workgroup M-step to fetch in the round trip every iteration waits for.  Measured on one box (scripts/gpu_ab.sh; the rows first as
+// a build constant 2 / 4 / 8, then -- with the M-step told its iteration's parity, which halves the fetch on its own -- through TDLO_ACC_ROWS):
+//   C5 (782 workgroups of an fp64 E-step of 14 us, uneven work; 1 202 sums): M-step 17.59 / 17.73 / 18.14 us, E-step the same -> 2;
+//   C2 (196 workgroups, fp32): E-step 5.26 / 4.60 / 4.52 us as a constant; with the parity known, iteration 13.13 (4 rows) against 12.99 us (8) -> 8;
+//   C4 (977 workgroups of equal work, finishing together): E-step 17.7 (4) against 16.95 us (8) -> 8.
+// The totals are integers: every choice gives the same bits.  Only the plain one-frame chain M-step is instantiated for fewer rows (tdlo_mstep_chain.hip);
+// every other M-step adds up all eight (the unused ones are zero).  TDLO_ACC_ROWS=2|4|8 overrides.
+static void choose_acc_rows(const tdlo_ctx *c, FrameDev &f, bool merged) {
+    static const int env = getenv("TDLO_ACC_ROWS") ? atoi(getenv("TDLO_ACC_ROWS")) : 0;
+    (void)c;
+    int r = kAccRows;
+    if (!merged && !f.include_lle && !f.mstep_dense && f.M > kChunk && f.M <= kChainLdsMaxNodes && f.precision == TDLO_PREC_F64) r = 2;
+    if (env == 2 || env == 4 || env == 8) r = env;
+    f.acc_rows = r;
+}
+
 static bool estep2_eligible(const tdlo_ctx *c, const FrameDev &f) {
     return c->estep2_mode != 0 && f.precision == TDLO_PREC_F32 && f.M >= 8 && f.M <= kChunk;
 }
@@ -819,9 +836,11 @@ int prepare_frame(tdlo_ctx *c, int slot, const double *Y, int M, double sigma2, 
     }
     f.acc_boost_off = c->boost_off_once ? 1 : 0;
     f.estep_wide_min = c->estep_wide_min;
+    // (acc_rows: choose_acc_rows, once the E-step's geometry is final)
     // one frame whose cloud fills the GPU alone (2048 waves of 64 points: from there on two points per lane win, scripts/gpu_estep2_check.py /
     // profiles/r06_measured.log -- 131 072 points 4.8 against 5.3 us per E-step, 250 000 points (a shard of C4 on eight ranks) 5.5 against 7.3 us)
     if (estep2_eligible(c, f) && (c->estep2_mode == 1 || nbatch >= kEstep2MinWaves)) estep2_geometry(c, f, false);
+    choose_acc_rows(c, f, false);
     f.sums = blk + nc.sums; f.Ascr = blk + nc.Ascr; f.Yout = blk + nc.Yout; f.dbg = (unsigned long long *)(blk + nc.dbg);
     f.sync = s.sync;
     f.st = (IterState *)(blk + nc.st);
@@ -984,6 +1003,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         for (int i = 0; i < F; ++i) { waves += (c->fh[i].N0 + 63) / 64; elig = elig && estep2_eligible(c, c->fh[i]); }
         const bool two = elig && (c->estep2_mode == 1 || waves >= kEstep2MinWaves);
         for (int i = 0; i < F; ++i) if (two) estep2_geometry(c, c->fh[i], true);      // (a frame prepare_frame had given to k_estep2 on its own size keeps it only if the whole batch does:
+        for (int i = 0; i < F; ++i) choose_acc_rows(c, c->fh[i], true);
         if (!two) for (int i = 0; i < F; ++i) if (c->fh[i].estep2) return fail(c, TDLO_E_INVALID, "internal: a batch's frames disagree about the E-step kernel");   //  same M, precision and mode -- they cannot)
     }
     if (!p->include_lle) break;
@@ -1170,7 +1190,7 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
                     TDLO_RET(hipStreamWaitEvent(gs[g + 1], c->evx[g], 0));
                     TDLO_RET(launch_estep_only(fdg, fhg, Fg, 2, gs[g]));
                 } else {
-                    TDLO_RET(launch_iteration(fdg, fhg, Fg, gs[g]));
+                    TDLO_RET(launch_iteration(fdg, fhg, Fg, gs[g], enqueued - 1));      // (this call's count of the registration's iterations: mstep_parity_hint)
                 }
             }
             forked = true;
@@ -1258,13 +1278,13 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
                 const FrameDev *fdg = fdp + goff[g], *fhg = c->fh.data() + goff[g];
                 const int Fg = goff[g + 1] - goff[g];
                 if (!chain) {
-                    for (int it = 0; it < rest; ++it) { const hipError_t e = launch_iteration(fdg, fhg, Fg, gs[g]); if (e != hipSuccess) return (int)e; }
+                    for (int it = 0; it < rest; ++it) { const hipError_t e = launch_iteration(fdg, fhg, Fg, gs[g], 1 + it); if (e != hipSuccess) return (int)e; }
                     return 0;
                 }
                 auto bail = [&](hipError_t e) { broken.store(true); return (int)e; };
                 for (int it = 0; it < rest; ++it) {
                     hipError_t e;
-                    if (!chain_at(it)) { if ((e = launch_iteration(fdg, fhg, Fg, gs[g])) != hipSuccess) return bail(e); continue; }
+                    if (!chain_at(it)) { if ((e = launch_iteration(fdg, fhg, Fg, gs[g], 1 + it)) != hipSuccess) return bail(e); continue; }
                     // (the event of a chained iteration: every iteration -> a ring with the hazard check below; the four phase-setting iterations -> one event each)
                     const int slot = chain_all ? it % tdlo_ctx::kChainRing : (it == 4 ? 0 : (it == 10 ? 1 : (it == 22 ? 2 : 3)));
                     if (g > 0) {            // behind the E-step of the group in front, same iteration
@@ -2530,8 +2550,8 @@ int tdlo_profile_kernel(tdlo_ctx *c, int slot, int kind, int reps, float *avg_us
         // own start/stop events -- the duration a kernel trace reports, not a back-to-back average with hot caches
         std::vector<hipEvent_t> evs(2 * (size_t)reps, nullptr);
         for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
-        for (int w = 0; w < 3; ++w) HIPCHK(c, launch_iteration(c->fd, fh.data(), F, s));
-        for (int r = 0; r < reps; ++r) HIPCHK(c, launch_iteration_timed(c->fd, fh.data(), F, s, evs[2 * r], evs[2 * r + 1], nullptr, nullptr));
+        for (int w = 0; w < 3; ++w) HIPCHK(c, launch_iteration(c->fd, fh.data(), F, s, w));      // (the counter was set to 0 above)
+        for (int r = 0; r < reps; ++r) HIPCHK(c, launch_iteration_timed(c->fd, fh.data(), F, s, evs[2 * r], evs[2 * r + 1], nullptr, nullptr, 3 + r));
         HIPCHK(c, hipStreamSynchronize(s));
         double tot = 0;
         for (int r = 0; r < reps; ++r) { float ms = 0; hipEventElapsedTime(&ms, evs[2 * r], evs[2 * r + 1]); tot += ms; }
@@ -2600,9 +2620,9 @@ int tdlo_profile_iteration(tdlo_ctx *c, int reps, float *estep_us, float *mstep_
     HIPCHK(c, zero_accumulators(fh, F, s));
     std::vector<hipEvent_t> evs(4 * (size_t)reps, nullptr);
     for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
-    for (int w = 0; w < 3; ++w) HIPCHK(c, launch_iteration(c->fd, fh.data(), F, s));
+    for (int w = 0; w < 3; ++w) HIPCHK(c, launch_iteration(c->fd, fh.data(), F, s, w));      // (the counter was set to 0 above)
     HIPCHK(c, hipEventRecord(c->ev[0], s));
-    for (int r = 0; r < reps; ++r) HIPCHK(c, launch_iteration_timed(c->fd, fh.data(), F, s, evs[4 * r], evs[4 * r + 1], evs[4 * r + 2], evs[4 * r + 3]));
+    for (int r = 0; r < reps; ++r) HIPCHK(c, launch_iteration_timed(c->fd, fh.data(), F, s, evs[4 * r], evs[4 * r + 1], evs[4 * r + 2], evs[4 * r + 3], 3 + r));
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     HIPCHK(c, hipStreamSynchronize(s));
     double te = 0, tm = 0;

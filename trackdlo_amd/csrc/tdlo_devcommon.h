@@ -245,6 +245,7 @@ __device__ __forceinline__ long long acc_fix(double v, double scale) {
 __device__ __forceinline__ void acc_add(long long *row, int i, long long iv) {
     if (iv != 0) __hip_atomic_fetch_add(row + i, iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exact zeros (nodes outside the window) add nothing
 }
+__device__ __forceinline__ int acc_rows_used(const FrameDev &f) { const int r = f.acc_rows; return (r == 2 || r == 4) ? r : kAccRows; }
 __device__ __forceinline__ const long long *acc_rows(const FrameDev &f, int it) { return f.acc + (size_t)(it & 1) * kAccRows * acc_stride(f.M); }
 // element i of the sums of iteration `it`: the replica rows are added as integers (exact), one conversion
 __device__ __forceinline__ double acc_read(const FrameDev &f, const long long *rows, int i) {
@@ -257,13 +258,26 @@ __device__ __forceinline__ double acc_read(const FrameDev &f, const long long *r
 }
 // the same without a load that depends on the iteration counter (both parities are fetched, one is kept): for the one-workgroup M-steps,
 // whose first memory round trip is on the critical path of every iteration
+// (ROWS: the rows the E-step used, FrameDev::acc_rows -- the others are zero; a kernel instantiated for fewer rows fetches less in the round trip it waits for)
+template <int ROWS = kAccRows>
 __device__ __forceinline__ double acc_read_both(const FrameDev &f, int i, int it) {
     const auto a = TDLO_AS_GLOBAL(long long, f.acc);
     const int st = acc_stride(f.M);
     long long s0 = 0, s1 = 0;
 #pragma unroll
-    for (int r = 0; r < kAccRows; ++r) { s0 += a[(size_t)r * st + i]; s1 += a[(size_t)(kAccRows + r) * st + i]; }
+    for (int r = 0; r < ROWS; ++r) { s0 += a[(size_t)r * st + i]; s1 += a[(size_t)(kAccRows + r) * st + i]; }
     return ::ldexp((double)((it & 1) ? s1 : s0), -acc_shift(f, i));
+}
+// ... and when the launch was TOLD the iteration's parity (the host counts the iterations it enqueues: mstep_parity_hint in tdlo_mstep_chain.hip), that
+// parity's rows alone -- half the lines of the round trip every iteration waits for.  The kernel checks the word against the device's counter afterwards.
+template <int ROWS = kAccRows>
+__device__ __forceinline__ double acc_read_par(const FrameDev &f, int i, int par) {
+    const auto a = TDLO_AS_GLOBAL(long long, f.acc) + (size_t)par * kAccRows * acc_stride(f.M);
+    const int st = acc_stride(f.M);
+    long long s = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) s += a[(size_t)r * st + i];
+    return ::ldexp((double)s, -acc_shift(f, i));
 }
 // the rows of the other parity are cleared for the next E-step (nobody touches them while an M-step runs)
 template <int NT> __device__ __forceinline__ void acc_clear_other(const FrameDev &f, int it, int t) {

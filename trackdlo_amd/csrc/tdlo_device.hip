@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(EB) void k_estep(const FrameDev *__restrict__ frame
     }
     __syncthreads();
     ESTAMP(6);
-    long long *arow = f.acc + ((size_t)(EARLY ? par_e : (TDLO_AS_GLOBAL(IterState, f.st)->it & 1)) * kAccRows + (blockIdx.x % kAccRows)) * acc_stride(M);
+    long long *arow = f.acc + ((size_t)(EARLY ? par_e : (TDLO_AS_GLOBAL(IterState, f.st)->it & 1)) * kAccRows + (blockIdx.x & (acc_rows_used(f) - 1))) * acc_stride(M);
     {
         const long long *accAll = (const long long *)(scratch + 16);
         for (int i = tid; i < 4 * M; i += EB) {
@@ -2325,12 +2325,14 @@ hipError_t launch_prologue_direct(const FrameDev *fh, const double *host_up, dou
     return hipGetLastError();
 }
 
-hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s) {
+hipError_t launch_iteration(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s, int iteration) {
     const bool f64 = fh[0].precision == TDLO_PREC_F64;
     if (fh[0].vis_branch) TDLO_TRY(f64 ? launch_dmin_T<double>(fd, fh, F, s) : launch_dmin_T<float>(fd, fh, F, s));
     TDLO_TRY(f64 ? launch_estep_T<double>(fd, fh, F, s) : launch_estep_T<float>(fd, fh, F, s));
-    TDLO_TRY(f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s));
-    return hipSuccess;
+    mstep_parity_hint(iteration);          // (the caller's count of the registration's iterations: the chain M-step fetches that parity's sums only)
+    const hipError_t e = f64 ? launch_mstep_T<double>(fd, fh, F, 0, s) : launch_mstep_T<float>(fd, fh, F, 0, s);
+    mstep_parity_hint(-1);
+    return e;
 }
 
 hipError_t launch_iteration_spin(const FrameDev *fd, FrameDev *fh, hipStream_t s_e, hipStream_t s_m, bool first, unsigned *ecount, unsigned *mtag) {
@@ -2346,10 +2348,10 @@ hipError_t launch_iteration_spin(const FrameDev *fd, FrameDev *fh, hipStream_t s
 }
 
 hipError_t launch_iteration_timed(const FrameDev *fd, const FrameDev *fh, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
-                                  hipEvent_t m_start, hipEvent_t m_stop) {
+                                  hipEvent_t m_start, hipEvent_t m_stop, int iteration) {
     g_estep_ev[0] = e_start; g_estep_ev[1] = e_stop;
     g_mstep_ev[0] = m_start; g_mstep_ev[1] = m_stop;
-    const hipError_t e = launch_iteration(fd, fh, F, s);
+    const hipError_t e = launch_iteration(fd, fh, F, s, iteration);
     g_estep_ev[0] = g_estep_ev[1] = nullptr;
     g_mstep_ev[0] = g_mstep_ev[1] = nullptr;
     return e;

@@ -424,7 +424,7 @@ __device__ __forceinline__ void estep2_chunk(const FrameDev &f, const int chunk,
         sw->status = TDLO_E_NUMERIC; sw->converged = 0; sw->done = 1;
     }
     __syncthreads();
-    long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (chunk % kAccRows)) * acc_stride(M);
+    long long *arow = f.acc + ((size_t)(TDLO_AS_GLOBAL(IterState, f.st)->it & 1) * kAccRows + (chunk & (acc_rows_used(f) - 1))) * acc_stride(M);
     for (int i = tid; i < 4 * M; i += EB) acc_add(arow, (i & 3) * M + (i >> 2), accL[i]);
     if (tid == 0) {
         long long q = 0;

@@ -176,6 +176,10 @@ struct FrameDev {
     // fp64 E-step, chains beyond 64 nodes: a batch whose node window holds at least this many nodes (and at most 320) goes lane = node (tdlo_estep_wide.h;
     // TDLO_ESTEP_WIDE=0: never -- the comparator; =n: from n nodes on)
     int estep_wide_min;
+    // how many of the kAccRows replica rows of the accumulators the E-step's workgroups spread their atomics over (workgroup b adds to row b & (acc_rows - 1);
+    // 2, 4 or 8; 0 reads as 8): the unused rows stay zero, so a reader may add up all kAccRows (exact either way) -- the chain M-step, whose first memory
+    // round trip is on every iteration's critical path, requests only the used ones (choose_acc_rows in tdlo_api.cpp has the measurements)
+    int acc_rows;
 };
 constexpr int kSpinWordM = 110, kSpinWordE = 111;
 
@@ -234,12 +238,12 @@ bool prologue_direct_ok(const FrameDev &f);
 bool prologue_pair_ok(const FrameDev &f);      // the fused form itself (not the reused-sort set-up): a second registration's set-up can ride along
 hipError_t launch_prologue_direct(const FrameDev *fh, const double *host_up, double *dev_up, int up_doubles, int yin_off, unsigned epoch, hipStream_t s,
                                   const FrameDev *f2 = nullptr, const double *host_up2 = nullptr, double *dev_up2 = nullptr, int up_doubles2 = 0);
-hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s);
+hipError_t launch_iteration(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, int iteration = -1);      // (iteration: mstep_parity_hint)
 // one iteration of the spin-ahead loop (FrameDev::spin_on): the E-step on s_e, the M-step on s_m; fh[0]'s spin fields are set per launch (the one-frame kernels take
 // the descriptor by value).  ecount / mtag: the slot's running counts behind the tags.
 hipError_t launch_iteration_spin(const FrameDev *frames_dev, FrameDev *frames_host, hipStream_t s_e, hipStream_t s_m, bool first, unsigned *ecount, unsigned *mtag);
 hipError_t launch_iteration_timed(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop,
-                                  hipEvent_t m_start, hipEvent_t m_stop);
+                                  hipEvent_t m_start, hipEvent_t m_stop, int iteration = -1);
 const char *mstep_kernel_name(const FrameDev *frames_host, int F);
 // tdlo_estep2.hip: the E-step with two points per lane (FrameDev::estep2)
 hipError_t launch_estep2(const FrameDev *frames_dev, const FrameDev *frames_host, int F, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
@@ -267,6 +271,7 @@ hipError_t launch_mstep_pivot_mcu(const FrameDev *frames_dev, const FrameDev *fr
 bool mstep_pivot_mcu_enabled();
 // tdlo_mstep_chain.hip: M-step without the LLE term as a Kalman / Rauch-Tung-Striebel smoother along the chain, any M
 hipError_t launch_mstep_chain(const FrameDev *frames_dev, const FrameDev *frames_host, int F, int from_sums, bool f64, hipStream_t s);
+void mstep_parity_hint(int iteration);          // (tdlo_mstep_chain.hip) the iteration this thread's next chain M-step launches belong to; -1: unknown
 hipError_t launch_lle_band_debug(const double *Y_dev, int M, double *Hb_dev, hipStream_t s);      // test aid: the device form of lle_regulariser_band (tdlo_lle_dev.h), M <= 256
 bool mstep_chain_enabled();
 int mstep_set_dense(int on);      // returns the previous setting

@@ -54,18 +54,20 @@
 // The dense kernels stay in the tree: with the LLE term (include_lle, the pre-processing registration of tracking_step) the
 // system is not of this form, and TDLO_MSTEP=dense selects them as comparators for the tests.
 #include "tdlo_mstep_chain_body.h"
+#include <cstdlib>
 
 namespace tdlo {
 extern thread_local hipEvent_t g_mstep_ev[2];       // tdlo_device.hip: start/stop events for the M-step dispatch (tdlo_profile_iteration)
 
 // (the body: tdlo_mstep_chain_body.h, mstep_chain_run)
-template <typename T, bool SINGLE, bool XCH, bool TRK = false, bool SPIN = false>
-__global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums) {
+template <typename T, bool SINGLE, bool XCH, bool TRK = false, bool SPIN = false, int ROWS = kAccRows, bool HINT = false>
+__global__ __launch_bounds__(kCB) void k_mstep_chain(const FrameDev *__restrict__ frames, const FrameDev f0, int from_sums_in) {
+    const int from_sums = from_sums_in & 0xff, par_hint = (from_sums_in >> 8) & 1;          // (HINT: bit 8 carries the iteration's parity)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // One wave walks a chain of dependent instructions.  In a batch the other stream groups' E-steps fill the same SIMDs with waves that always have
     // something to issue: at the default priority this wave takes its turn among them (C3: 10.0 us per M-step against 7.4 us with the GPU to itself)
     if (!SINGLE) __builtin_amdgcn_s_setprio(3);
-    mstep_chain_run<T, SINGLE, XCH, TRK, SPIN>(SINGLE ? f0 : frames[blockIdx.x], from_sums, smem);
+    mstep_chain_run<T, SINGLE, XCH, TRK, SPIN, ROWS, HINT>(SINGLE ? f0 : frames[blockIdx.x], from_sums, smem, par_hint);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,6 +252,14 @@ template <typename K> static hipError_t set_lds_c(K kernel, size_t bytes) {
     return hipSuccess;
 }
 
+// The iteration a caller is about to enqueue, counted from the registration's first (the device's counter IterState::it starts at 0 in the set-up kernel and goes
+// up by one per M-step): the plain chain M-steps launched by this thread then fetch that parity's accumulator rows only.  -1: not known (both parities, as before).
+static thread_local int g_par_hint = -1;
+void mstep_parity_hint(int iteration) {
+    static const int flip = getenv("TDLO_TEST_PARITY_FLIP") ? atoi(getenv("TDLO_TEST_PARITY_FLIP")) : 0;      // (test hook: every hint wrong -- the kernel's check must catch it)
+    g_par_hint = iteration < 0 ? -1 : ((iteration + flip) & 1);
+}
+
 template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd, const FrameDev *fh, int F, int from_sums, hipStream_t s) {
     hipError_t e;
     if (fh[0].M > kChainLdsMaxNodes) {          // long chains: one direction, compact records (k_mstep_chain_long)
@@ -281,13 +291,20 @@ template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd,
         if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false, false, true>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
         else hipLaunchKernelGGL((k_mstep_chain<T, true, false, false, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
     } else if (F == 1) {
-        if ((e = set_lds_c(k_mstep_chain<T, true, false>, lds)) != hipSuccess) return e;
-        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, true, false>), dim3(1), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
-        else hipLaunchKernelGGL((k_mstep_chain<T, true, false>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
+        // (the plain one-frame kernel exists for 2, 4 and all 8 replica rows of the accumulators: FrameDev::acc_rows says how many the E-step in front used;
+        //  every other variant adds up all eight -- the unused ones are zero)
+        //  When the caller has said which iteration this is (mstep_parity_hint), the HINT instantiation asks for that parity's rows alone.
+        const int hint = from_sums == 0 ? g_par_hint : -1, fsh = from_sums | ((hint > 0 ? 1 : 0) << 8);
+#define TDLO_CHAIN1(SGL, ROWS, HINT, NWG) do { \
+        if ((e = set_lds_c(k_mstep_chain<T, SGL, false, false, false, ROWS, HINT>, lds)) != hipSuccess) return e; \
+        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, SGL, false, false, false, ROWS, HINT>), dim3(NWG), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], fsh); \
+        else hipLaunchKernelGGL((k_mstep_chain<T, SGL, false, false, false, ROWS, HINT>), dim3(NWG), dim3(kCB), lds, s, fd, fh[0], fsh); } while (0)
+        if (hint >= 0) { if (fh[0].acc_rows == 2) TDLO_CHAIN1(true, 2, true, 1); else if (fh[0].acc_rows == 4) TDLO_CHAIN1(true, 4, true, 1); else TDLO_CHAIN1(true, kAccRows, true, 1); }
+        else { if (fh[0].acc_rows == 2) TDLO_CHAIN1(true, 2, false, 1); else if (fh[0].acc_rows == 4) TDLO_CHAIN1(true, 4, false, 1); else TDLO_CHAIN1(true, kAccRows, false, 1); }
     } else {
-        if ((e = set_lds_c(k_mstep_chain<T, false, false>, lds)) != hipSuccess) return e;
-        if (g_mstep_ev[0]) hipExtLaunchKernelGGL((k_mstep_chain<T, false, false>), dim3(F), dim3(kCB), lds, s, g_mstep_ev[0], g_mstep_ev[1], 0, fd, fh[0], from_sums);
-        else hipLaunchKernelGGL((k_mstep_chain<T, false, false>), dim3(F), dim3(kCB), lds, s, fd, fh[0], from_sums);
+        const int hint = from_sums == 0 ? g_par_hint : -1, fsh = from_sums | ((hint > 0 ? 1 : 0) << 8);
+        if (hint >= 0) TDLO_CHAIN1(false, kAccRows, true, F); else TDLO_CHAIN1(false, kAccRows, false, F);
+#undef TDLO_CHAIN1
     }
     return hipGetLastError();
 }

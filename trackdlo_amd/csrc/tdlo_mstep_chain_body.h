@@ -99,8 +99,10 @@ struct ChainCarve {
 // instantiation is the kernel of the registrations proper, unchanged.
 // SPIN (round 6 experiment, FrameDev::spin_on): the launch was dispatched behind the M-step of the iteration before while THIS iteration's E-step still
 // runs on another stream -- everything but the sums is requested, then the kernel waits for the E-step's workgroups to have counted themselves in.
-template <typename T, bool SINGLE, bool XCH, bool TRK = false, bool SPIN = false>
-__device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums, char *smem) {
+// ROWS: how many replica rows of the accumulators the E-step in front used (FrameDev::acc_rows; the launcher instantiates 2 / 4 for the plain one-frame kernel)
+// HINT: the launch carries the iteration's parity (par_hint, 0 / 1): the sums are requested from that parity's rows alone, without waiting for the device's counter
+template <typename T, bool SINGLE, bool XCH, bool TRK = false, bool SPIN = false, int ROWS = kAccRows, bool HINT = false>
+__device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums, char *smem, int par_hint = 0) {
     constexpr int MB = kCB;
     // One wave walks a chain of dependent instructions.  In a batch the other stream groups' E-steps fill the same SIMDs with waves that always have
     // something to issue: at the default priority this wave takes its turn among them (C3: 10.0 us per M-step against 7.4 us with the GPU to itself)
@@ -185,13 +187,13 @@ __device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums
         __syncthreads();
         spin_lost = red[29] == 0.0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        sq[0] = acc_read_both(f, t < nS ? t : nS - 1, itn);
+        sq[0] = acc_read_both<ROWS>(f, t < nS ? t : nS - 1, itn);
 #pragma unroll
         for (int u = 1; u < 9; ++u) sq[u] = 0.0;
     } else {
     // (the first element without a branch -- index clamped, the accumulators exist in every mode: inside a conditional block the compiler sums the
     //  16 rows on the spot, i.e. waits for them BEFORE it requests the slot below: two memory round trips in a row instead of one)
-    sq[0] = acc_read_both(f, t < nS ? t : nS - 1, itn);
+    sq[0] = HINT ? acc_read_par<ROWS>(f, t < nS ? t : nS - 1, par_hint) : acc_read_both<ROWS>(f, t < nS ? t : nS - 1, itn);
 #pragma unroll
     for (int u = 1; u < 9; ++u) sq[u] = 0.0;
     }
@@ -215,7 +217,7 @@ __device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums
         // parity only: inside `if (i < nS)` blocks every element's eight rows were waited for before the next element's were requested
         // (fetch at M = 300: 10 500 clocks, 7 000 of them these serial round trips).
         if (from_sums != 1) {
-            const auto rows = TDLO_AS_GLOBAL(long long, f.acc) + (size_t)(itn & 1) * kAccRows * acc_stride(M);
+            const auto rows = TDLO_AS_GLOBAL(long long, f.acc) + (size_t)(HINT ? par_hint : (itn & 1)) * kAccRows * acc_stride(M);
             const int stride = acc_stride(M);
             auto more = [&](auto U0c, auto U1c) __attribute__((always_inline)) {        // elements U0 .. U1 - 1, all rows requested before any is summed
                 constexpr int U0 = decltype(U0c)::value, U1 = decltype(U1c)::value;
@@ -227,7 +229,7 @@ __device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums
                     ix[u - U0] = i < nS ? i : nS - 1;
                     long long a = 0;
 #pragma unroll
-                    for (int r = 0; r < kAccRows; ++r) a += rows[(size_t)r * stride + ix[u - U0]];
+                    for (int r = 0; r < ROWS; ++r) a += rows[(size_t)r * stride + ix[u - U0]];
                     sa[u - U0] = a;
                 }
 #pragma unroll
@@ -235,13 +237,13 @@ __device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums
             };
             using std::integral_constant;
             switch ((nS + MB - 1) / MB) {       // (two elements, 64 .. 127 nodes: both parities without waiting for the counter, as before; at most four
-                case 2: if (t + MB < nS) sq[1] = acc_read_both(f, t + MB, itn); break;                          //  elements at a time)
+                case 2: if (t + MB < nS) sq[1] = HINT ? acc_read_par<ROWS>(f, t + MB, par_hint) : acc_read_both<ROWS>(f, t + MB, itn); break;                          //  elements at a time)
                 case 3: more(integral_constant<int, 1>(), integral_constant<int, 3>()); break;
                 case 4: more(integral_constant<int, 1>(), integral_constant<int, 4>()); break;
                 case 5: more(integral_constant<int, 1>(), integral_constant<int, 5>()); break;
                 default:        // more than 319 nodes: element by element as before (two groups of four in flight measured slower: 32 000 against 16 500 clocks at M = 512)
 #pragma unroll
-                    for (int u = 1; u < 9; ++u) { const int i = t + u * MB; if (i < nS) sq[u] = acc_read_both(f, i, itn); }
+                    for (int u = 1; u < 9; ++u) { const int i = t + u * MB; if (i < nS) sq[u] = HINT ? acc_read_par<ROWS>(f, i, par_hint) : acc_read_both<ROWS>(f, i, itn); }
                     break;
             }
         }
@@ -312,6 +314,12 @@ __device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums
         return;
     }
     CSTAMP(1);
+    if (HINT && from_sums != 1 && (itn & 1) != par_hint) {
+        // the host's count of the iterations it has enqueued and the device's counter disagree (a registration continued by a caller that did not say so):
+        // the sums are read again, the ordinary way.  Never seen in the tests' routes; kept so that the hint can only cost time, never a result.
+#pragma unroll
+        for (int u = 0; u < 9; ++u) { const int i = t + u * MB; if (i < nS) sq[u] = acc_read_both<ROWS>(f, i, itn); }
+    }
     if (from_sums != 1) {
 #pragma unroll
         for (int u = 0; u < 9; ++u) { const int i = t + u * MB; if (i < nS) S[i] = sq[u]; }
