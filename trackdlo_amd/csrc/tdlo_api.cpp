@@ -1004,6 +1004,14 @@ int run_frames(tdlo_ctx *c, int F, const int *slots, double *Y, int M, double *s
         const bool two = elig && (c->estep2_mode == 1 || waves >= kEstep2MinWaves);
         for (int i = 0; i < F; ++i) if (two) estep2_geometry(c, c->fh[i], true);      // (a frame prepare_frame had given to k_estep2 on its own size keeps it only if the whole batch does:
         for (int i = 0; i < F; ++i) choose_acc_rows(c, c->fh[i], true);
+        // a batch of short fp32 chains without the LLE term whose frames have at most 64 E-step workgroups each (C3: 49): two replica rows -- no more atomics
+        // per address than one 50 000-point frame puts on eight -- and a quarter of the sums for every frame's M-step to fetch (one choice for the whole batch)
+        {
+            static const int env = getenv("TDLO_ACC_ROWS") ? atoi(getenv("TDLO_ACC_ROWS")) : 0;
+            bool small = env == 0 && !p->include_lle;
+            for (int i = 0; i < F; ++i) small = small && c->fh[i].nblkE <= 64 && !c->fh[i].mstep_dense && c->fh[i].M <= kChunk;
+            if (small) for (int i = 0; i < F; ++i) c->fh[i].acc_rows = 2;
+        }
         if (!two) for (int i = 0; i < F; ++i) if (c->fh[i].estep2) return fail(c, TDLO_E_INVALID, "internal: a batch's frames disagree about the E-step kernel");   //  same M, precision and mode -- they cannot)
     }
     if (!p->include_lle) break;

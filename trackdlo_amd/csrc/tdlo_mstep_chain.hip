@@ -303,7 +303,10 @@ template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd,
         else { if (fh[0].acc_rows == 2) TDLO_CHAIN1(true, 2, false, 1); else if (fh[0].acc_rows == 4) TDLO_CHAIN1(true, 4, false, 1); else TDLO_CHAIN1(true, kAccRows, false, 1); }
     } else {
         const int hint = from_sums == 0 ? g_par_hint : -1, fsh = from_sums | ((hint > 0 ? 1 : 0) << 8);
-        if (hint >= 0) TDLO_CHAIN1(false, kAccRows, true, F); else TDLO_CHAIN1(false, kAccRows, false, F);
+        // (a batch whose frames ALL spread over two rows -- run_frames decides that for the whole batch -- gets the two-row instantiation)
+        bool two = true;
+        for (int i = 0; i < F; ++i) two = two && fh[i].acc_rows == 2;
+        if (hint >= 0 && two) TDLO_CHAIN1(false, 2, true, F); else if (hint >= 0) TDLO_CHAIN1(false, kAccRows, true, F); else TDLO_CHAIN1(false, kAccRows, false, F);
 #undef TDLO_CHAIN1
     }
     return hipGetLastError();
