@@ -2090,11 +2090,15 @@ int tdlo_split_run(tdlo_ctx *c, void *nccl_comm, double *Y, int M, double *sigma
     }
     if (timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     const bool visb = f.vis_branch != 0;
+    int split_it = 0;
     auto iteration = [&]() -> int {
         if (oneshot) {
             if (visb) HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 1, s));      // k_dmin: its last workgroup exchanges the minima
             HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 0, s));
-            HIPCHK(c, launch_estep_only(c->fd, c->fh.data(), 1, 5, s));                // M-step with the exchange of the sums inside
+            mstep_parity_hint(split_it++);                                             // (this call's count of the registration's iterations: tdlo_mstep_chain.hip)
+            const hipError_t me = launch_estep_only(c->fd, c->fh.data(), 1, 5, s);     // M-step with the exchange of the sums inside
+            mstep_parity_hint(-1);
+            HIPCHK(c, me);
         } else {
             int e;
             if (visb) {

@@ -279,6 +279,11 @@ template <typename T> static hipError_t launch_mstep_chain_T(const FrameDev *fd,
     const size_t lds = mstep_chain_lds_bytes(fh[0].M);
     if (from_sums == 3) {          // one frame (a shard of the split cloud), exchange inside the kernel
         if (F != 1) return hipErrorInvalidValue;
+        if (g_par_hint >= 0) {          // (tdlo_split_run counts its iterations as run_frames does: the shard's own sums from that parity's rows alone)
+            if ((e = set_lds_c(k_mstep_chain<T, true, true, false, false, kAccRows, true>, lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL((k_mstep_chain<T, true, true, false, false, kAccRows, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums | (g_par_hint << 8));
+            return hipGetLastError();
+        }
         if ((e = set_lds_c(k_mstep_chain<T, true, true>, lds)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_mstep_chain<T, true, true>), dim3(1), dim3(kCB), lds, s, fd, fh[0], from_sums);
     } else if (F == 1 && (fh[0].spec_flag != nullptr || fh[0].lle_next != nullptr || ((from_sums == 1 || fh[0].late_mstep != 0) && fh[0].late_aJ != nullptr))) {
