@@ -125,6 +125,13 @@ __device__ __forceinline__ void mstep_chain_run(const FrameDev &f, int from_sums
 #define CSTAMP(i) do { } while (0)
 #endif
     CSTAMP(0);
+    if (SINGLE) {
+        // (the descriptor is the kernel's argument block: ALL the pointers this kernel starts from are asked for here, in one scalar round trip with the few
+        //  the sums' addresses need -- left to the compiler they are fetched in three batches, each waited for where it is first used, and the slot's
+        //  requests below leave 600 clocks after the sums')
+        const void *p0 = f.st, *p1 = f.chain, *p2 = f.nodes, *p3 = f.Y, *p4 = f.Y0, *p5 = f.aJ, *p6 = f.aYd;
+        asm volatile("" :: "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6));
+    }
     const auto stg = TDLO_AS_GLOBAL(IterState, st);
     const int done = stg->done;
     const double sigma2 = stg->sigma2;
