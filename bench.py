@@ -181,7 +181,7 @@ class _ClockSampler:
 
     def summary(self):
         if not self.dev:
-            return dict(sclk_mhz_mean=None, power_w_mean=None, source=None)
+            return dict(sclk_mhz_mean=None, power_w_mean=None, source=None, host_load_1m=_host_load())
         def col(i):
             v = [s[i] for s in self.samples if s[i] is not None]
             return v
@@ -190,7 +190,18 @@ class _ClockSampler:
         return dict(sclk_mhz_mean=round(sum(sc) / len(sc), 1) if sc else None, sclk_mhz_min=round(min(sc), 1) if sc else None,
                     sclk_mhz_idle=None if not self.idle or self.idle[0] is None else round(self.idle[0], 1), mclk_mhz=self._mclk(),
                     power_w_mean=round(sum(pw) / len(pw), 1) if pw else None, power_cap_w=None if cap is None else round(cap / 1e6, 1),
-                    gpu_busy_pct_mean=round(sum(bz) / len(bz), 1) if bz else None, samples=len(self.samples), period_s=self.period, source=self.dev[2])
+                    gpu_busy_pct_mean=round(sum(bz) / len(bz), 1) if bz else None, samples=len(self.samples), period_s=self.period, source=self.dev[2],
+                    host_load_1m=_host_load())
+
+
+def _host_load():
+    """The host's one-minute load average per CPU: a batch's loop is enqueued by three host threads, and a box whose CPUs are busy with somebody else's work
+    starves them (one collection box of round 6 gave C3 1.19 M it/s where every other gave 1.25 - 1.29 M, with the same kernel times)."""
+    try:
+        with open("/proc/loadavg") as fh:
+            return round(float(fh.read().split()[0]) / max(1, os.cpu_count() or 1), 3)
+    except (OSError, ValueError):
+        return None
 
 
 def _stub_mark(line):
@@ -381,7 +392,7 @@ def _compact(full):
               "self_exchange_iters_per_s"):
         if k in full:
             o[k] = full[k]
-    for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_cap_w"):      # the GPU's clocks and power while the timed region ran (_ClockSampler)
+    for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_cap_w", "host_load_1m"):      # the GPU's clocks and power while the timed region ran (_ClockSampler); the host's load per CPU
         o[k] = (full.get("clocks") or {}).get(k)
     if full.get("stub"):
         o["stub"] = full["stub"]
